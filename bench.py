@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Throughput harness for the hot path: PointNet++ SSG (BASELINE config 2), forward + backward + Adam,
+point-clouds/sec on synthetic B x 2048 x 3 clouds resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1 is launched by torchrun, one rank per GPU)
+
+A "step" = one training step of `pointnet2_cls_ssg` on one batch of 256 clouds per GPU (weak scaling):
+geometry (FPS / ball query / grouping) -> shared MLPs + BN + max-pool -> FC head -> loss -> backward ->
+flat-bucket gradient all-reduce (RCCL) -> TF-Adam update.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from scanobjectnn_amd import _lib, dist as D  # noqa: E402
+from scanobjectnn_amd import train_util as TU  # noqa: E402
+from scanobjectnn_amd.graph import Model  # noqa: E402
+from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_PEAK_TFLOPS = 157.3   # f32 vector == f32-input MFMA peak
+
+MODELS = {
+    "pointnet2_cls_ssg": ("scanobjectnn_amd.pointnet2.pointnet2_cls_ssg", False, 256, 2048),
+    "pointnet2_cls_bga": ("scanobjectnn_amd.pointnet2.pointnet2_cls_bga", True, 128, 2048),
+    "pointnet2_cls_msg": ("scanobjectnn_amd.pointnet2.pointnet2_cls_msg", False, 256, 4096),
+    "dgcnn": ("scanobjectnn_amd.dgcnn.dgcnn", False, 256, 2048),
+    "dgcnn_bga": ("scanobjectnn_amd.dgcnn.dgcnn_bga", True, 128, 2048),
+}
+
+
+# ---- algorithmic bytes / flops per launch of each pcops kernel (SURVEY.md §8d formulas) ------------
+def _algo(name, a):
+    """returns (bytes, flops_or_pairs) for one launch given the C-ABI argument tuple"""
+    if name == "pcops_query_ball_point":
+        b, n, m, _r, s = a[:5]
+        return b * (12 * n + 12 * m + 4 * m * s + 4 * m), b * m * n
+    if name == "pcops_query_ball_point_multi":
+        b, n, m = a[:3]
+        return b * (12 * n + 12 * m), b * m * n
+    if name == "pcops_farthest_point_sample":
+        b, n, m = a[:3]
+        return b * (12 * n + 4 * m), b * (m - 1) * n
+    if name == "pcops_gather_point":
+        b, n, m = a[:3]
+        return b * (16 * m + 12 * m), 0
+    if name == "pcops_gather_point_grad":
+        b, n, m = a[:3]
+        return b * (16 * m + 12 * n), 0
+    if name == "pcops_group_point":
+        b, n, c, m, s = a[:5]
+        return b * (4 * n * c + 4 * m * s + 4 * m * s * c), 0
+    if name == "pcops_group_point_grad":
+        b, n, c, m, s = a[:5]
+        return b * (4 * n * c + 4 * m * s + 4 * m * s * c), 0
+    if name == "pcops_three_nn":
+        b, n, m = a[:3]
+        return b * (12 * n + 12 * m + 24 * n), b * n * m
+    if name in ("pcops_three_interpolate", "pcops_three_interpolate_grad"):
+        b, m, c, n = a[:4] if name == "pcops_three_interpolate" else (a[0], a[3], a[2], a[1])
+        return b * (4 * m * c + 24 * n + 4 * n * c), 0
+    if name == "pcops_knn_graph":
+        b, n, c, k = a[:4]
+        return b * (4 * n * c + 4 * n * k), 2 * b * n * n * c
+    if name in ("pcops_edge_feature", "pcops_edge_feature_grad"):
+        b, n, c, k = a[:4]
+        return b * (4 * n * c + 4 * n * k + 8 * n * k * c), 0
+    return 0, 0
+
+
+class KernelTimer:
+    """HIP-event timing of every libpcops launch on the stream it is launched on (torch's current
+    stream: `_lib.call` passes torch.cuda.current_stream() to the C ABI, and torch.cuda.Event.record()
+    records on that same stream)."""
+
+    def __init__(self):
+        self.records = []     # (name, args, start_event, end_event)
+        self._open = None
+
+    def __call__(self, name, phase, args):
+        if phase == "pre":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._open = ev
+        else:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.records.append((name, args, self._open, ev))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, args, s, e in self.records:
+            ms = s.elapsed_time(e)
+            by, work = _algo(name, args)
+            key = (name,) + tuple(x for x in args[:5] if isinstance(x, (int, float)))
+            d = agg.setdefault(key, {"kernel": name, "shape": list(key[1:]), "launches": 0, "ms": 0.0,
+                                     "bytes": by, "work": work})
+            d["launches"] += 1
+            d["ms"] += ms
+        out = []
+        for d in agg.values():
+            avg_ms = d["ms"] / d["launches"]
+            d["avg_us"] = avg_ms * 1e3
+            d["gbs"] = d["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            d["gwork_s"] = d["work"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            out.append(d)
+        out.sort(key=lambda d: -d["ms"])
+        return out
+
+
+def cpu_baseline(model_name, n_points, seconds_budget=20.0):
+    """The CPU restatement (oracle/ref_models.py + the C oracle for the geometry) of the SAME step
+    (forward + backward, training-mode BN, no optimiser), timed on the host cores of this box."""
+    from oracle import ref_models as R
+    import importlib
+    modpath, has_mask, _, _ = MODELS[model_name]
+    mod = importlib.import_module(modpath)
+    ref_fn = getattr(R, model_name)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 4
+    c = synth_clouds(bs, n_points, seed=99)
+    # variables: build the product graph once on the GPU to get identically-shaped weights
+    net = Model(mod.get_model, device="cuda:0", seed=0).build(torch.from_numpy(c[:2]).cuda())
+    P = {k: v.requires_grad_(v.is_floating_point()) for k, v in R.params_from_state_dict(net.state_dict()).items()}
+    y = torch.from_numpy(synth_labels(bs)).long()
+    x = torch.from_numpy(c)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        out = ref_fn(x, P, True)
+        logits = out[0] if isinstance(out, tuple) else out
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        if isinstance(out, tuple):
+            loss = loss + out[1].square().mean()
+        loss.backward()
+        done += bs
+        el = time.perf_counter() - t0
+        if el > seconds_budget or done >= 64:
+            break
+    return {"value": done / el, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": "%d clouds of %d pts, %s forward+backward (train-mode BN), oracle/ref_models.py "
+                      "(C oracle geometry, 1 thread) + torch-CPU fp32 algebra (%d threads), %.1f s"
+                      % (done, n_points, model_name, cores, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="pointnet2_cls_ssg", choices=sorted(MODELS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--num_point", type=int, default=0)
+    ap.add_argument("--kind", default="surface", choices=["surface", "ball"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="eval-mode forward throughput (not the metric)")
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _lib.load()
+
+    import importlib
+    modpath, has_mask, cfg_batch, cfg_n = MODELS[args.model]
+    mod = importlib.import_module(modpath)
+    B = args.batch or cfg_batch
+    N = args.num_point or cfg_n
+
+    x = torch.from_numpy(synth_clouds(B, N, seed=1234 + rank, kind=args.kind)).to(dev)
+    y = torch.from_numpy(synth_labels(B, seed=1234 + rank)).to(dev)
+    mask = torch.from_numpy(synth_masks(B, N, seed=1234 + rank)).to(dev) if has_mask else None
+
+    net = Model(mod.get_model, device=dev, seed=0).build(x[:2].contiguous())
+    fp = TU.FlatParams(net)
+    D.broadcast_(fp.flat)                       # identical replicas
+    opt = TU.TFAdam(fp)
+    global_batch = B * world
+    state = {"step": 0}
+
+    def train_step():
+        s = state["step"]
+        lr = TU.get_learning_rate(s, global_batch)
+        bn_decay = TU.get_bn_decay(s, global_batch)
+        fp.zero_grad()
+        out = net(x, is_training=True, bn_decay=bn_decay)
+        if has_mask:
+            loss = mod.get_loss(out[0], out[1], y, mask)[0]
+        else:
+            loss = mod.get_loss(out[0], y, out[1])
+        loss.backward()
+        D.allreduce_mean_(fp.grad, world)
+        opt.step(lr)
+        state["step"] = s + 1
+        return loss
+
+    def fwd_step():
+        with torch.no_grad():
+            return net(x, is_training=False)
+
+    step = fwd_step if args.forward_only else train_step
+
+    for _ in range(args.warmup):
+        step()
+    timer = KernelTimer()
+    _lib._hooks.append(timer)
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = time.perf_counter() - t0
+    _lib._hooks.remove(timer)
+    elapsed = D.max_over_ranks(elapsed, dev)
+    kernels = timer.summary()
+
+    if rank != 0:
+        return
+    value = global_batch * args.steps / elapsed
+    dom = kernels[0] if kernels else None
+    roofline = None
+    if dom is not None:
+        roofline = {"kernel": dom["kernel"], "shape": dom["shape"], "bound": "hbm",
+                    "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
+                    "algorithmic_bytes_per_launch": dom["bytes"],
+                    "pair_or_flop_rate_G_per_s": dom["gwork_s"]}
+    line = {
+        "metric": "point-clouds/sec fwd+bwd at B×2048×3, 15-cls" if not args.forward_only
+                  else "point-clouds/sec forward (eval) at B×2048×3, 15-cls",
+        "value": value, "unit": "clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s PB_T50_RS-shaped synthetic clouds (%s), %d pts, batch %d per GPU, "
+                               "train step = fwd+bwd+allreduce+Adam" % (args.model, args.kind, N, B),
+                   "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world},
+        "roofline": roofline,
+        "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s")} for d in kernels],
+    }
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(args.model, N)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

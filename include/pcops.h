@@ -1,0 +1,130 @@
+/*
+ * pcops.h -- C ABI of libpcops.so: the MI355X (gfx950) point-cloud operator library.
+ *
+ * Drop-in boundary for the native layer of the reference's PointNet++ tf_ops and
+ * the DGCNN kNN-graph path.  Every entry point keeps the scalar/pointer list and
+ * argument meaning of the launcher it replaces (cited per function; paths are
+ * relative to the reference's pointnet2/tf_ops/), adds an explicit stream, and
+ * returns a status instead of void.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HIP), fp32 / int32, dense row-major, the
+ *     (B,N,3) AoS layout of the reference at the boundary;
+ *   - the caller owns every buffer; the library never allocates, frees or
+ *     synchronises; work is enqueued on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream);
+ *   - gradient launchers zero their output themselves (the reference's glue does a
+ *     cudaMemset first: grouping/tf_grouping.cpp:204, sampling/tf_sampling.cpp:174,
+ *     3d_interpolation/tf_interpolate.cpp:258);
+ *   - return PCOPS_OK (0) or a negative pcops_status; argument checks mirror the
+ *     OP_REQUIRES of the reference's OpKernels;
+ *   - re-entrant, no global mutable state.
+ */
+#ifndef PCOPS_H
+#define PCOPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pcops_stream_t; /* hipStream_t */
+
+typedef enum pcops_status {
+    PCOPS_OK = 0,
+    PCOPS_ERR_NULL_POINTER = -1,
+    PCOPS_ERR_BAD_SHAPE = -2,     /* negative/zero extents where the reference rejects them */
+    PCOPS_ERR_BAD_ARGUMENT = -3,  /* radius <= 0, nsample <= 0, k <= 0, k > n ... */
+    PCOPS_ERR_UNSUPPORTED = -4,   /* shape outside what the gfx950 kernels are built for */
+    PCOPS_ERR_LAUNCH = -5         /* hipGetLastError() != hipSuccess after the launch */
+} pcops_status;
+
+const char *pcops_strerror(int status);
+int pcops_abi_version(void);
+
+/* ------------------------------------------------------------------ sampling */
+/* farthestpointsamplingLauncher(b,n,m,inp,temp,out)   sampling/tf_sampling.cpp:94,
+ * kernel sampling/tf_sampling_g.cu:105-170.  inp (b,n,3) -> out (b,m) int32.
+ * `temp` is the reference's (32,n) scratch; this implementation keeps the running
+ * min-distances in registers, needs no scratch and ignores it (may be NULL);
+ * pcops_farthest_point_sample_workspace_bytes() reports 0. */
+int pcops_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
+                                int *out, pcops_stream_t stream);
+unsigned long long pcops_farthest_point_sample_workspace_bytes(int b, int n);
+
+/* gatherpointLauncher(b,n,m,inp,idx,out)   sampling/tf_sampling.cpp:125, :172-181 */
+int pcops_gather_point(int b, int n, int m, const float *inp, const int *idx,
+                       float *out, pcops_stream_t stream);
+/* scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)   sampling/tf_sampling.cpp:150, :183-192 */
+int pcops_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx,
+                            float *inp_g, pcops_stream_t stream);
+
+/* ------------------------------------------------------------------ grouping */
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)
+ * grouping/tf_grouping.cpp:66, kernel grouping/tf_grouping_g.cu:3-36.
+ * xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> idx (b,m,nsample), pts_cnt (b,m).
+ * Rows with no hit are written as 0 (unspecified in the reference). */
+int pcops_query_ball_point(int b, int n, int m, float radius, int nsample,
+                           const float *xyz1, const float *xyz2, int *idx,
+                           int *pts_cnt, pcops_stream_t stream);
+
+/* MSG form: `nscale` radii over the same (xyz1, xyz2) pair in ONE pass over the
+ * dataset (pointnet_sa_module_msg issues them back to back, utils/pointnet_util.py:
+ * 175-179).  radius[s], nsample[s] are HOST arrays; idx[s] / pts_cnt[s] are host
+ * arrays of device pointers.  nscale <= 4. */
+int pcops_query_ball_point_multi(int b, int n, int m, int nscale, const float *radius,
+                                 const int *nsample, const float *xyz1,
+                                 const float *xyz2, int *const *idx,
+                                 int *const *pts_cnt, pcops_stream_t stream);
+
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out)   grouping/tf_grouping.cpp:142, :40-57 */
+int pcops_group_point(int b, int n, int c, int m, int nsample, const float *points,
+                      const int *idx, float *out, pcops_stream_t stream);
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)  tf_grouping.cpp:173, :61-78 */
+int pcops_group_point_grad(int b, int n, int c, int m, int nsample,
+                           const float *grad_out, const int *idx, float *grad_points,
+                           pcops_stream_t stream);
+
+/* selectionSortLauncher(b,n,m,k,dist,outi,out)   grouping/tf_grouping.cpp:108, :83-123.
+ * Full (b,m,n) outputs like the op; first k columns sorted, literal unstable order. */
+int pcops_selection_sort(int b, int n, int m, int k, const float *dist, int *outi,
+                         float *out, pcops_stream_t stream);
+
+/* ------------------------------------------------------------ 3d_interpolation */
+/* threenn_cpu(b,n,m,xyz1,xyz2,dist,idx)   3d_interpolation/tf_interpolate.cpp:60-103
+ * (CPU-only in the reference).  xyz1 (b,n,3) unknown, xyz2 (b,m,3) known. */
+int pcops_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2,
+                   float *dist, int *idx, pcops_stream_t stream);
+/* threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)   tf_interpolate.cpp:107-127 */
+int pcops_three_interpolate(int b, int m, int c, int n, const float *points,
+                            const int *idx, const float *weight, float *out,
+                            pcops_stream_t stream);
+/* threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)  tf_interpolate.cpp:131-153 */
+int pcops_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out,
+                                 const int *idx, const float *weight,
+                                 float *grad_points, pcops_stream_t stream);
+
+/* ------------------------------------------------------------- DGCNN kNN graph */
+/* The reference has no native code here (dgcnn/utils/tf_util.py:638-706 is
+ * matmul + top_k + gather in TF-Python); these are the native units a TF-style
+ * glue would bind for the same three functions.
+ * pairwise_distance: x (b,n,c) -> adj (b,n,n), D_ij = (s_i + (-2 <x_i,x_j>)) + s_j. */
+int pcops_pairwise_distance(int b, int n, int c, const float *x, float *adj,
+                            pcops_stream_t stream);
+/* knn = top_k(-adj,k): adj (rows,n) -> nn_idx (rows,k), ascending distance, ties ->
+ * lower index. */
+int pcops_knn_topk(int rows, int n, int k, const float *adj, int *nn_idx,
+                   pcops_stream_t stream);
+/* fused pairwise_distance + knn, never materialising (n,n): x (b,n,c) -> (b,n,k) */
+int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
+                    pcops_stream_t stream);
+/* get_edge_feature: x (b,n,c), nn_idx (b,n,k) -> out (b,n,k,2c) = [x_i | x_j - x_i] */
+int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn_idx,
+                       float *out, pcops_stream_t stream);
+/* gradient of the above w.r.t. x: grad_out (b,n,k,2c) -> grad_x (b,n,c) */
+int pcops_edge_feature_grad(int b, int n, int c, int k, const float *grad_out,
+                            const int *nn_idx, float *grad_x, pcops_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCOPS_H */

@@ -1,0 +1,214 @@
+"""CPU restatement of the model-level callers: PointNet++ SA / SA-MSG
+/ FP modules, the SSG / BGA / MSG classifiers, the DGCNN EdgeConv stack and its BGA variant.
+
+TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).  Independent of the product's host
+code: geometry comes from the C oracle (oracle/pcops_oracle.c), dense algebra from torch-CPU fp32 ops,
+variables are looked up by the TF scope names of the reference in a plain dict
+(`layer1/conv0/weights`, `layer1/conv0/bn/{beta,gamma,moving_mean,moving_variance}`, `fc1/weights` ...).
+"parity unpinned": TensorFlow is absent, so conv/BN/top_k semantics follow TF 1.10 documentation
+(DESIGN.md lists every assumption).  Dropout is the identity here (tests disable it on both sides).
+
+Each function cites the reference lines it restates (paths relative to the reference root).
+"""
+import numpy as np
+import torch
+
+from . import oracle as O
+
+EPS = 1e-3
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _idx(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).long()
+
+
+def batch_gather(x, idx):
+    """x (B,N,C), idx (B,...) long -> (B,...,C)"""
+    b = x.shape[0]
+    flat = idx.reshape(b, -1)
+    out = torch.gather(x, 1, flat.unsqueeze(-1).expand(-1, -1, x.shape[2]))
+    return out.reshape(*idx.shape, x.shape[2])
+
+
+def bn(x, P, scope, training, flavour="contrib"):
+    """pointnet2/utils/tf_util.py:512-531 ("contrib") / dgcnn/utils/tf_util.py:462-535 ("moments")"""
+    c = x.shape[-1]
+    flat = x.reshape(-1, c)
+    if training:
+        var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+    else:
+        if flavour == "dist":
+            mean, var = P[scope + "/pop_mean"], P[scope + "/pop_var"]
+        else:
+            mean, var = P[scope + "/moving_mean"], P[scope + "/moving_variance"]
+    out = (flat - mean) * torch.rsqrt(var + EPS) * P[scope + "/gamma"] + P[scope + "/beta"]
+    return out.reshape(x.shape)
+
+
+def dense(x, P, scope, training, use_bn=True, act=True, flavour="contrib"):
+    """1x1 conv / conv1d(1) / fully_connected: X·W + b -> BN -> ReLU (tf_util.py:120-185,327-363)"""
+    w = P[scope + "/weights"]
+    w = w.reshape(-1, w.shape[-1])
+    out = x.reshape(-1, x.shape[-1]) @ w + P[scope + "/biases"]
+    out = out.reshape(*x.shape[:-1], w.shape[-1])
+    if use_bn:
+        out = bn(out, P, scope + "/bn", training, flavour)
+    return torch.relu(out) if act else out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True):
+    """pointnet2/utils/pointnet_util.py:22-56"""
+    fps = O.farthest_point_sample(npoint, _np(xyz))
+    new_xyz = batch_gather(xyz, _idx(fps))
+    idx, _ = O.query_ball_point(radius, nsample, _np(xyz), _np(new_xyz))
+    idx = _idx(idx)
+    grouped_xyz = batch_gather(xyz, idx) - new_xyz.unsqueeze(2)
+    if points is None:
+        return new_xyz, grouped_xyz, idx
+    grouped_points = batch_gather(points, idx)
+    return new_xyz, (torch.cat([grouped_xyz, grouped_points], -1) if use_xyz else grouped_points), idx
+
+
+def sa_module(xyz, points, npoint, radius, nsample, mlp, P, scope, training, group_all=False):
+    """pointnet2/utils/pointnet_util.py:87-154 (pooling='max', mlp2=None)"""
+    if group_all:
+        b = xyz.shape[0]
+        new_xyz = torch.zeros((b, 1, 3))
+        new_points = (xyz if points is None else torch.cat([xyz, points], 2)).unsqueeze(1)
+    else:
+        new_xyz, new_points, _ = sample_and_group(npoint, radius, nsample, xyz, points)
+    for i in range(len(mlp)):
+        new_points = dense(new_points, P, "%s/conv%d" % (scope, i), training)
+    return new_xyz, new_points.amax(dim=2)
+
+
+def sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, P, scope, training):
+    """pointnet2/utils/pointnet_util.py:156-196; concat order [feats | xyz] (:184)"""
+    fps = O.farthest_point_sample(npoint, _np(xyz))
+    new_xyz = batch_gather(xyz, _idx(fps))
+    outs = []
+    for i, (r, s) in enumerate(zip(radius_list, nsample_list)):
+        idx = _idx(O.query_ball_point(r, s, _np(xyz), _np(new_xyz))[0])
+        g = batch_gather(xyz, idx) - new_xyz.unsqueeze(2)
+        if points is not None:
+            g = torch.cat([batch_gather(points, idx), g], -1)
+        for j in range(len(mlp_list[i])):
+            g = dense(g, P, "%s/conv%d_%d" % (scope, i, j), training)
+        outs.append(g.amax(dim=2))
+    return new_xyz, torch.cat(outs, -1)
+
+
+def fp_module(xyz1, xyz2, points1, points2, mlp, P, scope, training):
+    """pointnet2/utils/pointnet_util.py:199-229"""
+    dist, idx = O.three_nn(_np(xyz1), _np(xyz2))
+    dist = torch.clamp_min(torch.from_numpy(dist), 1e-10)
+    inv = 1.0 / dist
+    w = inv / inv.sum(dim=2, keepdim=True)
+    nb = batch_gather(points2, _idx(idx))                     # (B,n,3,C)
+    interp = nb[:, :, 0] * w[:, :, 0:1] + nb[:, :, 1] * w[:, :, 1:2] + nb[:, :, 2] * w[:, :, 2:3]
+    x = interp if points1 is None else torch.cat([interp, points1], 2)
+    for i in range(len(mlp)):
+        x = dense(x, P, "%s/conv_%d" % (scope, i), training)
+    return x
+
+
+def _cls_head(feat, P, training, num_class_scope="fc3"):
+    net = dense(feat, P, "fc1", training)
+    net = dense(net, P, "fc2", training)
+    return net, dense(net, P, num_class_scope, training, use_bn=False, act=False)
+
+
+def pointnet2_cls_ssg(point_cloud, P, training):
+    """pointnet2/models/pointnet2_cls_ssg.py:23-47"""
+    l1_xyz, l1 = sa_module(point_cloud, None, 512, 0.2, 32, [64, 64, 128], P, "layer1", training)
+    l2_xyz, l2 = sa_module(l1_xyz, l1, 128, 0.4, 64, [128, 128, 256], P, "layer2", training)
+    _, l3 = sa_module(l2_xyz, l2, None, None, None, [256, 512, 1024], P, "layer3", training, group_all=True)
+    return _cls_head(l3.reshape(point_cloud.shape[0], -1), P, training)[1]
+
+
+def pointnet2_cls_msg(point_cloud, P, training):
+    """layer: pointnet_util.py:156-196; hyper-parameters: upstream PointNet++ (not in the reference)"""
+    l1_xyz, l1 = sa_module_msg(point_cloud, None, 512, [0.1, 0.2, 0.4], [16, 32, 128],
+                               [[32, 32, 64], [64, 64, 128], [64, 96, 128]], P, "layer1", training)
+    l2_xyz, l2 = sa_module_msg(l1_xyz, l1, 128, [0.2, 0.4, 0.8], [32, 64, 128],
+                               [[64, 64, 128], [128, 128, 256], [128, 128, 256]], P, "layer2", training)
+    _, l3 = sa_module(l2_xyz, l2, None, None, None, [256, 512, 1024], P, "layer3", training, group_all=True)
+    return _cls_head(l3.reshape(point_cloud.shape[0], -1), P, training)[1]
+
+
+def pointnet2_cls_bga(point_cloud, P, training):
+    """pointnet2/models/pointnet2_cls_bga.py:21-75 -> (class_pred, seg_pred)"""
+    l0_xyz = point_cloud[:, :, :3]
+    l1_xyz, l1 = sa_module(l0_xyz, None, 512, 0.2, 64, [64, 64, 128], P, "layer1", training)
+    l2_xyz, l2 = sa_module(l1_xyz, l1, 128, 0.4, 64, [128, 128, 256], P, "layer2", training)
+    l3_xyz, l3 = sa_module(l2_xyz, l2, None, None, None, [256, 512, 1024], P, "layer3", training, group_all=True)
+    fc2, class_pred = _cls_head(l3.reshape(point_cloud.shape[0], -1), P, training)
+    class_vector = fc2.unsqueeze(1)
+    l2p = fp_module(l2_xyz, l3_xyz, l2, class_vector, [256, 256], P, "fa_layer1", training)
+    l1p = fp_module(l1_xyz, l2_xyz, l1, l2p, [256, 128], P, "fa_layer2", training)
+    l0p = fp_module(l0_xyz, l1_xyz, None, l1p, [128, 128, 128], P, "fa_layer3", training)
+    net = dense(l0p, P, "seg_fc1", training)
+    return class_pred, dense(net, P, "seg_fc2", training, use_bn=False, act=False)
+
+
+# ------------------------------------------------------------------------------- DGCNN
+def _edge_features(x, k, nn=None):
+    """dgcnn/utils/tf_util.py:638-706 via the fused oracle graph.  `nn` overrides the graph (tests feed
+    the product's own indices so that a 1e-6 feature difference cannot flip a near-tie neighbour)."""
+    nn = _idx(O.knn_graph(_np(x), k) if nn is None else nn)
+    nb = batch_gather(x, nn)                                   # (B,N,k,C)
+    ctr = x.unsqueeze(2).expand_as(nb)
+    return torch.cat([ctr, nb - ctr], -1)
+
+
+def _dgcnn_backbone(point_cloud, P, training, k=20, nn_list=None):
+    """dgcnn/models/dgcnn.py:31-86, transform_nets.py:10-55"""
+    b, n, _ = point_cloud.shape
+    nn_list = list(nn_list) if nn_list is not None else [None] * 5
+    ef = _edge_features(point_cloud, k, nn_list[0])
+    t = dense(ef, P, "transform_net1/tconv1", training, flavour="moments")
+    t = dense(t, P, "transform_net1/tconv2", training, flavour="moments").amax(dim=2, keepdim=True)
+    t = dense(t, P, "transform_net1/tconv3", training, flavour="moments").amax(dim=1).reshape(b, -1)
+    t = dense(t, P, "transform_net1/tfc1", training, flavour="moments")
+    t = dense(t, P, "transform_net1/tfc2", training, flavour="moments")
+    tr = t @ P["transform_net1/transform_XYZ/weights"] + (P["transform_net1/transform_XYZ/biases"]
+                                                          + torch.eye(3).flatten())
+    x = point_cloud @ tr.reshape(b, 3, 3)
+    nets = []
+    for li, scope in enumerate(("dgcnn1", "dgcnn2", "dgcnn3", "dgcnn4")):
+        x = dense(_edge_features(x, k, nn_list[li + 1]), P, scope, training, flavour="moments").amax(dim=2)
+        nets.append(x)
+    agg = dense(torch.cat(nets, -1), P, "agg", training, flavour="moments")       # (B,N,1024)
+    return nets, agg
+
+
+def dgcnn(point_cloud, P, training, nn_list=None):
+    """dgcnn/models/dgcnn.py:24-102"""
+    _, agg = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
+    net = dense(agg.amax(dim=1), P, "fc1", training, flavour="moments")
+    net = dense(net, P, "fc2", training, flavour="moments")
+    return dense(net, P, "fc3", training, use_bn=False, act=False)
+
+
+def dgcnn_bga(point_cloud, P, training, nn_list=None):
+    """dgcnn/models/dgcnn_bga.py:27-134 -> (class_pred, seg_pred)"""
+    b, n, _ = point_cloud.shape
+    nets, agg = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
+    out_max = agg.amax(dim=1)
+    net = dense(out_max, P, "fc1", training, flavour="moments")
+    fc2 = dense(net, P, "fc2", training, flavour="moments")
+    class_pred = dense(fc2, P, "fc3", training, use_bn=False, act=False)
+    cat = torch.cat([fc2.unsqueeze(1).expand(b, n, 256), out_max.unsqueeze(1).expand(b, n, 1024)] + nets, -1)
+    s = dense(cat, P, "seg/conv1", training, flavour="dist")
+    s = dense(s, P, "seg/conv2", training, flavour="dist")
+    return class_pred, dense(s, P, "seg/conv3", training, use_bn=False, act=False)
+
+
+def params_from_state_dict(sd, prefix="graph."):
+    """product Model.state_dict() -> {tf_scope_name: cpu tensor}"""
+    return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().float().cpu().clone()
+            for k, v in sd.items()}

@@ -1,0 +1,106 @@
+"""ctypes binding of libpcops.so (the C ABI of include/pcops.h).
+
+The product path is HIP-only: there is NO CPU fallback.  A missing library, a CPU
+tensor or a non-zero status raises immediately (the CPU restatement under oracle/ is
+test infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcops.so")
+
+_I, _F, _P, _U64 = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong
+
+# name -> (argtypes without the trailing stream, has_stream)
+SIGNATURES = {
+    "pcops_farthest_point_sample": ([_I, _I, _I, _P, _P, _P], True),
+    "pcops_gather_point": ([_I, _I, _I, _P, _P, _P], True),
+    "pcops_gather_point_grad": ([_I, _I, _I, _P, _P, _P], True),
+    "pcops_query_ball_point": ([_I, _I, _I, _F, _I, _P, _P, _P, _P], True),
+    "pcops_query_ball_point_multi": ([_I, _I, _I, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_group_point": ([_I, _I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_group_point_grad": ([_I, _I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_selection_sort": ([_I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_three_nn": ([_I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_three_interpolate": ([_I, _I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_three_interpolate_grad": ([_I, _I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_pairwise_distance": ([_I, _I, _I, _P, _P], True),
+    "pcops_knn_topk": ([_I, _I, _I, _P, _P], True),
+    "pcops_knn_graph": ([_I, _I, _I, _I, _P, _P], True),
+    "pcops_edge_feature": ([_I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_edge_feature_grad": ([_I, _I, _I, _I, _P, _P, _P], True),
+}
+PLAIN = {
+    "pcops_strerror": ([_I], C.c_char_p),
+    "pcops_abi_version": ([], _I),
+    "pcops_farthest_point_sample_workspace_bytes": ([_I, _I], _U64),
+}
+
+_lib = None
+
+
+class PcopsError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libpcops.so; raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PcopsError(
+            "libpcops.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C scanobjectnn_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, _) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = list(argtypes) + [_P]
+        fn.restype = _I
+    for name, (argtypes, restype) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def strerror(status):
+    return load().pcops_strerror(int(status)).decode()
+
+
+def ptr(t):
+    """device pointer of a tensor that already passed check()"""
+    return t.data_ptr() if t is not None else None
+
+
+def check(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise PcopsError("%s is on %s: pcops ops run on the MI355X only (no CPU fallback)"
+                         % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
+    return t.contiguous()
+
+
+_hooks = []  # profiling hooks: callables (name, phase, args) with phase in {"pre", "post"}
+
+
+def call(name, *args):
+    """Invoke a stream-taking entry point on torch's current HIP stream."""
+    lib = load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for h in _hooks:
+        h(name, "pre", args)
+    status = getattr(lib, name)(*args, stream)
+    for h in _hooks:
+        h(name, "post", args)
+    if status != 0:
+        raise PcopsError("%s failed: %s (status %d)" % (name, strerror(status), status))

@@ -1,0 +1,346 @@
+// knn.hip -- DGCNN dynamic-graph ops for gfx950: pairwise_distance, knn (top-k), the fused
+// knn_graph that never materialises the (n,n) adjacency, and get_edge_feature(+grad).
+//
+// The reference has no native code here: dgcnn/utils/tf_util.py:638-706 builds the graph in
+// TF-Python (matmul + top_k + gather) and writes a (B,N,N) fp32 matrix five times per forward.
+// Arithmetic contract (shared with oracle/pcops_oracle.c, "parity unpinned" w.r.t. TensorFlow):
+//   inner_ij = fmaf chain over c ascending from +0, s_i likewise, D_ij = (s_i + (-2*inner)) + s_j;
+//   top-k ascending in D, ties -> lower j.  Zero-padding the channel axis is exact
+//   (fmaf(0,0,acc) == acc), which lets the fused kernel keep the query row in VGPRs at a
+//   compile-time width.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ fused kNN graph
+// grid (query tiles, clouds); one lane per query row, the row's channels in VGPRs; candidate
+// rows staged TJ at a time in LDS and read wave-uniformly (ds_read_b128 broadcast); each lane's
+// sorted top-k list lives in LDS as [slot][lane] (conflict free).
+template <int C, int TJ>
+__global__ __launch_bounds__(256) void knn_graph_kernel(int n, int c, int k,
+                                                        const float *__restrict__ x,
+                                                        int *__restrict__ nn_idx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nthr = blockDim.x;
+    float *cand = lds;                    // [TJ][C]
+    float *sj = cand + TJ * C;            // [TJ]
+    float *lv = sj + TJ;                  // [k][nthr]
+    int *li = reinterpret_cast<int *>(lv + k * nthr);
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const float *xb = x + (size_t)b * n * c;
+    const int i = blockIdx.x * nthr + tid;
+    const bool valid = i < n;
+
+    float xi[C];
+#pragma unroll
+    for (int l = 0; l < C; ++l) xi[l] = (valid && l < c) ? xb[(size_t)i * c + l] : 0.f;
+    float si = 0.f;
+#pragma unroll
+    for (int l = 0; l < C; ++l) si = fmaf(xi[l], xi[l], si);
+
+    for (int s = 0; s < k; ++s) {
+        lv[s * nthr + tid] = INFINITY;
+        li[s * nthr + tid] = 0;
+    }
+    float worst = INFINITY;
+
+    for (int j0 = 0; j0 < n; j0 += TJ) {
+        const int tn = min(TJ, n - j0);
+        __syncthreads();
+        for (int e = tid; e < tn * C; e += nthr) {
+            const int r = e / C, l = e - r * C;
+            cand[e] = l < c ? xb[(size_t)(j0 + r) * c + l] : 0.f;
+        }
+        __syncthreads();
+        for (int r = tid; r < tn; r += nthr) {
+            float s = 0.f;
+            for (int l = 0; l < C; ++l) s = fmaf(cand[r * C + l], cand[r * C + l], s);
+            sj[r] = s;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < tn; ++jj) {
+            const float *cr = cand + jj * C;
+            float inner = 0.f;
+#pragma unroll
+            for (int l = 0; l < C; l += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(cr + l);
+                inner = fmaf(xi[l + 0], v.x, inner);
+                inner = fmaf(xi[l + 1], v.y, inner);
+                inner = fmaf(xi[l + 2], v.z, inner);
+                inner = fmaf(xi[l + 3], v.w, inner);
+            }
+            const float d = (si + (-2.f * inner)) + sj[jj];
+            if (valid && d < worst) {
+                int pos = k - 1;
+                while (pos > 0) {
+                    const float pv = lv[(pos - 1) * nthr + tid];
+                    if (!(d < pv)) break;
+                    lv[pos * nthr + tid] = pv;
+                    li[pos * nthr + tid] = li[(pos - 1) * nthr + tid];
+                    --pos;
+                }
+                lv[pos * nthr + tid] = d;
+                li[pos * nthr + tid] = j0 + jj;
+                worst = lv[(k - 1) * nthr + tid];
+            }
+        }
+    }
+    if (valid) {
+        int *o = nn_idx + ((size_t)b * n + i) * k;
+        for (int s = 0; s < k; ++s) o[s] = li[s * nthr + tid];
+    }
+}
+
+template <int C>
+int launch_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx, hipStream_t st) {
+    constexpr int TJ = C <= 32 ? 128 : 64;
+    int threads = n >= 256 ? 256 : ((n + kWave - 1) / kWave) * kWave;
+    while (threads > 64 && (size_t)(TJ * C + TJ + 2 * k * threads) * 4 > 64 * 1024) threads -= 64;
+    const size_t lds = (size_t)(TJ * C + TJ + 2 * k * threads) * 4;
+    if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((knn_graph_kernel<C, TJ>), dim3(cdiv(n, threads), b), dim3(threads), lds, st,
+                       n, c, k, x, nn_idx);
+    return pcops_launch_status();
+}
+
+// ------------------------------------------------------------------ materialised path
+// pairwise_distance: 64x64 output tile per workgroup, 4x4 outputs per lane, channel chunks of
+// CK staged in LDS; the fmaf chains run c-ascending across chunks.
+constexpr int kPdT = 64, kPdCK = 32;
+
+__global__ __launch_bounds__(256) void pairwise_distance_kernel(int n, int c,
+                                                                const float *__restrict__ x,
+                                                                float *__restrict__ adj) {
+    __shared__ float xi[kPdT][kPdCK + 1];
+    __shared__ float xj[kPdT][kPdCK + 1];
+    __shared__ float ssi[kPdT], ssj[kPdT];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * kPdT, j0 = blockIdx.x * kPdT;
+    const int tid = threadIdx.x;
+    const int ti = tid / 16, tj = tid % 16;
+    const float *xb = x + (size_t)b * n * c;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) acc[a][d] = 0.f;
+    float srow = 0.f;  // lanes 0..63: s of i-rows, lanes 64..127: s of j-rows
+
+    for (int c0 = 0; c0 < c; c0 += kPdCK) {
+        const int cn = min(kPdCK, c - c0);
+        __syncthreads();
+        for (int e = tid; e < kPdT * kPdCK; e += 256) {
+            const int r = e / kPdCK, l = e - r * kPdCK;
+            xi[r][l] = (i0 + r < n && l < cn) ? xb[(size_t)(i0 + r) * c + c0 + l] : 0.f;
+            xj[r][l] = (j0 + r < n && l < cn) ? xb[(size_t)(j0 + r) * c + c0 + l] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int l = 0; l < cn; ++l) srow = fmaf(xi[tid][l], xi[tid][l], srow);
+        } else if (tid < 128) {
+            for (int l = 0; l < cn; ++l) srow = fmaf(xj[tid - 64][l], xj[tid - 64][l], srow);
+        }
+        for (int l = 0; l < cn; ++l) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = xi[ti * 4 + a][l];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) bv[d] = xj[tj * 4 + d][l];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[a][d] = fmaf(av[a], bv[d], acc[a][d]);
+        }
+    }
+    if (tid < 64) ssi[tid] = srow;
+    else if (tid < 128) ssj[tid - 64] = srow;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = i0 + ti * 4 + a;
+        if (i >= n) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int j = j0 + tj * 4 + d;
+            if (j < n)
+                adj[((size_t)b * n + i) * n + j] = (ssi[ti * 4 + a] + (-2.f * acc[a][d])) + ssj[tj * 4 + d];
+        }
+    }
+}
+
+// top_k(-adj, k) on a materialised (rows, n) matrix.  64 rows per workgroup (one lane each);
+// 64x64 tiles are loaded coalesced and transposed through LDS; sorted lists in LDS.
+__global__ __launch_bounds__(64) void knn_topk_kernel(long long rows, int n, int k,
+                                                      const float *__restrict__ adj,
+                                                      int *__restrict__ nn_idx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *tile = lds;             // [64][65]
+    float *lv = tile + 64 * 65;    // [k][64]
+    int *li = reinterpret_cast<int *>(lv + k * 64);
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const bool valid = r0 + tid < rows;
+    for (int s = 0; s < k; ++s) {
+        lv[s * 64 + tid] = INFINITY;
+        li[s * 64 + tid] = 0;
+    }
+    float worst = INFINITY;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int tn = min(64, n - j0);
+        __syncthreads();
+        for (int r = 0; r < 64; ++r)
+            if (r0 + r < rows && tid < tn) tile[r * 65 + tid] = adj[(r0 + r) * n + j0 + tid];
+        __syncthreads();
+        for (int jj = 0; jj < tn; ++jj) {
+            const float d = tile[tid * 65 + jj];
+            if (valid && d < worst) {
+                int pos = k - 1;
+                while (pos > 0) {
+                    const float pv = lv[(pos - 1) * 64 + tid];
+                    if (!(d < pv)) break;
+                    lv[pos * 64 + tid] = pv;
+                    li[pos * 64 + tid] = li[(pos - 1) * 64 + tid];
+                    --pos;
+                }
+                lv[pos * 64 + tid] = d;
+                li[pos * 64 + tid] = j0 + jj;
+                worst = lv[(k - 1) * 64 + tid];
+            }
+        }
+    }
+    if (valid)
+        for (int s = 0; s < k; ++s) nn_idx[(r0 + tid) * k + s] = li[s * 64 + tid];
+}
+
+// ------------------------------------------------------------------ edge features
+// out[b,i,s,:] = [x_i | x_j - x_i], j = nn_idx[b,i,s]
+template <int VEC>
+__global__ __launch_bounds__(256) void edge_feature_kernel(long long total, int n, int cv, int k,
+                                                           const float *__restrict__ x,
+                                                           const int *__restrict__ nn_idx,
+                                                           float *__restrict__ out) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const vec_t *xv = reinterpret_cast<const vec_t *>(x);
+    vec_t *ov = reinterpret_cast<vec_t *>(out);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        const long long edge = e / cv;  // (b, i, s)
+        const int col = (int)(e - edge * cv);
+        const long long node = edge / k;  // (b, i)
+        const long long bi = node / n;
+        const int j = nn_idx[edge];
+        const vec_t ci = xv[node * cv + col];
+        const vec_t cj = xv[(bi * n + j) * cv + col];
+        ov[edge * 2 * cv + col] = ci;
+        ov[edge * 2 * cv + cv + col] = cj - ci;
+    }
+}
+
+// grad_x[b,i,:] += sum_s (ga - gb)[b,i,s,:] ; grad_x[b,nn[b,i,s],:] += gb[b,i,s,:]
+__global__ __launch_bounds__(256) void edge_feature_grad_kernel(long long total, int n, int c, int k,
+                                                                const float *__restrict__ grad_out,
+                                                                const int *__restrict__ nn_idx,
+                                                                float *__restrict__ grad_x) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        const long long node = e / c;  // (b, i)
+        const int col = (int)(e - node * c);
+        const long long bi = node / n;
+        float central = 0.f;
+        for (int s = 0; s < k; ++s) {
+            const long long edge = node * k + s;
+            const float ga = grad_out[edge * 2 * c + col];
+            const float gb = grad_out[edge * 2 * c + c + col];
+            central += ga - gb;
+            atomicAdd(&grad_x[(bi * n + nn_idx[edge]) * (long long)c + col], gb);
+        }
+        atomicAdd(&grad_x[e], central);
+    }
+}
+
+}  // namespace
+
+extern "C" int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
+                               pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 1);
+    PCOPS_REQUIRE_ARG(k > 0 && k <= n);  // tf.nn.top_k: k must not exceed the last dimension
+    if (b == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(x);
+    PCOPS_REQUIRE_PTR(nn_idx);
+    hipStream_t st = as_stream(stream);
+    if (c <= 4) return launch_knn_graph<4>(b, n, c, k, x, nn_idx, st);
+    if (c <= 8) return launch_knn_graph<8>(b, n, c, k, x, nn_idx, st);
+    if (c <= 16) return launch_knn_graph<16>(b, n, c, k, x, nn_idx, st);
+    if (c <= 32) return launch_knn_graph<32>(b, n, c, k, x, nn_idx, st);
+    if (c <= 64) return launch_knn_graph<64>(b, n, c, k, x, nn_idx, st);
+    if (c <= 128) return launch_knn_graph<128>(b, n, c, k, x, nn_idx, st);
+    return PCOPS_ERR_UNSUPPORTED;
+}
+
+extern "C" int pcops_pairwise_distance(int b, int n, int c, const float *x, float *adj,
+                                       pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 1);
+    if ((long long)b * n == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(x);
+    PCOPS_REQUIRE_PTR(adj);
+    PCOPS_REQUIRE_SHAPE(b <= 65535);
+    hipLaunchKernelGGL(pairwise_distance_kernel, dim3(cdiv(n, kPdT), cdiv(n, kPdT), b), dim3(256), 0,
+                       as_stream(stream), n, c, x, adj);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_knn_topk(int rows, int n, int k, const float *adj, int *nn_idx,
+                              pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(rows >= 0 && n >= 0);
+    PCOPS_REQUIRE_ARG(k > 0 && k <= n);
+    if (rows == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(adj);
+    PCOPS_REQUIRE_PTR(nn_idx);
+    const size_t lds = (size_t)(64 * 65 + 2 * k * 64) * 4;
+    if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(knn_topk_kernel, dim3(cdiv(rows, 64)), dim3(64), lds, as_stream(stream),
+                       (long long)rows, n, k, adj, nn_idx);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn_idx,
+                                  float *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 0 && k >= 0);
+    if ((long long)b * n * k * c == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(x);
+    PCOPS_REQUIRE_PTR(nn_idx);
+    PCOPS_REQUIRE_PTR(out);
+    const bool v4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+    const int cv = v4 ? c / 4 : c;
+    const long long total = (long long)b * n * k * cv;
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    if (v4)
+        hipLaunchKernelGGL((edge_feature_kernel<4>), dim3(grid), dim3(256), 0, as_stream(stream), total,
+                           n, cv, k, x, nn_idx, out);
+    else
+        hipLaunchKernelGGL((edge_feature_kernel<1>), dim3(grid), dim3(256), 0, as_stream(stream), total,
+                           n, cv, k, x, nn_idx, out);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_edge_feature_grad(int b, int n, int c, int k, const float *grad_out,
+                                       const int *nn_idx, float *grad_x, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 0 && k >= 0);
+    const long long total = (long long)b * n * c;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(grad_x);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)total, st) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    if (k == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(grad_out);
+    PCOPS_REQUIRE_PTR(nn_idx);
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(edge_feature_grad_kernel, dim3(grid), dim3(256), 0, st, total, n, c, k,
+                       grad_out, nn_idx, grad_x);
+    return pcops_launch_status();
+}

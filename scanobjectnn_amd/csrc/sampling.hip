@@ -1,0 +1,201 @@
+// sampling.hip -- farthest point sampling, gather_point and its gradient for gfx950.
+//
+// Replaces sampling/tf_sampling_g.cu:105-192 + the launchers at :203-211 of the
+// reference (behaviour only; the design is CDNA4-first):
+//   * FPS: one workgroup per cloud, the cloud's xyz AND the running min-distance
+//     live in VGPRs for the whole kernel (P points per lane), the picked point is
+//     broadcast from an LDS copy, the argmax is a 64-bit packed-key wave reduction
+//     (DPP/bpermute) + one LDS slot per wave, ONE barrier per round (double-buffered
+//     slots).  No global scratch (`temp` of the reference is unused).
+//   * tie rule of the reference's 512-thread tree (smaller k mod 512, then smaller k)
+//     is encoded in the low word of the key, so it holds for any thread count.
+// Distances are uncontracted fp32 (file is compiled with -ffp-contract=off).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned fps_tiebreak(unsigned k) {
+    // larger value == preferred: smaller (k mod 512) first, then smaller k
+    return 0xFFFFFFFFu - (((k & 511u) << 22) | (k >> 9));
+}
+__device__ __forceinline__ int fps_decode(unsigned long long key) {
+    const unsigned tb = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+    return (int)(((tb & 0x3FFFFFu) << 9) | (tb >> 22));
+}
+
+// T threads per cloud, P points per thread (n <= T*P).  LDSPTS: keep a float4 copy of
+// the cloud in LDS for the per-round broadcast of the picked point.
+template <int T, int P, bool LDSPTS>
+__global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__restrict__ inp,
+                                                int *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NW = T / kWave;
+    unsigned long long *slots = reinterpret_cast<unsigned long long *>(smem_raw);  // [2][NW]
+    float4 *pts = reinterpret_cast<float4 *>(smem_raw + ((2 * NW * 8 + 15) / 16) * 16);
+
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    const float *p = inp + (size_t)b * n * 3;
+    int *o = out + (size_t)b * m;
+
+    float px[P], py[P], pz[P], md[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + i * T;
+        if (k < n) {
+            px[i] = p[k * 3 + 0];
+            py[i] = p[k * 3 + 1];
+            pz[i] = p[k * 3 + 2];
+            if (LDSPTS) pts[k] = make_float4(px[i], py[i], pz[i], 0.f);
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+        }
+        md[i] = 1e38f;
+    }
+    if (t == 0) o[0] = 0;
+    if (LDSPTS) __syncthreads();
+
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        float x1, y1, z1;
+        if (LDSPTS) {
+            const float4 q = pts[old];
+            x1 = q.x; y1 = q.y; z1 = q.z;
+        } else {
+            x1 = p[old * 3 + 0]; y1 = p[old * 3 + 1]; z1 = p[old * 3 + 2];
+        }
+        unsigned long long best = 0ull;  // below every valid key
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int k = t + i * T;
+            const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const float d2 = fminf(d, md[i]);
+            md[i] = d2;
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(d2) << 32) | fps_tiebreak((unsigned)k);
+            best = (k < n && key > best) ? key : best;
+        }
+        best = wave_max_u64(best);
+        if (NW > 1) {
+            unsigned long long *s = slots + (j & 1) * NW;
+            if ((t & (kWave - 1)) == 0) s[t / kWave] = best;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const unsigned long long v = s[w];
+                best = v > best ? v : best;
+            }
+        }
+        old = fps_decode(best);
+        if (t == 0) o[j] = old;
+    }
+}
+
+template <int T, int P>
+int launch_fps(int b, int n, int m, const float *inp, int *out, hipStream_t st) {
+    constexpr int NW = T / kWave;
+    const size_t slot_bytes = ((2 * NW * 8 + 15) / 16) * 16;
+    const size_t pts_bytes = (size_t)n * 16;
+    if (slot_bytes + pts_bytes <= 140 * 1024) {
+        if (slot_bytes + pts_bytes > 48 * 1024) {
+            // >64 KiB of dynamic LDS needs an explicit opt-in (idempotent, per kernel)
+            static const hipError_t once = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(&fps_kernel<T, P, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            (void)once;
+        }
+        hipLaunchKernelGGL((fps_kernel<T, P, true>), dim3(b), dim3(T), slot_bytes + pts_bytes, st,
+                           n, m, inp, out);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<T, P, false>), dim3(b), dim3(T), slot_bytes, st, n, m, inp,
+                           out);
+    }
+    return pcops_launch_status();
+}
+
+__global__ __launch_bounds__(256) void gather_point_kernel(long long total, int n, int m,
+                                                           const float *__restrict__ inp,
+                                                           const int *__restrict__ idx,
+                                                           float *__restrict__ out) {
+    // one thread per output float: total = b*m*3
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        const long long row = e / 3;
+        const int l = (int)(e - row * 3);
+        const long long bi = row / m;
+        const int a = idx[row];
+        out[e] = inp[(bi * n + a) * 3 + l];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_point_grad_kernel(long long total, int n, int m,
+                                                                const float *__restrict__ out_g,
+                                                                const int *__restrict__ idx,
+                                                                float *__restrict__ inp_g) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (long long)gridDim.x * 256) {
+        const long long row = e / 3;
+        const int l = (int)(e - row * 3);
+        const long long bi = row / m;
+        const int a = idx[row];
+        atomicAdd(&inp_g[(bi * n + a) * 3 + l], out_g[e]);
+    }
+}
+
+}  // namespace
+
+extern "C" unsigned long long pcops_farthest_point_sample_workspace_bytes(int, int) { return 0ull; }
+
+extern "C" int pcops_farthest_point_sample(int b, int n, int m, const float *inp, float * /*temp*/,
+                                           int *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0);
+    PCOPS_REQUIRE_ARG(m > 0);  // tf_sampling.cpp:99 npoint>0
+    if (b == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_SHAPE(n >= 1);
+    PCOPS_REQUIRE_PTR(inp);
+    PCOPS_REQUIRE_PTR(out);
+    hipStream_t st = as_stream(stream);
+    if (n <= 64) return launch_fps<64, 1>(b, n, m, inp, out, st);
+    if (n <= 128) return launch_fps<64, 2>(b, n, m, inp, out, st);
+    if (n <= 256) return launch_fps<64, 4>(b, n, m, inp, out, st);
+    if (n <= 512) return launch_fps<64, 8>(b, n, m, inp, out, st);
+    if (n <= 1024) return launch_fps<256, 4>(b, n, m, inp, out, st);
+    if (n <= 2048) return launch_fps<256, 8>(b, n, m, inp, out, st);
+    if (n <= 4096) return launch_fps<512, 8>(b, n, m, inp, out, st);
+    if (n <= 8192) return launch_fps<1024, 8>(b, n, m, inp, out, st);
+    if (n <= 16384) return launch_fps<1024, 16>(b, n, m, inp, out, st);
+    return PCOPS_ERR_UNSUPPORTED;
+}
+
+extern "C" int pcops_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out,
+                                  pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0);
+    const long long total = (long long)b * m * 3;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(inp);
+    PCOPS_REQUIRE_PTR(idx);
+    PCOPS_REQUIRE_PTR(out);
+    const unsigned grid = cdiv(total, 256) < 4096u ? cdiv(total, 256) : 4096u;
+    hipLaunchKernelGGL(gather_point_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, n, m,
+                       inp, idx, out);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx,
+                                       float *inp_g, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0);
+    if ((long long)b * n == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(inp_g);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(inp_g, 0, sizeof(float) * (size_t)b * n * 3, st) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    const long long total = (long long)b * m * 3;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(out_g);
+    PCOPS_REQUIRE_PTR(idx);
+    const unsigned grid = cdiv(total, 256) < 4096u ? cdiv(total, 256) : 4096u;
+    hipLaunchKernelGGL(gather_point_grad_kernel, dim3(grid), dim3(256), 0, st, total, n, m, out_g,
+                       idx, inp_g);
+    return pcops_launch_status();
+}

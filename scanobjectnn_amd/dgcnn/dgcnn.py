@@ -1,0 +1,60 @@
+"""DGCNN classifier -- mirror of `dgcnn/models/dgcnn.py` (placeholder_inputs :17-21,
+get_model :24-102, get_loss :105-111).  BASELINE config 3.  The five graph rebuilds use the fused
+`knn_graph` (same indices as pairwise_distance+knn, no (B,N,N) tensor)."""
+import torch
+import torch.nn.functional as F
+
+from . import tf_util
+from ..graph import variable_scope
+from .transform_nets import input_transform_net
+
+NUM_CLASSES = 15
+
+
+def placeholder_inputs(batch_size, num_point, device=None):
+    pointclouds_pl = torch.zeros((batch_size, num_point, 3), dtype=torch.float32, device=device)
+    labels_pl = torch.zeros((batch_size,), dtype=torch.int32, device=device)
+    return pointclouds_pl, labels_pl
+
+
+def _edge_conv(x, width, scope, k, is_training, bn_decay):
+    nn_idx = tf_util.knn_graph(x, k=k)
+    edge_feature = tf_util.get_edge_feature(x, nn_idx=nn_idx, k=k)
+    net = tf_util.conv2d(edge_feature, width, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                         is_training=is_training, scope=scope, bn_decay=bn_decay)
+    return net.amax(dim=-2, keepdim=True)                       # (B,N,1,width)
+
+
+def backbone(point_cloud, is_training, bn_decay, k=20):
+    """shared by dgcnn / dgcnn_bga: returns (net1..net4, agg) with agg (B,N,1,1024)"""
+    nn_idx = tf_util.knn_graph(point_cloud, k=k)
+    edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
+    with variable_scope('transform_net1'):
+        transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
+    point_cloud_transformed = torch.matmul(point_cloud, transform)
+    net1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay)
+    net2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay)
+    net3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay)
+    net4 = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay)
+    agg = tf_util.conv2d(torch.cat([net1, net2, net3, net4], dim=-1), 1024, [1, 1], padding='VALID',
+                         stride=[1, 1], bn=True, is_training=is_training, scope='agg', bn_decay=bn_decay)
+    return net1, net2, net3, net4, agg
+
+
+def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
+    """point_cloud (B,N,3) -> logits (B,num_class), end_points"""
+    batch_size = point_cloud.shape[0]
+    end_points = {}
+    *_, agg = backbone(point_cloud, is_training, bn_decay)
+    net = agg.amax(dim=1, keepdim=True).reshape(batch_size, -1)
+    net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='fc1', bn_decay=bn_decay)
+    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp1')
+    net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='fc2', bn_decay=bn_decay)
+    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp2')
+    net = tf_util.fully_connected(net, num_class, activation_fn=None, scope='fc3')
+    return net, end_points
+
+
+def get_loss(pred, label, end_points=None, num_class=NUM_CLASSES):
+    """softmax CE with label_smoothing 0.2 (tf.losses.softmax_cross_entropy: onehot*(1-s) + s/C)"""
+    return F.cross_entropy(pred, label.long(), label_smoothing=0.2)

@@ -1,0 +1,176 @@
+"""DGCNN layer wrappers + dynamic-graph ops -- mirror of `dgcnn/utils/tf_util.py`
+(conv2d :115, fully_connected :317, max_pool2d :357, batch_norm_template :462 (EMA flavour),
+batch_norm_dist_template :502 ("dist" flavour, used with is_dist=True), dropout :614,
+pairwise_distance :638, knn :660, get_edge_feature :674) on libpcops.
+
+BN here is the explicit `tf.nn.moments` flavour: batch mean / BIASED variance in training, eps 1e-3,
+moving stats m <- decay*m + (1-decay)*batch with decay = bn_decay or 0.9, biased variance in the moving
+stats too (unlike the pointnet2 flavour).  The EMA flavour's zero-debiasing of TF's
+ExponentialMovingAverage on tensors is not reproduced (eval-only detail).
+
+The graph ops keep the reference's three-function API; `knn_graph` is the fused fast path that never
+materialises the (B,N,N) adjacency and yields the same indices.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+from ..graph import constant_initializer, get_variable, variable_scope
+from ..pointnet2.tf_util import (_dense, _variable_with_weight_decay, avg_pool2d, dropout,  # noqa: F401
+                                 max_pool2d, relu)
+
+BN_EPS = 1e-3
+
+
+def _batch_norm(inputs, is_training, scope, bn_decay, names):
+    c = inputs.shape[-1]
+    decay = float(bn_decay) if bn_decay is not None else 0.9
+    with variable_scope(scope):
+        beta = get_variable('beta', [c], constant_initializer(0.0))
+        gamma = get_variable('gamma', [c], constant_initializer(1.0))
+        mov_mean = get_variable(names[0], [c], constant_initializer(0.0), trainable=False)
+        mov_var = get_variable(names[1], [c], constant_initializer(1.0), trainable=False)
+    flat = inputs.reshape(-1, c)
+    if is_training:
+        var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+        with torch.no_grad():
+            mov_mean.mul_(decay).add_(mean.detach(), alpha=1.0 - decay)
+            mov_var.mul_(decay).add_(var.detach(), alpha=1.0 - decay)
+    else:
+        mean, var = mov_mean, mov_var
+    scale = gamma * torch.rsqrt(var + BN_EPS)
+    out = flat * scale + (beta - mean * scale)
+    return out.reshape(inputs.shape)
+
+
+def batch_norm_template(inputs, is_training, scope, moments_dims, bn_decay):
+    """tf_util.py:462-499"""
+    return _batch_norm(inputs, is_training, scope, bn_decay, ('moving_mean', 'moving_variance'))
+
+
+def batch_norm_dist_template(inputs, is_training, scope, moments_dims, bn_decay):
+    """tf_util.py:502-535"""
+    return _batch_norm(inputs, is_training, scope, bn_decay, ('pop_mean', 'pop_var'))
+
+
+def _bn(inputs, is_training, bn_decay, scope, is_dist):
+    fn = batch_norm_dist_template if is_dist else batch_norm_template
+    return fn(inputs, is_training, scope, None, bn_decay)
+
+
+def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME',
+           use_xavier=True, stddev=1e-3, weight_decay=0.0, activation_fn=relu, bn=False,
+           bn_decay=None, is_training=None, is_dist=False):
+    """tf_util.py:115-173 (NHWC only).  1x1 kernels (and [1,K] VALID over width K)."""
+    kernel_h, kernel_w = kernel_size
+    if list(stride) != [1, 1]:
+        raise NotImplementedError("conv2d: only stride [1,1] is used by the in-scope models")
+    with variable_scope(scope):
+        b, h, w, cin = inputs.shape
+        kernel = _variable_with_weight_decay('weights', [kernel_h, kernel_w, cin, num_output_channels],
+                                             stddev=stddev, wd=weight_decay or None, use_xavier=use_xavier)
+        biases = get_variable('biases', [num_output_channels], constant_initializer(0.0))
+        if kernel_h == 1 and kernel_w == 1:
+            out = _dense(inputs.reshape(-1, cin), kernel.view(cin, num_output_channels), biases)
+            out = out.view(b, h, w, num_output_channels)
+        elif kernel_h == 1 and kernel_w == w and padding == 'VALID':
+            out = _dense(inputs.reshape(b * h, w * cin), kernel.view(w * cin, num_output_channels), biases)
+            out = out.view(b, h, 1, num_output_channels)
+        else:
+            raise NotImplementedError("conv2d: kernel %s / padding %s not used in scope" % (kernel_size, padding))
+        if bn:
+            out = _bn(out, is_training, bn_decay, 'bn', is_dist)
+        if activation_fn is not None:
+            out = activation_fn(out)
+        return out
+
+
+def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=0.0,
+                    activation_fn=relu, bn=False, bn_decay=None, is_training=None, is_dist=False):
+    """tf_util.py:317-354"""
+    with variable_scope(scope):
+        nin = inputs.shape[-1]
+        weights = _variable_with_weight_decay('weights', [nin, num_outputs], stddev=stddev,
+                                              wd=weight_decay or None, use_xavier=use_xavier)
+        biases = get_variable('biases', [num_outputs], constant_initializer(0.0))
+        out = _dense(inputs, weights, biases)
+        if bn:
+            out = _bn(out, is_training, bn_decay, 'bn', is_dist)
+        if activation_fn is not None:
+            out = activation_fn(out)
+        return out
+
+
+# ---------------------------------------------------------------------------- graph ops
+def _squeeze_cloud(point_cloud):
+    """tf_util.py:647-650 / :685-688: tf.squeeze, re-expanding the batch axis when it was 1."""
+    og = point_cloud.shape[0]
+    x = point_cloud.squeeze()
+    if og == 1:
+        x = x.unsqueeze(0)
+    if x.dim() != 3:
+        raise ValueError("expected (B,N,C) or (B,N,1,C) with N,C > 1, got %s" % (tuple(point_cloud.shape),))
+    return x
+
+
+def pairwise_distance(point_cloud):
+    """(B,N,C) or (B,N,1,C) -> (B,N,N) f32, D_ij = (s_i + (-2<x_i,x_j>)) + s_j"""
+    x = _lib.check(_squeeze_cloud(point_cloud).detach(), torch.float32, "point_cloud", 3)
+    b, n, c = x.shape
+    adj = torch.empty((b, n, n), dtype=torch.float32, device=x.device)
+    _lib.call("pcops_pairwise_distance", b, n, c, _lib.ptr(x), _lib.ptr(adj))
+    return adj
+
+
+def knn(adj_matrix, k=20):
+    """(B,N,N) -> (B,N,k) i32: k smallest per row, ties -> lower index (tf.nn.top_k(-adj))"""
+    adj = _lib.check(adj_matrix.detach(), torch.float32, "adj_matrix", 3)
+    b, n, n2 = adj.shape
+    if not 0 < k <= n2:
+        raise ValueError("input must have at least k columns")  # tf.nn.top_k
+    out = torch.empty((b, n, k), dtype=torch.int32, device=adj.device)
+    _lib.call("pcops_knn_topk", b * n, n2, k, _lib.ptr(adj), _lib.ptr(out))
+    return out
+
+
+def knn_graph(point_cloud, k=20):
+    """fused pairwise_distance + knn: (B,N,C)|(B,N,1,C) -> (B,N,k) i32, identical indices"""
+    x = _lib.check(_squeeze_cloud(point_cloud).detach(), torch.float32, "point_cloud", 3)
+    b, n, c = x.shape
+    if not 0 < k <= n:
+        raise ValueError("input must have at least k columns")
+    out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
+    _lib.call("pcops_knn_graph", b, n, c, k, _lib.ptr(x), _lib.ptr(out))
+    return out
+
+
+class _EdgeFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nn_idx):
+        b, n, c = x.shape
+        k = nn_idx.shape[2]
+        out = torch.empty((b, n, k, 2 * c), dtype=torch.float32, device=x.device)
+        _lib.call("pcops_edge_feature", b, n, c, k, _lib.ptr(x), _lib.ptr(nn_idx), _lib.ptr(out))
+        ctx.save_for_backward(nn_idx)
+        ctx.shape = (b, n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (nn_idx,) = ctx.saved_tensors
+        b, n, c = ctx.shape
+        k = nn_idx.shape[2]
+        grad_out = grad_out.contiguous()
+        grad_x = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+        _lib.call("pcops_edge_feature_grad", b, n, c, k, _lib.ptr(grad_out), _lib.ptr(nn_idx),
+                  _lib.ptr(grad_x))
+        return grad_x, None
+
+
+def get_edge_feature(point_cloud, nn_idx, k=20):
+    """(B,N,C)|(B,N,1,C), nn_idx (B,N,k) -> (B,N,k,2C) = [x_i | x_j - x_i]"""
+    x = _lib.check(_squeeze_cloud(point_cloud), torch.float32, "point_cloud", 3)
+    nn_idx = _lib.check(nn_idx, torch.int32, "nn_idx", 3)
+    if nn_idx.shape[:2] != x.shape[:2] or nn_idx.shape[2] != k:
+        raise ValueError("nn_idx must be (B,N,k)")
+    return _EdgeFeature.apply(x, nn_idx)

@@ -1,0 +1,29 @@
+"""Input T-Net on edge features -- mirror of `dgcnn/models/transform_nets.py:10-55`."""
+import torch
+
+from . import tf_util
+from ..graph import constant_initializer, get_variable, variable_scope
+
+
+def input_transform_net(edge_feature, is_training, bn_decay=None, K=3, is_dist=False):
+    """edge_feature (B,N,k,2C) -> transform (B,K,K)"""
+    batch_size, num_point = edge_feature.shape[0], edge_feature.shape[1]
+    net = tf_util.conv2d(edge_feature, 64, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                         is_training=is_training, scope='tconv1', bn_decay=bn_decay, is_dist=is_dist)
+    net = tf_util.conv2d(net, 128, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                         is_training=is_training, scope='tconv2', bn_decay=bn_decay, is_dist=is_dist)
+    net = net.amax(dim=-2, keepdim=True)
+    net = tf_util.conv2d(net, 1024, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                         is_training=is_training, scope='tconv3', bn_decay=bn_decay, is_dist=is_dist)
+    net = tf_util.max_pool2d(net, [num_point, 1], padding='VALID', scope='tmaxpool')
+    net = net.reshape(batch_size, -1)
+    net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='tfc1',
+                                  bn_decay=bn_decay, is_dist=is_dist)
+    net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='tfc2',
+                                  bn_decay=bn_decay, is_dist=is_dist)
+    with variable_scope('transform_XYZ'):
+        weights = get_variable('weights', [256, K * K], constant_initializer(0.0))
+        biases = get_variable('biases', [K * K], constant_initializer(0.0))
+        eye = torch.eye(K, dtype=torch.float32, device=net.device).flatten()
+        transform = torch.addmm(biases + eye, net, weights)
+    return transform.view(batch_size, K, K)

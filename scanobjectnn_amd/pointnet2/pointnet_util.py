@@ -1,0 +1,125 @@
+"""PointNet++ layers -- mirror of `pointnet2/utils/pointnet_util.py` on the libpcops ops.
+
+Same function names, positional order, keyword defaults and return tuples as the reference:
+sample_and_group (:22-56), sample_and_group_all (:59-84), pointnet_sa_module (:87-154),
+pointnet_sa_module_msg (:156-196), pointnet_fp_module (:199-229).  Channel order of every concat
+follows SURVEY.md Appendix A9.
+"""
+import torch
+
+from . import tf_util
+from ..graph import variable_scope
+from .tf_grouping import group_point, knn_point, query_ball_point, query_ball_point_multi
+from .tf_interpolate import three_interpolate, three_nn
+from .tf_sampling import farthest_point_sample, gather_point
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    """xyz (B,N,3), points (B,N,C)|None ->
+    new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx (B,npoint,nsample),
+    grouped_xyz (B,npoint,nsample,3) (centred on the sampled point)."""
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)  # translation normalisation (:46)
+    if points is None:
+        new_points = grouped_xyz
+    else:
+        grouped_points = group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """One group holding the whole cloud, centroid (0,0,0) (:59-84)."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).expand(b, 1, n)
+    grouped_xyz = xyz.view(b, 1, n, 3)
+    if points is None:
+        new_points = grouped_xyz
+    else:
+        new_points = (torch.cat([xyz, points], dim=2) if use_xyz else points).unsqueeze(1)
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def _mlp_stack(x, widths, scope_fmt, bn, is_training, bn_decay, data_format):
+    for i, width in enumerate(widths):
+        x = tf_util.conv2d(x, width, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                           is_training=is_training, scope=scope_fmt % i, bn_decay=bn_decay,
+                           data_format=data_format)
+    return x
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training,
+                       bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True,
+                       use_nchw=False):
+    """Set abstraction.  Returns new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]),
+    idx (B,npoint,nsample)."""
+    # NCHW is a TF conv-layout hint; here every 1x1 conv is the same channel-last contraction, so
+    # the flag only changes nothing numerically (the reference transposes in and out, :116-123).
+    with variable_scope(scope):
+        if group_all:
+            nsample = xyz.shape[1]
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz,
+                                                                     points, knn, use_xyz)
+        new_points = _mlp_stack(new_points, mlp, 'conv%d', bn, is_training, bn_decay, 'NHWC')
+
+        if pooling == 'max':
+            new_points = new_points.amax(dim=2, keepdim=True)
+        elif pooling == 'avg':
+            new_points = new_points.mean(dim=2, keepdim=True)
+        elif pooling == 'weighted_avg':
+            dists = grouped_xyz.norm(dim=-1, p=2, keepdim=True)
+            exp_dists = torch.exp(-dists * 5)
+            weights = exp_dists / exp_dists.sum(dim=2, keepdim=True)
+            new_points = (new_points * weights).sum(dim=2, keepdim=True)
+        elif pooling == 'max_and_avg':
+            new_points = torch.cat([new_points.mean(dim=2, keepdim=True),
+                                    new_points.amax(dim=2, keepdim=True)], dim=-1)
+        else:
+            raise ValueError("unknown pooling %r" % (pooling,))
+
+        if mlp2 is not None:
+            new_points = _mlp_stack(new_points, mlp2, 'conv_post_%d', bn, is_training, bn_decay, 'NHWC')
+        return new_xyz, new_points.squeeze(2), idx
+
+
+def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training,
+                           bn_decay, scope, bn=True, use_xyz=True, use_nchw=False):
+    """Multi-scale grouping: one FPS, then per radius ball query -> group -> [feats | xyz] -> MLP ->
+    max; scales concatenated.  Returns new_xyz (B,npoint,3), new_points (B,npoint,sum mlp[k][-1])."""
+    with variable_scope(scope):
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        scales = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz)  # one dataset pass
+        outs = []
+        for i, (idx, _cnt) in enumerate(scales):
+            grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
+            if points is None:
+                grouped = grouped_xyz
+            else:
+                grouped = group_point(points, idx)
+                if use_xyz:
+                    grouped = torch.cat([grouped, grouped_xyz], dim=-1)  # note: feats first (:184)
+            grouped = _mlp_stack(grouped, mlp_list[i], 'conv%d_' % i + '%d', bn, is_training,
+                                 bn_decay, 'NHWC')
+            outs.append(grouped.amax(dim=2))
+        return new_xyz, torch.cat(outs, dim=-1)
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+    """Feature propagation: xyz1 (B,n1,3) dense, xyz2 (B,n2,3) sparse, points1 (B,n1,C1)|None,
+    points2 (B,n2,C2) -> (B,n1,mlp[-1])."""
+    with variable_scope(scope):
+        dist, idx = three_nn(xyz1, xyz2)
+        inv = 1.0 / torch.clamp_min(dist, 1e-10)            # (:212-215), 1/inf = 0 for m<3
+        weight = inv / inv.sum(dim=2, keepdim=True)
+        interpolated = three_interpolate(points2, idx, weight)
+        new_points1 = interpolated if points1 is None else torch.cat([interpolated, points1], dim=2)
+        new_points1 = _mlp_stack(new_points1.unsqueeze(2), mlp, 'conv_%d', bn, is_training, bn_decay,
+                                 'NHWC')
+        return new_points1.squeeze(2)

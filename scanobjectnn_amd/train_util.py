@@ -1,0 +1,71 @@
+"""Training-step semantics of the reference trainers, restated:
+learning-rate / BN-decay schedules (`pointnet2/train.py:116-134`), TF-flavoured Adam
+(`tf.train.AdamOptimizer` defaults, epsilon OUTSIDE the bias-corrected sqrt), on flat parameter /
+gradient buffers so that one data-parallel step is: backward -> ONE all-reduce of a flat fp32 bucket
+-> ONE fused optimiser update.
+"""
+import math
+
+import torch
+
+BASE_LEARNING_RATE = 1e-3   # train.py:31
+DECAY_STEP = 200000         # train.py:34
+DECAY_RATE = 0.7            # train.py:35
+BN_INIT_DECAY = 0.5         # train.py:78
+BN_DECAY_DECAY_RATE = 0.5   # train.py:79
+BN_DECAY_CLIP = 0.99        # train.py:81
+
+
+def get_learning_rate(global_step, batch_size, base_lr=BASE_LEARNING_RATE, decay_step=DECAY_STEP,
+                      decay_rate=DECAY_RATE):
+    """train.py:116-124: max(base * rate^floor(step*B/decay_step), 1e-5) (staircase)"""
+    lr = base_lr * decay_rate ** math.floor(global_step * batch_size / decay_step)
+    return max(lr, 0.00001)
+
+
+def get_bn_decay(global_step, batch_size, bn_decay_decay_step=float(DECAY_STEP)):
+    """train.py:126-134: min(0.99, 1 - 0.5 * 0.5^floor(step*B/decay_step))"""
+    bn_momentum = BN_INIT_DECAY * BN_DECAY_DECAY_RATE ** math.floor(global_step * batch_size / bn_decay_decay_step)
+    return min(BN_DECAY_CLIP, 1 - bn_momentum)
+
+
+class FlatParams:
+    """Re-homes every parameter of `module` (and its gradient) as a view into ONE flat fp32 buffer."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+        self.numel = n
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+class TFAdam:
+    """tf.train.AdamOptimizer(lr): m,v EMA; lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)."""
+
+    def __init__(self, flat, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.fp = flat
+        self.b1, self.b2, self.eps = beta1, beta2, epsilon
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, lr):
+        self.t += 1
+        g = self.fp.grad
+        self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        self.fp.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr_t)

@@ -1,0 +1,76 @@
+"""DGCNN graph ops (HIP, through the C ABI) against the CPU oracle: bit-exact indices, exact
+distances (same fmaf chains), exact edge features; gradient of get_edge_feature to 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from scanobjectnn_amd.dgcnn import tf_util as dg
+from scanobjectnn_amd.synth import synth_clouds
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("b,n,c,k", [(2, 2048, 3, 20), (2, 512, 64, 20), (1, 300, 64, 20), (3, 100, 7, 5),
+                                     (2, 64, 128, 20), (1, 21, 3, 20), (2, 257, 16, 33)])
+def test_knn_graph_vs_oracle(b, n, c, k):
+    rng = np.random.default_rng(n + c)
+    x = synth_clouds(b, n, seed=n) if c == 3 else rng.standard_normal((b, n, c)).astype(np.float32)
+    if n > 30:
+        x[0, 17] = x[0, 3]                                     # exact duplicate -> distance tie at 0
+    nn = dg.knn_graph(T(x), k=k)
+    np.testing.assert_array_equal(N(nn), O.knn_graph(x, k))
+
+
+def test_knn_graph_4d_input_and_lattice_ties():
+    rng = np.random.default_rng(0)
+    x = (rng.integers(0, 4, (2, 200, 1, 3)) * 0.25).astype(np.float32)     # heavy ties
+    nn = dg.knn_graph(T(x), k=20)
+    np.testing.assert_array_equal(N(nn), O.knn_graph(x[:, :, 0, :], 20))
+
+
+@pytest.mark.parametrize("b,n,c", [(2, 300, 3), (1, 130, 64), (2, 64, 40)])
+def test_materialised_path_vs_oracle_and_fused(b, n, c):
+    rng = np.random.default_rng(c)
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    adj = dg.pairwise_distance(T(x))
+    np.testing.assert_array_equal(N(adj), O.pairwise_distance(x))
+    nn = dg.knn(adj, k=20)
+    np.testing.assert_array_equal(N(nn), O.knn(N(adj), 20))
+    assert torch.equal(nn, dg.knn_graph(T(x), k=20))
+
+
+def test_edge_feature_and_grad():
+    rng = np.random.default_rng(1)
+    for (b, n, c, k) in [(2, 128, 3, 20), (2, 100, 64, 20), (1, 50, 5, 7)]:
+        x = rng.standard_normal((b, n, c)).astype(np.float32)
+        nn = rng.integers(0, n, (b, n, k)).astype(np.int32)
+        xt = T(x).requires_grad_(True)
+        ef = dg.get_edge_feature(xt, T(nn), k=k)
+        np.testing.assert_array_equal(N(ef), O.get_edge_feature(x, nn, k))
+        go = rng.standard_normal(tuple(ef.shape)).astype(np.float32)
+        ef.backward(T(go))
+        # dense fp64 reference of the gradient
+        gx = np.zeros((b, n, c))
+        ga, gb = go[..., :c].astype(np.float64), go[..., c:].astype(np.float64)
+        gx += (ga - gb).sum(axis=2)
+        for bi in range(b):
+            np.add.at(gx[bi], nn[bi].reshape(-1), gb[bi].reshape(-1, c))
+        np.testing.assert_allclose(N(xt.grad), gx, rtol=1e-5, atol=1e-4)
+
+
+def test_knn_argument_errors():
+    x = T(np.zeros((1, 10, 3), np.float32))
+    with pytest.raises(ValueError):
+        dg.knn_graph(x, k=11)
+    with pytest.raises(ValueError):
+        dg.knn_graph(x, k=0)

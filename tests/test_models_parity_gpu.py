@@ -1,0 +1,130 @@
+"""Logit parity of the product models (HIP ops + device algebra) against the CPU restatement
+(oracle/ref_models.py) with identical weights: |Δ| <= 1e-4 fp32 (BASELINE.json north_star), in eval mode
+(moving statistics) and in training mode (batch statistics; dropout disabled on both sides because the
+two RNGs cannot be aligned).  Gradients of the training loss agree to 1e-3 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import ref_models as R
+from scanobjectnn_amd.graph import Model
+from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _randomise(net, seed):
+    """non-trivial BN affine + moving stats, small random biases (defaults are 0/1 and would hide bugs)"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in list(net.named_parameters()) + list(net.named_buffers()):
+            if name.endswith("gamma"):
+                p.copy_((0.5 + torch.rand(p.shape, generator=g)).to(p.device))
+            elif name.endswith("beta") or name.endswith("biases"):
+                p.copy_((0.2 * torch.randn(p.shape, generator=g)).to(p.device))
+            elif name.endswith("moving_mean") or name.endswith("pop_mean"):
+                p.copy_((0.1 * torch.randn(p.shape, generator=g)).to(p.device))
+            elif name.endswith("moving_variance") or name.endswith("pop_var"):
+                p.copy_((0.5 + torch.rand(p.shape, generator=g)).to(p.device))
+            elif name.endswith("transform_XYZ/weights"):
+                p.copy_((0.01 * torch.randn(p.shape, generator=g)).to(p.device))
+
+
+def _no_dropout(monkeypatch):
+    from scanobjectnn_amd.pointnet2 import tf_util as t2
+    from scanobjectnn_amd.dgcnn import tf_util as td
+    ident = lambda inputs, is_training, scope, keep_prob=0.5, noise_shape=None: inputs  # noqa: E731
+    monkeypatch.setattr(t2, "dropout", ident)
+    monkeypatch.setattr(td, "dropout", ident)
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("name", ["ssg", "msg"])
+def test_pointnet2_cls_logits(name, training, monkeypatch):
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_msg, pointnet2_cls_ssg
+    mod, ref = {"ssg": (pointnet2_cls_ssg, R.pointnet2_cls_ssg), "msg": (pointnet2_cls_msg, R.pointnet2_cls_msg)}[name]
+    _no_dropout(monkeypatch)
+    c = synth_clouds(6, 1024, seed=3)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(mod.get_model, device=DEV, seed=1).build(x)
+    _randomise(net, 5)
+    P = R.params_from_state_dict(net.state_dict())
+    with torch.no_grad():
+        logits, _ = net(x, is_training=training, bn_decay=0.9)
+        want = ref(torch.from_numpy(c), P, training)
+    assert (logits.cpu() - want).abs().max().item() <= TOL
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga as m
+    _no_dropout(monkeypatch)
+    c = synth_clouds(4, 1024, seed=4)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(m.get_model, device=DEV, seed=2).build(x)
+    _randomise(net, 6)
+    P = R.params_from_state_dict(net.state_dict())
+    with torch.no_grad():
+        cls, seg = net(x, is_training=training, bn_decay=0.9)
+        wc, ws = R.pointnet2_cls_bga(torch.from_numpy(c), P, training)
+    assert (cls.cpu() - wc).abs().max().item() <= TOL
+    assert (seg.cpu() - ws).abs().max().item() <= TOL
+
+
+def test_pointnet2_ssg_training_gradients(monkeypatch):
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg as m
+    _no_dropout(monkeypatch)
+    c = synth_clouds(4, 512, seed=7)
+    y = synth_labels(4)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(m.get_model, device=DEV, seed=3).build(x)
+    _randomise(net, 8)
+    P = {k: v.requires_grad_(v.is_floating_point()) for k, v in R.params_from_state_dict(net.state_dict()).items()}
+    logits, _ = net(x, is_training=True, bn_decay=0.9)
+    m.get_loss(logits, torch.from_numpy(y).to(DEV)).backward()
+    want = R.pointnet2_cls_ssg(torch.from_numpy(c), P, True)
+    torch.nn.functional.cross_entropy(want, torch.from_numpy(y).long()).backward()
+    for name, p in net.named_parameters():
+        ref = P[name[len("graph."):]].grad
+        scale = ref.abs().max().item() + 1e-6
+        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-3 * scale + 1e-6, name
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("name", ["dgcnn", "dgcnn_bga"])
+def test_dgcnn_logits(name, training, monkeypatch):
+    from scanobjectnn_amd.dgcnn import dgcnn, dgcnn_bga
+    from scanobjectnn_amd.dgcnn import tf_util as td
+    _no_dropout(monkeypatch)
+    mod = {"dgcnn": dgcnn, "dgcnn_bga": dgcnn_bga}[name]
+    c = synth_clouds(3, 256, seed=5)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(mod.get_model, device=DEV, seed=4).build(x)
+    _randomise(net, 9)
+    P = R.params_from_state_dict(net.state_dict())
+    graphs = []
+    real = td.knn_graph
+
+    def recording(point_cloud, k=20):
+        nn = real(point_cloud, k=k)
+        # the HIP graph is bit-exact w.r.t. the oracle GIVEN the same input tensor
+        inp = point_cloud.detach().reshape(point_cloud.shape[0], point_cloud.shape[1], -1).cpu().numpy()
+        np.testing.assert_array_equal(nn.cpu().numpy(), O.knn_graph(inp, k))
+        graphs.append(nn.cpu().numpy())
+        return nn
+
+    monkeypatch.setattr(td, "knn_graph", recording)
+    with torch.no_grad():
+        out = net(x, is_training=training, bn_decay=0.9)
+    assert len(graphs) == 5
+    if name == "dgcnn":
+        want = R.dgcnn(torch.from_numpy(c), P, training, nn_list=graphs)
+        assert (out[0].cpu() - want).abs().max().item() <= TOL
+    else:
+        wc, ws = R.dgcnn_bga(torch.from_numpy(c), P, training, nn_list=graphs)
+        assert (out[0].cpu() - wc).abs().max().item() <= TOL
+        assert (out[1].cpu() - ws).abs().max().item() <= TOL
