@@ -77,6 +77,12 @@ def _algo(name, a):
     return 0, 0
 
 
+_NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcops_group_point": 5,
+           "pcops_group_point_grad": 5, "pcops_three_interpolate": 4, "pcops_three_interpolate_grad": 4,
+           "pcops_knn_graph": 4, "pcops_edge_feature": 4, "pcops_edge_feature_grad": 4,
+           "pcops_selection_sort": 4, "pcops_pairwise_distance": 3, "pcops_knn_topk": 3}
+
+
 class KernelTimer:
     """HIP-event timing of every libpcops launch on the stream it is launched on (torch's current
     stream: `_lib.call` passes torch.cuda.current_stream() to the C ABI, and torch.cuda.Event.record()
@@ -102,7 +108,7 @@ class KernelTimer:
         for name, args, s, e in self.records:
             ms = s.elapsed_time(e)
             by, work = _algo(name, args)
-            key = (name,) + tuple(x for x in args[:5] if isinstance(x, (int, float)))
+            key = (name,) + tuple(args[:_NSHAPE.get(name, 3)])
             d = agg.setdefault(key, {"kernel": name, "shape": list(key[1:]), "launches": 0, "ms": 0.0,
                                      "bytes": by, "work": work})
             d["launches"] += 1
@@ -126,7 +132,7 @@ def cpu_baseline(model_name, n_points, seconds_budget=20.0):
     modpath, has_mask, _, _ = MODELS[model_name]
     mod = importlib.import_module(modpath)
     ref_fn = getattr(R, model_name)
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)   # more threads only oversubscribe these small GEMMs
     torch.set_num_threads(cores)
     bs = 4
     c = synth_clouds(bs, n_points, seed=99)

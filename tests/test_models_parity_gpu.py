@@ -48,7 +48,7 @@ def test_pointnet2_cls_logits(name, training, monkeypatch):
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_msg, pointnet2_cls_ssg
     mod, ref = {"ssg": (pointnet2_cls_ssg, R.pointnet2_cls_ssg), "msg": (pointnet2_cls_msg, R.pointnet2_cls_msg)}[name]
     _no_dropout(monkeypatch)
-    c = synth_clouds(6, 1024, seed=3)
+    c = synth_clouds(16, 1024, seed=3)   # >=16 so the FC-level batch norm is not degenerate
     x = torch.from_numpy(c).to(DEV)
     net = Model(mod.get_model, device=DEV, seed=1).build(x)
     _randomise(net, 5)
@@ -63,7 +63,7 @@ def test_pointnet2_cls_logits(name, training, monkeypatch):
 def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga as m
     _no_dropout(monkeypatch)
-    c = synth_clouds(4, 1024, seed=4)
+    c = synth_clouds(12, 1024, seed=4)
     x = torch.from_numpy(c).to(DEV)
     net = Model(m.get_model, device=DEV, seed=2).build(x)
     _randomise(net, 6)
@@ -101,7 +101,7 @@ def test_dgcnn_logits(name, training, monkeypatch):
     from scanobjectnn_amd.dgcnn import tf_util as td
     _no_dropout(monkeypatch)
     mod = {"dgcnn": dgcnn, "dgcnn_bga": dgcnn_bga}[name]
-    c = synth_clouds(3, 256, seed=5)
+    c = synth_clouds(12, 256, seed=5)
     x = torch.from_numpy(c).to(DEV)
     net = Model(mod.get_model, device=DEV, seed=4).build(x)
     _randomise(net, 9)
