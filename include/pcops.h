@@ -124,6 +124,72 @@ int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn
 int pcops_edge_feature_grad(int b, int n, int c, int k, const float *grad_out,
                             const int *nn_idx, float *grad_x, pcops_stream_t stream);
 
+/* ------------------------------------------------- shared per-point MLP (1x1 conv + BN + ReLU [+ max-pool])
+ * The reference has no native code for this stage: it is a chain of TensorFlow ops per layer
+ * (pointnet2/utils/pointnet_util.py:117-127 conv2d stack + reduce_max, :223-227 FP stack;
+ * pointnet2/utils/tf_util.py:120-185 conv2d = tf.nn.conv2d + bias_add + batch_norm + relu, :512-531;
+ * dgcnn/models/dgcnn.py:39-48).  These are the native units a TF-style glue would bind instead: one fused
+ * fp32-MFMA pass per layer and direction.  All matrices row-major; X/Y rows = (batch, point, sample)
+ * flattened; per-channel vectors must be 16-byte aligned and padded to a multiple of 4 floats.
+ *
+ * forward:   Y[M,N] = f(X)[M,K] W[K,N] + bias,  f = identity (pro_scale == NULL) or relu(x*pro_scale[k] +
+ *            pro_shift[k]) (= BN+ReLU of the previous layer applied on the fly).  stats_partial (may be NULL):
+ *            float [pcops_mlp_stats_rows(M)][2][N] per-row-group column sums of Y and Y*Y. */
+int pcops_mlp_stats_rows(int M);
+unsigned long long pcops_mlp_reduce_workspace_bytes(int N);
+int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                       const float *pro_shift, const float *W, const float *bias, float *Y,
+                       float *stats_partial, pcops_stream_t stream);
+/* batch statistics -> mean, rstd = 1/sqrt(var+eps) (biased var), scale = gamma*rstd, shift = beta - mean*scale;
+ * moving_* (may be NULL) <- decay*moving + (1-decay)*batch (unbiased batch variance if unbiased_moving_var).
+ * P = rows of stats_partial, R = rows the statistics run over, workspace >= pcops_mlp_reduce_workspace_bytes(N). */
+int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
+                          const float *gamma, const float *beta, float eps, float decay,
+                          int unbiased_moving_var, float *moving_mean, float *moving_var, float *mean,
+                          float *rstd, float *scale, float *shift, pcops_stream_t stream);
+/* eval mode: scale/shift from the moving statistics */
+int pcops_mlp_bn_eval_coeffs(int N, const float *gamma, const float *beta, const float *moving_mean,
+                             const float *moving_var, float eps, float *scale, float *shift,
+                             pcops_stream_t stream);
+/* out[g,c] = max_s relu(scale[c]*Y[g*S+s,c] + shift[c]), argmax[g,c] (may be NULL) = first s attaining it. S<=256 */
+int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const float *scale,
+                              const float *shift, float *out, unsigned char *argmax,
+                              pcops_stream_t stream);
+/* out = relu(scale*Y + shift) (stack output without pooling) */
+int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *scale, const float *shift,
+                            float *out, pcops_stream_t stream);
+/* backward.  BN backward is folded into dY = p.G + q.Y + t with G = upstream grad masked by the ReLU.
+ * relu_mask_stats: Gm = Gout*[relu(bn(Y))>0] and partial (sum Gm, sum Gm*Y): [pcops_mlp_bwd_stats_rows(R)][2][C]
+ * pool_bwd_stats : the same sums for a max-pooled output, from (gpool, argmax): [..pool_stats_rows(G)][2][C]
+ * bn_bwd_coeffs  : sums -> dgamma, dbeta, p, q, t */
+int pcops_mlp_bwd_stats_rows(long long R);
+int pcops_mlp_bwd_pool_stats_rows(long long G);
+int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float *Y, const float *scale,
+                              const float *shift, float *Gm, float *stats_partial, pcops_stream_t stream);
+int pcops_mlp_pool_bwd_stats(long long G, int S, int C, const float *gpool, const unsigned char *argmax,
+                             const float *Y, const float *scale, const float *shift, float *stats_partial,
+                             pcops_stream_t stream);
+int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partial, void *workspace,
+                            const float *gamma, const float *mean, const float *rstd, float *dgamma,
+                            float *dbeta, float *p, float *q, float *t, pcops_stream_t stream);
+/* dgrad: Gprev[M,Nout] = mask . (dY[M,K] Wt[K,Nout]); dY from (G,Y,p,q,t) or, when gpool != NULL, from the
+ * pooled form (gpool, argmax, S, pool_scale, pool_shift).  Yprev != NULL: mask = [relu(bn_prev(Yprev)) > 0]
+ * and stats_partial [pcops_mlp_stats_rows(M)][2][Nout] gets (sum Gprev, sum Gprev*Yprev); Yprev == NULL: plain. */
+int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                         const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                         int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                         const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
+                         float *stats_partial, pcops_stream_t stream);
+/* wgrad: dW[K,N] = A^T dY, db[N] (may be NULL) = 1^T dY; A = X or relu(X*a_scale + a_shift); dY as above.
+ * partial: caller scratch of pcops_mlp_wgrad_splits(M,K,N) * (K*N + N) floats. */
+int pcops_mlp_wgrad_splits(long long M, int K, int N);
+int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
+                    const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                    const float *t, const float *gpool, const unsigned char *argmax, int S,
+                    const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                    pcops_stream_t stream);
+int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcops.so")
 
-_I, _F, _P, _U64 = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong
+_I, _F, _P, _U64, _LL = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong, C.c_longlong
 
 # name -> (argtypes without the trailing stream, has_stream)
 SIGNATURES = {
@@ -32,11 +32,27 @@ SIGNATURES = {
     "pcops_knn_graph": ([_I, _I, _I, _I, _P, _P], True),
     "pcops_edge_feature": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_edge_feature_grad": ([_I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_finalize": ([_I, _I, _LL, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_eval_coeffs": ([_I, _P, _P, _P, _P, _F, _P, _P], True),
+    "pcops_mlp_bn_relu_maxpool": ([_LL, _I, _I, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_relu_apply": ([_LL, _I, _P, _P, _P, _P], True),
+    "pcops_mlp_relu_mask_stats": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_bwd_stats": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_bwd_coeffs": ([_I, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
     "pcops_abi_version": ([], _I),
     "pcops_farthest_point_sample_workspace_bytes": ([_I, _I], _U64),
+    "pcops_mlp_stats_rows": ([_I], _I),
+    "pcops_mlp_reduce_workspace_bytes": ([_I], _U64),
+    "pcops_mlp_bwd_stats_rows": ([_LL], _I),
+    "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
+    "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
 }
 
 _lib = None

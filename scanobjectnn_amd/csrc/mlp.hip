@@ -1,0 +1,890 @@
+// mlp.hip -- the shared per-point MLP (1x1 conv + bias + BatchNorm + ReLU [+ max-pool over the
+// neighbourhood]) of PointNet++ set abstraction / feature propagation and DGCNN EdgeConv, forward
+// and backward, as fused fp32-MFMA kernels for gfx950.
+//
+// Reference call sites (TensorFlow ops, no native code of its own): pointnet2/utils/pointnet_util.py:
+// 117-127 (conv2d stack + reduce_max), :223-227 (FP stack); pointnet2/utils/tf_util.py:120-185
+// (conv2d = tf.nn.conv2d + bias_add + batch_norm + relu), :512-531 (BN); dgcnn/models/dgcnn.py:39-48.
+// Every activation tensor there makes a full HBM round trip per op; here one layer = ONE pass:
+//
+//   fwd   Y_l = relu(bn_{l-1}(Y_{l-1})) W_l + b_l        BN+ReLU of the PREVIOUS layer is applied while
+//                                                        the A tile is staged (prologue); the epilogue
+//                                                        emits per-channel sum / sum-of-squares partials
+//   dgrad G_{l-1} = relu'_{l-1} . (dY_l W_l^T)           dY_l = p.G_l + q.Y_l + t (BN backward folded into
+//                                                        three per-channel vectors) computed in the
+//                                                        prologue; ReLU mask + the two BN-backward
+//                                                        reductions of layer l-1 in the epilogue
+//   wgrad dW_l = A_{l-1}^T dY_l, db_l = 1^T dY_l         both operands rebuilt in registers from the raw
+//                                                        tensors, fragment-shaped straight from HBM
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, k ascending within a chunk) -- no
+// reduced precision anywhere.  Tiles: 128 rows x (64|128) cols per workgroup of 4 waves, K in chunks
+// of 32 staged through LDS with 16-byte reads; the A fragment uses the "label permutation" trick: a
+// lane reads 4 consecutive k of its row with ONE ds_read_b128 and feeds them to 4 MFMAs whose k labels
+// are matched on the B side, so no transpose is ever needed.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBM = 128;   // rows per tile (4 waves x 32)
+constexpr int kBK = 32;    // K chunk
+constexpr int kLdA = 36;   // A tile row stride in floats (16 B aligned, conflict-free b128 reads)
+
+enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3 };
+enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2 };
+
+struct GemmArgs {
+    int M, K, N;
+    int tiles_per_block;
+    // A operand
+    const float *X;      // A_PLAIN/A_BNRELU: input rows;  A_DY: G (masked upstream grad);  A_DYPOOL: unused
+    int ldx;
+    const float *X2;     // A_DY/A_DYPOOL: raw Y of this layer (same shape/ld as X)
+    const float *v0;     // A_BNRELU: scale[k];  A_DY*: p[k]
+    const float *v1;     // A_BNRELU: shift[k];  A_DY*: q[k]
+    const float *v2;     //                      A_DY*: t[k]
+    const float *v3;     // A_DYPOOL: bn scale[k] of this layer (for the relu mask at the argmax)
+    const float *v4;     // A_DYPOOL: bn shift[k]
+    const float *gpool;  // A_DYPOOL: upstream grad of the pooled output [M/S][K]
+    const unsigned char *argmax;  // A_DYPOOL: [M/S][K]
+    int S;
+    // B operand: row-major [K][N]
+    const float *W;
+    // epilogue
+    const float *bias;   // E_FWD (may be null)
+    float *Y;            // output [M][N]
+    int ldy;
+    const float *Yprev;  // E_MASK: raw Y of the previous layer [M][N]
+    const float *msc;    // E_MASK: bn scale / shift of the previous layer
+    const float *msh;
+    float *stats;        // [gridDim.y][2][N] partial column sums (null: none)
+};
+
+__device__ __forceinline__ float4 ld4(const float *p, bool vec, int k, int K) {
+    // 4 consecutive floats starting at column k of a row (zero beyond K); vec: 16-byte aligned fast path
+    if (vec) return (k < K) ? *reinterpret_cast<const float4 *>(p + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r;
+    r.x = k + 0 < K ? p[k + 0] : 0.f;
+    r.y = k + 1 < K ? p[k + 1] : 0.f;
+    r.z = k + 2 < K ? p[k + 2] : 0.f;
+    r.w = k + 3 < K ? p[k + 3] : 0.f;
+    return r;
+}
+
+template <int NT, int AM, int EM>
+__global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
+    constexpr int BN = NT * 32;
+    __shared__ __attribute__((aligned(16))) float As[kBM * kLdA];
+    __shared__ __attribute__((aligned(16))) float Bs[kBK * BN];
+    __shared__ float red[4][2][BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BN;
+    const int M = a.M, K = a.K, N = a.N;
+    const bool xvec = (a.ldx % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0) &&
+                      (AM < A_DY || (reinterpret_cast<uintptr_t>(a.X2) & 15) == 0);
+    const bool wvec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.W) & 15) == 0);
+
+    // staging coordinates (fixed per thread)
+    const int a_kq = (tid & 7) * 4;    // k offset inside the chunk
+    const int a_r = tid >> 3;          // row 0..31 (+32 per pass)
+    const int b_nq = (tid % (BN / 4)) * 4;
+    const int b_k = tid / (BN / 4);    // 0..(1024/BN - 1), + (256*4/BN) per pass
+    constexpr int B_PASS = (kBK * BN / 4) / 256;   // float4 per thread: 2 (BN=64) or 4 (BN=128)
+    constexpr int B_KSTEP = 256 / (BN / 4);
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
+
+    const int tile0 = blockIdx.y * a.tiles_per_block;
+    for (int tt = 0; tt < a.tiles_per_block; ++tt) {
+        const long long row0 = (long long)(tile0 + tt) * kBM;
+        if (row0 >= M) break;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+
+        float4 ra[4], rb[B_PASS];
+        auto load_chunk = [&](int kc) {
+            const int k = kc * kBK + a_kq;
+            float4 c0, c1, c2, c3, c4;
+            if (AM != A_PLAIN) {
+                c0 = ld4(a.v0, true, k, (K + 3) & ~3);
+                c1 = ld4(a.v1, true, k, (K + 3) & ~3);
+                if (AM >= A_DY) c2 = ld4(a.v2, true, k, (K + 3) & ~3);
+                if (AM == A_DYPOOL) {
+                    c3 = ld4(a.v3, true, k, (K + 3) & ~3);
+                    c4 = ld4(a.v4, true, k, (K + 3) & ~3);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const long long r = row0 + a_r + 32 * p;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < M) {
+                    if (AM == A_PLAIN) {
+                        x = ld4(a.X + r * a.ldx, xvec, k, K);
+                    } else if (AM == A_BNRELU) {
+                        x = ld4(a.X + r * a.ldx, xvec, k, K);
+                        x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
+                        x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
+                        x.z = fmaxf(fmaf(x.z, c0.z, c1.z), 0.f);
+                        x.w = fmaxf(fmaf(x.w, c0.w, c1.w), 0.f);
+                    } else if (AM == A_DY) {
+                        const float4 g = ld4(a.X + r * a.ldx, xvec, k, K);
+                        const float4 y = ld4(a.X2 + r * a.ldx, xvec, k, K);
+                        x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
+                        x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
+                        x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
+                        x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
+                    } else {  // A_DYPOOL: G is non-zero only at the arg-max row of each (group, channel)
+                        const float4 y = ld4(a.X2 + r * a.ldx, xvec, k, K);
+                        const long long g = r / a.S;
+                        const int s = (int)(r - g * a.S);
+                        const float yy[4] = {y.x, y.y, y.z, y.w};
+                        const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, cc1[4] = {c1.x, c1.y, c1.z, c1.w};
+                        const float cc2[4] = {c2.x, c2.y, c2.z, c2.w}, cc3[4] = {c3.x, c3.y, c3.z, c3.w};
+                        const float cc4[4] = {c4.x, c4.y, c4.z, c4.w};
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float gm = 0.f;
+                            if (k + e < K && a.argmax[g * K + k + e] == s && fmaf(yy[e], cc3[e], cc4[e]) > 0.f)
+                                gm = a.gpool[g * K + k + e];
+                            o[e] = (k + e < K) ? fmaf(cc0[e], gm, fmaf(cc1[e], yy[e], cc2[e])) : 0.f;
+                        }
+                        x = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                    if (AM >= A_DY) {  // rows are exact zeros beyond K (t[k] would leak otherwise)
+                        if (k + 0 >= K) x.x = 0.f;
+                        if (k + 1 >= K) x.y = 0.f;
+                        if (k + 2 >= K) x.z = 0.f;
+                        if (k + 3 >= K) x.w = 0.f;
+                    }
+                }
+                ra[p] = x;
+            }
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p) {
+                const int kk = kc * kBK + b_k + B_KSTEP * p;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kk < K) w = ld4(a.W + (long long)kk * N, wvec, n0 + b_nq, N);
+                rb[p] = w;
+            }
+        };
+
+        const int nchunk = (K + kBK - 1) / kBK;
+        load_chunk(0);
+        for (int kc = 0; kc < nchunk; ++kc) {
+            __syncthreads();  // previous chunk's MFMA reads are done
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                *reinterpret_cast<float4 *>(&As[(a_r + 32 * p) * kLdA + a_kq]) = ra[p];
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p)
+                *reinterpret_cast<float4 *>(&Bs[(b_k + B_KSTEP * p) * BN + b_nq]) = rb[p];
+            __syncthreads();
+            if (kc + 1 < nchunk) load_chunk(kc + 1);  // global loads fly under the MFMAs below
+
+            const float *arow = &As[(wave * 32 + (lane & 31)) * kLdA + 4 * (lane >> 5)];
+            const float *bcol = &Bs[(4 * (lane >> 5)) * BN + (lane & 31)];
+#pragma unroll
+            for (int it = 0; it < kBK / 8; ++it) {
+                const float4 av = *reinterpret_cast<const float4 *>(arow + 8 * it);
+                const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float bv = bcol[(8 * it + t) * BN + 32 * nt];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ epilogue
+        // acc[nt][v]: col = n0 + 32 nt + (lane & 31), row = row0 + 32 wave + (v&3) + 8 (v>>2) + 4 (lane>>5)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 32 * nt + (lane & 31);
+            const bool ncol = n < N;
+            float bias = 0.f, msc = 0.f, msh = 0.f;
+            if (EM == E_FWD && a.bias && ncol) bias = a.bias[n];
+            if (EM == E_MASK && ncol) { msc = a.msc[n]; msh = a.msh[n]; }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long long r = row0 + 32 * wave + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                if (r < M && ncol) {
+                    float o = acc[nt][v];
+                    if (EM == E_FWD) {
+                        o += bias;
+                        s1[nt] += o;
+                        s2[nt] = fmaf(o, o, s2[nt]);
+                    } else if (EM == E_MASK) {
+                        const float yp = a.Yprev[r * a.ldy + n];
+                        o = fmaf(yp, msc, msh) > 0.f ? o : 0.f;
+                        s1[nt] += o;
+                        s2[nt] = fmaf(o, yp, s2[nt]);
+                    }
+                    a.Y[r * a.ldy + n] = o;
+                }
+            }
+        }
+    }
+
+    if (EM != E_PLAIN && a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            s1[nt] += __shfl_xor(s1[nt], 32, 64);
+            s2[nt] += __shfl_xor(s2[nt], 32, 64);
+            if (lane < 32) {
+                red[wave][0][32 * nt + lane] = s1[nt];
+                red[wave][1][32 * nt + lane] = s2[nt];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            if (n0 + c < N) {
+                const float v = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+                a.stats[((long long)blockIdx.y * 2 + which) * N + n0 + c] = v;
+            }
+        }
+    }
+}
+
+template <int AM, int EM>
+int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
+    const int tiles = (a.M + kBM - 1) / kBM;
+    // enough row-tile groups to fill the chip a few times over, few enough that the partial-statistics
+    // buffer stays small
+    int tpb = 1;
+    while (tiles / tpb > 4096) tpb *= 2;
+    a.tiles_per_block = tpb;
+    const int gy = (tiles + tpb - 1) / tpb;
+    if (a.N <= 64) {
+        hipLaunchKernelGGL((gemm_rt_kernel<2, AM, EM>), dim3((a.N + 63) / 64, gy), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((gemm_rt_kernel<4, AM, EM>), dim3((a.N + 127) / 128, gy), dim3(256), 0, st, a);
+    }
+    return pcops_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reduction of partial statistics [P][2][N] -> double [2][N], two stages, deterministic
+constexpr int kRedSlices = 32;
+
+__global__ __launch_bounds__(256) void colreduce_stage1(int P, int N, const float *__restrict__ part,
+                                                        double *__restrict__ ws) {
+    // grid (ceil(N/32), 2, kRedSlices); thread (c = tid%32, g = tid/32)
+    __shared__ double sm[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    const int which = blockIdx.y, slice = blockIdx.z;
+    const int per = (P + kRedSlices - 1) / kRedSlices;
+    const int p0 = slice * per, p1 = min(P, p0 + per);
+    double s = 0.0;
+    if (c < N)
+        for (int p = p0 + g; p < p1; p += 8) s += (double)part[((long long)p * 2 + which) * N + c];
+    sm[g][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (g == 0 && c < N) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += sm[i][threadIdx.x];
+        ws[((long long)slice * 2 + which) * N + c] = t;
+    }
+}
+
+// forward BN: statistics -> (mean, rstd, scale, shift) and the moving-average update
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int N, double R, const double *__restrict__ ws,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float decay, int unbiased,
+                                                          float *__restrict__ moving_mean,
+                                                          float *__restrict__ moving_var,
+                                                          float *__restrict__ mean_o, float *__restrict__ rstd_o,
+                                                          float *__restrict__ scale_o, float *__restrict__ shift_o) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < kRedSlices; ++s) {
+        s1 += ws[((long long)s * 2 + 0) * N + c];
+        s2 += ws[((long long)s * 2 + 1) * N + c];
+    }
+    const double mean = s1 / R;
+    double var = s2 / R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)mean * sc;
+    if (moving_mean) {
+        const double uv = (unbiased && R > 1.0) ? var * (R / (R - 1.0)) : var;
+        moving_mean[c] = decay * moving_mean[c] + (1.f - decay) * (float)mean;
+        moving_var[c] = decay * moving_var[c] + (1.f - decay) * (float)uv;
+    }
+}
+
+// eval-mode BN: moving statistics -> (scale, shift)
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(int N, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const float *__restrict__ mm,
+                                                             const float *__restrict__ mv, float eps,
+                                                             float *__restrict__ scale_o,
+                                                             float *__restrict__ shift_o) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const float sc = gamma[c] * (1.0f / sqrtf(mv[c] + eps));
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - mm[c] * sc;
+}
+
+// backward BN: sums (sum G, sum G*Y) -> dgamma, dbeta and the dY = p*G + q*Y + t coefficient vectors
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_kernel(int N, double R, const double *__restrict__ ws,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                            float *__restrict__ p_o, float *__restrict__ q_o,
+                                                            float *__restrict__ t_o) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    double sg = 0.0, sgy = 0.0;
+    for (int s = 0; s < kRedSlices; ++s) {
+        sg += ws[((long long)s * 2 + 0) * N + c];
+        sgy += ws[((long long)s * 2 + 1) * N + c];
+    }
+    const double mu = mean[c], rs = rstd[c], g = gamma[c];
+    const double dga = (sgy - mu * sg) * rs;
+    const double p = g * rs;
+    const double q = -p * rs * dga / R;
+    const double t = -p * sg / R - q * mu;
+    dgamma[c] = (float)dga;
+    dbeta[c] = (float)sg;
+    p_o[c] = (float)p;
+    q_o[c] = (float)q;
+    t_o[c] = (float)t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[g][c] = max_s relu(scale[c]*Y[g*S+s][c] + shift[c]); argmax = first s reaching it
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int S, int C,
+                                                              const float *__restrict__ Y,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              float *__restrict__ out,
+                                                              unsigned char *__restrict__ argmax) {
+    const int c4n = C / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < G * c4n; e += (long long)gridDim.x * 256) {
+        const long long g = e / c4n;
+        const int c = (int)(e - g * c4n) * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float m[4] = {-1.f, -1.f, -1.f, -1.f};
+        int am[4] = {0, 0, 0, 0};
+        const float *base = Y + (g * S) * C + c;
+        for (int s = 0; s < S; ++s) {
+            const float4 y = *reinterpret_cast<const float4 *>(base + (long long)s * C);
+            const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
+            const float a2 = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
+            if (a0 > m[0]) { m[0] = a0; am[0] = s; }
+            if (a1 > m[1]) { m[1] = a1; am[1] = s; }
+            if (a2 > m[2]) { m[2] = a2; am[2] = s; }
+            if (a3 > m[3]) { m[3] = a3; am[3] = s; }
+        }
+        *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(m[0], m[1], m[2], m[3]);
+        if (argmax) {
+            uchar4 q;
+            q.x = (unsigned char)am[0]; q.y = (unsigned char)am[1];
+            q.z = (unsigned char)am[2]; q.w = (unsigned char)am[3];
+            *reinterpret_cast<uchar4 *>(argmax + g * C + c) = q;
+        }
+    }
+}
+
+// A[r][c] = relu(scale[c]*Y[r][c] + shift[c])   (stack output without pooling)
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(long long total4, int C,
+                                                            const float *__restrict__ Y,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift,
+                                                            float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int c = (int)((e * 4) % C);
+        const float4 y = reinterpret_cast<const float4 *>(Y)[e];
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float4 o;
+        o.x = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f);
+        o.y = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
+        o.z = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f);
+        o.w = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
+        reinterpret_cast<float4 *>(out)[e] = o;
+    }
+}
+
+// backward of relu(bn(Y)) for a materialised upstream grad Gout: Gm = Gout*[a>0], partial sums
+// (sum Gm, sum Gm*Y) per 128-row tile: stats [P][2][C]
+__global__ __launch_bounds__(256) void relu_mask_stats_kernel(long long R, int C, const float *__restrict__ Gout,
+                                                              const float *__restrict__ Y,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift,
+                                                              float *__restrict__ Gm, float *__restrict__ stats,
+                                                              int rows_per_block) {
+    // block: 256 threads = (C/4 column-quads) x (256/(C/4)) row lanes ... generic: thread owns column quad
+    // cq = tid % c4n and strides rows by 256 / c4n; requires c4n <= 256 and 256 % c4n == 0 or loops columns.
+    extern __shared__ float sm[];  // [rl][2][C]
+    const int c4n = C / 4;
+    const int rl = max(1, 256 / c4n);  // row lanes
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(R, r0 + rows_per_block);
+    for (int cq = threadIdx.x % min(c4n, 256); cq < c4n; cq += 256) {
+        const int c = cq * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+        const int lane_r = (c4n >= 256) ? 0 : threadIdx.x / c4n;
+        if (lane_r < rl) {
+            for (long long r = r0 + lane_r; r < r1; r += rl) {
+                const float4 g = *reinterpret_cast<const float4 *>(Gout + r * C + c);
+                const float4 y = *reinterpret_cast<const float4 *>(Y + r * C + c);
+                float4 o;
+                o.x = fmaf(y.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
+                o.y = fmaf(y.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+                o.z = fmaf(y.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
+                o.w = fmaf(y.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+                *reinterpret_cast<float4 *>(Gm + r * C + c) = o;
+                a1[0] += o.x; a1[1] += o.y; a1[2] += o.z; a1[3] += o.w;
+                a2[0] = fmaf(o.x, y.x, a2[0]); a2[1] = fmaf(o.y, y.y, a2[1]);
+                a2[2] = fmaf(o.z, y.z, a2[2]); a2[3] = fmaf(o.w, y.w, a2[3]);
+            }
+            for (int e = 0; e < 4; ++e) {
+                sm[(lane_r * 2 + 0) * C + c + e] = a1[e];
+                sm[(lane_r * 2 + 1) * C + c + e] = a2[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        float t = 0.f;
+        for (int l = 0; l < rl; ++l) t += sm[(l * 2 + which) * C + c];
+        stats[((long long)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
+// backward of the max-pool + relu + bn for the pooled upstream grad: partial sums over groups of
+// Gm = gpool*[a_argmax>0] and Gm*Y_argmax; stats [P][2][C], one block per `groups_per_block` groups
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long G, int S, int C,
+                                                             const float *__restrict__ gpool,
+                                                             const unsigned char *__restrict__ argmax,
+                                                             const float *__restrict__ Y,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift,
+                                                             float *__restrict__ stats, int groups_per_block) {
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    const long long g1 = min(G, g0 + groups_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sc = scale[c], sh = shift[c];
+        float a1 = 0.f, a2 = 0.f;
+        for (long long g = g0; g < g1; ++g) {
+            const int s = argmax[g * C + c];
+            const float y = Y[(g * S + s) * C + c];
+            const float gm = fmaf(y, sc, sh) > 0.f ? gpool[g * C + c] : 0.f;
+            a1 += gm;
+            a2 = fmaf(gm, y, a2);
+        }
+        stats[((long long)blockIdx.x * 2 + 0) * C + c] = a1;
+        stats[((long long)blockIdx.x * 2 + 1) * C + c] = a2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: dW[K][N] (+)= A^T dY over a slice of rows; both operands rebuilt from raw tensors and loaded
+// fragment-shaped straight from HBM (lane = (row parity, channel group); VK/VN consecutive channels per
+// lane feed VK*VN MFMAs whose row/column labels are the permuted channels 32-strided... see header).
+struct WgradArgs {
+    long long M;
+    int K, N;
+    int rows_per_block;
+    int amode;               // A_PLAIN | A_BNRELU for the A^T side
+    const float *X; int ldx; const float *asc; const float *ash;
+    int dmode;               // A_DY | A_DYPOOL for the dY side
+    const float *G; const float *Y; int ldy;
+    const float *p; const float *q; const float *t;
+    const float *dsc; const float *dsh; const float *gpool; const unsigned char *argmax; int S;
+    float *part;             // [gridDim.z][K][N] partial dW
+    float *dbpart;           // [gridDim.z][N] partial db (written by blockIdx.x == 0)
+};
+
+template <int VK, int VN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    // block tile: channels k0..k0+32*VK of A, n0..n0+32*VN of dY; 4 waves take interleaved row pairs
+    __shared__ float red[32 * VK * 32 * VN];
+    __shared__ float redb[32 * VN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * 32 * VK, n0 = blockIdx.y * 32 * VN;
+    const int K = a.K, N = a.N;
+    const long long r0 = (long long)blockIdx.z * a.rows_per_block;
+    const long long r1 = min(a.M, r0 + a.rows_per_block);
+    const int half = lane >> 5, li = lane & 31;
+
+    // per-lane channel constants
+    float asc[VK], ash[VK], cp[VN], cq[VN], ct[VN], dsc[VN], dsh[VN];
+    bool kin[VK], nin[VN];
+#pragma unroll
+    for (int e = 0; e < VK; ++e) {
+        const int k = k0 + li * VK + e;
+        kin[e] = k < K;
+        asc[e] = (a.amode == A_BNRELU && kin[e]) ? a.asc[k] : 1.f;
+        ash[e] = (a.amode == A_BNRELU && kin[e]) ? a.ash[k] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+        const int n = n0 + li * VN + e;
+        nin[e] = n < N;
+        cp[e] = nin[e] ? a.p[n] : 0.f;
+        cq[e] = nin[e] ? a.q[n] : 0.f;
+        ct[e] = nin[e] ? a.t[n] : 0.f;
+        dsc[e] = (a.dmode == A_DYPOOL && nin[e]) ? a.dsc[n] : 0.f;
+        dsh[e] = (a.dmode == A_DYPOOL && nin[e]) ? a.dsh[n] : 0.f;
+    }
+
+    f32x16 acc[VK][VN];
+#pragma unroll
+    for (int i = 0; i < VK; ++i)
+#pragma unroll
+        for (int j = 0; j < VN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    float dbs[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) dbs[e] = 0.f;
+
+    for (long long rb = r0 + 2 * wave; rb < r1; rb += 8) {
+        // wave-uniform trip count: lanes 0-31 take row rb, lanes 32-63 row rb+1 of the pair
+        const long long r = rb + half;
+        const bool rin = r < r1;
+        float av[VK], dv[VN];
+#pragma unroll
+        for (int e = 0; e < VK; ++e) {
+            float x = 0.f;
+            if (rin && kin[e]) {
+                x = a.X[r * a.ldx + k0 + li * VK + e];
+                if (a.amode == A_BNRELU) x = fmaxf(fmaf(x, asc[e], ash[e]), 0.f);
+            }
+            av[e] = x;
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            float d = 0.f;
+            if (rin && nin[e]) {
+                const int n = n0 + li * VN + e;
+                const float y = a.Y[r * a.ldy + n];
+                float gm;
+                if (a.dmode == A_DY) {
+                    gm = a.G[r * a.ldy + n];
+                } else {
+                    const long long g = r / a.S;
+                    const int s = (int)(r - g * a.S);
+                    gm = (a.argmax[g * N + n] == s && fmaf(y, dsc[e], dsh[e]) > 0.f) ? a.gpool[g * N + n] : 0.f;
+                }
+                d = fmaf(cp[e], gm, fmaf(cq[e], y, ct[e]));
+            }
+            dv[e] = d;
+            dbs[e] += d;
+        }
+#pragma unroll
+        for (int i = 0; i < VK; ++i)
+#pragma unroll
+            for (int j = 0; j < VN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], dv[j], acc[i][j], 0, 0, 0);
+    }
+
+    // acc[i][j][v]: A-channel k0 + VK*(row label) + i, row label = (v&3) + 8 (v>>2) + 4 half;
+    //               dY-channel n0 + VN*(lane&31) + j
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < VK; ++i)
+#pragma unroll
+                for (int j = 0; j < VN; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int kl = ((v & 3) + 8 * (v >> 2) + 4 * half) * VK + i;
+                        const int nl = li * VN + j;
+                        float *dst = &red[kl * 32 * VN + nl];
+                        *dst = (w == 0 ? 0.f : *dst) + acc[i][j][v];
+                    }
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float s = dbs[e] + __shfl_xor(dbs[e], 32, 64);
+                if (half == 0) redb[li * VN + e] = (w == 0 ? 0.f : redb[li * VN + e]) + s;
+            }
+        }
+    }
+    __syncthreads();
+    float *out = a.part + (long long)blockIdx.z * K * N;
+    for (int i = tid; i < 32 * VK * 32 * VN; i += 256) {
+        const int kl = i / (32 * VN), nl = i % (32 * VN);
+        if (k0 + kl < K && n0 + nl < N) out[(long long)(k0 + kl) * N + n0 + nl] = red[i];
+    }
+    if (blockIdx.x == 0 && a.dbpart)
+        for (int i = tid; i < 32 * VN; i += 256)
+            if (n0 + i < N) a.dbpart[(long long)blockIdx.z * N + n0 + i] = redb[i];
+}
+
+// sum partials [P][L] -> out[L] (deterministic), one thread per element
+__global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, const float *__restrict__ part,
+                                                           float *__restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[(long long)p * L + i];
+    out[i] = (float)s;
+}
+
+// Wt[n][k] = W[k][n]
+__global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const float *__restrict__ W,
+                                                        float *__restrict__ Wt) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (k0 + i < K && n0 + tx < N) t[i][tx] = W[(long long)(k0 + i) * N + n0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
+}
+
+int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
+    hipLaunchKernelGGL(colreduce_stage1, dim3((N + 31) / 32, 2, kRedSlices), dim3(256), 0, st, P, N, part, ws);
+    return pcops_launch_status();
+}
+
+}  // namespace
+
+// ============================================================================ C ABI
+extern "C" {
+
+int pcops_mlp_stats_rows(int M) {
+    // number of row-tile groups (= partial statistics rows) gemm kernels emit for M rows
+    const int tiles = (M + kBM - 1) / kBM;
+    int tpb = 1;
+    while (tiles / tpb > 4096) tpb *= 2;
+    return (tiles + tpb - 1) / tpb;
+}
+
+unsigned long long pcops_mlp_reduce_workspace_bytes(int N) {
+    return (unsigned long long)kRedSlices * 2 * (unsigned long long)N * sizeof(double);
+}
+
+int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                       const float *pro_shift, const float *W, const float *bias, float *Y,
+                       float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 0 && K >= 1 && N >= 1 && ldx >= K);
+    if (M == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
+    if (pro_scale) PCOPS_REQUIRE_SHAPE(K % 4 == 0);  // coefficient vectors are read 4 at a time
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    if (pro_scale) return launch_gemm_rt<A_BNRELU, E_FWD>(a, as_stream(stream));
+    return launch_gemm_rt<A_PLAIN, E_FWD>(a, as_stream(stream));
+}
+
+int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
+                          const float *gamma, const float *beta, float eps, float decay,
+                          int unbiased_moving_var, float *moving_mean, float *moving_var, float *mean,
+                          float *rstd, float *scale, float *shift, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(P >= 1 && N >= 1 && R >= 1);
+    PCOPS_REQUIRE_PTR(stats_partial); PCOPS_REQUIRE_PTR(workspace); PCOPS_REQUIRE_PTR(gamma);
+    PCOPS_REQUIRE_PTR(beta); PCOPS_REQUIRE_PTR(mean); PCOPS_REQUIRE_PTR(rstd); PCOPS_REQUIRE_PTR(scale);
+    PCOPS_REQUIRE_PTR(shift);
+    PCOPS_REQUIRE_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+    hipStream_t st = as_stream(stream);
+    double *ws = static_cast<double *>(workspace);
+    int rc = reduce_stats(P, N, stats_partial, ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (double)R, ws, gamma,
+                       beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean, rstd, scale, shift);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_bn_eval_coeffs(int N, const float *gamma, const float *beta, const float *moving_mean,
+                             const float *moving_var, float eps, float *scale, float *shift,
+                             pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(N >= 1);
+    PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(beta); PCOPS_REQUIRE_PTR(moving_mean);
+    PCOPS_REQUIRE_PTR(moving_var); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift);
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), N, gamma,
+                       beta, moving_mean, moving_var, eps, scale, shift);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const float *scale,
+                              const float *shift, float *out, unsigned char *argmax,
+                              pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && S >= 1 && S <= 256 && C >= 4 && C % 4 == 0);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
+    const long long total = G * (C / 4);
+    const unsigned grid = cdiv(total, 256) < 32768u ? cdiv(total, 256) : 32768u;
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(256), 0, as_stream(stream), G, S, C, Y, scale,
+                       shift, out, argmax);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *scale, const float *shift,
+                            float *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(R >= 0 && C >= 4 && C % 4 == 0);
+    if (R == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
+    const long long total4 = R * C / 4;
+    const unsigned grid = cdiv(total4, 256) < 32768u ? cdiv(total4, 256) : 32768u;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total4, C, Y, scale,
+                       shift, out);
+    return pcops_launch_status();
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+int pcops_mlp_bwd_stats_rows(long long R) { return (int)((R + 511) / 512); }
+int pcops_mlp_bwd_pool_stats_rows(long long G) { return (int)((G + 63) / 64); }
+
+/* Gm = Gout * [relu(bn(Y)) > 0]; partial sums (sum Gm, sum Gm*Y) -> stats [pcops_mlp_bwd_stats_rows(R)][2][C] */
+int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float *Y, const float *scale,
+                              const float *shift, float *Gm, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(R >= 1 && C >= 4 && C % 4 == 0);
+    PCOPS_REQUIRE_PTR(Gout); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift);
+    PCOPS_REQUIRE_PTR(Gm); PCOPS_REQUIRE_PTR(stats_partial);
+    const int c4n = C / 4;
+    PCOPS_REQUIRE_SHAPE(c4n >= 256 || 256 % c4n == 0);
+    const int rl = c4n >= 256 ? 1 : 256 / c4n;
+    const size_t lds = (size_t)rl * 2 * C * sizeof(float);
+    if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(relu_mask_stats_kernel, dim3(pcops_mlp_bwd_stats_rows(R)), dim3(256), lds,
+                       as_stream(stream), R, C, Gout, Y, scale, shift, Gm, stats_partial, 512);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_pool_bwd_stats(long long G, int S, int C, const float *gpool, const unsigned char *argmax,
+                             const float *Y, const float *scale, const float *shift, float *stats_partial,
+                             pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 1 && S >= 1 && C >= 1);
+    PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale);
+    PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(stats_partial);
+    hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), 0,
+                       as_stream(stream), G, S, C, gpool, argmax, Y, scale, shift, stats_partial, 64);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partial, void *workspace,
+                            const float *gamma, const float *mean, const float *rstd, float *dgamma,
+                            float *dbeta, float *p, float *q, float *t, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(P >= 1 && N >= 1 && R >= 1);
+    PCOPS_REQUIRE_PTR(stats_partial); PCOPS_REQUIRE_PTR(workspace); PCOPS_REQUIRE_PTR(gamma);
+    PCOPS_REQUIRE_PTR(mean); PCOPS_REQUIRE_PTR(rstd); PCOPS_REQUIRE_PTR(dgamma); PCOPS_REQUIRE_PTR(dbeta);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    hipStream_t st = as_stream(stream);
+    double *ws = static_cast<double *>(workspace);
+    int rc = reduce_stats(P, N, stats_partial, ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (double)R, ws, gamma,
+                       mean, rstd, dgamma, dbeta, p, q, t);
+    return pcops_launch_status();
+}
+
+/* Gprev[M][Nout] = mask . (dY[M][K] Wt[K][Nout]),  dY = p.G + q.Y + t  (or the pooled form when gpool!=NULL)
+ * mask = [relu(bn_prev(Yprev)) > 0] when Yprev != NULL (then stats_partial gets (sum Gprev, sum Gprev*Yprev)),
+ * no mask / no stats when Yprev == NULL (first layer: plain dX). */
+int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                         const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                         int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                         const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
+                         float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 0 && K >= 1 && Nout >= 1);
+    if (M == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(Gprev);
+    PCOPS_REQUIRE_SHAPE(K % 4 == 0);
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = Nout; a.X = G; a.X2 = Y; a.ldx = K; a.v0 = p; a.v1 = q; a.v2 = t;
+    a.v3 = pool_scale; a.v4 = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    a.W = Wt; a.Y = Gprev; a.ldy = Nout; a.Yprev = Yprev; a.msc = prev_scale; a.msh = prev_shift;
+    a.stats = stats_partial;
+    hipStream_t st = as_stream(stream);
+    if (gpool) {
+        PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
+        a.X = Y;  // alignment probe only
+        if (Yprev) return launch_gemm_rt<A_DYPOOL, E_MASK>(a, st);
+        return launch_gemm_rt<A_DYPOOL, E_PLAIN>(a, st);
+    }
+    PCOPS_REQUIRE_PTR(G);
+    if (Yprev) return launch_gemm_rt<A_DY, E_MASK>(a, st);
+    return launch_gemm_rt<A_DY, E_PLAIN>(a, st);
+}
+
+int pcops_mlp_wgrad_splits(long long M, int K, int N) {
+    // row slices: enough blocks to fill the chip ~4x, at most 512 partial copies
+    const int kb = (K + 63) / 64, nb = (N + 127) / 128;
+    long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    long long rows = (M + want - 1) / want;
+    rows = ((rows + 7) / 8) * 8;
+    if (rows < 8) rows = 8;
+    return (int)((M + rows - 1) / rows);
+}
+
+/* dW[K][N] = A^T dY, db[N] = 1^T dY;  A = X (a_scale==NULL) or relu(X*a_scale + a_shift);
+ * dY as in pcops_mlp_gemm_dgrad.  partial: float [splits][K][N] + [splits][N] scratch (caller). */
+int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
+                    const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                    const float *t, const float *gpool, const unsigned char *argmax, int S,
+                    const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                    pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
+    hipStream_t st = as_stream(stream);
+    const int splits = pcops_mlp_wgrad_splits(M, K, N);
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.rows_per_block = (int)((((M + splits - 1) / splits) + 7) / 8 * 8);
+    a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = X; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
+    hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3((K + 63) / 64, (N + 127) / 128, splits), dim3(256), 0, st, a);
+    int rc = pcops_launch_status();
+    if (rc) return rc;
+    const long long L = (long long)K * N;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 256)), dim3(256), 0, st, splits, L, partial, dW);
+    if (db)
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, splits, (long long)N,
+                           a.dbpart, db);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(K >= 1 && N >= 1);
+    PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Wt);
+    hipLaunchKernelGGL(transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, as_stream(stream), K, N,
+                       W, Wt);
+    return pcops_launch_status();
+}
+
+}  // extern "C"

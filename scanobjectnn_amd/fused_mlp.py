@@ -1,0 +1,191 @@
+"""Fused shared-MLP stack: L x [1x1 conv + bias + BatchNorm + ReLU] (+ max-pool over the neighbourhood),
+forward and backward, on the hand-written fp32-MFMA kernels of libpcops (csrc/mlp.hip).
+
+This is the device-side replacement for the per-layer TensorFlow op chain the reference builds in
+`pointnet_sa_module` / `pointnet_fp_module` / EdgeConv (pointnet2/utils/pointnet_util.py:117-127,223-227;
+pointnet2/utils/tf_util.py:120-185,512-531; dgcnn/models/dgcnn.py:39-48): each layer is ONE pass over the
+activations in each direction (BN+ReLU of the previous layer folded into the operand load, batch statistics
+emitted by the GEMM epilogue, BN backward folded into three per-channel vectors).  Same math as the
+layer-by-layer path (`tf_util.conv2d` in sequence): batch mean / biased variance in training, eps, decay and
+moving-average semantics are parameters so both BN flavours of the reference are covered.
+"""
+import torch
+
+from . import _lib
+
+
+def _f32(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+def _vec(n, dev):
+    """per-channel vector, padded to a multiple of 4 floats (kernels read them 16 bytes at a time)"""
+    return torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=dev)
+
+
+def _workspace(n, dev):
+    lib = _lib.load()
+    return torch.empty(int(lib.pcops_mlp_reduce_workspace_bytes(n)) // 8, dtype=torch.float64, device=dev)
+
+
+class FusedMLPStack(torch.autograd.Function):
+    """apply(x2d, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
+    per_layer (6 each): weights (K,N)-viewable, biases (N), gamma, beta, moving_mean, moving_var
+    x2d: (R, K0) fp32 contiguous.  Returns (R//S, C_L) if pool else (R, C_L)."""
+
+    @staticmethod
+    def forward(ctx, x2d, S, pool, training, decay, eps, unbiased, L, *tensors):
+        lib = _lib.load()
+        dev = x2d.device
+        R, K0 = x2d.shape
+        layers = [tensors[6 * i:6 * i + 6] for i in range(L)]
+        Ys, means, rstds, scales, shifts, Ws = [], [], [], [], [], []
+        src, ld, sc_prev, sh_prev, K = x2d, K0, None, None, K0
+        for (w, b, gamma, beta, mm, mv) in layers:
+            N = w.shape[-1]
+            W2 = w.detach().reshape(-1, N)
+            assert W2.shape[0] == K and W2.is_contiguous()
+            Y = _f32((R, N), dev)
+            scale, shift = _vec(N, dev), _vec(N, dev)
+            if training:
+                P = lib.pcops_mlp_stats_rows(R)
+                part = _f32((P, 2, N), dev)
+                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld,
+                          sc_prev.data_ptr() if sc_prev is not None else None,
+                          sh_prev.data_ptr() if sh_prev is not None else None,
+                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), part.data_ptr())
+                mean, rstd = _vec(N, dev), _vec(N, dev)
+                ws = _workspace(N, dev)
+                _lib.call("pcops_mlp_bn_finalize", P, N, R, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                          beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
+                          mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+                means.append(mean)
+                rstds.append(rstd)
+            else:
+                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld,
+                          sc_prev.data_ptr() if sc_prev is not None else None,
+                          sh_prev.data_ptr() if sh_prev is not None else None,
+                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), None)
+                _lib.call("pcops_mlp_bn_eval_coeffs", N, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
+                          mv.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr())
+            Ys.append(Y)
+            scales.append(scale)
+            shifts.append(shift)
+            Ws.append(W2)
+            src, ld, sc_prev, sh_prev, K = Y, N, scale, shift, N
+
+        C = K
+        argmax = None
+        if pool:
+            G = R // S
+            out = _f32((G, C), dev)
+            argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if training else None
+            _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                      shifts[-1].data_ptr(), out.data_ptr(), argmax.data_ptr() if argmax is not None else None)
+        else:
+            out = _f32((R, C), dev)
+            _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                      shifts[-1].data_ptr(), out.data_ptr())
+        if training:
+            ctx.saved = (x2d, Ys, means, rstds, scales, shifts, Ws, [l[2] for l in layers], argmax)
+            ctx.meta = (S, pool, L, R, K0)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x2d, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
+        S, pool, L, R, K0 = ctx.meta
+        dev = grad_out.device
+        grad_out = grad_out.contiguous()
+        grads = [None] * (6 * L)
+
+        # ---- top of the stack: statistics of the masked upstream gradient
+        C = Ys[-1].shape[1]
+        ws = _workspace(max(y.shape[1] for y in Ys), dev)
+        if pool:
+            G = R // S
+            P = lib.pcops_mlp_bwd_pool_stats_rows(G)
+            part = _f32((P, 2, C), dev)
+            _lib.call("pcops_mlp_pool_bwd_stats", G, S, C, grad_out.data_ptr(), argmax.data_ptr(),
+                      Ys[-1].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(), part.data_ptr())
+            Gm = None
+        else:
+            P = lib.pcops_mlp_bwd_stats_rows(R)
+            part = _f32((P, 2, C), dev)
+            Gm = _f32((R, C), dev)
+            _lib.call("pcops_mlp_relu_mask_stats", R, C, grad_out.data_ptr(), Ys[-1].data_ptr(),
+                      scales[-1].data_ptr(), shifts[-1].data_ptr(), Gm.data_ptr(), part.data_ptr())
+
+        for l in range(L - 1, -1, -1):
+            N = Ys[l].shape[1]
+            K = Ws[l].shape[0]
+            dgamma, dbeta = _f32(N, dev), _f32(N, dev)
+            p, q, t = _vec(N, dev), _vec(N, dev), _vec(N, dev)
+            _lib.call("pcops_mlp_bn_bwd_coeffs", P, N, R, part.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
+                      means[l].data_ptr(), rstds[l].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                      p.data_ptr(), q.data_ptr(), t.data_ptr())
+            pooled = pool and l == L - 1
+            gp = grad_out.data_ptr() if pooled else None
+            am = argmax.data_ptr() if pooled else None
+            psc = scales[l].data_ptr() if pooled else None
+            psh = shifts[l].data_ptr() if pooled else None
+            Gptr = None if pooled else Gm.data_ptr()
+            if l == 0:
+                src, ld, asc, ash = x2d, K0, None, None
+            else:
+                src, ld, asc, ash = Ys[l - 1], Ys[l - 1].shape[1], scales[l - 1].data_ptr(), shifts[l - 1].data_ptr()
+            # dW, db
+            splits = lib.pcops_mlp_wgrad_splits(R, K, N)
+            scratch = _f32(splits * (K * N + N), dev)
+            dW, db = _f32((K, N), dev), _f32(N, dev)
+            _lib.call("pcops_mlp_wgrad", R, K, N, src.data_ptr(), ld, asc, ash, Gptr, Ys[l].data_ptr(),
+                      p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S, psc, psh, scratch.data_ptr(),
+                      dW.data_ptr(), db.data_ptr())
+            grads[6 * l + 0] = dW
+            grads[6 * l + 1] = db
+            grads[6 * l + 2] = dgamma
+            grads[6 * l + 3] = dbeta
+            # dA_{l-1}
+            if l > 0 or ctx.needs_input_grad[0]:
+                Wt = _f32((N, K), dev)
+                _lib.call("pcops_mlp_transpose", K, N, Ws[l].data_ptr(), Wt.data_ptr())
+                Gprev = _f32((R, K), dev)
+                if l > 0:
+                    P = lib.pcops_mlp_stats_rows(R)
+                    part = _f32((P, 2, K), dev)
+                    _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
+                              t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), Ys[l - 1].data_ptr(),
+                              scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Gprev.data_ptr(),
+                              part.data_ptr())
+                else:
+                    _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
+                              t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), None, None, None,
+                              Gprev.data_ptr(), None)
+                Gm = Gprev
+        dx = Gm if ctx.needs_input_grad[0] else None
+        # reshape weight grads to the variables' own shapes
+        out = [dx, None, None, None, None, None, None, None]
+        for i in range(L):
+            out.extend(grads[6 * i:6 * i + 4])
+            out.extend([None, None])
+        return tuple(out)
+
+
+def fused_supported(x, widths, bn, activation_relu):
+    if not (bn and activation_relu and x.is_cuda and x.dtype == torch.float32):
+        return False
+    if any(w % 32 != 0 for w in widths):
+        return False
+    return True
+
+
+def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
+    """x: (..., K0) channel-last; rows are flattened; S rows per pooling group (contiguous)."""
+    x2d = x.reshape(-1, x.shape[-1]).contiguous()
+    L = len(layer_tensors)
+    flat = []
+    for (w, b, gamma, beta, mm, mv) in layer_tensors:
+        flat.extend([w.reshape(-1, w.shape[-1]), b, gamma, beta, mm, mv])
+    return FusedMLPStack.apply(x2d, int(S), bool(pool), bool(training), float(decay), float(eps),
+                               bool(unbiased), L, *flat)

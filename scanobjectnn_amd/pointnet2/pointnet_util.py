@@ -8,6 +8,7 @@ follows SURVEY.md Appendix A9.
 import torch
 
 from . import tf_util
+from .. import fused_mlp
 from ..graph import variable_scope
 from .tf_grouping import group_point, knn_point, query_ball_point, query_ball_point_multi
 from .tf_interpolate import three_interpolate, three_nn
@@ -45,7 +46,18 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
-def _mlp_stack(x, widths, scope_fmt, bn, is_training, bn_decay, data_format):
+def _mlp_stack(x, widths, scope_fmt, bn, is_training, bn_decay, data_format, pool_max=False):
+    """the reference's `for i, num_out_channel in enumerate(mlp): conv2d(...)` loops (+ the max over the
+    neighbourhood axis when pool_max), fused on the device when the stack is the standard BN+ReLU one"""
+    if tf_util.FUSED_MLP and fused_mlp.fused_supported(x, widths, bn, True):
+        if pool_max and x.shape[2] > 256:   # arg-max is kept in 8 bits: pool outside the kernel
+            return tf_util.conv2d_stack(x, widths, scope_fmt, is_training, bn_decay).amax(dim=2, keepdim=True)
+        return tf_util.conv2d_stack(x, widths, scope_fmt, is_training, bn_decay, pool_max=pool_max)
+    x = _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_format)
+    return x.amax(dim=2, keepdim=True) if pool_max else x
+
+
+def _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_format):
     for i, width in enumerate(widths):
         x = tf_util.conv2d(x, width, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
                            is_training=is_training, scope=scope_fmt % i, bn_decay=bn_decay,
@@ -67,10 +79,11 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         else:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz,
                                                                      points, knn, use_xyz)
-        new_points = _mlp_stack(new_points, mlp, 'conv%d', bn, is_training, bn_decay, 'NHWC')
+        new_points = _mlp_stack(new_points, mlp, 'conv%d', bn, is_training, bn_decay, 'NHWC',
+                                pool_max=(pooling == 'max'))
 
         if pooling == 'max':
-            new_points = new_points.amax(dim=2, keepdim=True)
+            pass  # fused into the stack above
         elif pooling == 'avg':
             new_points = new_points.mean(dim=2, keepdim=True)
         elif pooling == 'weighted_avg':
@@ -106,8 +119,8 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
                 if use_xyz:
                     grouped = torch.cat([grouped, grouped_xyz], dim=-1)  # note: feats first (:184)
             grouped = _mlp_stack(grouped, mlp_list[i], 'conv%d_' % i + '%d', bn, is_training,
-                                 bn_decay, 'NHWC')
-            outs.append(grouped.amax(dim=2))
+                                 bn_decay, 'NHWC', pool_max=True)
+            outs.append(grouped.squeeze(2))
         return new_xyz, torch.cat(outs, dim=-1)
 
 

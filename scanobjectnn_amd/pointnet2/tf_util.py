@@ -13,9 +13,12 @@ Semantics restated from the reference + the TF 1.10 behaviour it relies on (SURV
   * dropout = tf.nn.dropout(keep_prob): kept values scaled by 1/keep_prob, identity in eval.
 `is_training` is a Python bool here (the reference feeds a bool placeholder).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
+from .. import fused_mlp
 from ..graph import (constant_initializer, get_variable, truncated_normal_initializer,
                      variable_scope, xavier_initializer, get_default_graph)
 
@@ -103,6 +106,41 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
         if activation_fn is not None:
             out = activation_fn(out)
         return out
+
+
+def _stack_variables(cin, widths, scope_fmt, stddev, weight_decay, use_xavier, mov_names):
+    """creates / fetches exactly the variables a chain of conv2d(..., bn=True) calls would"""
+    layers = []
+    for i, width in enumerate(widths):
+        with variable_scope(scope_fmt % i):
+            kernel = _variable_with_weight_decay('weights', [1, 1, cin, width], stddev=stddev,
+                                                 wd=weight_decay, use_xavier=use_xavier)
+            biases = get_variable('biases', [width], constant_initializer(0.0))
+            with variable_scope('bn'):
+                beta = get_variable('beta', [width], constant_initializer(0.0))
+                gamma = get_variable('gamma', [width], constant_initializer(1.0))
+                mm = get_variable(mov_names[0], [width], constant_initializer(0.0), trainable=False)
+                mv = get_variable(mov_names[1], [width], constant_initializer(1.0), trainable=False)
+        layers.append((kernel.view(cin, width), biases, gamma, beta, mm, mv))
+        cin = width
+    return layers
+
+
+FUSED_MLP = os.environ.get("PCOPS_FUSED_MLP", "1") != "0"
+
+
+def conv2d_stack(inputs, widths, scope_fmt, is_training, bn_decay, pool_max=False, use_xavier=True,
+                 stddev=1e-3, weight_decay=None, unbiased_moving_var=True,
+                 mov_names=('moving_mean', 'moving_variance')):
+    """`len(widths)` x conv2d([1,1], VALID, bn=True, relu) in sequence (variables named scope_fmt % i, exactly
+    as the reference's loops create them: pointnet_util.py:117-122,186-189,223-227), optionally followed by
+    the max over axis 2 (pointnet_util.py:127) -- executed as ONE fused fp32-MFMA pipeline (fused_mlp.py).
+    inputs (B,H,W,C) channel-last.  Returns (B,H,W,widths[-1]) or, with pool_max, (B,H,1,widths[-1])."""
+    b, h, w, cin = inputs.shape
+    layers = _stack_variables(cin, widths, scope_fmt, stddev, weight_decay, use_xavier, mov_names)
+    decay = bn_decay if bn_decay is not None else 0.9
+    out = fused_mlp.mlp_stack(inputs, w, pool_max, is_training, decay, BN_EPS, unbiased_moving_var, layers)
+    return out.view(b, h, 1 if pool_max else w, widths[-1])
 
 
 def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME',

@@ -1,0 +1,127 @@
+"""The fused shared-MLP stack (csrc/mlp.hip via fused_mlp.py) against a plain PyTorch fp32/fp64 reference of
+the same op chain: L x [X·W + b -> BatchNorm (batch stats, biased var, eps 1e-3) -> ReLU] (-> max over S).
+Forward within 1e-4 (abs, activations are O(1)); parameter / input gradients within 1e-3 relative to the
+gradient's max; moving statistics updated like TF (decay, unbiased variance)."""
+import pytest
+import torch
+
+from scanobjectnn_amd import fused_mlp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EPS = 1e-3
+
+
+def make_layers(k0, widths, seed, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    layers, cin = [], k0
+    for w in widths:
+        W = (torch.randn(cin, w, generator=g) / cin ** 0.5).to(DEV)
+        b = (0.1 * torch.randn(w, generator=g)).to(DEV)
+        gamma = (0.5 + torch.rand(w, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(w, generator=g)).to(DEV)
+        mm = (0.1 * torch.randn(w, generator=g)).to(DEV)
+        mv = (0.5 + torch.rand(w, generator=g)).to(DEV)
+        layers.append([W, b, gamma, beta, mm, mv])
+        cin = w
+    return layers
+
+
+def reference(x, layers, S, pool, training, dtype):
+    a = x.to(dtype)
+    for (W, b, gamma, beta, mm, mv) in layers:
+        y = a @ W.to(dtype) + b.to(dtype)
+        if training:
+            var, mean = torch.var_mean(y, dim=0, unbiased=False)
+        else:
+            mean, var = mm.to(dtype), mv.to(dtype)
+        a = torch.relu((y - mean) * torch.rsqrt(var + EPS) * gamma.to(dtype) + beta.to(dtype))
+    if pool:
+        a = a.view(-1, S, a.shape[1]).amax(dim=1)
+    return a
+
+
+CASES = [  # (R, S, K0, widths, pool)
+    (512 * 32, 32, 3, [64, 64, 128], True),        # SA1 shape (small batch)
+    (128 * 64, 64, 131, [128, 128, 256], True),    # SA2: K0 not a multiple of 4
+    (4 * 128, 128, 259, [256, 512, 1024], True),   # SA3 group_all
+    (1000, 1, 384, [256, 128], False),             # FP stack, ragged row count
+    (777, 1, 128, [128], False),                   # single layer
+    (130 * 20, 20, 6, [64], True),                 # EdgeConv-like
+]
+
+
+@pytest.mark.parametrize("R,S,K0,widths,pool", CASES)
+def test_forward_train_and_eval(R, S, K0, widths, pool):
+    g = torch.Generator().manual_seed(R + K0)
+    x = torch.randn(R, K0, generator=g).to(DEV)
+    for training in (True, False):
+        layers = make_layers(K0, widths, seed=K0)
+        mov_before = [(l[4].clone(), l[5].clone()) for l in layers]
+        out = fused_mlp.mlp_stack(x, S, pool, training, 0.9, EPS, True, [tuple(l) for l in layers])
+        want = reference(x, layers if not training else [l[:4] + list(mb) for l, mb in zip(layers, mov_before)],
+                         S, pool, training, torch.float64)
+        assert out.shape == want.shape
+        assert (out.double() - want).abs().max().item() < 1e-4
+        if training:   # TF moving-average update with the unbiased batch variance
+            a = x.double()
+            for l, (mm0, mv0) in zip(layers, mov_before):
+                y = a @ l[0].double() + l[1].double()
+                var, mean = torch.var_mean(y, dim=0, unbiased=False)
+                n = y.shape[0]
+                assert torch.allclose(l[4].double(), 0.9 * mm0.double() + 0.1 * mean, atol=1e-5)
+                assert torch.allclose(l[5].double(), 0.9 * mv0.double() + 0.1 * var * n / (n - 1), atol=1e-5)
+                a = torch.relu((y - mean) * torch.rsqrt(var + EPS) * l[2].double() + l[3].double())
+        else:
+            for l, (mm0, mv0) in zip(layers, mov_before):
+                assert torch.equal(l[4], mm0) and torch.equal(l[5], mv0)
+
+
+@pytest.mark.parametrize("R,S,K0,widths,pool", CASES)
+def test_backward(R, S, K0, widths, pool):
+    g = torch.Generator().manual_seed(R + 7)
+    x = torch.randn(R, K0, generator=g).to(DEV).requires_grad_(True)
+    layers = make_layers(K0, widths, seed=K0 + 1)
+    for l in layers:
+        for t in l[:4]:
+            t.requires_grad_(True)
+    out = fused_mlp.mlp_stack(x, S, pool, True, 0.9, EPS, True, [tuple(l) for l in layers])
+    go = torch.randn(out.shape, generator=g).to(DEV)
+    out.backward(go)
+    got = [x.grad.clone()] + [t.grad.clone() for l in layers for t in l[:4]]
+
+    xr = x.detach().double().requires_grad_(True)
+    lr = [[t.detach().double().requires_grad_(True) for t in l[:4]] + [l[4], l[5]] for l in layers]
+    reference(xr, lr, S, pool, True, torch.float64).backward(go.double())
+    want = [xr.grad] + [t.grad for l in lr for t in l[:4]]
+    names = ["dx"] + ["L%d.%s" % (i, n) for i in range(len(layers)) for n in ("dW", "db", "dgamma", "dbeta")]
+    for name, a, b in zip(names, got, want):
+        scale = b.abs().max().item() + 1e-12
+        err = (a.double() - b).abs().max().item()
+        # conv biases in front of a BN get an analytically zero gradient: compare absolutely
+        tol = 1e-3 * scale if not name.endswith("db") else 1e-3 * max(scale, go.abs().max().item())
+        assert err <= tol + 1e-6, (name, err, scale)
+
+
+def test_fused_equals_layerwise_model(monkeypatch):
+    """pointnet2_cls_ssg with the fused stacks == the same model through tf_util.conv2d layer by layer"""
+    from scanobjectnn_amd.graph import Model
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg as m
+    from scanobjectnn_amd.pointnet2 import tf_util
+    from scanobjectnn_amd.synth import synth_clouds
+    x = torch.from_numpy(synth_clouds(8, 1024, seed=1)).to(DEV)
+    net = Model(m.get_model, device=DEV, seed=0).build(x)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tf_util, "FUSED_MLP", fused)
+        net.load_state_dict(sd)
+        torch.manual_seed(0)
+        logits, _ = net(x, is_training=True, bn_decay=0.9)
+        net.zero_grad()
+        logits.square().mean().backward()
+        outs.append((logits.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4
+    for n in outs[0][1]:
+        a, b = outs[0][1][n], outs[1][1][n]
+        assert (a - b).abs().max().item() <= 2e-3 * (b.abs().max().item() + 1e-6) + 1e-6, n
