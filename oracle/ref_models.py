@@ -1,7 +1,8 @@
 """CPU restatement of the model-level callers: PointNet++ SA / SA-MSG
 / FP modules, the SSG / BGA / MSG classifiers, the DGCNN EdgeConv stack and its BGA variant.
 
-TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).  Independent of the product's host
+TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).  dtype-generic: fp32 tensors give the
+CPU baseline, fp64 tensors the high-precision truth used by the parity tests.  Independent of the product's host
 code: geometry comes from the C oracle (oracle/pcops_oracle.c), dense algebra from torch-CPU fp32 ops,
 variables are looked up by the TF scope names of the reference in a plain dict
 (`layer1/conv0/weights`, `layer1/conv0/bn/{beta,gamma,moving_mean,moving_variance}`, `fc1/weights` ...).
@@ -77,7 +78,7 @@ def sa_module(xyz, points, npoint, radius, nsample, mlp, P, scope, training, gro
     """pointnet2/utils/pointnet_util.py:87-154 (pooling='max', mlp2=None)"""
     if group_all:
         b = xyz.shape[0]
-        new_xyz = torch.zeros((b, 1, 3))
+        new_xyz = torch.zeros((b, 1, 3), dtype=xyz.dtype)
         new_points = (xyz if points is None else torch.cat([xyz, points], 2)).unsqueeze(1)
     else:
         new_xyz, new_points, _ = sample_and_group(npoint, radius, nsample, xyz, points)
@@ -105,7 +106,7 @@ def sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, P, s
 def fp_module(xyz1, xyz2, points1, points2, mlp, P, scope, training):
     """pointnet2/utils/pointnet_util.py:199-229"""
     dist, idx = O.three_nn(_np(xyz1), _np(xyz2))
-    dist = torch.clamp_min(torch.from_numpy(dist), 1e-10)
+    dist = torch.clamp_min(torch.from_numpy(dist).to(points2.dtype), 1e-10)
     inv = 1.0 / dist
     w = inv / inv.sum(dim=2, keepdim=True)
     nb = batch_gather(points2, _idx(idx))                     # (B,n,3,C)
@@ -176,7 +177,7 @@ def _dgcnn_backbone(point_cloud, P, training, k=20, nn_list=None):
     t = dense(t, P, "transform_net1/tfc1", training, flavour="moments")
     t = dense(t, P, "transform_net1/tfc2", training, flavour="moments")
     tr = t @ P["transform_net1/transform_XYZ/weights"] + (P["transform_net1/transform_XYZ/biases"]
-                                                          + torch.eye(3).flatten())
+                                                          + torch.eye(3, dtype=t.dtype).flatten())
     x = point_cloud @ tr.reshape(b, 3, 3)
     nets = []
     for li, scope in enumerate(("dgcnn1", "dgcnn2", "dgcnn3", "dgcnn4")):
@@ -208,7 +209,9 @@ def dgcnn_bga(point_cloud, P, training, nn_list=None):
     return class_pred, dense(s, P, "seg/conv3", training, use_bn=False, act=False)
 
 
-def params_from_state_dict(sd, prefix="graph."):
-    """product Model.state_dict() -> {tf_scope_name: cpu tensor}"""
-    return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().float().cpu().clone()
+def params_from_state_dict(sd, prefix="graph.", dtype=torch.float32):
+    """product Model.state_dict() -> {tf_scope_name: cpu tensor}.  dtype=torch.float64 gives the
+    high-precision "truth" the fp32 paths are judged against (every function here follows its inputs'
+    dtype; the geometry oracle always sees the fp32 coordinates, which doubles hold exactly)."""
+    return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().cpu().to(dtype).clone()
             for k, v in sd.items()}

@@ -103,25 +103,36 @@ def test_backward(R, S, K0, widths, pool):
         assert err <= tol + 1e-6, (name, err, scale)
 
 
-def test_fused_equals_layerwise_model(monkeypatch):
-    """pointnet2_cls_ssg with the fused stacks == the same model through tf_util.conv2d layer by layer"""
+def test_fused_model_as_accurate_as_layerwise(monkeypatch):
+    """pointnet2_cls_ssg through the fused stacks vs the same model through tf_util.conv2d layer by layer
+    (library GEMM + torch BN), both judged against the float64 restatement: same logits (1e-4), and the fused
+    gradients are at least as close to the truth as the layer-wise ones (up to 2x + a small floor)."""
+    from oracle import ref_models as R
     from scanobjectnn_amd.graph import Model
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg as m
     from scanobjectnn_amd.pointnet2 import tf_util
     from scanobjectnn_amd.synth import synth_clouds
-    x = torch.from_numpy(synth_clouds(8, 1024, seed=1)).to(DEV)
+    c = synth_clouds(8, 1024, seed=1)
+    x = torch.from_numpy(c).to(DEV)
+    monkeypatch.setattr(tf_util, "dropout", lambda inputs, is_training, scope, keep_prob=0.5, noise_shape=None: inputs)
     net = Model(m.get_model, device=DEV, seed=0).build(x)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
+    P = {k: v.requires_grad_(v.is_floating_point())
+         for k, v in R.params_from_state_dict(sd, dtype=torch.float64).items()}
+    truth = R.pointnet2_cls_ssg(torch.from_numpy(c).double(), P, True)
+    truth.square().mean().backward()
     outs = []
     for fused in (True, False):
         monkeypatch.setattr(tf_util, "FUSED_MLP", fused)
         net.load_state_dict(sd)
-        torch.manual_seed(0)
         logits, _ = net(x, is_training=True, bn_decay=0.9)
         net.zero_grad()
         logits.square().mean().backward()
-        outs.append((logits.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}))
-    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4
+        outs.append((logits.detach().cpu().double(), {n: p.grad.cpu().double() for n, p in net.named_parameters()}))
+    assert (outs[0][0] - truth.detach()).abs().max().item() < 1e-4
     for n in outs[0][1]:
-        a, b = outs[0][1][n], outs[1][1][n]
-        assert (a - b).abs().max().item() <= 2e-3 * (b.abs().max().item() + 1e-6) + 1e-6, n
+        ref = P[n[len("graph."):]].grad
+        scale = ref.abs().max().item()
+        e_fused = (outs[0][1][n] - ref).abs().max().item()
+        e_layer = (outs[1][1][n] - ref).abs().max().item()
+        assert e_fused <= 2.0 * e_layer + 1e-3 * scale + 1e-5, (n, e_fused, e_layer, scale)
