@@ -22,6 +22,8 @@
 // of 32 staged through LDS with 16-byte reads; the A fragment uses the "label permutation" trick: a
 // lane reads 4 consecutive k of its row with ONE ds_read_b128 and feeds them to 4 MFMAs whose k labels
 // are matched on the B side, so no transpose is ever needed.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -277,6 +279,290 @@ int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
         hipLaunchKernelGGL((gemm_rt_kernel<4, AM, EM>), dim3((a.N + 127) / 128, gy), dim3(256), 0, st, a);
     }
     return pcops_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_ws: "wave-stream" variant of the same GEMM for the big-row / small-K layers (K <= 256 staged in
+// chunks of <= 128, N tile 64|128): the weight tile stays RESIDENT in LDS for the life of a persistent
+// workgroup, and every wave streams its own 32-row tiles independently -- coalesced 16-byte global loads
+// prefetched one tile ahead in registers, operand transform applied on the way into a wave-private LDS
+// stripe, fragments read back with ds_read_b128 -- so the main loop has NO workgroup barrier at all.
+template <int NT, int AM, int EM, int KC>
+__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
+    constexpr int BN = NT * 32;
+    constexpr int LDW = KC + 4;            // wave stripe row stride (floats): 16 B aligned, conflict-free b128
+    constexpr int NLD = KC / 8;            // float4 loads per lane per 32 x KC stripe
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = a.M, K = a.K, N = a.N;
+    const int nchunk = (K + KC - 1) / KC;
+    const int Kp = nchunk * KC;
+    float *Ws = lds;                                   // [Kp][BN]
+    float *Aw = lds + (size_t)Kp * BN + wave * 32 * LDW;   // [32][LDW] per wave
+    float *red = lds + (size_t)Kp * BN + 4 * 32 * LDW; // [4][2][BN]
+    const int n0 = blockIdx.x * BN;
+
+    // ---- weights: loaded once per workgroup
+    for (int e = tid; e < Kp * (BN / 4); e += 256) {
+        const int k = e / (BN / 4), nq = (e % (BN / 4)) * 4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K) {
+            const float *src = a.W + (long long)k * N;
+            const int n = n0 + nq;
+            if (n + 3 < N && (N % 4 == 0)) {
+                w = *reinterpret_cast<const float4 *>(src + n);
+            } else {
+                w.x = n + 0 < N ? src[n + 0] : 0.f;
+                w.y = n + 1 < N ? src[n + 1] : 0.f;
+                w.z = n + 2 < N ? src[n + 2] : 0.f;
+                w.w = n + 3 < N ? src[n + 3] : 0.f;
+            }
+        }
+        *reinterpret_cast<float4 *>(&Ws[k * BN + nq]) = w;
+    }
+    __syncthreads();
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
+
+    const long long ntiles = ((long long)M + 31) / 32;
+    const long long tstride = (long long)gridDim.y * 4;
+    // stripe coordinates of this lane's j-th float4: element index e = lane + 64 j -> (row, col4)
+    constexpr int C4 = KC / 4;             // float4 per stripe row
+    float4 pa[NLD], pb[(AM >= A_DY) ? NLD : 1];
+
+    auto issue = [&](long long tile, int kc) {
+        const long long row0 = tile * 32;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = lane + 64 * j;
+            const int r = e / C4, c = (e % C4) * 4 + kc * KC;
+            const long long row = row0 + r;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+            if (row < M && c < K) {
+                if (AM != A_DYPOOL) x = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
+                if (AM >= A_DY) y = *reinterpret_cast<const float4 *>(a.X2 + row * a.ldx + c);
+            }
+            pa[j] = x;
+            if (AM >= A_DY) pb[j] = y;
+        }
+    };
+    auto stage = [&](long long tile, int kc) {   // prefetched registers -> transformed -> wave stripe
+        const long long row0 = tile * 32;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = lane + 64 * j;
+            const int r = e / C4, cl = (e % C4) * 4, c = cl + kc * KC;
+            float4 x = pa[j];
+            if (AM != A_PLAIN) {
+                const bool in = (row0 + r < M) && (c < K);
+                if (AM == A_BNRELU) {
+                    const float4 c0 = *reinterpret_cast<const float4 *>(a.v0 + (c < K ? c : 0));
+                    const float4 c1 = *reinterpret_cast<const float4 *>(a.v1 + (c < K ? c : 0));
+                    x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
+                    x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
+                    x.z = fmaxf(fmaf(x.z, c0.z, c1.z), 0.f);
+                    x.w = fmaxf(fmaf(x.w, c0.w, c1.w), 0.f);
+                } else {
+                    const int cc = c < K ? c : 0;
+                    const float4 c0 = *reinterpret_cast<const float4 *>(a.v0 + cc);
+                    const float4 c1 = *reinterpret_cast<const float4 *>(a.v1 + cc);
+                    const float4 c2 = *reinterpret_cast<const float4 *>(a.v2 + cc);
+                    const float4 y = pb[j];
+                    float4 g = x;
+                    if (AM == A_DYPOOL) {
+                        const long long row = row0 + r;
+                        const long long gi = (row < M ? row : 0) / a.S;
+                        const int s = (int)((row < M ? row : 0) - gi * a.S);
+                        const float4 c3 = *reinterpret_cast<const float4 *>(a.v3 + cc);
+                        const float4 c4 = *reinterpret_cast<const float4 *>(a.v4 + cc);
+                        const uchar4 am = *reinterpret_cast<const uchar4 *>(a.argmax + gi * K + cc);
+                        const float4 gp = *reinterpret_cast<const float4 *>(a.gpool + gi * K + cc);
+                        g.x = (am.x == s && fmaf(y.x, c3.x, c4.x) > 0.f) ? gp.x : 0.f;
+                        g.y = (am.y == s && fmaf(y.y, c3.y, c4.y) > 0.f) ? gp.y : 0.f;
+                        g.z = (am.z == s && fmaf(y.z, c3.z, c4.z) > 0.f) ? gp.z : 0.f;
+                        g.w = (am.w == s && fmaf(y.w, c3.w, c4.w) > 0.f) ? gp.w : 0.f;
+                    }
+                    x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
+                    x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
+                    x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
+                    x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
+                }
+                if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
+        }
+    };
+
+    long long tile = (long long)blockIdx.y * 4 + wave;
+    if (tile < ntiles) issue(tile, 0);
+    for (; tile < ntiles; tile += tstride) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+
+        for (int kc = 0; kc < nchunk; ++kc) {
+            __builtin_amdgcn_wave_barrier();
+            stage(tile, kc);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // prefetch the next stripe (next K chunk of this tile, or chunk 0 of the next tile)
+            if (kc + 1 < nchunk) issue(tile, kc + 1);
+            else if (tile + tstride < ntiles) issue(tile + tstride, 0);
+
+            const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
+            const float *bcol = &Ws[(kc * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
+#pragma unroll 4
+            for (int it = 0; it < KC / 8; ++it) {
+                const float4 av = *reinterpret_cast<const float4 *>(arow + 8 * it);
+                const float ae[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float bv = bcol[(8 * it + t) * BN + 32 * nt];
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+
+        // ---- epilogue (same contract as gemm_rt_kernel)
+        const long long row0 = tile * 32;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + 32 * nt + (lane & 31);
+            const bool ncol = n < N;
+            float bias = 0.f, msc = 0.f, msh = 0.f;
+            if (EM == E_FWD && a.bias && ncol) bias = a.bias[n];
+            if (EM == E_MASK && ncol) { msc = a.msc[n]; msh = a.msh[n]; }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long long r = row0 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+                if (r < M && ncol) {
+                    float o = acc[nt][v];
+                    if (EM == E_FWD) {
+                        o += bias;
+                        s1[nt] += o;
+                        s2[nt] = fmaf(o, o, s2[nt]);
+                    } else if (EM == E_MASK) {
+                        const float yp = a.Yprev[r * a.ldy + n];
+                        o = fmaf(yp, msc, msh) > 0.f ? o : 0.f;
+                        s1[nt] += o;
+                        s2[nt] = fmaf(o, yp, s2[nt]);
+                    }
+                    a.Y[r * a.ldy + n] = o;
+                }
+            }
+        }
+    }
+
+    if (EM != E_PLAIN && a.stats) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            s1[nt] += __shfl_xor(s1[nt], 32, 64);
+            s2[nt] += __shfl_xor(s2[nt], 32, 64);
+            if (lane < 32) {
+                red[(wave * 2 + 0) * BN + 32 * nt + lane] = s1[nt];
+                red[(wave * 2 + 1) * BN + 32 * nt + lane] = s2[nt];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            if (n0 + c < N) {
+                const float v = (red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) +
+                                (red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c]);
+                a.stats[((long long)blockIdx.y * 2 + which) * N + n0 + c] = v;
+            }
+        }
+    }
+}
+
+// number of persistent workgroups along the row axis (= partial-statistics rows) for the wave-stream kernel
+static int ws_grid_rows(int M, int ncolblocks) {
+    const long long ntiles = ((long long)M + 31) / 32;
+    long long want = 512 / (ncolblocks > 0 ? ncolblocks : 1);   // ~2 workgroups per CU overall
+    if (want < 1) want = 1;
+    const long long maxg = (ntiles + 3) / 4;
+    return (int)(want < maxg ? want : maxg);
+}
+
+static bool ws_eligible(const GemmArgs &a, int am) {
+    if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
+    if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
+    if (am == A_DYPOOL && (a.K % 4 != 0)) return false;
+    return true;
+}
+
+template <int AM, int EM>
+int launch_gemm_ws(GemmArgs &a, hipStream_t st) {
+    // KC: stripe width; BN: 128 when the resident weight tile fits beside the stripes, else 64
+    const int KC = a.K <= 64 ? 64 : 128;
+    const int nchunk = (a.K + KC - 1) / KC;
+    const int Kp = nchunk * KC;
+    auto lds_bytes = [&](int bn) { return (size_t)(Kp * bn + 4 * 32 * (KC + 4) + 8 * bn) * sizeof(float); };
+    int bn = (a.N > 64 && lds_bytes(128) <= 160 * 1024) ? 128 : 64;
+    if (lds_bytes(bn) > 160 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    const int ncb = (a.N + bn - 1) / bn;
+    const int gy = ws_grid_rows(a.M, ncb);
+    const size_t lds = lds_bytes(bn);
+#define PCOPS_WS_LAUNCH(NT_, KC_)                                                                     \
+    do {                                                                                              \
+        auto kern = gemm_ws_kernel<NT_, AM, EM, KC_>;                                                 \
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),            \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                                     160 * 1024);                                     \
+        (void)once;                                                                                   \
+        hipLaunchKernelGGL(kern, dim3(ncb, gy), dim3(256), lds, st, a);                               \
+    } while (0)
+    if (bn == 128 && KC == 128) PCOPS_WS_LAUNCH(4, 128);
+    else if (bn == 128) PCOPS_WS_LAUNCH(4, 64);
+    else if (KC == 128) PCOPS_WS_LAUNCH(2, 128);
+    else PCOPS_WS_LAUNCH(2, 64);
+#undef PCOPS_WS_LAUNCH
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_mlp_stats_rows(int M);
+
+static bool ws_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_GEMM_WS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// one entry for both variants: the wave-stream kernel when the shape suits it, the tiled kernel otherwise.
+// The partial-statistics buffer always has pcops_mlp_stats_rows(M) rows; rows a kernel does not emit are zeroed.
+template <int AM, int EM>
+int launch_gemm(GemmArgs &a, hipStream_t st) {
+    if (ws_enabled() && ws_eligible(a, AM)) {
+        int rc = launch_gemm_ws<AM, EM>(a, st);
+        if (rc != PCOPS_ERR_UNSUPPORTED) {
+            if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
+                const int KC = a.K <= 64 ? 64 : 128;
+                const int Kp = (a.K + KC - 1) / KC * KC;
+                const bool big = (a.N > 64) &&
+                                 ((size_t)(Kp * 128 + 4 * 32 * (KC + 4) + 8 * 128) * sizeof(float) <= 160 * 1024);
+                const int ncb = (a.N + (big ? 128 : 64) - 1) / (big ? 128 : 64);
+                const int gy = ws_grid_rows(a.M, ncb);
+                const int P = pcops_mlp_stats_rows(a.M);
+                if (gy < P &&
+                    hipMemsetAsync(a.stats + (size_t)gy * 2 * a.N, 0, sizeof(float) * (size_t)(P - gy) * 2 * a.N, st) !=
+                        hipSuccess)
+                    return PCOPS_ERR_LAUNCH;
+            }
+            return rc;
+        }
+    }
+    return launch_gemm_rt<AM, EM>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,7 +965,8 @@ int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
 extern "C" {
 
 int pcops_mlp_stats_rows(int M) {
-    // number of row-tile groups (= partial statistics rows) gemm kernels emit for M rows
+    // upper bound of the partial-statistics rows any gemm kernel emits for M rows (buffers are sized with
+    // it; kernels that launch fewer row groups leave the tail ZERO -- see zero_stats_tail)
     const int tiles = (M + kBM - 1) / kBM;
     int tpb = 1;
     while (tiles / tpb > 4096) tpb *= 2;
@@ -701,8 +988,8 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
-    if (pro_scale) return launch_gemm_rt<A_BNRELU, E_FWD>(a, as_stream(stream));
-    return launch_gemm_rt<A_PLAIN, E_FWD>(a, as_stream(stream));
+    if (pro_scale) return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
+    return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));
 }
 
 int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
@@ -828,12 +1115,12 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
     if (gpool) {
         PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
         a.X = Y;  // alignment probe only
-        if (Yprev) return launch_gemm_rt<A_DYPOOL, E_MASK>(a, st);
-        return launch_gemm_rt<A_DYPOOL, E_PLAIN>(a, st);
+        if (Yprev) return launch_gemm<A_DYPOOL, E_MASK>(a, st);
+        return launch_gemm<A_DYPOOL, E_PLAIN>(a, st);
     }
     PCOPS_REQUIRE_PTR(G);
-    if (Yprev) return launch_gemm_rt<A_DY, E_MASK>(a, st);
-    return launch_gemm_rt<A_DY, E_PLAIN>(a, st);
+    if (Yprev) return launch_gemm<A_DY, E_MASK>(a, st);
+    return launch_gemm<A_DY, E_PLAIN>(a, st);
 }
 
 int pcops_mlp_wgrad_splits(long long M, int K, int N) {

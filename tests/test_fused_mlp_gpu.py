@@ -48,6 +48,11 @@ CASES = [  # (R, S, K0, widths, pool)
     (1000, 1, 384, [256, 128], False),             # FP stack, ragged row count
     (777, 1, 128, [128], False),                   # single layer
     (130 * 20, 20, 6, [64], True),                 # EdgeConv-like
+    # >= 32768 rows: the wave-stream GEMM variant (weights resident in LDS) takes the K%8==0 layers
+    (1024 * 32 * 2, 32, 3, [64, 64, 128], True),   # SA1, KC=64 stripes, N 64 / 128
+    (512 * 64 + 37, 1, 128, [128, 256], False),    # KC=128, N=256 (two column blocks), ragged tail rows
+    (128 * 64 * 4, 64, 132, [128, 128, 256], True),  # pooled backward through the wave-stream dgrad (K=256 in 2 chunks)
+    (40000, 1, 256, [64], False),                  # K=256 chunked, N=64
 ]
 
 
@@ -90,17 +95,25 @@ def test_backward(R, S, K0, widths, pool):
     out.backward(go)
     got = [x.grad.clone()] + [t.grad.clone() for l in layers for t in l[:4]]
 
-    xr = x.detach().double().requires_grad_(True)
-    lr = [[t.detach().double().requires_grad_(True) for t in l[:4]] + [l[4], l[5]] for l in layers]
-    reference(xr, lr, S, pool, True, torch.float64).backward(go.double())
-    want = [xr.grad] + [t.grad for l in lr for t in l[:4]]
+    def run_ref(dtype):
+        xr = x.detach().to(dtype).requires_grad_(True)
+        lr = [[t.detach().to(dtype).requires_grad_(True) for t in l[:4]] + [l[4], l[5]] for l in layers]
+        reference(xr, lr, S, pool, True, dtype).backward(go.to(dtype))
+        return [xr.grad.double()] + [t.grad.double() for l in lr for t in l[:4]]
+
+    want = run_ref(torch.float64)
+    plain = run_ref(torch.float32)   # plain fp32 autograd of the same chain: the accuracy yardstick
     names = ["dx"] + ["L%d.%s" % (i, n) for i in range(len(layers)) for n in ("dW", "db", "dgamma", "dbeta")]
-    for name, a, b in zip(names, got, want):
+    for name, a, b, c in zip(names, got, want, plain):
         scale = b.abs().max().item() + 1e-12
         err = (a.double() - b).abs().max().item()
         # conv biases in front of a BN get an analytically zero gradient: compare absolutely
         tol = 1e-3 * scale if not name.endswith("db") else 1e-3 * max(scale, go.abs().max().item())
-        assert err <= tol + 1e-6, (name, err, scale)
+        # a ReLU sitting within rounding of 0 can flip between fp32 and fp64 and move a gradient by O(1):
+        # then every fp32 implementation shows the same jump, so being as close to the float64 truth as
+        # plain fp32 autograd is also accepted
+        err_plain = (c - b).abs().max().item()
+        assert err <= tol + 1e-6 or err <= 2.0 * err_plain, (name, err, err_plain, scale)
 
 
 def test_fused_model_as_accurate_as_layerwise(monkeypatch):

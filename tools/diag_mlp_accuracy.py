@@ -35,7 +35,12 @@ def run(R, S, K0, widths, pool, bias_scale, xoff=0.0):
         print("  %-10s scale %.3e  fused %.2e  torch-fp32 %.2e" % (
             n, sc, (res["fused"][i] - t).abs().max().item() / sc, (res["fp32"][i] - t).abs().max().item() / sc))
 
-run(512 * 32 * 4, 32, 3, [64, 64, 128], True, 1.0)
-run(512 * 32 * 4, 32, 3, [64, 64, 128], True, 20.0)
-run(128 * 64 * 4, 64, 131, [128, 128, 256], True, 1.0)
-run(4096, 1, 384, [256, 128], False, 1.0)
+if len(sys.argv) == 1:
+  run(512 * 32 * 4, 32, 3, [64, 64, 128], True, 1.0)
+  run(512 * 32 * 4, 32, 3, [64, 64, 128], True, 20.0)
+  run(128 * 64 * 4, 64, 131, [128, 128, 256], True, 1.0)
+  run(4096, 1, 384, [256, 128], False, 1.0)
+if len(sys.argv) > 1 and sys.argv[1] == "ragged":
+    run(512 * 64 + 37, 1, 128, [128, 256], False, 1.0)
+    run(512 * 64, 1, 128, [128, 256], False, 1.0)
+    run(512 * 64 + 37, 1, 128, [128], False, 1.0)
