@@ -283,28 +283,42 @@ int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------------
 // gemm_ws: "wave-stream" variant of the same GEMM for the big-row / small-K layers (K <= 256 staged in
-// chunks of <= 128, N tile 64|128): the weight tile stays RESIDENT in LDS for the life of a persistent
-// workgroup, and every wave streams its own 32-row tiles independently -- coalesced 16-byte global loads
-// prefetched one tile ahead in registers, operand transform applied on the way into a wave-private LDS
-// stripe, fragments read back with ds_read_b128 -- so the main loop has NO workgroup barrier at all.
+// stripes of <= 128, N tile 64|128): the weight tile and every per-channel coefficient vector stay RESIDENT
+// in LDS for the life of a persistent workgroup, and every wave streams its own 32-row tiles independently:
+//   * all global reads of a tile (operand stripes, the mask tensor of the epilogue, pooled-gradient side
+//     inputs) are issued one stage AHEAD as coalesced 16-byte loads into registers, with clamped addresses
+//     instead of branches; nothing is loaded right before it is needed, so the only vmcnt waits are for data
+//     requested a whole tile earlier and the epilogue's stores never have to drain (gfx950 counts loads and
+//     stores on one vmcnt);
+//   * the operand transform is applied on the way into a wave-private LDS stripe; fragments come back with
+//     ds_read_b128 (label-permutation trick, see header);
+//   * the accumulator tile is transposed through the same stripe so that outputs leave as 16-byte stores of
+//     whole 512-byte row segments, and the per-channel statistics accumulate in the lane that owns the column;
+//   * the main loop contains NO workgroup barrier.
 template <int NT, int AM, int EM, int KC>
 __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
     constexpr int BN = NT * 32;
-    constexpr int LDW = KC + 4;            // wave stripe row stride (floats): 16 B aligned, conflict-free b128
-    constexpr int NLD = KC / 8;            // float4 loads per lane per 32 x KC stripe
+    constexpr int LDW = (KC > BN ? KC : BN) + 4;   // stripe row stride (floats): 16 B aligned, conflict-free b128
+    constexpr int C4 = KC / 4;                     // float4 per operand stripe row
+    constexpr int NLD = KC / 8;                    // float4 per lane per 32 x KC operand stripe
+    constexpr int O4 = BN / 4;                     // float4 per output tile row
+    constexpr int NST = BN / 8;                    // float4 per lane per 32 x BN output tile
+    constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : 5));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = a.M, K = a.K, N = a.N;
     const int nchunk = (K + KC - 1) / KC;
     const int Kp = nchunk * KC;
-    float *Ws = lds;                                   // [Kp][BN]
-    float *Aw = lds + (size_t)Kp * BN + wave * 32 * LDW;   // [32][LDW] per wave
-    float *red = lds + (size_t)Kp * BN + 4 * 32 * LDW; // [4][2][BN]
+    float *Ws = lds;                                        // [Kp][BN]
+    float *coef = Ws + (size_t)Kp * BN;                     // [5][Kp]
+    float *ecoef = coef + 5 * Kp;                           // [2][BN]: bias | (mask scale, mask shift)
+    float *Aw = ecoef + 2 * BN + wave * 32 * LDW;           // [32][LDW] per wave
+    float *red = ecoef + 2 * BN + 4 * 32 * LDW;             // [4][2][BN]
     const int n0 = blockIdx.x * BN;
 
-    // ---- weights: loaded once per workgroup
-    for (int e = tid; e < Kp * (BN / 4); e += 256) {
-        const int k = e / (BN / 4), nq = (e % (BN / 4)) * 4;
+    // ---- resident data: weights + coefficient vectors, loaded once per workgroup
+    for (int e = tid; e < Kp * O4; e += 256) {
+        const int k = e / O4, nq = (e % O4) * 4;
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
             const float *src = a.W + (long long)k * N;
@@ -320,98 +334,139 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
         }
         *reinterpret_cast<float4 *>(&Ws[k * BN + nq]) = w;
     }
+    {
+        const float *vs[5] = {a.v0, a.v1, a.v2, a.v3, a.v4};
+        for (int e = tid; e < NCOEF * Kp; e += 256) {
+            const int which = e / Kp, k = e % Kp;
+            coef[which * Kp + k] = k < K ? vs[which][k] : 0.f;
+        }
+        for (int e = tid; e < BN; e += 256) {
+            const int n = n0 + e;
+            float e0 = 0.f, e1 = 0.f;
+            if (n < N) {
+                if (EM == E_FWD && a.bias) e0 = a.bias[n];
+                if (EM == E_MASK) { e0 = a.msc[n]; e1 = a.msh[n]; }
+            }
+            ecoef[e] = e0;
+            ecoef[BN + e] = e1;
+        }
+    }
     __syncthreads();
 
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) s1[i] = s2[i] = 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // statistics of this lane's 4 columns
+    const int ocq = (lane % O4) * 4;                 // this lane's output column quad (fixed: 64 % O4 == 0)
+    const bool ocin = n0 + ocq < N;                  // N % 4 == 0 is required by the launcher for this kernel
+    float4 eb = make_float4(0.f, 0.f, 0.f, 0.f), em = eb;
+    eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
+    em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
 
     const long long ntiles = ((long long)M + 31) / 32;
     const long long tstride = (long long)gridDim.y * 4;
-    // stripe coordinates of this lane's j-th float4: element index e = lane + 64 j -> (row, col4)
-    constexpr int C4 = KC / 4;             // float4 per stripe row
-    float4 pa[NLD], pb[(AM >= A_DY) ? NLD : 1];
+    float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
+    float4 pb[(AM >= A_DY) ? NLD : 1];               // A_DY*: raw Y
+    unsigned pm[(AM == A_DYPOOL) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
+    float4 py[(EM == E_MASK) ? NST : 1];             // E_MASK: raw Y of the previous layer (output shaped)
 
-    auto issue = [&](long long tile, int kc) {
+    auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int e = lane + 64 * j;
-            const int r = e / C4, c = (e % C4) * 4 + kc * KC;
-            const long long row = row0 + r;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-            if (row < M && c < K) {
-                if (AM != A_DYPOOL) x = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
-                if (AM >= A_DY) y = *reinterpret_cast<const float4 *>(a.X2 + row * a.ldx + c);
+            const int r = e / C4;
+            int c = (e % C4) * 4 + kc * KC;
+            c = c < K ? c : K - 4;
+            long long row = row0 + r;
+            row = row < M ? row : M - 1;
+            if (AM == A_DYPOOL) {
+                const long long gi = row / a.S;
+                pa[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
+                pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
+            } else {
+                pa[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
             }
-            pa[j] = x;
-            if (AM >= A_DY) pb[j] = y;
+            if (AM >= A_DY) pb[j] = *reinterpret_cast<const float4 *>(a.X2 + row * a.ldx + c);
         }
     };
-    auto stage = [&](long long tile, int kc) {   // prefetched registers -> transformed -> wave stripe
+    auto issue_epi = [&](long long tile) {
+        if (EM == E_MASK) {
+            const long long row0 = tile * 32;
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int e = lane + 64 * j;
+                long long row = row0 + e / O4;
+                row = row < M ? row : M - 1;
+                const int n = ocin ? n0 + ocq : 0;
+                py[j] = *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldy + n);
+            }
+        }
+    };
+    auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
         const long long row0 = tile * 32;
+        const int cl = (lane % C4) * 4;              // fixed per lane (64 % C4 == 0)
+        const int c = cl + kc * KC;
+        float4 c0, c1, c2, c3, c4;
+        if (NCOEF >= 2) {
+            c0 = *reinterpret_cast<const float4 *>(&coef[0 * Kp + c]);
+            c1 = *reinterpret_cast<const float4 *>(&coef[1 * Kp + c]);
+        }
+        if (NCOEF >= 3) c2 = *reinterpret_cast<const float4 *>(&coef[2 * Kp + c]);
+        if (NCOEF >= 5) {
+            c3 = *reinterpret_cast<const float4 *>(&coef[3 * Kp + c]);
+            c4 = *reinterpret_cast<const float4 *>(&coef[4 * Kp + c]);
+        }
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int e = lane + 64 * j;
-            const int r = e / C4, cl = (e % C4) * 4, c = cl + kc * KC;
+            const int r = (lane + 64 * j) / C4;
+            const bool in = (row0 + r < M) && (c < K);
             float4 x = pa[j];
-            if (AM != A_PLAIN) {
-                const bool in = (row0 + r < M) && (c < K);
-                if (AM == A_BNRELU) {
-                    const float4 c0 = *reinterpret_cast<const float4 *>(a.v0 + (c < K ? c : 0));
-                    const float4 c1 = *reinterpret_cast<const float4 *>(a.v1 + (c < K ? c : 0));
-                    x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
-                    x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
-                    x.z = fmaxf(fmaf(x.z, c0.z, c1.z), 0.f);
-                    x.w = fmaxf(fmaf(x.w, c0.w, c1.w), 0.f);
-                } else {
-                    const int cc = c < K ? c : 0;
-                    const float4 c0 = *reinterpret_cast<const float4 *>(a.v0 + cc);
-                    const float4 c1 = *reinterpret_cast<const float4 *>(a.v1 + cc);
-                    const float4 c2 = *reinterpret_cast<const float4 *>(a.v2 + cc);
-                    const float4 y = pb[j];
-                    float4 g = x;
-                    if (AM == A_DYPOOL) {
-                        const long long row = row0 + r;
-                        const long long gi = (row < M ? row : 0) / a.S;
-                        const int s = (int)((row < M ? row : 0) - gi * a.S);
-                        const float4 c3 = *reinterpret_cast<const float4 *>(a.v3 + cc);
-                        const float4 c4 = *reinterpret_cast<const float4 *>(a.v4 + cc);
-                        const uchar4 am = *reinterpret_cast<const uchar4 *>(a.argmax + gi * K + cc);
-                        const float4 gp = *reinterpret_cast<const float4 *>(a.gpool + gi * K + cc);
-                        g.x = (am.x == s && fmaf(y.x, c3.x, c4.x) > 0.f) ? gp.x : 0.f;
-                        g.y = (am.y == s && fmaf(y.y, c3.y, c4.y) > 0.f) ? gp.y : 0.f;
-                        g.z = (am.z == s && fmaf(y.z, c3.z, c4.z) > 0.f) ? gp.z : 0.f;
-                        g.w = (am.w == s && fmaf(y.w, c3.w, c4.w) > 0.f) ? gp.w : 0.f;
-                    }
-                    x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
-                    x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
-                    x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
-                    x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
+            if (AM == A_BNRELU) {
+                x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
+                x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
+                x.z = fmaxf(fmaf(x.z, c0.z, c1.z), 0.f);
+                x.w = fmaxf(fmaf(x.w, c0.w, c1.w), 0.f);
+            } else if (AM >= A_DY) {
+                const float4 y = pb[j];
+                float4 g = x;
+                if (AM == A_DYPOOL) {
+                    const long long row = row0 + r;
+                    const int s = (int)(row % a.S);
+                    const unsigned am = pm[j];
+                    g.x = ((am & 0xffu) == (unsigned)s && fmaf(y.x, c3.x, c4.x) > 0.f) ? x.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == (unsigned)s && fmaf(y.y, c3.y, c4.y) > 0.f) ? x.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == (unsigned)s && fmaf(y.z, c3.z, c4.z) > 0.f) ? x.z : 0.f;
+                    g.w = ((am >> 24) == (unsigned)s && fmaf(y.w, c3.w, c4.w) > 0.f) ? x.w : 0.f;
                 }
-                if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
+                x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
+                x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
+                x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
             }
+            if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
         }
     };
 
     long long tile = (long long)blockIdx.y * 4 + wave;
-    if (tile < ntiles) issue(tile, 0);
+    if (tile < ntiles) {
+        issue(tile, 0);
+        issue_epi(tile);
+    }
     for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        const bool more = tile + tstride < ntiles;
 
         for (int kc = 0; kc < nchunk; ++kc) {
             __builtin_amdgcn_wave_barrier();
             stage(tile, kc);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // prefetch the next stripe (next K chunk of this tile, or chunk 0 of the next tile)
+            // next stripe: the next K chunk of this tile, or chunk 0 of this wave's next tile
             if (kc + 1 < nchunk) issue(tile, kc + 1);
-            else if (tile + tstride < ntiles) issue(tile + tstride, 0);
+            else if (more) issue(tile + tstride, 0);
 
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
             const float *bcol = &Ws[(kc * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
@@ -431,44 +486,59 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        // ---- epilogue (same contract as gemm_rt_kernel)
+        // ---- epilogue: accumulators -> stripe (transposed) -> 16-byte row-segment stores
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                Aw[((v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)) * LDW + 32 * nt + (lane & 31)] = acc[nt][v];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const long long row0 = tile * 32;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + 32 * nt + (lane & 31);
-            const bool ncol = n < N;
-            float bias = 0.f, msc = 0.f, msh = 0.f;
-            if (EM == E_FWD && a.bias && ncol) bias = a.bias[n];
-            if (EM == E_MASK && ncol) { msc = a.msc[n]; msh = a.msh[n]; }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const long long r = row0 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                if (r < M && ncol) {
-                    float o = acc[nt][v];
-                    if (EM == E_FWD) {
-                        o += bias;
-                        s1[nt] += o;
-                        s2[nt] = fmaf(o, o, s2[nt]);
-                    } else if (EM == E_MASK) {
-                        const float yp = a.Yprev[r * a.ldy + n];
-                        o = fmaf(yp, msc, msh) > 0.f ? o : 0.f;
-                        s1[nt] += o;
-                        s2[nt] = fmaf(o, yp, s2[nt]);
-                    }
-                    a.Y[r * a.ldy + n] = o;
+        for (int j = 0; j < NST; ++j) {
+            const int r = (lane + 64 * j) / O4;
+            const long long row = row0 + r;
+            float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocq]);
+            if (row < M && ocin) {
+                if (EM == E_FWD) {
+                    o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
+                    s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
+                    s2[0] = fmaf(o.x, o.x, s2[0]); s2[1] = fmaf(o.y, o.y, s2[1]);
+                    s2[2] = fmaf(o.z, o.z, s2[2]); s2[3] = fmaf(o.w, o.w, s2[3]);
+                } else if (EM == E_MASK) {
+                    const float4 yp = py[j];
+                    o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
+                    o.y = fmaf(yp.y, eb.y, em.y) > 0.f ? o.y : 0.f;
+                    o.z = fmaf(yp.z, eb.z, em.z) > 0.f ? o.z : 0.f;
+                    o.w = fmaf(yp.w, eb.w, em.w) > 0.f ? o.w : 0.f;
+                    s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
+                    s2[0] = fmaf(o.x, yp.x, s2[0]); s2[1] = fmaf(o.y, yp.y, s2[1]);
+                    s2[2] = fmaf(o.z, yp.z, s2[2]); s2[3] = fmaf(o.w, yp.w, s2[3]);
                 }
+                *reinterpret_cast<float4 *>(a.Y + row * a.ldy + n0 + ocq) = o;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (more) issue_epi(tile + tstride);
     }
 
     if (EM != E_PLAIN && a.stats) {
+        // lanes l, l + O4, l + 2 O4 ... own the same 4 columns
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            s1[nt] += __shfl_xor(s1[nt], 32, 64);
-            s2[nt] += __shfl_xor(s2[nt], 32, 64);
-            if (lane < 32) {
-                red[(wave * 2 + 0) * BN + 32 * nt + lane] = s1[nt];
-                red[(wave * 2 + 1) * BN + 32 * nt + lane] = s2[nt];
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int off = 32; off >= O4; off >>= 1) {
+                s1[e] += __shfl_xor(s1[e], off, 64);
+                s2[e] += __shfl_xor(s2[e], off, 64);
+            }
+        }
+        if (lane < O4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(wave * 2 + 0) * BN + ocq + e] = s1[e];
+                red[(wave * 2 + 1) * BN + ocq + e] = s2[e];
             }
         }
         __syncthreads();
@@ -483,6 +553,12 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
     }
 }
 
+static size_t ws_lds_bytes(int Kp, int KC, int bn) {
+    // weights + 5 coefficient vectors + 2 epilogue vectors + 4 wave stripes + statistics scratch
+    const int ldw = (KC > bn ? KC : bn) + 4;
+    return (size_t)(Kp * bn + 5 * Kp + 2 * bn + 4 * 32 * ldw + 8 * bn) * sizeof(float);
+}
+
 // number of persistent workgroups along the row axis (= partial-statistics rows) for the wave-stream kernel
 static int ws_grid_rows(int M, int ncolblocks) {
     const long long ntiles = ((long long)M + 31) / 32;
@@ -494,7 +570,10 @@ static int ws_grid_rows(int M, int ncolblocks) {
 
 static bool ws_eligible(const GemmArgs &a, int am) {
     if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
-    if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0) return false;
+    if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
+    if (am == A_DYPOOL && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
+        return false;
     if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
     if (am == A_DYPOOL && (a.K % 4 != 0)) return false;
     return true;
@@ -506,7 +585,7 @@ int launch_gemm_ws(GemmArgs &a, hipStream_t st) {
     const int KC = a.K <= 64 ? 64 : 128;
     const int nchunk = (a.K + KC - 1) / KC;
     const int Kp = nchunk * KC;
-    auto lds_bytes = [&](int bn) { return (size_t)(Kp * bn + 4 * 32 * (KC + 4) + 8 * bn) * sizeof(float); };
+    auto lds_bytes = [&](int bn) { return ws_lds_bytes(Kp, KC, bn); };
     int bn = (a.N > 64 && lds_bytes(128) <= 160 * 1024) ? 128 : 64;
     if (lds_bytes(bn) > 160 * 1024) return PCOPS_ERR_UNSUPPORTED;
     const int ncb = (a.N + bn - 1) / bn;
@@ -549,8 +628,7 @@ int launch_gemm(GemmArgs &a, hipStream_t st) {
             if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
                 const int KC = a.K <= 64 ? 64 : 128;
                 const int Kp = (a.K + KC - 1) / KC * KC;
-                const bool big = (a.N > 64) &&
-                                 ((size_t)(Kp * 128 + 4 * 32 * (KC + 4) + 8 * 128) * sizeof(float) <= 160 * 1024);
+                const bool big = (a.N > 64) && (ws_lds_bytes(Kp, KC, 128) <= 160 * 1024);
                 const int ncb = (a.N + (big ? 128 : 64) - 1) / (big ? 128 : 64);
                 const int gy = ws_grid_rows(a.M, ncb);
                 const int P = pcops_mlp_stats_rows(a.M);
