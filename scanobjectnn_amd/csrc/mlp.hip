@@ -1009,6 +1009,222 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             if (n0 + i < N) a.dbpart[(long long)blockIdx.z * N + n0 + i] = redb[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad_ws: wave-stream weight gradient.  Same operand contract as wgrad_kernel, different machine mapping:
+// persistent workgroups, every wave owns its own row stripes and a PRIVATE (32 TK x 32 TN) accumulator tile;
+// the stripes of all three source tensors are prefetched one stripe ahead with 16-byte loads, transformed
+// (BN+ReLU on the A side, dY = p.G + q.Y + t on the other) on their way into wave-private LDS, and read back
+// as fragments with conflict-free ds_read_b32 (lane = channel, half-wave = row parity).  No workgroup barrier
+// in the main loop; coefficient vectors live in LDS; the four wave tiles are summed through LDS at the end
+// and each workgroup writes ONE partial tile (summed deterministically by sum_partials_kernel).
+template <int TK, int TN, int RS, int AMODE, int DMODE>
+__global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
+    constexpr int KB = 32 * TK, NB = 32 * TN;
+    constexpr int A4 = KB / 4, D4 = NB / 4;            // float4 per stripe row
+    constexpr int NA = RS * A4 / 64, ND = RS * D4 / 64; // float4 per lane per stripe
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, N = a.N;
+    const long long M = a.M;
+    const int k0 = blockIdx.x * KB, n0 = blockIdx.y * NB;
+    float *coefA = lds;                       // [2][KB]  scale, shift (A side)
+    float *coefD = coefA + 2 * KB;            // [5][NB]  p, q, t, pool scale, pool shift
+    float *As = coefD + 5 * NB + wave * RS * (KB + NB);   // [RS][KB]
+    float *Ds = As + RS * KB;                 // [RS][NB]
+    float *red = coefD + 5 * NB + 4 * RS * (KB + NB);     // [KB][NB] + [NB]
+
+    for (int e = tid; e < KB; e += 256) {
+        const int k = k0 + e;
+        const bool in = k < K;
+        coefA[e] = (AMODE == A_BNRELU && in) ? a.asc[k] : 0.f;
+        coefA[KB + e] = (AMODE == A_BNRELU && in) ? a.ash[k] : 0.f;
+    }
+    for (int e = tid; e < NB; e += 256) {
+        const int n = n0 + e;
+        const bool in = n < N;
+        coefD[e] = in ? a.p[n] : 0.f;
+        coefD[NB + e] = in ? a.q[n] : 0.f;
+        coefD[2 * NB + e] = in ? a.t[n] : 0.f;
+        coefD[3 * NB + e] = (DMODE == A_DYPOOL && in) ? a.dsc[n] : 0.f;
+        coefD[4 * NB + e] = (DMODE == A_DYPOOL && in) ? a.dsh[n] : 0.f;
+    }
+    __syncthreads();
+
+    // fixed per-lane stripe coordinates: element e = lane + 64 j -> (row e / X4, column quad e % X4)
+    const int acq = (lane % A4) * 4, dcq = (lane % D4) * 4;
+    const bool ain = k0 + acq < K, din = n0 + dcq < N;        // K % 4 == 0 and N % 4 == 0 (launcher)
+    const int acl = ain ? k0 + acq : 0, dcl = din ? n0 + dcq : 0;
+    const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
+    const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+    const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
+    const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
+    const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
+    const float4 cds = *reinterpret_cast<const float4 *>(&coefD[3 * NB + dcq]);
+    const float4 cdh = *reinterpret_cast<const float4 *>(&coefD[4 * NB + dcq]);
+
+    f32x16 acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float4 px[NA], pg[ND], py[ND];
+    unsigned pm[(DMODE == A_DYPOOL) ? ND : 1];
+    const long long nstripes = (M + RS - 1) / RS;
+    const long long sstride = (long long)gridDim.z * 4;
+
+    auto issue = [&](long long stripe) {
+        const long long row0 = stripe * RS;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            long long row = row0 + (lane + 64 * j) / A4;
+            row = row < M ? row : M - 1;
+            px[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + acl);
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            long long row = row0 + (lane + 64 * j) / D4;
+            row = row < M ? row : M - 1;
+            py[j] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + dcl);
+            if (DMODE == A_DYPOOL) {
+                const long long gi = row / a.S;
+                pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+            } else {
+                pg[j] = *reinterpret_cast<const float4 *>(a.G + row * a.ldy + dcl);
+            }
+        }
+    };
+    auto stage = [&](long long stripe) {
+        const long long row0 = stripe * RS;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int r = (lane + 64 * j) / A4;
+            float4 x = px[j];
+            if (AMODE == A_BNRELU) {
+                x.x = fmaxf(fmaf(x.x, casc.x, cash.x), 0.f);
+                x.y = fmaxf(fmaf(x.y, casc.y, cash.y), 0.f);
+                x.z = fmaxf(fmaf(x.z, casc.z, cash.z), 0.f);
+                x.w = fmaxf(fmaf(x.w, casc.w, cash.w), 0.f);
+            }
+            if (!(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(&As[r * KB + acq]) = x;
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int r = (lane + 64 * j) / D4;
+            const float4 y = py[j];
+            float4 g = pg[j];
+            if (DMODE == A_DYPOOL) {
+                const unsigned s = (unsigned)((row0 + r) % a.S);
+                const unsigned am = pm[j];
+                g.x = ((am & 0xffu) == s && fmaf(y.x, cds.x, cdh.x) > 0.f) ? g.x : 0.f;
+                g.y = (((am >> 8) & 0xffu) == s && fmaf(y.y, cds.y, cdh.y) > 0.f) ? g.y : 0.f;
+                g.z = (((am >> 16) & 0xffu) == s && fmaf(y.z, cds.z, cdh.z) > 0.f) ? g.z : 0.f;
+                g.w = ((am >> 24) == s && fmaf(y.w, cds.w, cdh.w) > 0.f) ? g.w : 0.f;
+            }
+            float4 d;
+            d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
+            d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
+            d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
+            d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+            if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
+            *reinterpret_cast<float4 *>(&Ds[r * NB + dcq]) = d;
+        }
+    };
+
+    long long stripe = (long long)blockIdx.z * 4 + wave;
+    if (stripe < nstripes) issue(stripe);
+    const int half = lane >> 5, li = lane & 31;
+    for (; stripe < nstripes; stripe += sstride) {
+        __builtin_amdgcn_wave_barrier();
+        stage(stripe);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (stripe + sstride < nstripes) issue(stripe + sstride);
+#pragma unroll 2
+        for (int it = 0; it < RS / 2; ++it) {
+            float av[TK], dv[TN];
+#pragma unroll
+            for (int i = 0; i < TK; ++i) av[i] = As[(2 * it + half) * KB + 32 * i + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dv[j] = Ds[(2 * it + half) * NB + 32 * j + li];
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], dv[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- sum the four wave tiles (and db) through LDS, write this workgroup's partial
+    // acc[i][j][v]: A channel 32 i + (v&3) + 8 (v>>2) + 4 half, dY channel 32 j + li
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        float *dst = &red[(32 * i + (v & 3) + 8 * (v >> 2) + 4 * half) * NB + 32 * j + li];
+                        *dst = (w == 0 ? 0.f : *dst) + acc[i][j][v];
+                    }
+            // lanes l, l + D4, ... own the same 4 dY columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = dbs[e];
+#pragma unroll
+                for (int off = 32; off >= D4; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (lane < D4) red[KB * NB + dcq + e] = (w == 0 ? 0.f : red[KB * NB + dcq + e]) + s;
+            }
+        }
+    }
+    __syncthreads();
+    float *out = a.part + (long long)blockIdx.z * K * N;
+    for (int i = tid; i < KB * NB; i += 256) {
+        const int kl = i / NB, nl = i % NB;
+        if (k0 + kl < K && n0 + nl < N) out[(long long)(k0 + kl) * N + n0 + nl] = red[i];
+    }
+    if (blockIdx.x == 0 && a.dbpart)
+        for (int i = tid; i < NB; i += 256)
+            if (n0 + i < N) a.dbpart[(long long)blockIdx.z * N + n0 + i] = red[KB * NB + i];
+}
+
+struct WsWgradPlan {
+    int tk, tn, rs, kblocks, nblocks, groups;
+    size_t lds;
+};
+
+static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
+                          const void *gpool, const void *argmax, WsWgradPlan *pl) {
+    if (M < 16 * 1024) return false;
+    if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
+        (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return false;
+    if (K <= 64 && N <= 64) { pl->tk = 2; pl->tn = 2; pl->rs = 32; }
+    else if (K <= 64) { pl->tk = 2; pl->tn = 4; pl->rs = 32; }
+    else { pl->tk = 4; pl->tn = 4; pl->rs = 16; }
+    const int KB = 32 * pl->tk, NB = 32 * pl->tn;
+    pl->kblocks = (K + KB - 1) / KB;
+    pl->nblocks = (N + NB - 1) / NB;
+    int groups = 512 / (pl->kblocks * pl->nblocks);    // ~2 workgroups per CU over the whole grid
+    if (groups < 1) groups = 1;
+    const long long maxg = ((M + pl->rs - 1) / pl->rs + 3) / 4;
+    if (groups > maxg) groups = (int)maxg;
+    pl->groups = groups;
+    pl->lds = (size_t)(2 * KB + 5 * NB + 4 * pl->rs * (KB + NB) + KB * NB + NB) * sizeof(float);
+    return pl->lds <= 160 * 1024;
+}
+
 // sum partials [P][L] -> out[L] (deterministic), one thread per element
 __global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, const float *__restrict__ part,
                                                            float *__restrict__ out) {
@@ -1202,7 +1418,19 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
 }
 
 int pcops_mlp_wgrad_splits(long long M, int K, int N) {
-    // row slices: enough blocks to fill the chip ~4x, at most 512 partial copies
+    // upper bound of the partial copies either wgrad kernel writes (scratch is sized with it)
+    const int kb = (K + 63) / 64, nb = (N + 127) / 128;
+    long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    long long rows = (M + want - 1) / want;
+    rows = ((rows + 7) / 8) * 8;
+    if (rows < 8) rows = 8;
+    int legacy = (int)((M + rows - 1) / rows);
+    return legacy < 512 ? 512 : legacy;
+}
+
+static int wgrad_legacy_splits(long long M, int K, int N) {
     const int kb = (K + 63) / 64, nb = (N + 127) / 128;
     long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
     if (want < 1) want = 1;
@@ -1224,16 +1452,44 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
     hipStream_t st = as_stream(stream);
-    const int splits = pcops_mlp_wgrad_splits(M, K, N);
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
     WgradArgs a = {};
     a.M = M; a.K = K; a.N = N;
-    a.rows_per_block = (int)((((M + splits - 1) / splits) + 7) / 8 * 8);
     a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = X; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
     a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
     a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
-    a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-    if (!gpool) PCOPS_REQUIRE_PTR(G);
-    hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3((K + 63) / 64, (N + 127) / 128, splits), dim3(256), 0, st, a);
+    int splits;
+    WsWgradPlan pl;
+    if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
+        splits = pl.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(pl.kblocks, pl.nblocks, pl.groups);
+#define PCOPS_WG_LAUNCH(TK_, TN_, RS_, AM_, DM_)                                                           \
+    do {                                                                                                   \
+        auto kern = wgrad_ws_kernel<TK_, TN_, RS_, AM_, DM_>;                                              \
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                 \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)once;                                                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, a);                                          \
+    } while (0)
+#define PCOPS_WG_MODES(TK_, TN_, RS_)                                                                      \
+    do {                                                                                                   \
+        if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DY);        \
+        else if (a.amode == A_BNRELU) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DYPOOL);                  \
+        else if (a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DY);                           \
+        else PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DYPOOL);                                            \
+    } while (0)
+        if (pl.tk == 2 && pl.tn == 2) PCOPS_WG_MODES(2, 2, 32);
+        else if (pl.tk == 2) PCOPS_WG_MODES(2, 4, 32);
+        else PCOPS_WG_MODES(4, 4, 16);
+#undef PCOPS_WG_MODES
+#undef PCOPS_WG_LAUNCH
+    } else {
+        splits = wgrad_legacy_splits(M, K, N);
+        a.rows_per_block = (int)((((M + splits - 1) / splits) + 7) / 8 * 8);
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3((K + 63) / 64, (N + 127) / 128, splits), dim3(256), 0, st, a);
+    }
     int rc = pcops_launch_status();
     if (rc) return rc;
     const long long L = (long long)K * N;
