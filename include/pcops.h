@@ -190,6 +190,22 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
                     pcops_stream_t stream);
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
 
+/* --------------------------------------------- first grouped layer in front of the grouping (gather.hip)
+ * A 1x1 conv is linear: concat(xyz[idx] - new_xyz, points[idx]) W = (xyz W_xyz + points W_f)[idx] - new_xyz W_xyz
+ * (pointnet2/utils/pointnet_util.py:44-54,117-122; EdgeConv: dgcnn/utils/tf_util.py:699-705 + dgcnn.py:39-44), so
+ * the contraction runs once per SOURCE point and the (b,m,s,c) activation is a gather + add:
+ *     Y[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:]        Q (b,n,c), Ctr (b,m,c), idx (b,m,s)
+ * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y). */
+int pcops_sa_gather_stats_rows(long long groups);
+int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
+                        float *Y, float *stats_partial, pcops_stream_t stream);
+/* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
+ * pcops_mlp_gemm_dgrad); dQ (b,n,c) = scatter-add of dY over idx (zeroed here), dCtr (b,m,c) = sum over s */
+int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
+                         const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                         const float *pool_scale, const float *pool_shift, const int *idx, float *dQ,
+                         float *dCtr, pcops_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,13 +1,19 @@
 """Fused shared-MLP stack: L x [1x1 conv + bias + BatchNorm + ReLU] (+ max-pool over the neighbourhood),
-forward and backward, on the hand-written fp32-MFMA kernels of libpcops (csrc/mlp.hip).
+forward and backward, on the hand-written fp32-MFMA kernels of libpcops (csrc/mlp.hip, csrc/gather.hip).
 
 This is the device-side replacement for the per-layer TensorFlow op chain the reference builds in
 `pointnet_sa_module` / `pointnet_fp_module` / EdgeConv (pointnet2/utils/pointnet_util.py:117-127,223-227;
 pointnet2/utils/tf_util.py:120-185,512-531; dgcnn/models/dgcnn.py:39-48): each layer is ONE pass over the
 activations in each direction (BN+ReLU of the previous layer folded into the operand load, batch statistics
 emitted by the GEMM epilogue, BN backward folded into three per-channel vectors).  Same math as the
-layer-by-layer path (`tf_util.conv2d` in sequence): batch mean / biased variance in training, eps, decay and
+layer-by-layer path (`tf_util.conv2d` in sequence): batch mean / biased variance in training; eps, decay and
 moving-average semantics are parameters so both BN flavours of the reference are covered.
+
+Two kinds of first layer:
+  dense   Y1 = X W1 + b1 on a materialised (rows, K) input (FP stacks, group_all, anything already grouped);
+  gather  Y1[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] -- the first conv of a GROUPED stack applied before
+          the grouping (it is linear; see csrc/gather.hip), so neither the grouped input nor a (3+C)-wide
+          concat is ever built and its backward is one scatter-add.
 """
 import torch
 
@@ -28,32 +34,52 @@ def _workspace(n, dev):
     return torch.empty(int(lib.pcops_mlp_reduce_workspace_bytes(n)) // 8, dtype=torch.float64, device=dev)
 
 
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
 class FusedMLPStack(torch.autograd.Function):
-    """apply(x2d, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
-    per_layer (6 each): weights (K,N)-viewable, biases (N), gamma, beta, moving_mean, moving_var
-    x2d: (R, K0) fp32 contiguous.  Returns (R//S, C_L) if pool else (R, C_L)."""
+    """apply(a0, a1, a2, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
+
+    dense first layer : a0 = x2d (R, K0), a1 = a2 = None
+    gather first layer: a0 = Q (B, N, C1), a1 = Ctr (B, M, C1), a2 = idx (B, M, S) int32; R = B*M*S
+    per_layer (6 each): weights (K,N), biases (N), gamma, beta, moving_mean, moving_var -- the first two are None
+    for a gather first layer.  Returns (R//S, C_L) if pool else (R, C_L)."""
 
     @staticmethod
-    def forward(ctx, x2d, S, pool, training, decay, eps, unbiased, L, *tensors):
+    def forward(ctx, a0, a1, a2, S, pool, training, decay, eps, unbiased, L, *tensors):
         lib = _lib.load()
-        dev = x2d.device
-        R, K0 = x2d.shape
+        dev = a0.device
+        gather = a2 is not None
         layers = [tensors[6 * i:6 * i + 6] for i in range(L)]
+        if gather:
+            B, Nsrc, C1 = a0.shape
+            M = a1.shape[1]
+            R, K0 = B * M * S, None
+        else:
+            R, K0 = a0.shape
         Ys, means, rstds, scales, shifts, Ws = [], [], [], [], [], []
-        src, ld, sc_prev, sh_prev, K = x2d, K0, None, None, K0
-        for (w, b, gamma, beta, mm, mv) in layers:
-            N = w.shape[-1]
-            W2 = w.detach().reshape(-1, N)
-            assert W2.shape[0] == K and W2.is_contiguous()
-            Y = _f32((R, N), dev)
+        src, ld, sc_prev, sh_prev, K = a0, K0, None, None, K0
+        for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
+            if li == 0 and gather:
+                N = C1
+                Y = _f32((R, N), dev)
+                P = lib.pcops_sa_gather_stats_rows(B * M)
+                part = _f32((P, 2, N), dev) if training else None
+                _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, a0.data_ptr(), a1.data_ptr(), a2.data_ptr(),
+                          Y.data_ptr(), _p(part))
+                W2 = None
+            else:
+                N = w.shape[-1]
+                W2 = w.detach().reshape(-1, N)
+                assert W2.shape[0] == K and W2.is_contiguous()
+                Y = _f32((R, N), dev)
+                P = lib.pcops_mlp_stats_rows(R)
+                part = _f32((P, 2, N), dev) if training else None
+                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
+                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
             scale, shift = _vec(N, dev), _vec(N, dev)
             if training:
-                P = lib.pcops_mlp_stats_rows(R)
-                part = _f32((P, 2, N), dev)
-                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld,
-                          sc_prev.data_ptr() if sc_prev is not None else None,
-                          sh_prev.data_ptr() if sh_prev is not None else None,
-                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), part.data_ptr())
                 mean, rstd = _vec(N, dev), _vec(N, dev)
                 ws = _workspace(N, dev)
                 _lib.call("pcops_mlp_bn_finalize", P, N, R, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
@@ -62,10 +88,6 @@ class FusedMLPStack(torch.autograd.Function):
                 means.append(mean)
                 rstds.append(rstd)
             else:
-                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld,
-                          sc_prev.data_ptr() if sc_prev is not None else None,
-                          sh_prev.data_ptr() if sh_prev is not None else None,
-                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), None)
                 _lib.call("pcops_mlp_bn_eval_coeffs", N, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
                           mv.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr())
             Ys.append(Y)
@@ -81,24 +103,25 @@ class FusedMLPStack(torch.autograd.Function):
             out = _f32((G, C), dev)
             argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if training else None
             _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
-                      shifts[-1].data_ptr(), out.data_ptr(), argmax.data_ptr() if argmax is not None else None)
+                      shifts[-1].data_ptr(), out.data_ptr(), _p(argmax))
         else:
             out = _f32((R, C), dev)
             _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
                       shifts[-1].data_ptr(), out.data_ptr())
         if training:
-            ctx.saved = (x2d, Ys, means, rstds, scales, shifts, Ws, [l[2] for l in layers], argmax)
-            ctx.meta = (S, pool, L, R, K0)
+            ctx.saved = (a0, a1, a2, Ys, means, rstds, scales, shifts, Ws, [l[2] for l in layers], argmax)
+            ctx.meta = (S, pool, L, R, K0, gather)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        x2d, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
-        S, pool, L, R, K0 = ctx.meta
+        a0, a1, a2, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
+        S, pool, L, R, K0, gather = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grads = [None] * (6 * L)
+        d0 = d1 = None
 
         # ---- top of the stack: statistics of the masked upstream gradient
         C = Ys[-1].shape[1]
@@ -119,23 +142,35 @@ class FusedMLPStack(torch.autograd.Function):
 
         for l in range(L - 1, -1, -1):
             N = Ys[l].shape[1]
-            K = Ws[l].shape[0]
             dgamma, dbeta = _f32(N, dev), _f32(N, dev)
             p, q, t = _vec(N, dev), _vec(N, dev), _vec(N, dev)
             _lib.call("pcops_mlp_bn_bwd_coeffs", P, N, R, part.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
                       means[l].data_ptr(), rstds[l].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                       p.data_ptr(), q.data_ptr(), t.data_ptr())
+            grads[6 * l + 2] = dgamma
+            grads[6 * l + 3] = dbeta
             pooled = pool and l == L - 1
             gp = grad_out.data_ptr() if pooled else None
             am = argmax.data_ptr() if pooled else None
             psc = scales[l].data_ptr() if pooled else None
             psh = shifts[l].data_ptr() if pooled else None
             Gptr = None if pooled else Gm.data_ptr()
+
+            if l == 0 and gather:
+                B, Nsrc, _ = a0.shape
+                M = a1.shape[1]
+                d0 = _f32((B, Nsrc, N), dev)
+                d1 = _f32((B, M, N), dev)
+                _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
+                          q.data_ptr(), t.data_ptr(), gp, am, psc, psh, a2.data_ptr(), d0.data_ptr(),
+                          d1.data_ptr())
+                break
+
+            K = Ws[l].shape[0]
             if l == 0:
-                src, ld, asc, ash = x2d, K0, None, None
+                src, ld, asc, ash = a0, K0, None, None
             else:
                 src, ld, asc, ash = Ys[l - 1], Ys[l - 1].shape[1], scales[l - 1].data_ptr(), shifts[l - 1].data_ptr()
-            # dW, db
             splits = lib.pcops_mlp_wgrad_splits(R, K, N)
             scratch = _f32(splits * (K * N + N), dev)
             dW, db = _f32((K, N), dev), _f32(N, dev)
@@ -144,9 +179,6 @@ class FusedMLPStack(torch.autograd.Function):
                       dW.data_ptr(), db.data_ptr())
             grads[6 * l + 0] = dW
             grads[6 * l + 1] = db
-            grads[6 * l + 2] = dgamma
-            grads[6 * l + 3] = dbeta
-            # dA_{l-1}
             if l > 0 or ctx.needs_input_grad[0]:
                 Wt = _f32((N, K), dev)
                 _lib.call("pcops_mlp_transpose", K, N, Ws[l].data_ptr(), Wt.data_ptr())
@@ -162,10 +194,10 @@ class FusedMLPStack(torch.autograd.Function):
                     _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
                               t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), None, None, None,
                               Gprev.data_ptr(), None)
+                    d0 = Gprev
                 Gm = Gprev
-        dx = Gm if ctx.needs_input_grad[0] else None
-        # reshape weight grads to the variables' own shapes
-        out = [dx, None, None, None, None, None, None, None]
+
+        out = [d0 if ctx.needs_input_grad[0] else None, d1, None, None, None, None, None, None, None, None]
         for i in range(L):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
@@ -180,12 +212,28 @@ def fused_supported(x, widths, bn, activation_relu):
     return True
 
 
+def _flat(layer_tensors, first_gather):
+    flat = []
+    for i, (w, b, gamma, beta, mm, mv) in enumerate(layer_tensors):
+        if i == 0 and first_gather:
+            flat.extend([None, None, gamma, beta, mm, mv])
+        else:
+            flat.extend([w.reshape(-1, w.shape[-1]), b, gamma, beta, mm, mv])
+    return flat
+
+
 def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
     """x: (..., K0) channel-last; rows are flattened; S rows per pooling group (contiguous)."""
     x2d = x.reshape(-1, x.shape[-1]).contiguous()
-    L = len(layer_tensors)
-    flat = []
-    for (w, b, gamma, beta, mm, mv) in layer_tensors:
-        flat.extend([w.reshape(-1, w.shape[-1]), b, gamma, beta, mm, mv])
-    return FusedMLPStack.apply(x2d, int(S), bool(pool), bool(training), float(decay), float(eps),
-                               bool(unbiased), L, *flat)
+    return FusedMLPStack.apply(x2d, None, None, int(S), bool(pool), bool(training), float(decay), float(eps),
+                               bool(unbiased), len(layer_tensors), *_flat(layer_tensors, False))
+
+
+def gather_mlp_stack(Q, Ctr, idx, pool, training, decay, eps, unbiased, layer_tensors):
+    """Grouped stack whose first conv was applied before the grouping: Y1 = Q[idx] + Ctr.
+    Q (B,N,C1), Ctr (B,M,C1), idx (B,M,S) int32; layer_tensors[0] supplies only the BN variables of layer 1.
+    Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
+    S = idx.shape[2]
+    return FusedMLPStack.apply(Q.contiguous(), Ctr.contiguous(), idx.contiguous(), int(S), bool(pool),
+                               bool(training), float(decay), float(eps), bool(unbiased), len(layer_tensors),
+                               *_flat(layer_tensors, True))

@@ -65,22 +65,80 @@ def _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_for
     return x
 
 
+def _first_layer_before_grouping(xyz, points, new_xyz, w1, b1, use_xyz, xyz_first):
+    """The first 1x1 conv of a grouped stack is linear, so it is applied to the SOURCE points:
+         concat(xyz[idx] - new_xyz, points[idx]) W  =  Q[idx] + Ctr,   Q = xyz W_xyz + points W_f + b,
+                                                                        Ctr = -new_xyz W_xyz
+    (B*N rows through a library GEMM instead of B*M*S; the gather + add is csrc/gather.hip).  `xyz_first`:
+    channel order of the reference's concat -- [xyz | feats] in sample_and_group (:50), [feats | xyz] in the MSG
+    module (:184)."""
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    c1 = w1.shape[1]
+    xyz2d, ctr2d = xyz.reshape(b * n, 3), new_xyz.reshape(b * m, 3)
+    if points is None:
+        q = torch.addmm(b1, xyz2d, w1)
+        ctr = -(ctr2d @ w1)
+    else:
+        cf = points.shape[-1]
+        pts2d = points.reshape(b * n, cf)
+        if use_xyz:
+            w_xyz, w_f = (w1[:3], w1[3:]) if xyz_first else (w1[cf:], w1[:cf])
+            q = torch.addmm(b1, pts2d, w_f) + xyz2d @ w_xyz
+            ctr = -(ctr2d @ w_xyz)
+        else:
+            q = torch.addmm(b1, pts2d, w1)
+            ctr = torch.zeros((b * m, c1), dtype=torch.float32, device=xyz.device)
+    return q.view(b, n, c1), ctr.view(b, m, c1)
+
+
+def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training, bn_decay, use_xyz,
+                       xyz_first, pool_max):
+    """grouped shared MLP without ever building the grouped input: returns (B,M,1,C) if pool_max else (B,M,S,C)"""
+    b, m, s = idx.shape
+    cin = (points.shape[-1] if points is not None else 0) + (3 if (use_xyz or points is None) else 0)
+    layers = tf_util._stack_variables(cin, widths, scope_fmt, 1e-3, None, True, ('moving_mean', 'moving_variance'))
+    q, ctr = _first_layer_before_grouping(xyz, points, new_xyz, layers[0][0], layers[0][1], use_xyz, xyz_first)
+    decay = bn_decay if bn_decay is not None else 0.9
+    out = fused_mlp.gather_mlp_stack(q, ctr, idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers)
+    return out.view(b, m, 1 if pool_max else s, widths[-1])
+
+
+def _gather_fusable(points, widths, bn, nsample, pool_max):
+    c1 = widths[0]
+    return (tf_util.FUSED_MLP and bn and all(w % 32 == 0 for w in widths) and 256 % (c1 // 4) == 0
+            and (c1 >= 256 or 256 % c1 == 0) and c1 <= 1024 and (not pool_max or nsample <= 256))
+
+
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training,
                        bn_decay, scope, bn=True, pooling='max', knn=False, use_xyz=True,
                        use_nchw=False):
     """Set abstraction.  Returns new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1] or mlp2[-1]),
     idx (B,npoint,nsample)."""
     # NCHW is a TF conv-layout hint; here every 1x1 conv is the same channel-last contraction, so
-    # the flag only changes nothing numerically (the reference transposes in and out, :116-123).
+    # the flag changes nothing numerically (the reference transposes in and out, :116-123).
     with variable_scope(scope):
-        if group_all:
-            nsample = xyz.shape[1]
-            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+        pool_max = pooling == 'max'
+        if (not group_all and pooling in ('max', 'avg', 'max_and_avg') and xyz.is_cuda
+                and _gather_fusable(points, mlp, bn, nsample, pool_max)):
+            # fast path: sample -> query -> [first conv before grouping] -> gather+add -> fused stack
+            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+            if knn:
+                _, idx = knn_point(nsample, xyz, new_xyz)
+            else:
+                idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+            new_points = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp, 'conv%d', is_training, bn_decay,
+                                            use_xyz, True, pool_max)
+            grouped_xyz = None
         else:
-            new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz,
-                                                                     points, knn, use_xyz)
-        new_points = _mlp_stack(new_points, mlp, 'conv%d', bn, is_training, bn_decay, 'NHWC',
-                                pool_max=(pooling == 'max'))
+            if group_all:
+                nsample = xyz.shape[1]
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+            else:
+                new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz,
+                                                                         points, knn, use_xyz)
+            new_points = _mlp_stack(new_points, mlp, 'conv%d', bn, is_training, bn_decay, 'NHWC',
+                                    pool_max=pool_max)
 
         if pooling == 'max':
             pass  # fused into the stack above
@@ -111,15 +169,19 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         scales = query_ball_point_multi(radius_list, nsample_list, xyz, new_xyz)  # one dataset pass
         outs = []
         for i, (idx, _cnt) in enumerate(scales):
-            grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
-            if points is None:
-                grouped = grouped_xyz
+            fmt = 'conv%d_' % i + '%d'
+            if xyz.is_cuda and _gather_fusable(points, mlp_list[i], bn, idx.shape[2], True):
+                grouped = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp_list[i], fmt, is_training, bn_decay,
+                                             use_xyz, False, True)          # [feats | xyz] order (:184)
             else:
-                grouped = group_point(points, idx)
-                if use_xyz:
-                    grouped = torch.cat([grouped, grouped_xyz], dim=-1)  # note: feats first (:184)
-            grouped = _mlp_stack(grouped, mlp_list[i], 'conv%d_' % i + '%d', bn, is_training,
-                                 bn_decay, 'NHWC', pool_max=True)
+                grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
+                if points is None:
+                    grouped = grouped_xyz
+                else:
+                    grouped = group_point(points, idx)
+                    if use_xyz:
+                        grouped = torch.cat([grouped, grouped_xyz], dim=-1)  # note: feats first (:184)
+                grouped = _mlp_stack(grouped, mlp_list[i], fmt, bn, is_training, bn_decay, 'NHWC', pool_max=True)
             outs.append(grouped.squeeze(2))
         return new_xyz, torch.cat(outs, dim=-1)
 

@@ -74,7 +74,7 @@ def test_pointnet2_cls_logits(name, training, monkeypatch):
 def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga as m
     _no_dropout(monkeypatch)
-    c = synth_clouds(12, 1024, seed=4)
+    c = synth_clouds(16, 1024, seed=4)
     x = torch.from_numpy(c).to(DEV)
     net = Model(m.get_model, device=DEV, seed=2).build(x)
     _randomise(net, 6)
@@ -100,8 +100,13 @@ def test_pointnet2_ssg_training_gradients(monkeypatch):
     m.get_loss(logits, torch.from_numpy(y).to(DEV)).backward()
     want = R.pointnet2_cls_ssg(torch.from_numpy(c).double(), P, True)
     torch.nn.functional.cross_entropy(want, torch.from_numpy(y).long()).backward()
+    names = dict(net.named_parameters())
     for name, p in net.named_parameters():
         ref = P[name[len("graph."):]].grad
+        if name.endswith("biases") and name[:-len("biases")] + "bn/gamma" in names:
+            # bias in front of a batch norm: analytically zero gradient, only rounding noise on both sides
+            assert p.grad.abs().max().item() < 1e-3 and ref.abs().max().item() < 1e-9, name
+            continue
         scale = ref.abs().max().item() + 1e-6
         assert (p.grad.cpu().double() - ref).abs().max().item() <= 5e-3 * scale + 1e-6, name
 
