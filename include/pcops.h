@@ -191,20 +191,27 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
 
 /* --------------------------------------------- first grouped layer in front of the grouping (gather.hip)
- * A 1x1 conv is linear: concat(xyz[idx] - new_xyz, points[idx]) W = (xyz W_xyz + points W_f)[idx] - new_xyz W_xyz
- * (pointnet2/utils/pointnet_util.py:44-54,117-122; EdgeConv: dgcnn/utils/tf_util.py:699-705 + dgcnn.py:39-44), so
- * the contraction runs once per SOURCE point and the (b,m,s,c) activation is a gather + add:
- *     Y[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:]        Q (b,n,c), Ctr (b,m,c), idx (b,m,s)
+ * A 1x1 conv is linear: concat(xyz[idx] - new_xyz, points[idx]) W = (points W_f)[idx] + (xyz[idx] - new_xyz) W_xyz
+ * (pointnet2/utils/pointnet_util.py:44-54,117-122; EdgeConv concat(x_i, x_j - x_i): dgcnn/utils/tf_util.py:699-705
+ * + dgcnn.py:39-44), so the feature contraction runs once per SOURCE point and the (b,m,s,c) activation is
+ *     Y[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] + (xyz[b,idx,:] - new_xyz[b,j,:]) Wxyz + bias
+ * Q (b,n,c), Ctr (b,m,c), xyz (b,n,3), new_xyz (b,m,3), Wxyz (3,c), bias (c), idx (b,m,s); Q, Ctr, the coordinate
+ * term and bias are each optional (NULL); the coordinate term is evaluated on the centred offsets (no cancellation).
  * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y). */
 int pcops_sa_gather_stats_rows(long long groups);
-int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
-                        float *Y, float *stats_partial, pcops_stream_t stream);
+int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
+                        const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
+                        float *stats_partial, pcops_stream_t stream);
 /* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
- * pcops_mlp_gemm_dgrad); dQ (b,n,c) = scatter-add of dY over idx (zeroed here), dCtr (b,m,c) = sum over s */
+ * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
+ * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.
+ * wpartial: caller scratch of pcops_sa_scatter_rows(b*m) * 4 * c floats (needed for dWxyz / dbias). */
+int pcops_sa_scatter_rows(long long groups);
 int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,
-                         const float *pool_scale, const float *pool_shift, const int *idx, float *dQ,
-                         float *dCtr, pcops_stream_t stream);
+                         const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
+                         const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
+                         float *dbias, pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,8 +43,8 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
-    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P], True),
-    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 17, True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
@@ -56,6 +56,7 @@ PLAIN = {
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
+    "pcops_sa_scatter_rows": ([_LL], _I),
 }
 
 _lib = None

@@ -11,9 +11,9 @@ moving-average semantics are parameters so both BN flavours of the reference are
 
 Two kinds of first layer:
   dense   Y1 = X W1 + b1 on a materialised (rows, K) input (FP stacks, group_all, anything already grouped);
-  gather  Y1[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] -- the first conv of a GROUPED stack applied before
-          the grouping (it is linear; see csrc/gather.hip), so neither the grouped input nor a (3+C)-wide
-          concat is ever built and its backward is one scatter-add.
+  gather  Y1[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] + (xyz[b,idx] - new_xyz[b,j]) Wxyz + bias -- the first conv
+          of a GROUPED stack applied before the grouping (it is linear; see csrc/gather.hip), so neither the
+          grouped input nor a (3+C)-wide concat is ever built and its backward is one scatter-add.
 """
 import torch
 
@@ -39,22 +39,24 @@ def _p(t):
 
 
 class FusedMLPStack(torch.autograd.Function):
-    """apply(a0, a1, a2, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
+    """apply(a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
 
-    dense first layer : a0 = x2d (R, K0), a1 = a2 = None
-    gather first layer: a0 = Q (B, N, C1), a1 = Ctr (B, M, C1), a2 = idx (B, M, S) int32; R = B*M*S
+    dense first layer : a0 = x2d (R, K0); ctr .. bias = None
+    gather first layer: idx (B, M, S) int32 and any of a0 = Q (B, N, C1), ctr (B, M, C1),
+                        xyz (B, N, 3) + new_xyz (B, M, 3) + wxyz (3, C1), bias (C1);  R = B*M*S
     per_layer (6 each): weights (K,N), biases (N), gamma, beta, moving_mean, moving_var -- the first two are None
     for a gather first layer.  Returns (R//S, C_L) if pool else (R, C_L)."""
 
     @staticmethod
-    def forward(ctx, a0, a1, a2, S, pool, training, decay, eps, unbiased, L, *tensors):
+    def forward(ctx, a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased, L, *tensors):
         lib = _lib.load()
-        dev = a0.device
-        gather = a2 is not None
+        gather = idx is not None
+        dev = idx.device if gather else a0.device
         layers = [tensors[6 * i:6 * i + 6] for i in range(L)]
         if gather:
-            B, Nsrc, C1 = a0.shape
-            M = a1.shape[1]
+            B, M, _ = idx.shape
+            Nsrc = a0.shape[1] if a0 is not None else xyz.shape[1]
+            C1 = layers[0][2].shape[0]
             R, K0 = B * M * S, None
         else:
             R, K0 = a0.shape
@@ -66,8 +68,8 @@ class FusedMLPStack(torch.autograd.Function):
                 Y = _f32((R, N), dev)
                 P = lib.pcops_sa_gather_stats_rows(B * M)
                 part = _f32((P, 2, N), dev) if training else None
-                _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, a0.data_ptr(), a1.data_ptr(), a2.data_ptr(),
-                          Y.data_ptr(), _p(part))
+                _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
+                          _p(wxyz), _p(bias), idx.data_ptr(), Y.data_ptr(), _p(part))
                 W2 = None
             else:
                 N = w.shape[-1]
@@ -109,19 +111,20 @@ class FusedMLPStack(torch.autograd.Function):
             _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
                       shifts[-1].data_ptr(), out.data_ptr())
         if training:
-            ctx.saved = (a0, a1, a2, Ys, means, rstds, scales, shifts, Ws, [l[2] for l in layers], argmax)
+            ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
+                         [l[2] for l in layers], argmax)
             ctx.meta = (S, pool, L, R, K0, gather)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        a0, a1, a2, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
+        a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
         S, pool, L, R, K0, gather = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grads = [None] * (6 * L)
-        d0 = d1 = None
+        d0 = d1 = dwxyz = dbias = None
 
         # ---- top of the stack: statistics of the masked upstream gradient
         C = Ys[-1].shape[1]
@@ -157,13 +160,17 @@ class FusedMLPStack(torch.autograd.Function):
             Gptr = None if pooled else Gm.data_ptr()
 
             if l == 0 and gather:
-                B, Nsrc, _ = a0.shape
-                M = a1.shape[1]
-                d0 = _f32((B, Nsrc, N), dev)
-                d1 = _f32((B, M, N), dev)
+                B, M, _ = idx.shape
+                Nsrc = a0.shape[1] if a0 is not None else xyz.shape[1]
+                d0 = _f32((B, Nsrc, N), dev) if (a0 is not None and ctx.needs_input_grad[0]) else None
+                d1 = _f32((B, M, N), dev) if ctr is not None else None
+                dwxyz = _f32((3, N), dev) if wxyz is not None else None
+                dbias = _f32(N, dev) if bias is not None else None
+                wpart = _f32(lib.pcops_sa_scatter_rows(B * M) * 4 * N, dev) if (wxyz is not None or bias is not None) else None
                 _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
-                          q.data_ptr(), t.data_ptr(), gp, am, psc, psh, a2.data_ptr(), d0.data_ptr(),
-                          d1.data_ptr())
+                          q.data_ptr(), t.data_ptr(), gp, am, psc, psh, idx.data_ptr(),
+                          _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
+                          _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias))
                 break
 
             K = Ws[l].shape[0]
@@ -197,7 +204,8 @@ class FusedMLPStack(torch.autograd.Function):
                     d0 = Gprev
                 Gm = Gprev
 
-        out = [d0 if ctx.needs_input_grad[0] else None, d1, None, None, None, None, None, None, None, None]
+        out = [d0 if ctx.needs_input_grad[0] else None, d1, None, None, None, dwxyz, dbias,
+               None, None, None, None, None, None, None]
         for i in range(L):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
@@ -225,15 +233,20 @@ def _flat(layer_tensors, first_gather):
 def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
     """x: (..., K0) channel-last; rows are flattened; S rows per pooling group (contiguous)."""
     x2d = x.reshape(-1, x.shape[-1]).contiguous()
-    return FusedMLPStack.apply(x2d, None, None, int(S), bool(pool), bool(training), float(decay), float(eps),
-                               bool(unbiased), len(layer_tensors), *_flat(layer_tensors, False))
+    return FusedMLPStack.apply(x2d, None, None, None, None, None, None, int(S), bool(pool), bool(training),
+                               float(decay), float(eps), bool(unbiased), len(layer_tensors),
+                               *_flat(layer_tensors, False))
 
 
-def gather_mlp_stack(Q, Ctr, idx, pool, training, decay, eps, unbiased, layer_tensors):
-    """Grouped stack whose first conv was applied before the grouping: Y1 = Q[idx] + Ctr.
-    Q (B,N,C1), Ctr (B,M,C1), idx (B,M,S) int32; layer_tensors[0] supplies only the BN variables of layer 1.
-    Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
+def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
+                     new_xyz=None, wxyz=None, bias=None):
+    """Grouped stack whose first conv was applied before the grouping:
+         Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
+    idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
+    layer_tensors[0] supplies only the BN variables of layer 1.  Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
+    c = lambda t: t.contiguous() if t is not None else None   # noqa: E731
     S = idx.shape[2]
-    return FusedMLPStack.apply(Q.contiguous(), Ctr.contiguous(), idx.contiguous(), int(S), bool(pool),
-                               bool(training), float(decay), float(eps), bool(unbiased), len(layer_tensors),
-                               *_flat(layer_tensors, True))
+    return FusedMLPStack.apply(c(Q), c(Ctr), idx.contiguous(), c(xyz.detach()) if xyz is not None else None,
+                               c(new_xyz.detach()) if new_xyz is not None else None, c(wxyz), c(bias), int(S),
+                               bool(pool), bool(training), float(decay), float(eps), bool(unbiased),
+                               len(layer_tensors), *_flat(layer_tensors, True))

@@ -65,42 +65,33 @@ def _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_for
     return x
 
 
-def _first_layer_before_grouping(xyz, points, new_xyz, w1, b1, use_xyz, xyz_first):
-    """The first 1x1 conv of a grouped stack is linear, so it is applied to the SOURCE points:
-         concat(xyz[idx] - new_xyz, points[idx]) W  =  Q[idx] + Ctr,   Q = xyz W_xyz + points W_f + b,
-                                                                        Ctr = -new_xyz W_xyz
-    (B*N rows through a library GEMM instead of B*M*S; the gather + add is csrc/gather.hip).  `xyz_first`:
-    channel order of the reference's concat -- [xyz | feats] in sample_and_group (:50), [feats | xyz] in the MSG
-    module (:184)."""
-    b, n, _ = xyz.shape
-    m = new_xyz.shape[1]
+def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training, bn_decay, use_xyz,
+                       xyz_first, pool_max):
+    """Grouped shared MLP without ever building the grouped input.  The first 1x1 conv is linear, so
+         concat(xyz[idx] - new_xyz, points[idx]) W + b  =  (points W_f + b)[idx] + (xyz[idx] - new_xyz) W_xyz :
+    the feature part runs once per SOURCE point (B*N rows through a library GEMM instead of B*M*S) and the
+    three coordinate channels are evaluated inside the gather kernel on the centred offsets (csrc/gather.hip).
+    `xyz_first`: channel order of the reference's concat -- [xyz | feats] in sample_and_group (:50),
+    [feats | xyz] in the MSG module (:184).  Returns (B,M,1,C) if pool_max else (B,M,S,C)."""
+    b, m, s = idx.shape
+    n = xyz.shape[1]
+    cin = (points.shape[-1] if points is not None else 0) + (3 if (use_xyz or points is None) else 0)
+    layers = tf_util._stack_variables(cin, widths, scope_fmt, 1e-3, None, True, ('moving_mean', 'moving_variance'))
+    w1, b1 = layers[0][0], layers[0][1]
     c1 = w1.shape[1]
-    xyz2d, ctr2d = xyz.reshape(b * n, 3), new_xyz.reshape(b * m, 3)
+    kw = {}
     if points is None:
-        q = torch.addmm(b1, xyz2d, w1)
-        ctr = -(ctr2d @ w1)
+        kw = dict(xyz=xyz, new_xyz=new_xyz, wxyz=w1, bias=b1)
     else:
         cf = points.shape[-1]
         pts2d = points.reshape(b * n, cf)
         if use_xyz:
             w_xyz, w_f = (w1[:3], w1[3:]) if xyz_first else (w1[cf:], w1[:cf])
-            q = torch.addmm(b1, pts2d, w_f) + xyz2d @ w_xyz
-            ctr = -(ctr2d @ w_xyz)
+            kw = dict(Q=torch.addmm(b1, pts2d, w_f).view(b, n, c1), xyz=xyz, new_xyz=new_xyz, wxyz=w_xyz)
         else:
-            q = torch.addmm(b1, pts2d, w1)
-            ctr = torch.zeros((b * m, c1), dtype=torch.float32, device=xyz.device)
-    return q.view(b, n, c1), ctr.view(b, m, c1)
-
-
-def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training, bn_decay, use_xyz,
-                       xyz_first, pool_max):
-    """grouped shared MLP without ever building the grouped input: returns (B,M,1,C) if pool_max else (B,M,S,C)"""
-    b, m, s = idx.shape
-    cin = (points.shape[-1] if points is not None else 0) + (3 if (use_xyz or points is None) else 0)
-    layers = tf_util._stack_variables(cin, widths, scope_fmt, 1e-3, None, True, ('moving_mean', 'moving_variance'))
-    q, ctr = _first_layer_before_grouping(xyz, points, new_xyz, layers[0][0], layers[0][1], use_xyz, xyz_first)
+            kw = dict(Q=torch.addmm(b1, pts2d, w1).view(b, n, c1))
     decay = bn_decay if bn_decay is not None else 0.9
-    out = fused_mlp.gather_mlp_stack(q, ctr, idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers)
+    out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers, **kw)
     return out.view(b, m, 1 if pool_max else s, widths[-1])
 
 

@@ -143,15 +143,18 @@ def test_fused_model_as_accurate_as_layerwise(monkeypatch):
         logits.square().mean().backward()
         outs.append((logits.detach().cpu().double(), {n: p.grad.cpu().double() for n, p in net.named_parameters()}))
     assert (outs[0][0] - truth.detach()).abs().max().item() < 1e-4
+    # Frobenius norms: a single ReLU landing on the other side of 0 than in float64 moves one gradient element
+    # by O(1) in either fp32 path (see test_models_parity_gpu.py), which a max-norm comparison cannot absorb
+    tot = {"f": 0.0, "l": 0.0, "r": 0.0}
     for n in outs[0][1]:
-        ref = P[n[len("graph."):]].grad
-        scale = ref.abs().max().item()
-        e_fused = (outs[0][1][n] - ref).abs().max().item()
-        e_layer = (outs[1][1][n] - ref).abs().max().item()
         if n.endswith("biases") and n[:-len("biases")] + "bn/gamma" in outs[0][1]:
             continue   # analytically zero gradient (bias in front of a batch norm): rounding noise only
-        # BN-backward sums cancel heavily (|sum| << sum|.|), so even plain fp32 sits ~1e-3 from the truth here
-        assert e_fused <= 4.0 * e_layer + 2e-3 * scale + 1e-5, (n, e_fused, e_layer, scale)
+        ref = P[n[len("graph."):]].grad
+        tot["f"] += (outs[0][1][n] - ref).norm().item() ** 2
+        tot["l"] += (outs[1][1][n] - ref).norm().item() ** 2
+        tot["r"] += ref.norm().item() ** 2
+    e_fused, e_layer = (tot["f"] / tot["r"]) ** 0.5, (tot["l"] / tot["r"]) ** 0.5
+    assert e_fused <= max(4.0 * e_layer, 2e-2), (e_fused, e_layer)
 
 
 # ---------------------------------------------------------------------------- gather-first stacks
@@ -164,10 +167,19 @@ GATHER_CASES = [  # (B, N, M, S, widths, pool)
 ]
 
 
-def gather_reference(Q, Ctr, idx, layers, pool, training, dtype):
+def gather_reference(Q, Ctr, xyz, new_xyz, wxyz, bias, idx, layers, pool, training, dtype):
     B, M, S = idx.shape
-    y = torch.gather(Q.to(dtype), 1, idx.long().reshape(B, M * S, 1).expand(-1, -1, Q.shape[2]))
-    y = y.view(B, M, S, -1) + Ctr.to(dtype).unsqueeze(2)
+    ii = idx.long().reshape(B, M * S, 1)
+    y = 0
+    if Q is not None:
+        y = y + torch.gather(Q.to(dtype), 1, ii.expand(-1, -1, Q.shape[2])).view(B, M, S, -1)
+    if Ctr is not None:
+        y = y + Ctr.to(dtype).unsqueeze(2)
+    if wxyz is not None:
+        g = torch.gather(xyz.to(dtype), 1, ii.expand(-1, -1, 3)).view(B, M, S, 3) - new_xyz.to(dtype).unsqueeze(2)
+        y = y + g @ wxyz.to(dtype)
+    if bias is not None:
+        y = y + bias.to(dtype)
     a = None
     y = y.reshape(B * M * S, -1)
     for li, (W, b, gamma, beta, mm, mv) in enumerate(layers):
@@ -183,34 +195,49 @@ def gather_reference(Q, Ctr, idx, layers, pool, training, dtype):
     return a
 
 
+@pytest.mark.parametrize("form", ["q_ctr", "xyz_bias", "q_xyz"])
 @pytest.mark.parametrize("B,N,M,S,widths,pool", GATHER_CASES)
-def test_gather_stack_forward_backward(B, N, M, S, widths, pool):
+def test_gather_stack_forward_backward(B, N, M, S, widths, pool, form):
     g = torch.Generator().manual_seed(B * 1000 + N)
     C1 = widths[0]
-    Q0 = torch.randn(B, N, C1, generator=g).to(DEV)
-    Ctr0 = torch.randn(B, M, C1, generator=g).to(DEV)
+    src = {
+        "Q": torch.randn(B, N, C1, generator=g).to(DEV) if form != "xyz_bias" else None,
+        "Ctr": torch.randn(B, M, C1, generator=g).to(DEV) if form == "q_ctr" else None,
+        "xyz": torch.rand(B, N, 3, generator=g).to(DEV) if form != "q_ctr" else None,
+        "new_xyz": torch.rand(B, M, 3, generator=g).to(DEV) if form != "q_ctr" else None,
+        "wxyz": torch.randn(3, C1, generator=g).to(DEV) if form != "q_ctr" else None,
+        "bias": torch.randn(C1, generator=g).to(DEV) if form == "xyz_bias" else None,
+    }
     idx = torch.randint(0, N, (B, M, S), generator=g, dtype=torch.int32).to(DEV)
     idx[:, :, S // 2:] = idx[:, :, :1]                     # ball-query style padding: duplicate rows
     layers = make_layers(C1, widths, seed=N)                # layers[0]'s W/b are unused by the gather form
+    diff = ("Q", "Ctr", "wxyz", "bias")
+
+    def call(mode, training, s):
+        dt = torch.float64 if mode == "fp64" else torch.float32
+        ls = [[t.detach().to(dt).requires_grad_(training) for t in l[:4]] + [l[4].clone(), l[5].clone()] for l in layers]
+        if mode == "fused":
+            out = fused_mlp.gather_mlp_stack(idx, pool, training, 0.9, EPS, True, [tuple(l) for l in ls],
+                                             Q=s["Q"], Ctr=s["Ctr"], xyz=s["xyz"], new_xyz=s["new_xyz"],
+                                             wxyz=s["wxyz"], bias=s["bias"])
+        else:
+            out = gather_reference(s["Q"], s["Ctr"], s["xyz"], s["new_xyz"], s["wxyz"], s["bias"], idx, ls, pool,
+                                   training, dt)
+        return out, ls
+
     for training in (True, False):
-        ls = [[t.clone() for t in l] for l in layers]
-        out = fused_mlp.gather_mlp_stack(Q0, Ctr0, idx, pool, training, 0.9, EPS, True, [tuple(l) for l in ls])
-        want = gather_reference(Q0, Ctr0, idx, layers, pool, training, torch.float64)
+        out, _ = call("fused", training, src)
+        want, _ = call("fp64", training, src)
         assert (out.double() - want).abs().max().item() < 1e-4
 
     def run(mode):
         dt = torch.float64 if mode == "fp64" else torch.float32
-        Q = Q0.detach().to(dt).requires_grad_(True)
-        Ctr = Ctr0.detach().to(dt).requires_grad_(True)
-        ls = [[t.detach().to(dt).requires_grad_(True) for t in l[:4]] + [l[4].clone(), l[5].clone()] for l in layers]
-        if mode == "fused":
-            out = fused_mlp.gather_mlp_stack(Q, Ctr, idx, pool, True, 0.9, EPS, True, [tuple(l) for l in ls])
-        else:
-            out = gather_reference(Q, Ctr, idx, ls, pool, True, dt)
+        s = {k: (v.detach().to(dt).requires_grad_(k in diff) if v is not None else None) for k, v in src.items()}
+        out, ls = call(mode, True, s)
         torch.manual_seed(5)
         go = torch.randn(out.shape, device=DEV)
         out.backward(go.to(dt))
-        res = [Q.grad.double(), Ctr.grad.double()]
+        res = [s[k].grad.double() for k in diff if s[k] is not None]
         for li, l in enumerate(ls):
             for ti, t in enumerate(l[:4]):
                 if li == 0 and ti < 2:
@@ -219,7 +246,10 @@ def test_gather_stack_forward_backward(B, N, M, S, widths, pool):
         return res
 
     got, want, plain = run("fused"), run("fp64"), run("fp32")
+    gmax = max(b.abs().max().item() for b in want)
     for i, (a, b, c) in enumerate(zip(got, want, plain)):
-        scale = b.abs().max().item() + 1e-12
+        scale = b.abs().max().item()
+        if scale < 1e-6 * gmax:
+            continue          # analytically zero gradient (a bias in front of the batch norm): noise only
         err, err_plain = (a - b).abs().max().item(), (c - b).abs().max().item()
         assert err <= 1e-3 * scale + 1e-5 or err <= 2.0 * err_plain, (i, err, err_plain, scale)

@@ -44,3 +44,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "ragged":
     run(512 * 64 + 37, 1, 128, [128, 256], False, 1.0)
     run(512 * 64, 1, 128, [128, 256], False, 1.0)
     run(512 * 64 + 37, 1, 128, [128], False, 1.0)
+if len(sys.argv) > 1 and sys.argv[1] == "sa3":
+    run(16 * 128, 128, 259, [256, 512, 1024], True, 1.0)
+    run(16 * 128, 128, 260, [256, 512, 1024], True, 1.0)
+    run(16 * 128, 128, 256, [512, 1024], True, 1.0)
