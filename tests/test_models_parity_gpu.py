@@ -117,6 +117,11 @@ def test_pointnet2_ssg_training_gradients(monkeypatch):
             continue
         e = (p.grad.cpu().double() - ref).norm().item()
         r = ref.norm().item()
+        if r < 1e-9:
+            # analytically zero as well (e.g. layer3/conv2/bn/beta: the batch norm of fc1 makes the upstream
+            # gradient sum to zero over the batch): rounding noise only
+            assert e < 1e-5, (name, e, r)
+            continue
         assert e <= 5e-2 * r + 1e-7, (name, e, r)
         num += e * e
         den += r * r
