@@ -38,49 +38,79 @@ MODELS = {
 }
 
 
-# ---- algorithmic bytes / flops per launch of each pcops kernel (SURVEY.md §8d formulas) ------------
+# ---- algorithmic bytes / flops per launch of each pcops kernel (SURVEY.md §8d formulas) --------
 def _algo(name, a):
-    """returns (bytes, flops_or_pairs) for one launch given the C-ABI argument tuple"""
+    """returns (bytes, work, work_unit) for one launch given the C-ABI argument tuple; `work` = flops for the
+    MFMA kernels, pair tests for the search kernels"""
     if name == "pcops_query_ball_point":
         b, n, m, _r, s = a[:5]
-        return b * (12 * n + 12 * m + 4 * m * s + 4 * m), b * m * n
+        return b * (12 * n + 12 * m + 4 * m * s + 4 * m), b * m * n, "pairs"
     if name == "pcops_query_ball_point_multi":
         b, n, m = a[:3]
-        return b * (12 * n + 12 * m), b * m * n
+        return b * (12 * n + 12 * m), b * m * n, "pairs"
     if name == "pcops_farthest_point_sample":
         b, n, m = a[:3]
-        return b * (12 * n + 4 * m), b * (m - 1) * n
+        return b * (12 * n + 4 * m), b * (m - 1) * n, "pairs"
     if name == "pcops_gather_point":
         b, n, m = a[:3]
-        return b * (16 * m + 12 * m), 0
+        return b * (16 * m + 12 * m), 0, ""
     if name == "pcops_gather_point_grad":
         b, n, m = a[:3]
-        return b * (16 * m + 12 * n), 0
-    if name == "pcops_group_point":
+        return b * (16 * m + 12 * n), 0, ""
+    if name in ("pcops_group_point", "pcops_group_point_grad"):
         b, n, c, m, s = a[:5]
-        return b * (4 * n * c + 4 * m * s + 4 * m * s * c), 0
-    if name == "pcops_group_point_grad":
-        b, n, c, m, s = a[:5]
-        return b * (4 * n * c + 4 * m * s + 4 * m * s * c), 0
+        return b * (4 * n * c + 4 * m * s + 4 * m * s * c), 0, ""
     if name == "pcops_three_nn":
         b, n, m = a[:3]
-        return b * (12 * n + 12 * m + 24 * n), b * n * m
+        return b * (12 * n + 12 * m + 24 * n), b * n * m, "pairs"
     if name in ("pcops_three_interpolate", "pcops_three_interpolate_grad"):
         b, m, c, n = a[:4] if name == "pcops_three_interpolate" else (a[0], a[3], a[2], a[1])
-        return b * (4 * m * c + 24 * n + 4 * n * c), 0
+        return b * (4 * m * c + 24 * n + 4 * n * c), 0, ""
     if name == "pcops_knn_graph":
         b, n, c, k = a[:4]
-        return b * (4 * n * c + 4 * n * k), 2 * b * n * n * c
+        return b * (4 * n * c + 4 * n * k), 2 * b * n * n * c, "flop"
     if name in ("pcops_edge_feature", "pcops_edge_feature_grad"):
         b, n, c, k = a[:4]
-        return b * (4 * n * c + 4 * n * k + 8 * n * k * c), 0
-    return 0, 0
+        return b * (4 * n * c + 4 * n * k + 8 * n * k * c), 0, ""
+    # ---- shared-MLP kernels: activations only (weights / per-channel vectors are negligible)
+    if name == "pcops_mlp_gemm_fwd":          # Y[M,N] = f(X)[M,K] W
+        M, K, N = a[:3]
+        return 4 * (M * K + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_gemm_dgrad":        # Gprev[M,Nout] = mask . (dY[M,K] Wt); reads G?,Y (K wide), Yprev (Nout)
+        M, K, Nout = a[:3]
+        reads = (1 if a[3] is None else 2) * M * K + (M * Nout if a[14] is not None else 0)
+        return 4 * (reads + M * Nout), 2 * M * K * Nout, "flop"
+    if name == "pcops_mlp_wgrad":             # dW[K,N] = A[M,K]^T dY[M,N]; reads X, G?, Y
+        M, K, N = a[:3]
+        return 4 * (M * K + (1 if a[7] is None else 2) * M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_bn_relu_maxpool":
+        G, S, C = a[:3]
+        return 4 * G * S * C + 5 * G * C, 0, ""
+    if name == "pcops_mlp_bn_relu_apply":
+        R, C = a[:2]
+        return 8 * R * C, 0, ""
+    if name == "pcops_mlp_relu_mask_stats":
+        R, C = a[:2]
+        return 12 * R * C, 0, ""
+    if name == "pcops_mlp_pool_bwd_stats":
+        G, S, C = a[:3]
+        return 9 * G * C, 0, ""
+    if name == "pcops_sa_gather_fwd":         # Y (b,m,s,c) written once; Q read once (algorithmically), idx
+        b, n, m, s, c = a[:5]
+        return 4 * (b * m * s * c + (b * n * c if a[5] is not None else 0) + b * m * s), 0, ""
+    if name == "pcops_sa_scatter_bwd":        # reads G?,Y (b,m,s,c), idx; writes dQ (b,n,c)
+        b, n, m, s, c = a[:5]
+        return 4 * ((1 if a[5] is None else 2) * b * m * s * c + b * m * s + (b * n * c if a[17] is not None else 0)), 0, ""
+    return 0, 0, ""
 
 
 _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcops_group_point": 5,
            "pcops_group_point_grad": 5, "pcops_three_interpolate": 4, "pcops_three_interpolate_grad": 4,
            "pcops_knn_graph": 4, "pcops_edge_feature": 4, "pcops_edge_feature_grad": 4,
-           "pcops_selection_sort": 4, "pcops_pairwise_distance": 3, "pcops_knn_topk": 3}
+           "pcops_selection_sort": 4, "pcops_pairwise_distance": 3, "pcops_knn_topk": 3,
+           "pcops_sa_gather_fwd": 5, "pcops_sa_scatter_bwd": 5, "pcops_mlp_bn_finalize": 3,
+           "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
+           "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1}
 
 
 class KernelTimer:
@@ -107,10 +137,10 @@ class KernelTimer:
         agg = {}
         for name, args, s, e in self.records:
             ms = s.elapsed_time(e)
-            by, work = _algo(name, args)
+            by, work, unit = _algo(name, args)
             key = (name,) + tuple(args[:_NSHAPE.get(name, 3)])
             d = agg.setdefault(key, {"kernel": name, "shape": list(key[1:]), "launches": 0, "ms": 0.0,
-                                     "bytes": by, "work": work})
+                                     "bytes": by, "work": work, "work_unit": unit})
             d["launches"] += 1
             d["ms"] += ms
         out = []
@@ -122,6 +152,21 @@ class KernelTimer:
             out.append(d)
         out.sort(key=lambda d: -d["ms"])
         return out
+
+
+def _measured_traffic(dom):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE, collected by tools/collect_traffic.sh), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            table = json.load(open(f))
+        except Exception:
+            continue
+        key = "%s%s" % (dom["kernel"], tuple(dom["shape"]))
+        if key in table:
+            return table[key]
+    return None
 
 
 def cpu_baseline(model_name, n_points, seconds_budget=20.0):
@@ -241,12 +286,22 @@ def main():
     dom = kernels[0] if kernels else None
     roofline = None
     if dom is not None:
-        roofline = {"kernel": dom["kernel"], "shape": dom["shape"], "bound": "hbm",
-                    "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None,
-                    "avg_launch_us": dom["avg_us"], "launches": dom["launches"],
-                    "algorithmic_bytes_per_launch": dom["bytes"],
-                    "pair_or_flop_rate_G_per_s": dom["gwork_s"]}
+        # the binding roofline of the dominant kernel = the one it sits closer to: HBM for the streaming
+        # kernels; for the MFMA GEMMs whichever of (algorithmic bytes / 8 TB/s, flops / 157.3 TF/s) is larger
+        hbm_frac = dom["gbs"] / HBM_PEAK_GBS
+        mfma_frac = dom["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if dom["work_unit"] == "flop" else 0.0
+        traffic = _measured_traffic(dom)
+        if mfma_frac > hbm_frac:
+            roofline = {"bound": "mfma", "achieved": dom["gwork_s"] / 1e3, "peak": F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": mfma_frac, "traffic": traffic}
+        else:
+            roofline = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm_frac, "traffic": traffic}
+        roofline.update({"kernel": dom["kernel"], "shape": dom["shape"], "avg_launch_us": dom["avg_us"],
+                         "launches": dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"],
+                         "algorithmic_flops_per_launch": dom["work"] if dom["work_unit"] == "flop" else None,
+                         "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
+                         "share_of_step": dom["ms"] / (elapsed * 1e3)})
     line = {
         "metric": "point-clouds/sec fwd+bwd at B×2048×3, 15-cls" if not args.forward_only
                   else "point-clouds/sec forward (eval) at B×2048×3, 15-cls",
@@ -257,7 +312,8 @@ def main():
                                "train step = fwd+bwd+allreduce+Adam" % (args.model, args.kind, N, B),
                    "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world},
         "roofline": roofline,
-        "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s")} for d in kernels],
+        "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit")}
+                    for d in kernels[:24]],
     }
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.model, N)

@@ -1216,7 +1216,7 @@ static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, con
     const int KB = 32 * pl->tk, NB = 32 * pl->tn;
     pl->kblocks = (K + KB - 1) / KB;
     pl->nblocks = (N + NB - 1) / NB;
-    int groups = 512 / (pl->kblocks * pl->nblocks);    // ~2 workgroups per CU over the whole grid
+    int groups = 256 / (pl->kblocks * pl->nblocks);    // one persistent workgroup per CU over the whole grid
     if (groups < 1) groups = 1;
     const long long maxg = ((M + pl->rs - 1) / pl->rs + 3) / 4;
     if (groups > maxg) groups = (int)maxg;
@@ -1225,14 +1225,18 @@ static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, con
     return pl->lds <= 160 * 1024;
 }
 
-// sum partials [P][L] -> out[L] (deterministic), one thread per element
+// sum partials [P][L] -> out[L] (deterministic): 64 consecutive elements x 4 partial lanes per workgroup
 __global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, const float *__restrict__ part,
                                                            float *__restrict__ out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L) return;
+    __shared__ double sm[4][64];
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + c;
     double s = 0.0;
-    for (int p = 0; p < P; ++p) s += (double)part[(long long)p * L + i];
-    out[i] = (float)s;
+    if (i < L)
+        for (int p = pl; p < P; p += 4) s += (double)part[(long long)p * L + i];
+    sm[pl][c] = s;
+    __syncthreads();
+    if (pl == 0 && i < L) out[i] = (float)((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
 }
 
 // Wt[n][k] = W[k][n]
@@ -1493,9 +1497,9 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     int rc = pcops_launch_status();
     if (rc) return rc;
     const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 256)), dim3(256), 0, st, splits, L, partial, dW);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 64)), dim3(256), 0, st, splits, L, partial, dW);
     if (db)
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, splits, (long long)N,
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, splits, (long long)N,
                            a.dbpart, db);
     return pcops_launch_status();
 }

@@ -9,7 +9,12 @@ dev = "cuda:0"
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 def vec(n): return (torch.randn((n + 3) // 4 * 4, device=dev) * 0.1 + 1.0)
-SHAPES = [(4194304, 64, 64), (4194304, 64, 128), (2097152, 128, 128), (2097152, 128, 256), (32768, 256, 512), (32768, 512, 1024)]
+if "--shape" in sys.argv:
+    i = sys.argv.index("--shape")
+    ONLY = [tuple(int(v) for v in sys.argv[i + 1:i + 4])]
+else:
+    ONLY = None
+SHAPES = ONLY or [(4194304, 64, 64), (4194304, 64, 128), (2097152, 128, 128), (2097152, 128, 256), (32768, 256, 512), (32768, 512, 1024)]
 def timeit(fn):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
