@@ -169,7 +169,7 @@ def _measured_traffic(dom):
     return None
 
 
-def cpu_baseline(model_name, n_points, seconds_budget=20.0):
+def cpu_baseline(model_name, n_points, seconds_budget=15.0):
     """The CPU restatement (oracle/ref_models.py + the C oracle for the geometry) of the SAME step
     (forward + backward, training-mode BN, no optimiser), timed on the host cores of this box."""
     from oracle import ref_models as R
@@ -196,7 +196,7 @@ def cpu_baseline(model_name, n_points, seconds_budget=20.0):
         loss.backward()
         done += bs
         el = time.perf_counter() - t0
-        if el > seconds_budget or done >= 64:
+        if el > seconds_budget or done >= 1024:
             break
     return {"value": done / el, "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": "%d clouds of %d pts, %s forward+backward (train-mode BN), oracle/ref_models.py "
