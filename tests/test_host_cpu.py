@@ -1,0 +1,100 @@
+"""Host logic of the training loop, pinned by closed-form values: lr / BN-decay
+schedules, TF-flavoured Adam on flat buffers, the synthetic-cloud normalisation, and the TF1-style variable store."""
+import math
+
+import numpy as np
+import torch
+
+from scanobjectnn_amd import train_util as TU
+from scanobjectnn_amd.graph import Graph, constant_initializer, get_variable, variable_scope, xavier_initializer
+from scanobjectnn_amd.synth import center_data, normalize_data, synth_clouds
+
+
+def test_learning_rate_schedule():
+    """pointnet2/train.py:116-124 at B=16: staircase 0.7 every 200000 samples, floor 1e-5"""
+    assert TU.get_learning_rate(0, 16) == 1e-3
+    assert TU.get_learning_rate(12499, 16) == 1e-3                      # 199 984 samples
+    assert math.isclose(TU.get_learning_rate(12500, 16), 7e-4)         # 200 000 samples
+    assert math.isclose(TU.get_learning_rate(25000, 16), 4.9e-4)
+    assert TU.get_learning_rate(10 ** 6, 16) == 1e-5                   # 0.7^80 << 1e-5 -> clipped
+
+
+def test_bn_decay_schedule():
+    """pointnet2/train.py:126-134: min(0.99, 1 - 0.5*0.5^floor(step*B/200000))"""
+    assert TU.get_bn_decay(0, 16) == 0.5
+    assert TU.get_bn_decay(12499, 16) == 0.5
+    assert TU.get_bn_decay(12500, 16) == 0.75
+    assert TU.get_bn_decay(25000, 16) == 0.875
+    assert TU.get_bn_decay(10 ** 6, 16) == 0.99
+
+
+def test_tf_adam_one_and_two_steps_by_hand():
+    """tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps) (epsilon OUTSIDE)"""
+    lin = torch.nn.Linear(1, 1, bias=True)
+    with torch.no_grad():
+        lin.weight.fill_(2.0)
+        lin.bias.fill_(-1.0)
+    fp = TU.FlatParams(lin)
+    opt = TU.TFAdam(fp)
+    assert fp.flat.numel() == 2 and lin.weight.data_ptr() == fp.flat.data_ptr()
+    g1 = torch.tensor([0.5, -0.25])
+    fp.grad.copy_(g1)
+    opt.step(0.1)
+    m, v = 0.1 * g1, 0.001 * g1 * g1
+    lr_t = 0.1 * math.sqrt(1 - 0.999) / (1 - 0.9)
+    want = torch.tensor([2.0, -1.0]) - lr_t * m / (v.sqrt() + 1e-8)
+    assert torch.allclose(fp.flat, want, atol=1e-7)
+    g2 = torch.tensor([-1.0, 0.125])
+    fp.grad.copy_(g2)
+    opt.step(0.1)
+    m, v = 0.9 * m + 0.1 * g2, 0.999 * v + 0.001 * g2 * g2
+    lr_t = 0.1 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    want = want - lr_t * m / (v.sqrt() + 1e-8)
+    assert torch.allclose(fp.flat, want, atol=1e-7)
+    assert torch.allclose(lin.weight.flatten(), want[:1]) and torch.allclose(lin.bias, want[1:])
+
+
+def test_flat_params_gradients_accumulate_in_place():
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
+    fp = TU.FlatParams(net)
+    x = torch.randn(5, 3)
+    net(x).sum().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.equal(ref, fp.grad) and fp.grad.abs().sum() > 0
+    fp.zero_grad()
+    assert all(p.grad.abs().sum() == 0 for p in net.parameters())
+
+
+def test_center_and_normalize():
+    """data_utils.py:133-143,162-168"""
+    rng = np.random.default_rng(0)
+    pcs = rng.standard_normal((3, 50, 3)).astype(np.float32) * 4 + 2
+    c = center_data(pcs)
+    assert np.abs(c.mean(axis=1)).max() < 1e-5
+    n = normalize_data(c)
+    assert np.allclose(np.sqrt((n * n).sum(-1)).max(axis=1), 1.0, atol=1e-6)
+    s = synth_clouds(4, 256, seed=1)
+    assert s.dtype == np.float32 and s.shape == (4, 256, 3)
+    assert np.allclose(np.sqrt((s * s).sum(-1)).max(axis=1), 1.0, atol=1e-5)
+    assert np.array_equal(s, synth_clouds(4, 256, seed=1)) and not np.array_equal(s, synth_clouds(4, 256, seed=2))
+
+
+def test_variable_store_scopes_and_reuse():
+    g = Graph(seed=0)
+    with g.as_default():
+        with variable_scope("layer1"):
+            with variable_scope("conv0"):
+                w = get_variable("weights", [1, 1, 3, 64], xavier_initializer())
+                b = get_variable("biases", [64], constant_initializer(0.0))
+                with variable_scope("bn"):
+                    mm = get_variable("moving_mean", [64], constant_initializer(0.0), trainable=False)
+        with variable_scope("layer1"):
+            with variable_scope("conv0"):
+                w2 = get_variable("weights", [1, 1, 3, 64], xavier_initializer())
+    assert w is w2
+    names = dict(g.named_parameters())
+    assert set(names) == {"layer1/conv0/weights", "layer1/conv0/biases"}
+    assert "layer1/conv0/bn/moving_mean" in dict(g.named_buffers())
+    limit = math.sqrt(6.0 / (3 + 64))
+    assert w.abs().max().item() <= limit and w.abs().max().item() > 0.5 * limit and b.abs().sum() == 0
+    assert not mm.requires_grad
