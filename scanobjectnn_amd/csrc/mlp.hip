@@ -36,6 +36,24 @@ constexpr int kBK = 32;    // K chunk
 constexpr int kLdA = 36;   // A tile row stride in floats (16 B aligned, conflict-free b128 reads)
 
 enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3 };
+
+// ---- buffer-resource addressing (gfx950): ONE 32-bit VGPR offset per lane + a scalar offset per access, and the
+// hardware bounds check (offset >= num_records -> loads return 0, stores are dropped) replaces every row guard.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, long long bytes) {
+    const unsigned n = bytes <= 0 ? 0u : (bytes > 0xFFFFFFFFll ? 0xFFFFFFFFu : (unsigned)bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 x) {
+    u32x4 v;
+    v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y); v.z = __float_as_uint(x.z); v.w = __float_as_uint(x.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+constexpr unsigned kOOB = 0x7FFFFFF0u;   // a voffset no tensor reaches: forces the bounds check to fail
 enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2 };
 
 struct GemmArgs {
@@ -295,15 +313,21 @@ int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
 //   * the accumulator tile is transposed through the same stripe so that outputs leave as 16-byte stores of
 //     whole 512-byte row segments, and the per-channel statistics accumulate in the lane that owns the column;
 //   * the main loop contains NO workgroup barrier.
-template <int NT, int AM, int EM, int KC>
-__global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
+template <int NT, int AM, int EM, int KC, int WAVES, int EH>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs a) {
+    // WAVES waves per workgroup (4: one per SIMD, 8: two per SIMD so that one wave's staging / epilogue hides under
+    // its partner's MFMA phase); EH: the epilogue transposes the accumulator tile in EH column passes so that the
+    // wave stripe only needs max(KC, BN/EH) columns.
     constexpr int BN = NT * 32;
-    constexpr int LDW = (KC > BN ? KC : BN) + 4;   // stripe row stride (floats): 16 B aligned, conflict-free b128
+    constexpr int NTH = NT / EH;                   // accumulator tiles per epilogue pass
+    constexpr int BNH = BN / EH;                   // columns per epilogue pass
+    constexpr int LDW = (KC > BNH ? KC : BNH) + 4; // stripe row stride (floats): 16 B aligned, conflict-free b128
     constexpr int C4 = KC / 4;                     // float4 per operand stripe row
     constexpr int NLD = KC / 8;                    // float4 per lane per 32 x KC operand stripe
-    constexpr int O4 = BN / 4;                     // float4 per output tile row
-    constexpr int NST = BN / 8;                    // float4 per lane per 32 x BN output tile
+    constexpr int O4 = BNH / 4;                    // float4 per output row per pass
+    constexpr int NST = BNH / 8;                   // float4 per lane per pass
     constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : 5));
+    constexpr int NTHR = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = a.M, K = a.K, N = a.N;
@@ -313,12 +337,12 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
     float *coef = Ws + (size_t)Kp * BN;                     // [5][Kp]
     float *ecoef = coef + 5 * Kp;                           // [2][BN]: bias | (mask scale, mask shift)
     float *Aw = ecoef + 2 * BN + wave * 32 * LDW;           // [32][LDW] per wave
-    float *red = ecoef + 2 * BN + 4 * 32 * LDW;             // [4][2][BN]
+    float *red = ecoef + 2 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
     const int n0 = blockIdx.x * BN;
 
     // ---- resident data: weights + coefficient vectors, loaded once per workgroup
-    for (int e = tid; e < Kp * O4; e += 256) {
-        const int k = e / O4, nq = (e % O4) * 4;
+    for (int e = tid; e < Kp * (BN / 4); e += NTHR) {
+        const int k = e / (BN / 4), nq = (e % (BN / 4)) * 4;
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
             const float *src = a.W + (long long)k * N;
@@ -336,11 +360,11 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
     }
     {
         const float *vs[5] = {a.v0, a.v1, a.v2, a.v3, a.v4};
-        for (int e = tid; e < NCOEF * Kp; e += 256) {
+        for (int e = tid; e < NCOEF * Kp; e += NTHR) {
             const int which = e / Kp, k = e % Kp;
             coef[which * Kp + k] = k < K ? vs[which][k] : 0.f;
         }
-        for (int e = tid; e < BN; e += 256) {
+        for (int e = tid; e < BN; e += NTHR) {
             const int n = n0 + e;
             float e0 = 0.f, e1 = 0.f;
             if (n < N) {
@@ -353,51 +377,46 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
     }
     __syncthreads();
 
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // statistics of this lane's 4 columns
-    const int ocq = (lane % O4) * 4;                 // this lane's output column quad (fixed: 64 % O4 == 0)
-    const bool ocin = n0 + ocq < N;                  // N % 4 == 0 is required by the launcher for this kernel
-    float4 eb = make_float4(0.f, 0.f, 0.f, 0.f), em = eb;
-    eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
-    em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
+    float s1[EH][4], s2[EH][4];                      // statistics of this lane's 4 columns, per epilogue pass
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[h][e] = s2[h][e] = 0.f;
+    const int ocl = (lane % O4) * 4;                 // column quad inside a pass (fixed: 64 % O4 == 0)
 
     const long long ntiles = ((long long)M + 31) / 32;
-    const long long tstride = (long long)gridDim.y * 4;
+    const long long tstride = (long long)gridDim.y * WAVES;
     float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
     float4 pb[(AM >= A_DY) ? NLD : 1];               // A_DY*: raw Y
     unsigned pm[(AM == A_DYPOOL) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
-    float4 py[(EM == E_MASK) ? NST : 1];             // E_MASK: raw Y of the previous layer (output shaped)
 
+    // per-lane byte offsets inside a tile (the row part of element e = lane + 64 j is added as a SCALAR offset)
+    const unsigned xvoff = (unsigned)((lane / C4) * a.ldx + (lane % C4) * 4) * 4u;
+    const unsigned xrowstep = (unsigned)(64 / C4) * (unsigned)a.ldx * 4u;          // bytes per j
+    const unsigned yrowstep = (unsigned)(64 / O4) * (unsigned)a.ldy * 4u;
     auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
+        if (AM == A_DYPOOL) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int e = lane + 64 * j;
-            const int r = e / C4;
-            int c = (e % C4) * 4 + kc * KC;
-            c = c < K ? c : K - 4;
-            long long row = row0 + r;
-            row = row < M ? row : M - 1;
-            if (AM == A_DYPOOL) {
+            for (int j = 0; j < NLD; ++j) {
+                const int e = lane + 64 * j;
+                int c = (e % C4) * 4 + kc * KC;
+                c = c < K ? c : K - 4;
+                long long row = row0 + e / C4;
+                row = row < M ? row : M - 1;
                 const long long gi = row / a.S;
                 pa[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
                 pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
-            } else {
-                pa[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + c);
             }
-            if (AM >= A_DY) pb[j] = *reinterpret_cast<const float4 *>(a.X2 + row * a.ldx + c);
         }
-    };
-    auto issue_epi = [&](long long tile) {
-        if (EM == E_MASK) {
-            const long long row0 = tile * 32;
+        const long long left = ((long long)M - row0) * a.ldx * 4;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, left);
+        const __amdgpu_buffer_rsrc_t rx2 = make_rsrc((AM >= A_DY ? a.X2 : a.X) + row0 * a.ldx, left);
+        const unsigned kbytes = (unsigned)(kc * KC) * 4u;
 #pragma unroll
-            for (int j = 0; j < NST; ++j) {
-                const int e = lane + 64 * j;
-                long long row = row0 + e / O4;
-                row = row < M ? row : M - 1;
-                const int n = ocin ? n0 + ocq : 0;
-                py[j] = *reinterpret_cast<const float4 *>(a.Yprev + row * a.ldy + n);
-            }
+        for (int j = 0; j < NLD; ++j) {
+            if (AM != A_DYPOOL) pa[j] = buf_load4(rx, xvoff, kbytes + (unsigned)j * xrowstep);
+            if (AM >= A_DY) pb[j] = buf_load4(rx2, xvoff, kbytes + (unsigned)j * xrowstep);
         }
     };
     auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
@@ -446,11 +465,8 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
         }
     };
 
-    long long tile = (long long)blockIdx.y * 4 + wave;
-    if (tile < ntiles) {
-        issue(tile, 0);
-        issue_epi(tile);
-    }
+    long long tile = (long long)blockIdx.y * WAVES + wave;
+    if (tile < ntiles) issue(tile, 0);
     for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
 #pragma unroll
@@ -470,140 +486,175 @@ __global__ __launch_bounds__(256, 1) void gemm_ws_kernel(GemmArgs a) {
 
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
             const float *bcol = &Ws[(kc * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
-#pragma unroll 4
+            // software pipeline: the fragments of step it+1 are requested from LDS before the 4*NT MFMAs of step
+            // it are issued
+            float4 av_n = *reinterpret_cast<const float4 *>(arow);
+            float bv_n[4][NT];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv_n[t][nt] = bcol[t * BN + 32 * nt];
+#pragma unroll 2
             for (int it = 0; it < KC / 8; ++it) {
-                const float4 av = *reinterpret_cast<const float4 *>(arow + 8 * it);
-                const float ae[4] = {av.x, av.y, av.z, av.w};
+                const float ae[4] = {av_n.x, av_n.y, av_n.z, av_n.w};
+                float bv[4][NT];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const float bv = bcol[(8 * it + t) * BN + 32 * nt];
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv, acc[nt], 0, 0, 0);
-                    }
+                    for (int nt = 0; nt < NT; ++nt) bv[t][nt] = bv_n[t][nt];
+                if (it + 1 < KC / 8) {
+                    av_n = *reinterpret_cast<const float4 *>(arow + 8 * (it + 1));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bv_n[t][nt] = bcol[(8 * (it + 1) + t) * BN + 32 * nt];
                 }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv[t][nt], acc[nt], 0, 0, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        // ---- epilogue: accumulators -> stripe (transposed) -> 16-byte row-segment stores
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v)
-                Aw[((v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)) * LDW + 32 * nt + (lane & 31)] = acc[nt][v];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
+        const __amdgpu_buffer_rsrc_t rprev =
+            make_rsrc((EM == E_MASK ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-            const int r = (lane + 64 * j) / O4;
-            const long long row = row0 + r;
-            float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocq]);
-            if (row < M && ocin) {
-                if (EM == E_FWD) {
-                    o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
-                    s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
-                    s2[0] = fmaf(o.x, o.x, s2[0]); s2[1] = fmaf(o.y, o.y, s2[1]);
-                    s2[2] = fmaf(o.z, o.z, s2[2]); s2[3] = fmaf(o.w, o.w, s2[3]);
-                } else if (EM == E_MASK) {
-                    const float4 yp = py[j];
-                    o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
-                    o.y = fmaf(yp.y, eb.y, em.y) > 0.f ? o.y : 0.f;
-                    o.z = fmaf(yp.z, eb.z, em.z) > 0.f ? o.z : 0.f;
-                    o.w = fmaf(yp.w, eb.w, em.w) > 0.f ? o.w : 0.f;
-                    s1[0] += o.x; s1[1] += o.y; s1[2] += o.z; s1[3] += o.w;
-                    s2[0] = fmaf(o.x, yp.x, s2[0]); s2[1] = fmaf(o.y, yp.y, s2[1]);
-                    s2[2] = fmaf(o.z, yp.z, s2[2]); s2[3] = fmaf(o.w, yp.w, s2[3]);
-                }
-                *reinterpret_cast<float4 *>(a.Y + row * a.ldy + n0 + ocq) = o;
+        for (int h = 0; h < EH; ++h) {
+            const int ocq = h * BNH + ocl;                   // this lane's column quad in the BN-wide tile
+            const bool ocin = n0 + ocq < N;                  // N % 4 == 0 (launcher)
+            const unsigned yvoff = ocin ? (unsigned)((lane / O4) * a.ldy + n0 + ocq) * 4u : kOOB;
+            float4 py[(EM == E_MASK) ? NST : 1];
+            if (EM == E_MASK) {
+                // the mask tensor is requested HERE (not a tile ahead): it would cost NST more live float4 across the
+                // whole MFMA phase, and with two waves per SIMD the partner wave covers this latency
+#pragma unroll
+                for (int j = 0; j < NST; ++j) py[j] = buf_load4(rprev, yvoff, (unsigned)j * yrowstep);
             }
+            const float4 eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
+            const float4 em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int nt = 0; nt < NTH; ++nt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    Aw[((v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)) * LDW + 32 * nt + (lane & 31)] = acc[h * NTH + nt][v];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const int r = (lane + 64 * j) / O4;
+                const long long row = row0 + r;
+                float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocl]);
+                if (row < M && ocin) {
+                    if (EM == E_FWD) {
+                        o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
+                        s1[h][0] += o.x; s1[h][1] += o.y; s1[h][2] += o.z; s1[h][3] += o.w;
+                        s2[h][0] = fmaf(o.x, o.x, s2[h][0]); s2[h][1] = fmaf(o.y, o.y, s2[h][1]);
+                        s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
+                    } else if (EM == E_MASK) {
+                        const float4 yp = py[j];
+                        o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
+                        o.y = fmaf(yp.y, eb.y, em.y) > 0.f ? o.y : 0.f;
+                        o.z = fmaf(yp.z, eb.z, em.z) > 0.f ? o.z : 0.f;
+                        o.w = fmaf(yp.w, eb.w, em.w) > 0.f ? o.w : 0.f;
+                        s1[h][0] += o.x; s1[h][1] += o.y; s1[h][2] += o.z; s1[h][3] += o.w;
+                        s2[h][0] = fmaf(o.x, yp.x, s2[h][0]); s2[h][1] = fmaf(o.y, yp.y, s2[h][1]);
+                        s2[h][2] = fmaf(o.z, yp.z, s2[h][2]); s2[h][3] = fmaf(o.w, yp.w, s2[h][3]);
+                    }
+                }
+                buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (more) issue_epi(tile + tstride);
     }
 
     if (EM != E_PLAIN && a.stats) {
         // lanes l, l + O4, l + 2 O4 ... own the same 4 columns
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int off = 32; off >= O4; off >>= 1) {
-                s1[e] += __shfl_xor(s1[e], off, 64);
-                s2[e] += __shfl_xor(s2[e], off, 64);
-            }
-        }
-        if (lane < O4) {
+        for (int h = 0; h < EH; ++h) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                red[(wave * 2 + 0) * BN + ocq + e] = s1[e];
-                red[(wave * 2 + 1) * BN + ocq + e] = s2[e];
+#pragma unroll
+                for (int off = 32; off >= O4; off >>= 1) {
+                    s1[h][e] += __shfl_xor(s1[h][e], off, 64);
+                    s2[h][e] += __shfl_xor(s2[h][e], off, 64);
+                }
+            }
+            if (lane < O4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[(wave * 2 + 0) * BN + h * BNH + ocl + e] = s1[h][e];
+                    red[(wave * 2 + 1) * BN + h * BNH + ocl + e] = s2[h][e];
+                }
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
+        for (int i = tid; i < 2 * BN; i += NTHR) {
+            const int which = i / BN, c = i % BN;
             if (n0 + c < N) {
-                const float v = (red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) +
-                                (red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c]);
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) v += red[(w * 2 + which) * BN + c];
                 a.stats[((long long)blockIdx.y * 2 + which) * N + n0 + c] = v;
             }
         }
     }
 }
 
-static size_t ws_lds_bytes(int Kp, int KC, int bn) {
-    // weights + 5 coefficient vectors + 2 epilogue vectors + 4 wave stripes + statistics scratch
-    const int ldw = (KC > bn ? KC : bn) + 4;
-    return (size_t)(Kp * bn + 5 * Kp + 2 * bn + 4 * 32 * ldw + 8 * bn) * sizeof(float);
+struct WsPlan {
+    int kc, bn, waves, eh, ncb, gy;
+    size_t lds;
+};
+
+static size_t ws_lds_bytes(int Kp, int kc, int bn, int waves, int eh) {
+    // weights + 5 coefficient vectors + 2 epilogue vectors + wave stripes + statistics scratch
+    const int ldw = (kc > bn / eh ? kc : bn / eh) + 4;
+    return (size_t)(Kp * bn + 5 * Kp + 2 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
 }
 
-// number of persistent workgroups along the row axis (= partial-statistics rows) for the wave-stream kernel
-static int ws_grid_rows(int M, int ncolblocks) {
-    const long long ntiles = ((long long)M + 31) / 32;
-    long long want = 512 / (ncolblocks > 0 ? ncolblocks : 1);   // ~2 workgroups per CU overall
-    if (want < 1) want = 1;
-    const long long maxg = (ntiles + 3) / 4;
-    return (int)(want < maxg ? want : maxg);
-}
-
-static bool ws_eligible(const GemmArgs &a, int am) {
+static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
     if (am == A_DYPOOL && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
         return false;
-    if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
-    if (am == A_DYPOOL && (a.K % 4 != 0)) return false;
+    // 8 waves (two per SIMD) with 64-wide stripes; 128 output columns when the resident weight tile fits
+    pl->kc = 64;
+    pl->waves = 8;
+    const int Kp = (a.K + 63) / 64 * 64;
+    pl->bn = 64;
+    pl->eh = 1;
+    if (a.N > 64 && ws_lds_bytes(Kp, 64, 128, 8, 2) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
+    pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
+    if (pl->lds > 160 * 1024) return false;
+    pl->ncb = (a.N + pl->bn - 1) / pl->bn;
+    const long long ntiles = ((long long)a.M + 31) / 32;
+    long long want = 256 / pl->ncb;                          // one persistent workgroup per CU over the whole grid
+    if (want < 1) want = 1;
+    const long long maxg = (ntiles + pl->waves - 1) / pl->waves;
+    pl->gy = (int)(want < maxg ? want : maxg);
     return true;
 }
 
 template <int AM, int EM>
-int launch_gemm_ws(GemmArgs &a, hipStream_t st) {
-    // KC: stripe width; BN: 128 when the resident weight tile fits beside the stripes, else 64
-    const int KC = a.K <= 64 ? 64 : 128;
-    const int nchunk = (a.K + KC - 1) / KC;
-    const int Kp = nchunk * KC;
-    auto lds_bytes = [&](int bn) { return ws_lds_bytes(Kp, KC, bn); };
-    int bn = (a.N > 64 && lds_bytes(128) <= 160 * 1024) ? 128 : 64;
-    if (lds_bytes(bn) > 160 * 1024) return PCOPS_ERR_UNSUPPORTED;
-    const int ncb = (a.N + bn - 1) / bn;
-    const int gy = ws_grid_rows(a.M, ncb);
-    const size_t lds = lds_bytes(bn);
-#define PCOPS_WS_LAUNCH(NT_, KC_)                                                                     \
+int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
+#define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
-        auto kern = gemm_ws_kernel<NT_, AM, EM, KC_>;                                                 \
+        auto kern = gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_>;                                          \
         static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                      160 * 1024);                                     \
         (void)once;                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(ncb, gy), dim3(256), lds, st, a);                               \
+        hipLaunchKernelGGL(kern, dim3(pl.ncb, pl.gy), dim3(512), pl.lds, st, a);                      \
     } while (0)
-    if (bn == 128 && KC == 128) PCOPS_WS_LAUNCH(4, 128);
-    else if (bn == 128) PCOPS_WS_LAUNCH(4, 64);
-    else if (KC == 128) PCOPS_WS_LAUNCH(2, 128);
-    else PCOPS_WS_LAUNCH(2, 64);
+    if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
+    else PCOPS_WS_LAUNCH(2, 1);
 #undef PCOPS_WS_LAUNCH
     return pcops_launch_status();
 }
@@ -622,23 +673,16 @@ static bool ws_enabled() {
 // The partial-statistics buffer always has pcops_mlp_stats_rows(M) rows; rows a kernel does not emit are zeroed.
 template <int AM, int EM>
 int launch_gemm(GemmArgs &a, hipStream_t st) {
-    if (ws_enabled() && ws_eligible(a, AM)) {
-        int rc = launch_gemm_ws<AM, EM>(a, st);
-        if (rc != PCOPS_ERR_UNSUPPORTED) {
-            if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
-                const int KC = a.K <= 64 ? 64 : 128;
-                const int Kp = (a.K + KC - 1) / KC * KC;
-                const bool big = (a.N > 64) && (ws_lds_bytes(Kp, KC, 128) <= 160 * 1024);
-                const int ncb = (a.N + (big ? 128 : 64) - 1) / (big ? 128 : 64);
-                const int gy = ws_grid_rows(a.M, ncb);
-                const int P = pcops_mlp_stats_rows(a.M);
-                if (gy < P &&
-                    hipMemsetAsync(a.stats + (size_t)gy * 2 * a.N, 0, sizeof(float) * (size_t)(P - gy) * 2 * a.N, st) !=
-                        hipSuccess)
-                    return PCOPS_ERR_LAUNCH;
-            }
-            return rc;
+    WsPlan pl;
+    if (ws_enabled() && ws_plan(a, AM, &pl)) {
+        int rc = launch_gemm_ws<AM, EM>(a, pl, st);
+        if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
+            const int P = pcops_mlp_stats_rows(a.M);
+            if (pl.gy < P && hipMemsetAsync(a.stats + (size_t)pl.gy * 2 * a.N, 0,
+                                            sizeof(float) * (size_t)(P - pl.gy) * 2 * a.N, st) != hipSuccess)
+                return PCOPS_ERR_LAUNCH;
         }
+        return rc;
     }
     return launch_gemm_rt<AM, EM>(a, st);
 }
