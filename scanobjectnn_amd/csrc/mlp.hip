@@ -1120,25 +1120,28 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     const long long nstripes = (M + RS - 1) / RS;
     const long long sstride = (long long)gridDim.z * 4;
 
+    // one 32-bit lane offset per tensor + a scalar offset per access; rows beyond M fail the hardware bounds check
+    const unsigned xvoff = ain ? (unsigned)((lane / A4) * a.ldx + acl) * 4u : kOOB;
+    const unsigned dvoff = din ? (unsigned)((lane / D4) * a.ldy + dcl) * 4u : kOOB;
+    const unsigned xstep = (unsigned)(64 / A4) * (unsigned)a.ldx * 4u, dstep = (unsigned)(64 / D4) * (unsigned)a.ldy * 4u;
     auto issue = [&](long long stripe) {
         const long long row0 = stripe * RS;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc((DMODE == A_DYPOOL ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            long long row = row0 + (lane + 64 * j) / A4;
-            row = row < M ? row : M - 1;
-            px[j] = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + acl);
-        }
+        for (int j = 0; j < NA; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
-            long long row = row0 + (lane + 64 * j) / D4;
-            row = row < M ? row : M - 1;
-            py[j] = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + dcl);
+            py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
             if (DMODE == A_DYPOOL) {
+                long long row = row0 + (lane + 64 * j) / D4;
+                row = row < M ? row : M - 1;
                 const long long gi = row / a.S;
                 pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
                 pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
             } else {
-                pg[j] = *reinterpret_cast<const float4 *>(a.G + row * a.ldy + dcl);
+                pg[j] = buf_load4(rg, dvoff, (unsigned)j * dstep);
             }
         }
     };
@@ -1190,13 +1193,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (stripe + sstride < nstripes) issue(stripe + sstride);
+        float av_n[TK], dv_n[TN];
+#pragma unroll
+        for (int i = 0; i < TK; ++i) av_n[i] = As[half * KB + 32 * i + li];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dv_n[j] = Ds[half * NB + 32 * j + li];
 #pragma unroll 2
         for (int it = 0; it < RS / 2; ++it) {
             float av[TK], dv[TN];
 #pragma unroll
-            for (int i = 0; i < TK; ++i) av[i] = As[(2 * it + half) * KB + 32 * i + li];
+            for (int i = 0; i < TK; ++i) av[i] = av_n[i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) dv[j] = Ds[(2 * it + half) * NB + 32 * j + li];
+            for (int j = 0; j < TN; ++j) dv[j] = dv_n[j];
+            if (it + 1 < RS / 2) {       // fragments of the next row pair are requested before this pair's MFMAs
+#pragma unroll
+                for (int i = 0; i < TK; ++i) av_n[i] = As[(2 * (it + 1) + half) * KB + 32 * i + li];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dv_n[j] = Ds[(2 * (it + 1) + half) * NB + 32 * j + li];
+            }
 #pragma unroll
             for (int i = 0; i < TK; ++i)
 #pragma unroll
