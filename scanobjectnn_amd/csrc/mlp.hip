@@ -338,7 +338,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     float *ecoef = coef + 5 * Kp;                           // [2][BN]: bias | (mask scale, mask shift)
     float *Aw = ecoef + 2 * BN + wave * 32 * LDW;           // [32][LDW] per wave
     float *red = ecoef + 2 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
-    const int n0 = blockIdx.x * BN;
+    // grid = (row groups, column blocks): the column blocks of one row group have linear ids that differ by a
+    // multiple of 8, i.e. they run on the SAME XCD and the second reader of a stripe hits that XCD's L2
+    const int n0 = blockIdx.y * BN;
+    const int rowgrp = blockIdx.x, nrowgrp = gridDim.x;
 
     // ---- resident data: weights + coefficient vectors, loaded once per workgroup
     for (int e = tid; e < Kp * (BN / 4); e += NTHR) {
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const int ocl = (lane % O4) * 4;                 // column quad inside a pass (fixed: 64 % O4 == 0)
 
     const long long ntiles = ((long long)M + 31) / 32;
-    const long long tstride = (long long)gridDim.y * WAVES;
+    const long long tstride = (long long)nrowgrp * WAVES;
     float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
     float4 pb[(AM >= A_DY) ? NLD : 1];               // A_DY*: raw Y
     unsigned pm[(AM == A_DYPOOL) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         }
     };
 
-    long long tile = (long long)blockIdx.y * WAVES + wave;
+    long long tile = (long long)rowgrp * WAVES + wave;
     if (tile < ntiles) issue(tile, 0);
     for (; tile < ntiles; tile += tstride) {
         f32x16 acc[NT];
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < WAVES; ++w) v += red[(w * 2 + which) * BN + c];
-                a.stats[((long long)blockIdx.y * 2 + which) * N + n0 + c] = v;
+                a.stats[((long long)rowgrp * 2 + which) * N + n0 + c] = v;
             }
         }
     }
@@ -639,6 +642,7 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (want < 1) want = 1;
     const long long maxg = (ntiles + pl->waves - 1) / pl->waves;
     pl->gy = (int)(want < maxg ? want : maxg);
+    if (pl->gy >= 8) pl->gy &= ~7;                             // multiple of 8: see the grid comment in the kernel
     return true;
 }
 
@@ -651,7 +655,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                                      160 * 1024);                                     \
         (void)once;                                                                                   \
-        hipLaunchKernelGGL(kern, dim3(pl.ncb, pl.gy), dim3(512), pl.lds, st, a);                      \
+        hipLaunchKernelGGL(kern, dim3(pl.gy, pl.ncb), dim3(512), pl.lds, st, a);                      \
     } while (0)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
     else PCOPS_WS_LAUNCH(2, 1);
@@ -1070,7 +1074,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, N = a.N;
     const long long M = a.M;
-    const int k0 = blockIdx.x * KB, n0 = blockIdx.y * NB;
+    // grid = (row groups, K blocks, N blocks): the (K,N) blocks of one row group sit on the same XCD (linear ids
+    // differ by multiples of 8) so that re-reads of a stripe by a sibling block hit that XCD's L2
+    const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
     float *coefA = lds;                       // [2][KB]  scale, shift (A side)
     float *coefD = coefA + 2 * KB;            // [5][NB]  p, q, t, pool scale, pool shift
     float *As = coefD + 5 * NB + wave * RS * (KB + NB);   // [RS][KB]
@@ -1118,7 +1125,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     float4 px[NA], pg[ND], py[ND];
     unsigned pm[(DMODE == A_DYPOOL) ? ND : 1];
     const long long nstripes = (M + RS - 1) / RS;
-    const long long sstride = (long long)gridDim.z * 4;
+    const long long sstride = (long long)ngrp * 4;
 
     // one 32-bit lane offset per tensor + a scalar offset per access; rows beyond M fail the hardware bounds check
     const unsigned xvoff = ain ? (unsigned)((lane / A4) * a.ldx + acl) * 4u : kOOB;
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
         }
     };
 
-    long long stripe = (long long)blockIdx.z * 4 + wave;
+    long long stripe = (long long)grp * 4 + wave;
     if (stripe < nstripes) issue(stripe);
     const int half = lane >> 5, li = lane & 31;
     for (; stripe < nstripes; stripe += sstride) {
@@ -1245,14 +1252,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
         }
     }
     __syncthreads();
-    float *out = a.part + (long long)blockIdx.z * K * N;
+    float *out = a.part + (long long)grp * K * N;
     for (int i = tid; i < KB * NB; i += 256) {
         const int kl = i / NB, nl = i % NB;
         if (k0 + kl < K && n0 + nl < N) out[(long long)(k0 + kl) * N + n0 + nl] = red[i];
     }
-    if (blockIdx.x == 0 && a.dbpart)
+    if (blockIdx.y == 0 && a.dbpart)
         for (int i = tid; i < NB; i += 256)
-            if (n0 + i < N) a.dbpart[(long long)blockIdx.z * N + n0 + i] = red[KB * NB + i];
+            if (n0 + i < N) a.dbpart[(long long)grp * N + n0 + i] = red[KB * NB + i];
 }
 
 struct WsWgradPlan {
@@ -1278,6 +1285,7 @@ static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, con
     if (groups < 1) groups = 1;
     const long long maxg = ((M + pl->rs - 1) / pl->rs + 3) / 4;
     if (groups > maxg) groups = (int)maxg;
+    if (groups >= 8) groups &= ~7;
     pl->groups = groups;
     pl->lds = (size_t)(2 * KB + 5 * NB + 4 * pl->rs * (KB + NB) + KB * NB + NB) * sizeof(float);
     return pl->lds <= 160 * 1024;
@@ -1525,7 +1533,7 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
         splits = pl.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-        const dim3 grid(pl.kblocks, pl.nblocks, pl.groups);
+        const dim3 grid(pl.groups, pl.kblocks, pl.nblocks);
 #define PCOPS_WG_LAUNCH(TK_, TN_, RS_, AM_, DM_)                                                           \
     do {                                                                                                   \
         auto kern = wgrad_ws_kernel<TK_, TN_, RS_, AM_, DM_>;                                              \
