@@ -19,6 +19,9 @@ def placeholder_inputs(batch_size, num_point, device=None):
 
 def _edge_conv(x, width, scope, k, is_training, bn_decay):
     nn_idx = tf_util.knn_graph(x, k=k)
+    if tf_util.fused_ok(x, [width]):
+        # EdgeConv without the (B,N,k,2C) edge tensor: first conv per point, gather + add, fused BN/ReLU/max
+        return tf_util.edge_conv_stack(x, nn_idx, [width], [scope], is_training, bn_decay)
     edge_feature = tf_util.get_edge_feature(x, nn_idx=nn_idx, k=k)
     net = tf_util.conv2d(edge_feature, width, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                          is_training=is_training, scope=scope, bn_decay=bn_decay)
@@ -28,16 +31,23 @@ def _edge_conv(x, width, scope, k, is_training, bn_decay):
 def backbone(point_cloud, is_training, bn_decay, k=20):
     """shared by dgcnn / dgcnn_bga: returns (net1..net4, agg) with agg (B,N,1,1024)"""
     nn_idx = tf_util.knn_graph(point_cloud, k=k)
-    edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
     with variable_scope('transform_net1'):
-        transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
+        if tf_util.fused_ok(point_cloud, [64, 128]):
+            transform = input_transform_net(None, is_training, bn_decay, K=3, point_cloud=point_cloud, nn_idx=nn_idx)
+        else:
+            edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
+            transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
     point_cloud_transformed = torch.matmul(point_cloud, transform)
     net1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay)
     net2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay)
     net3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay)
     net4 = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay)
-    agg = tf_util.conv2d(torch.cat([net1, net2, net3, net4], dim=-1), 1024, [1, 1], padding='VALID',
-                         stride=[1, 1], bn=True, is_training=is_training, scope='agg', bn_decay=bn_decay)
+    cat = torch.cat([net1, net2, net3, net4], dim=-1)
+    if tf_util.fused_ok(cat, [1024]):
+        agg = tf_util.conv2d_stack(cat, [1024], ['agg'], is_training, bn_decay)
+    else:
+        agg = tf_util.conv2d(cat, 1024, [1, 1], padding='VALID', stride=[1, 1], bn=True, is_training=is_training,
+                             scope='agg', bn_decay=bn_decay)
     return net1, net2, net3, net4, agg
 
 

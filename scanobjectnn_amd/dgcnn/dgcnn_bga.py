@@ -34,10 +34,14 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 
     concat = torch.cat([class_vector.expand(batch_size, num_point, 1, 256), expand, net1, net2, net3, net4],
                        dim=-1)                                                             # 1600 ch
-    net = tf_util.conv2d(concat, 512, [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                         is_training=is_training, scope='seg/conv1', is_dist=True)
-    net = tf_util.conv2d(net, 256, [1, 1], padding='VALID', stride=[1, 1], bn=True,
-                         is_training=is_training, scope='seg/conv2', is_dist=True)
+    if tf_util.fused_ok(concat, [512, 256]):
+        # note: the reference passes no bn_decay here (dgcnn_bga.py:125-128) -> decay 0.9
+        net = tf_util.conv2d_stack(concat, [512, 256], ['seg/conv1', 'seg/conv2'], is_training, None, is_dist=True)
+    else:
+        net = tf_util.conv2d(concat, 512, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                             is_training=is_training, scope='seg/conv1', is_dist=True)
+        net = tf_util.conv2d(net, 256, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                             is_training=is_training, scope='seg/conv2', is_dist=True)
     net = tf_util.dropout(net, keep_prob=0.7, is_training=is_training, scope='dp1')
     net = tf_util.conv2d(net, 2, [1, 1], padding='VALID', stride=[1, 1], activation_fn=None,
                          scope='seg/conv3', is_dist=True)

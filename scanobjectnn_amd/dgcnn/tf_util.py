@@ -14,8 +14,9 @@ materialises the (B,N,N) adjacency and yields the same indices.
 import torch
 import torch.nn.functional as F
 
-from .. import _lib
+from .. import _lib, fused_mlp
 from ..graph import constant_initializer, get_variable, variable_scope
+from ..pointnet2 import tf_util as _pn2
 from ..pointnet2.tf_util import (_dense, _variable_with_weight_decay, avg_pool2d, dropout,  # noqa: F401
                                  max_pool2d, relu)
 
@@ -174,3 +175,39 @@ def get_edge_feature(point_cloud, nn_idx, k=20):
     if nn_idx.shape[:2] != x.shape[:2] or nn_idx.shape[2] != k:
         raise ValueError("nn_idx must be (B,N,k)")
     return _EdgeFeature.apply(x, nn_idx)
+
+
+# ---------------------------------------------------------------------------- fused EdgeConv / conv stacks
+def fused_ok(x, widths):
+    return (_pn2.FUSED_MLP and x.is_cuda and x.dtype == torch.float32 and all(w % 32 == 0 for w in widths)
+            and 256 % (widths[0] // 4) == 0 and (widths[0] >= 256 or 256 % widths[0] == 0) and widths[0] <= 1024)
+
+
+def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, is_dist=False):
+    """get_edge_feature + len(widths) x conv2d([1,1], bn, relu) + max over the k neighbours, without ever
+    building the (B,N,k,2C) edge tensor.  The first conv is linear in the edge feature [x_i | x_j - x_i]:
+        [x_i | x_j - x_i] W + b = x_i (W_a - W_b) + x_j W_b + b        (W = [W_a ; W_b], rows 0..C-1 / C..2C-1)
+    so it is evaluated once per POINT (two small library GEMMs) and the (B,N,k,C') activation is the gather + add
+    of csrc/gather.hip (`Q[b, nn_idx] + Ctr[b, i]`); the rest is the fused MLP stack.  Variables are exactly the
+    ones `conv2d(..., scope=scopes[i], bn=True)` creates (dgcnn/models/dgcnn.py:39-48, transform_nets.py:18-27).
+    point_cloud (B,N,C)|(B,N,1,C), nn_idx (B,N,k) -> (B,N,1,widths[-1])"""
+    x = _squeeze_cloud(point_cloud)
+    b, n, c = x.shape
+    names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
+    layers = _pn2._stack_variables(2 * c, widths, list(scopes), 1e-3, None, True, names)
+    w1, b1 = layers[0][0], layers[0][1]
+    w_a, w_b = w1[:c], w1[c:]
+    x2d = x.reshape(b * n, c)
+    q = (x2d @ w_b).view(b, n, widths[0])                       # neighbour term, gathered by nn_idx
+    ctr = torch.addmm(b1, x2d, w_a - w_b).view(b, n, widths[0])  # centre term + bias
+    decay = bn_decay if bn_decay is not None else 0.9
+    out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, Q=q, Ctr=ctr)
+    return out.view(b, n, 1, widths[-1])
+
+
+def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False):
+    """len(widths) x conv2d([1,1], bn, relu) on a channel-last (B,H,W,C) tensor through the fused MLP stack
+    (this module's BN flavour: biased variance in the moving statistics)."""
+    names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
+    return _pn2.conv2d_stack(inputs, widths, list(scopes), is_training, bn_decay, unbiased_moving_var=False,
+                             mov_names=names)

@@ -109,10 +109,11 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
 
 
 def _stack_variables(cin, widths, scope_fmt, stddev, weight_decay, use_xavier, mov_names):
-    """creates / fetches exactly the variables a chain of conv2d(..., bn=True) calls would"""
+    """creates / fetches exactly the variables a chain of conv2d(..., bn=True) calls would.
+    scope_fmt: a '%d' format, or a list/tuple with one scope name per layer."""
     layers = []
     for i, width in enumerate(widths):
-        with variable_scope(scope_fmt % i):
+        with variable_scope(scope_fmt[i] if isinstance(scope_fmt, (list, tuple)) else scope_fmt % i):
             kernel = _variable_with_weight_decay('weights', [1, 1, cin, width], stddev=stddev,
                                                  wd=weight_decay, use_xavier=use_xavier)
             biases = get_variable('biases', [width], constant_initializer(0.0))
