@@ -9,6 +9,7 @@
 //   (fmaf(0,0,acc) == acc), which lets the fused kernel keep the query row in VGPRs at a
 //   compile-time width.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -104,6 +105,148 @@ int launch_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx, hi
     if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((knn_graph_kernel<C, TJ>), dim3(cdiv(n, threads), b), dim3(threads), lds, st,
                        n, c, k, x, nn_idx);
+    return pcops_launch_status();
+}
+
+// ------------------------------------------------------------------ fused kNN graph on the matrix cores
+// D = -2 X X^T + s_i + s_j on v_mfma_f32_32x32x2_f32: gfx950's f32 MFMA is bit-for-bit a k-ordered fmaf chain,
+// i.e. exactly the arithmetic contract above (inner = fmaf chain over c ascending from +0), so the indices stay
+// bit-exact w.r.t. the oracle while the VALU is left free for the top-k bookkeeping.
+//   * workgroup = 4 waves = 128 query rows of one cloud; a wave owns 32 queries whose channels sit in VGPRs as
+//     MFMA B fragments (query = lane & 31, channel parity = lane >> 5);
+//   * candidates stream through LDS in chunks of 128 rows (row stride CP+1 -> conflict-free column reads);
+//     a 32-candidate x 32-query tile costs CP/2 MFMAs; candidates are the tile ROWS, so each lane sees 16
+//     candidates of ONE query per tile, in ascending index order -> strict '<' keeps the lower index on ties;
+//   * each lane keeps a sorted top-KL list in registers: insertion is one v_med3_f32 + one compare + two selects
+//     per slot; the two half-waves of a query (rows r and r+4 interleaved) are merged at the end with a
+//     (distance, index) lexicographic insertion.
+typedef float f32x16k __attribute__((ext_vector_type(16)));
+
+template <int KL>
+struct TopK {
+    float v[KL];
+    int ix[KL];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KL; ++s) { v[s] = INFINITY; ix[s] = 0; }
+    }
+    // candidates arrive in ascending index order: strict '<' on the value alone keeps the lower index first
+    __device__ __forceinline__ void insert_ascending(float d, int j) {
+        bool c_hi = d < v[KL - 1];
+#pragma unroll
+        for (int s = KL - 1; s >= 1; --s) {
+            const bool c_lo = d < v[s - 1];
+            const float nv = __builtin_amdgcn_fmed3f(v[s - 1], d, v[s]);
+            ix[s] = c_lo ? ix[s - 1] : (c_hi ? j : ix[s]);
+            v[s] = nv;
+            c_hi = c_lo;
+        }
+        if (c_hi) { v[0] = d; ix[0] = j; }
+    }
+    // general insertion: (distance, index) lexicographic
+    __device__ __forceinline__ void insert_lex(float d, int j) {
+        bool c_hi = d < v[KL - 1] || (d == v[KL - 1] && j < ix[KL - 1]);
+#pragma unroll
+        for (int s = KL - 1; s >= 1; --s) {
+            const bool c_lo = d < v[s - 1] || (d == v[s - 1] && j < ix[s - 1]);
+            const float nv = c_lo ? v[s - 1] : (c_hi ? d : v[s]);
+            ix[s] = c_lo ? ix[s - 1] : (c_hi ? j : ix[s]);
+            v[s] = nv;
+            c_hi = c_lo;
+        }
+        if (c_hi) { v[0] = d; ix[0] = j; }
+    }
+};
+
+template <int CP, int KL>
+__global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, const float *__restrict__ x,
+                                                          int *__restrict__ nn_idx) {
+    constexpr int CH = 128;            // candidate rows per LDS chunk
+    constexpr int LD = CP + 1;         // odd row stride: lanes 0..31 read 32 rows at one column without conflicts
+    constexpr int NKK = CP / 2;        // MFMAs per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cs = lds;                   // [CH][LD]
+    float *sc = cs + CH * LD;          // [CH]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    const float *xb = x + (size_t)b * n * c;
+    const int q = blockIdx.x * 128 + wave * 32 + li;       // this lane's query row
+    const bool qin = q < n;
+
+    // query fragments: bq[kk] = x[q][2 kk + half]; squared norm by the contract's fmaf chain
+    float bq[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int ch = 2 * kk + half;
+        bq[kk] = (qin && ch < c) ? xb[(size_t)q * c + ch] : 0.f;
+    }
+    float sq = 0.f;
+    if (qin)
+        for (int l = 0; l < c; ++l) sq = fmaf(xb[(size_t)q * c + l], xb[(size_t)q * c + l], sq);
+
+    TopK<KL> top;
+    top.init();
+
+    for (int j0 = 0; j0 < n; j0 += CH) {
+        const int tn = min(CH, n - j0);
+        __syncthreads();
+        for (int e = tid; e < CH * CP; e += 256) {
+            const int r = e / CP, l = e - r * CP;
+            cs[r * LD + l] = (r < tn && l < c) ? xb[(size_t)(j0 + r) * c + l] : 0.f;
+        }
+        __syncthreads();
+        if (tid < CH) {
+            float s = 0.f;
+            for (int l = 0; l < CP; ++l) s = fmaf(cs[tid * LD + l], cs[tid * LD + l], s);
+            sc[tid] = s;
+        }
+        __syncthreads();
+        for (int t = 0; t < (tn + 31) / 32; ++t) {
+            f32x16k acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            const float *arow = cs + (32 * t + li) * LD + half;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], bq[kk], acc, 0, 0, 0);
+            // acc[v]: candidate row 32 t + (v&3) + 8 (v>>2) + 4 half, query li
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * half;
+                const int j = j0 + row;
+                float d = (sq + (-2.f * acc[v])) + sc[row];
+                if (!(j < n)) d = INFINITY;
+                if (__any(d < top.v[KL - 1])) top.insert_ascending(d, j);
+            }
+        }
+    }
+
+    // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
+#pragma unroll
+    for (int s = 0; s < KL; ++s) {
+        const float pv = __shfl(top.v[s], li + 32, 64);
+        const int pi = __shfl(top.ix[s], li + 32, 64);
+        if (half == 0) top.insert_lex(pv, pi);
+    }
+    if (half == 0 && qin) {
+        int *o = nn_idx + ((size_t)b * n + q) * k;
+#pragma unroll
+        for (int s = 0; s < KL; ++s)
+            if (s < k) o[s] = top.ix[s];
+    }
+}
+
+template <int CP, int KL>
+int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, hipStream_t st) {
+    const size_t lds = (size_t)(128 * (CP + 1) + 128) * sizeof(float);
+    auto kern = knn_mfma_kernel<CP, KL>;
+    if (lds > 48 * 1024) {
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)once;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(n, 128), b), dim3(256), lds, st, n, c, k, x, nn_idx);
     return pcops_launch_status();
 }
 
@@ -271,7 +414,21 @@ extern "C" int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *
     if (b == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(x);
     PCOPS_REQUIRE_PTR(nn_idx);
+    PCOPS_REQUIRE_SHAPE(b <= 65535);
     hipStream_t st = as_stream(stream);
+    static const bool use_mfma = [] { const char *e = getenv("PCOPS_KNN_MFMA"); return !(e && e[0] == '0'); }();
+    if (use_mfma && k <= 32 && c <= 128) {
+#define PCOPS_KNN_CASE(CP_)                                                      \
+    do {                                                                         \
+        if (k <= 20) return launch_knn_mfma<CP_, 20>(b, n, c, k, x, nn_idx, st); \
+        return launch_knn_mfma<CP_, 32>(b, n, c, k, x, nn_idx, st);              \
+    } while (0)
+        if (c <= 4) PCOPS_KNN_CASE(4);
+        if (c <= 16) PCOPS_KNN_CASE(16);
+        if (c <= 64) PCOPS_KNN_CASE(64);
+        PCOPS_KNN_CASE(128);
+#undef PCOPS_KNN_CASE
+    }
     if (c <= 4) return launch_knn_graph<4>(b, n, c, k, x, nn_idx, st);
     if (c <= 8) return launch_knn_graph<8>(b, n, c, k, x, nn_idx, st);
     if (c <= 16) return launch_knn_graph<16>(b, n, c, k, x, nn_idx, st);
