@@ -215,3 +215,29 @@ def params_from_state_dict(sd, prefix="graph.", dtype=torch.float32):
     dtype; the geometry oracle always sees the fp32 coordinates, which doubles hold exactly)."""
     return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().cpu().to(dtype).clone()
             for k, v in sd.items()}
+
+
+# ------------------------------------------------------------------------------- PointNet (config 1)
+def _tnet(x, P, scope, training, head, k_out):
+    """pointnet/models/transform_nets.py:10-95; x (B,N,C)"""
+    t = dense(x, P, scope + "/tconv1", training)
+    t = dense(t, P, scope + "/tconv2", training)
+    t = dense(t, P, scope + "/tconv3", training).amax(dim=1)
+    t = dense(t, P, scope + "/tfc1", training)
+    t = dense(t, P, scope + "/tfc2", training)
+    out = t @ P["%s/%s/weights" % (scope, head)] + (P["%s/%s/biases" % (scope, head)] + torch.eye(k_out, dtype=t.dtype).flatten())
+    return out.reshape(x.shape[0], k_out, k_out)
+
+
+def pointnet_cls(point_cloud, P, training):
+    """pointnet/models/pointnet_cls.py:21-75 -> (logits, feature transform)"""
+    t1 = _tnet(point_cloud, P, "transform_net1", training, "transform_XYZ", 3)
+    net = dense(point_cloud @ t1, P, "conv1", training)
+    net = dense(net, P, "conv2", training)
+    t2 = _tnet(net, P, "transform_net2", training, "transform_feat", 64)
+    net = net @ t2
+    for s in ("conv3", "conv4", "conv5"):
+        net = dense(net, P, s, training)
+    net = dense(net.amax(dim=1), P, "fc1", training)
+    net = dense(net, P, "fc2", training)
+    return dense(net, P, "fc3", training, use_bn=False, act=False), t2

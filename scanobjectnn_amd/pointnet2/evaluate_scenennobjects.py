@@ -1,0 +1,67 @@
+"""Evaluation loop -- restates the metric loop of `pointnet2/evaluate_scenennobjects.py:152-231`:
+`num_votes` rotations about the up axis (angle vote/num_votes * 2π, provider.rotate_point_cloud_by_angle),
+logits SUMMED over the votes, argmax, overall accuracy and mean per-class accuracy.  Visual dumps are out of
+scope.  `eval_seg_one_epoch` adds the mask accuracy of `evaluate_seg_scenennobjects.py:336`
+(correct points / (seen clouds * points))."""
+import math
+
+import numpy as np
+import torch
+
+from .. import provider
+
+NUM_CLASSES = 15
+
+
+def vote_logits(predict, points, num_votes):
+    """sum over votes of predict(rotated points); predict: (B,N,3) tensor -> (B,C) logits"""
+    total = None
+    for vote_idx in range(num_votes):
+        rotated = provider.rotate_point_cloud_by_angle(points, vote_idx / float(num_votes) * math.pi * 2)
+        out = predict(rotated)
+        total = out if total is None else total + out
+    return total
+
+
+def accuracy_summary(pred, labels, num_classes=NUM_CLASSES):
+    """overall accuracy, mean per-class accuracy (classes never seen count as NaN -> ignored like np.mean would not;
+    the reference divides by zero there), per-class vector"""
+    pred, labels = np.asarray(pred), np.asarray(labels)
+    seen = np.bincount(labels, minlength=num_classes).astype(np.float64)
+    correct = np.bincount(labels[pred == labels], minlength=num_classes).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        per_class = correct / seen
+    return float((pred == labels).mean()), float(np.nanmean(per_class)), per_class
+
+
+@torch.no_grad()
+def eval_one_epoch(net, data, labels, batch_size, num_votes=1, device="cuda:0"):
+    """net: graph.Model of a classifier get_model; data (K,N,3), labels (K,).  Whole batches only (like the
+    reference: num_batches = K // BATCH_SIZE)."""
+    preds, seen = [], []
+    for b in range(data.shape[0] // batch_size):
+        pts = torch.as_tensor(data[b * batch_size:(b + 1) * batch_size], dtype=torch.float32, device=device)
+        logits = vote_logits(lambda p: net(p.contiguous(), is_training=False)[0], pts, num_votes)
+        preds.append(logits.argmax(dim=1).cpu().numpy())
+        seen.append(np.asarray(labels[b * batch_size:(b + 1) * batch_size]))
+    pred, lab = np.concatenate(preds), np.concatenate(seen)
+    acc, mean_class_acc, per_class = accuracy_summary(pred, lab)
+    return {"accuracy": acc, "avg_class_acc": mean_class_acc, "per_class": per_class, "pred": pred, "label": lab}
+
+
+@torch.no_grad()
+def eval_seg_one_epoch(net, data, labels, masks, batch_size, device="cuda:0"):
+    """BGA models: class accuracy + mask accuracy = correct points / (seen clouds * points)"""
+    cls_pred, seen, seg_correct, n_pts = [], [], 0, 0
+    for b in range(data.shape[0] // batch_size):
+        sl = slice(b * batch_size, (b + 1) * batch_size)
+        pts = torch.as_tensor(data[sl], dtype=torch.float32, device=device)
+        class_pred, seg_pred = net(pts.contiguous(), is_training=False)
+        cls_pred.append(class_pred.argmax(dim=1).cpu().numpy())
+        seen.append(np.asarray(labels[sl]))
+        seg_correct += int((seg_pred.argmax(dim=2).cpu().numpy() == np.asarray(masks[sl])).sum())
+        n_pts += masks[sl].size
+    pred, lab = np.concatenate(cls_pred), np.concatenate(seen)
+    acc, mean_class_acc, per_class = accuracy_summary(pred, lab)
+    return {"accuracy": acc, "avg_class_acc": mean_class_acc, "per_class": per_class,
+            "seg_accuracy": seg_correct / float(n_pts)}

@@ -1,0 +1,110 @@
+"""Host pipeline pieces, pinned by hand-computed values: vote rotation, the evaluation
+metrics, the feeder formulas, and the PointNet plumbing model (BASELINE config 1) end to end on the CPU against
+the float64 restatement."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import ref_models as R
+from scanobjectnn_amd import data_utils, provider
+from scanobjectnn_amd.graph import Model
+from scanobjectnn_amd.pointnet import pointnet_cls
+from scanobjectnn_amd.pointnet2 import evaluate_scenennobjects as EV
+from scanobjectnn_amd.synth import synth_clouds, synth_labels
+
+
+def test_rotate_by_angle_matches_reference_convention():
+    """provider.py:121-138: row vectors times [[c,0,s],[0,1,0],[-s,0,c]]"""
+    pts = np.array([[[1.0, 2.0, 0.0], [0.0, -1.0, 1.0]]], np.float32)
+    out = provider.rotate_point_cloud_by_angle(pts, math.pi / 2)
+    np.testing.assert_allclose(out, [[[0.0, 2.0, 1.0], [-1.0, -1.0, 0.0]]], atol=1e-6)
+    out0 = provider.rotate_point_cloud_by_angle(torch.from_numpy(pts), 0.0)
+    assert torch.equal(out0, torch.from_numpy(pts))
+    full = provider.rotate_point_cloud_by_angle(provider.rotate_point_cloud_by_angle(pts, 1.1), 2 * math.pi - 1.1)
+    np.testing.assert_allclose(full, pts, atol=1e-5)
+
+
+def test_random_rotation_and_jitter_properties():
+    g = torch.Generator().manual_seed(0)
+    x = torch.from_numpy(synth_clouds(4, 64, seed=3))
+    r = provider.rotate_point_cloud(x, generator=g)
+    assert torch.allclose(r[..., 1], x[..., 1], atol=1e-6)                       # up axis untouched
+    assert torch.allclose(r.norm(dim=-1), x.norm(dim=-1), atol=1e-5)             # rigid
+    assert not torch.allclose(r[0], r[1] - x[1] + x[0])                          # one angle per cloud
+    j = provider.jitter_point_cloud(x, sigma=0.01, clip=0.05, generator=g)
+    assert (j - x).abs().max().item() <= 0.05 + 1e-7 and (j - x).abs().max().item() > 0
+    s = provider.shuffle_points(x, generator=g)
+    assert torch.equal(s.sort(dim=1).values, x.sort(dim=1).values)
+
+
+def test_vote_sum_and_metrics_toy():
+    """6 samples, 3 classes, 2 votes: logits are SUMMED over votes before the argmax (evaluate_scenennobjects.py:189,196)"""
+    votes = [torch.tensor([[2.0, 1.0, 0.0], [0.0, 3.0, 1.0], [0.0, 0.2, 0.1], [1.0, 0.0, 0.9], [0.0, 1.0, 2.0], [5.0, 0.0, 0.0]]),
+             torch.tensor([[0.0, 2.5, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.4], [0.0, 0.0, 0.2], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])]
+    calls = []
+
+    def predict(p):
+        calls.append(p.clone())
+        return votes[len(calls) - 1]
+
+    pts = torch.zeros(6, 4, 3)
+    pts[:, :, 0] = 1.0
+    total = EV.vote_logits(predict, pts, 2)
+    assert torch.allclose(calls[1][0, 0], torch.tensor([-1.0, 0.0, 0.0]), atol=1e-6)   # second vote rotated by pi
+    pred = total.argmax(dim=1).numpy()
+    np.testing.assert_array_equal(pred, [1, 1, 2, 2, 1, 0])          # per-vote argmax would differ for samples 0 and 3
+    labels = np.array([0, 1, 2, 2, 1, 0])
+    acc, mca, per = EV.accuracy_summary(pred, labels, num_classes=3)
+    assert math.isclose(acc, 5 / 6) and np.allclose(per, [0.5, 1.0, 1.0]) and math.isclose(mca, 2.5 / 3)
+
+
+def test_feeder_formulas():
+    rng = np.random.RandomState(0)
+    pcs = rng.randn(5, 32, 3).astype(np.float32)
+    labels = np.arange(5)
+    masks = rng.randint(-1, 3, (5, 32))
+    s, l = data_utils.get_current_data_h5(pcs, labels, 16, rng=np.random.RandomState(1))
+    assert s.shape == (5, 16, 3) and sorted(l) == list(range(5))
+    # ONE point subset shared by all clouds: cloud l[i] keeps the same 16 point slots as every other cloud
+    slots = [np.flatnonzero((pcs[l[0]][:, None, :] == s[0][None, :, :]).all(-1).any(1))]
+    for i in range(1, 5):
+        slots.append(np.flatnonzero((pcs[l[i]][:, None, :] == s[i][None, :, :]).all(-1).any(1)))
+    assert all(np.array_equal(slots[0], x) for x in slots)
+    s2, l2, m2 = data_utils.get_current_data_withmask_h5(pcs, labels, masks, 32, shuffle=False)
+    assert np.array_equal(s2, pcs) and np.array_equal(m2, masks)
+    b = data_utils.convert_to_binary_mask(masks)
+    assert set(np.unique(b)) <= {0, 1} and np.array_equal(b == 0, masks == -1)
+
+
+def test_pointnet_cls_config1_cpu_plumbing():
+    """BASELINE config 1: PointNet OBJ_ONLY-shaped (32, 1024, 3) -> (32, 15) on the host CPU, eval-mode logits
+    against the float64 restatement (1e-4), loss incl. the orthogonality regulariser, backward runs."""
+    c = synth_clouds(32, 1024, seed=4)
+    x = torch.from_numpy(c)
+    net = Model(pointnet_cls.get_model, seed=0).build(x[:2])
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in list(net.named_parameters()) + list(net.named_buffers()):
+            if name.endswith("gamma") or name.endswith("moving_variance"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+            elif name.endswith("beta") or name.endswith("moving_mean"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith("transform_feat/weights") or name.endswith("transform_XYZ/weights"):
+                p.copy_(0.01 * torch.randn(p.shape, generator=g))
+    with torch.no_grad():
+        logits, ep = net(x, is_training=False)
+    assert logits.shape == (32, 15) and ep["transform"].shape == (32, 64, 64)
+    P = R.params_from_state_dict(net.state_dict(), dtype=torch.float64)
+    want, t2 = R.pointnet_cls(x.double(), P, False)
+    assert (logits.double() - want).abs().max().item() <= 1e-4
+    assert (ep["transform"].double() - t2).abs().max().item() <= 1e-4
+    logits, ep = net(x, is_training=True, bn_decay=0.5)
+    loss = pointnet_cls.get_loss(logits, torch.from_numpy(synth_labels(32)), ep)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None for p in net.parameters())
+    # the regulariser: identity transform -> zero penalty
+    eye = {"transform": torch.eye(64).repeat(2, 1, 1)}
+    z = torch.zeros(2, 15)
+    lab = torch.zeros(2, dtype=torch.long)
+    assert torch.isclose(pointnet_cls.get_loss(z, lab, eye), torch.tensor(math.log(15.0)))
