@@ -329,7 +329,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : 5));
     constexpr int NTHR = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave id as a SCALAR: everything derived from it (tile index, buffer descriptors) is then provably wave-uniform
+    // and hipcc does not wrap each buffer access in a waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = a.M, K = a.K, N = a.N;
     const int nchunk = (K + KC - 1) / KC;
     const int Kp = nchunk * KC;
@@ -1071,7 +1074,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     constexpr int A4 = KB / 4, D4 = NB / 4;            // float4 per stripe row
     constexpr int NA = RS * A4 / 64, ND = RS * D4 / 64; // float4 per lane per stripe
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: keeps the buffer descriptors wave-uniform
     const int K = a.K, N = a.N;
     const long long M = a.M;
     // grid = (row groups, K blocks, N blocks): the (K,N) blocks of one row group sit on the same XCD (linear ids
