@@ -76,6 +76,12 @@ def _algo(name, a):
     if name == "pcops_mlp_gemm_fwd":          # Y[M,N] = f(X)[M,K] W
         M, K, N = a[:3]
         return 4 * (M * K + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_gemm_fwd_pool":     # + raw extrema per group
+        M, K, N, S = a[:4]
+        return 4 * (M * K + M * N) + 5 * (M // S) * N, 2 * M * K * N, "flop"
+    if name == "pcops_mlp_pool_select":
+        G, C = a[:2]
+        return 8 * G * C, 0, ""
     if name == "pcops_mlp_gemm_dgrad":        # Gprev[M,Nout] = mask . (dY[M,K] Wt); reads G?,Y (K wide), Yprev (Nout)
         M, K, Nout = a[:3]
         reads = (1 if a[3] is None else 2) * M * K + (M * Nout if a[14] is not None else 0)
@@ -93,8 +99,8 @@ def _algo(name, a):
         R, C = a[:2]
         return 12 * R * C, 0, ""
     if name == "pcops_mlp_pool_bwd_stats":
-        G, S, C = a[:3]
-        return 9 * G * C, 0, ""
+        G, C = a[:2]
+        return 8 * G * C, 0, ""
     if name == "pcops_sa_gather_fwd":         # Y (b,m,s,c) written once; Q read once (algorithmically), idx
         b, n, m, s, c = a[:5]
         return 4 * (b * m * s * c + (b * n * c if a[5] is not None else 0) + b * m * s), 0, ""
@@ -110,7 +116,8 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_selection_sort": 4, "pcops_pairwise_distance": 3, "pcops_knn_topk": 3,
            "pcops_sa_gather_fwd": 5, "pcops_sa_scatter_bwd": 5, "pcops_mlp_bn_finalize": 3,
            "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
-           "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1}
+           "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
+           "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2}
 
 
 class KernelTimer:

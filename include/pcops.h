@@ -140,6 +140,20 @@ unsigned long long pcops_mlp_reduce_workspace_bytes(int N);
 int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                        const float *pro_shift, const float *W, const float *bias, float *Y,
                        float *stats_partial, pcops_stream_t stream);
+/* forward of a max-pooled LAST layer with the neighbourhood reduction (the reference's reduce_max over nsample,
+ * pointnet_util.py:127) fused into the GEMM epilogue.  BN+ReLU is monotone per channel -- increasing for
+ * gamma >= 0, decreasing for gamma < 0 (scale = gamma * rstd) -- so per group of S consecutive rows
+ *   ysel[g,c] = max_s y (gamma[c] >= 0) | min_s y (gamma[c] < 0),  argsel[g,c] = first row attaining it (8 bit)
+ * and, once scale/shift are known, pcops_mlp_pool_select gives out = relu(scale*ysel + shift) without re-reading
+ * Y.  S % 32 == 0, S <= 256, M % S == 0, ldx == K; PCOPS_ERR_UNSUPPORTED when the shape is outside what
+ * pcops_mlp_gemm_fwd_pool_supported(M,K,N,S) accepts. */
+int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S);
+int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx, const float *pro_scale,
+                            const float *pro_shift, const float *W, const float *bias, const float *gamma,
+                            float *Y, float *stats_partial, float *ysel, unsigned char *argsel,
+                            pcops_stream_t stream);
+int pcops_mlp_pool_select(long long G, int C, const float *ysel, const float *scale, const float *shift,
+                          float *out, pcops_stream_t stream);
 /* batch statistics -> mean, rstd = 1/sqrt(var+eps) (biased var), scale = gamma*rstd, shift = beta - mean*scale;
  * moving_* (may be NULL) <- decay*moving + (1-decay)*batch (unbiased batch variance if unbiased_moving_var).
  * P = rows of stats_partial, R = rows the statistics run over, workspace >= pcops_mlp_reduce_workspace_bytes(N). */
@@ -151,24 +165,24 @@ int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial,
 int pcops_mlp_bn_eval_coeffs(int N, const float *gamma, const float *beta, const float *moving_mean,
                              const float *moving_var, float eps, float *scale, float *shift,
                              pcops_stream_t stream);
-/* out[g,c] = max_s relu(scale[c]*Y[g*S+s,c] + shift[c]), argmax[g,c] (may be NULL) = first s attaining it. S<=256 */
+/* out[g,c] = max_s relu(scale[c]*Y[g*S+s,c] + shift[c]), argmax[g,c] (may be NULL) = first s attaining it,
+ * ysel[g,c] (may be NULL) = Y at that row.  S<=256 */
 int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const float *scale,
-                              const float *shift, float *out, unsigned char *argmax,
+                              const float *shift, float *out, unsigned char *argmax, float *ysel,
                               pcops_stream_t stream);
 /* out = relu(scale*Y + shift) (stack output without pooling) */
 int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *scale, const float *shift,
                             float *out, pcops_stream_t stream);
 /* backward.  BN backward is folded into dY = p.G + q.Y + t with G = upstream grad masked by the ReLU.
  * relu_mask_stats: Gm = Gout*[relu(bn(Y))>0] and partial (sum Gm, sum Gm*Y): [pcops_mlp_bwd_stats_rows(R)][2][C]
- * pool_bwd_stats : the same sums for a max-pooled output, from (gpool, argmax): [..pool_stats_rows(G)][2][C]
+ * pool_bwd_stats : the same sums for a max-pooled output, from (gpool, ysel = y at the pooled row): [..pool_stats_rows(G)][2][C]
  * bn_bwd_coeffs  : sums -> dgamma, dbeta, p, q, t */
 int pcops_mlp_bwd_stats_rows(long long R);
 int pcops_mlp_bwd_pool_stats_rows(long long G);
 int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float *Y, const float *scale,
                               const float *shift, float *Gm, float *stats_partial, pcops_stream_t stream);
-int pcops_mlp_pool_bwd_stats(long long G, int S, int C, const float *gpool, const unsigned char *argmax,
-                             const float *Y, const float *scale, const float *shift, float *stats_partial,
-                             pcops_stream_t stream);
+int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
+                             const float *shift, float *stats_partial, pcops_stream_t stream);
 int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partial, void *workspace,
                             const float *gamma, const float *mean, const float *rstd, float *dgamma,
                             float *dbeta, float *p, float *q, float *t, pcops_stream_t stream);

@@ -35,10 +35,12 @@ SIGNATURES = {
     "pcops_mlp_gemm_fwd": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_finalize": ([_I, _I, _LL, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_eval_coeffs": ([_I, _P, _P, _P, _P, _F, _P, _P], True),
-    "pcops_mlp_bn_relu_maxpool": ([_LL, _I, _I, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_relu_maxpool": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_pool": ([_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_select": ([_LL, _I, _P, _P, _P, _P], True),
     "pcops_mlp_bn_relu_apply": ([_LL, _I, _P, _P, _P, _P], True),
     "pcops_mlp_relu_mask_stats": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_pool_bwd_stats": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_bwd_stats": ([_LL, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_bwd_coeffs": ([_I, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
@@ -52,6 +54,7 @@ PLAIN = {
     "pcops_farthest_point_sample_workspace_bytes": ([_I, _I], _U64),
     "pcops_mlp_stats_rows": ([_I], _I),
     "pcops_mlp_reduce_workspace_bytes": ([_I], _U64),
+    "pcops_mlp_gemm_fwd_pool_supported": ([_I, _I, _I, _I], _I),
     "pcops_mlp_bwd_stats_rows": ([_LL], _I),
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),

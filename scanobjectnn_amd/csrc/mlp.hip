@@ -81,6 +81,14 @@ struct GemmArgs {
     const float *msc;    // E_MASK: bn scale / shift of the previous layer
     const float *msh;
     float *stats;        // [gridDim.y][2][N] partial column sums (null: none)
+    // fused neighbourhood pooling of the RAW outputs (forward, wave-stream kernel only): BN+ReLU is monotone per
+    // channel -- increasing for gamma >= 0, decreasing otherwise (scale = gamma * rstd) -- so per group of
+    // 32*pool_sub rows the pooled activation is relu(scale * ysel + shift) with ysel the max (gamma >= 0) or min
+    // (gamma < 0) of y over the group; psel gets the first row attaining it
+    int pool_sub;
+    const float *pgamma;                // [N]
+    float *ysel;                        // [M / (32 pool_sub)][N]
+    unsigned char *psel;                // [M / (32 pool_sub)][N]
 };
 
 __device__ __forceinline__ float4 ld4(const float *p, bool vec, int k, int K) {
@@ -167,8 +175,8 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
                         x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
                     } else {  // A_DYPOOL: G is non-zero only at the arg-max row of each (group, channel)
                         const float4 y = ld4(a.X2 + r * a.ldx, xvec, k, K);
-                        const long long g = r / a.S;
-                        const int s = (int)(r - g * a.S);
+                        const long long g = (long long)((unsigned)r / (unsigned)a.S);   // rows < 2^31 (launcher)
+                        const int s = (int)((unsigned)r - (unsigned)g * (unsigned)a.S);
                         const float yy[4] = {y.x, y.y, y.z, y.w};
                         const float cc0[4] = {c0.x, c0.y, c0.z, c0.w}, cc1[4] = {c1.x, c1.y, c1.z, c1.w};
                         const float cc2[4] = {c2.x, c2.y, c2.z, c2.w}, cc3[4] = {c3.x, c3.y, c3.z, c3.w};
@@ -313,7 +321,28 @@ int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
 //   * the accumulator tile is transposed through the same stripe so that outputs leave as 16-byte stores of
 //     whole 512-byte row segments, and the per-channel statistics accumulate in the lane that owns the column;
 //   * the main loop contains NO workgroup barrier.
-template <int NT, int AM, int EM, int KC, int WAVES, int EH>
+// (group, row-in-group) of row row0 + r for r < 64 without a per-element integer division: one division per
+// tile for row0 (wave-uniform), then t = s0 + r < S + 64 splits exactly through a float reciprocal
+// ((t + 0.5) / S is at least 1/(2S) >= 1/512 away from an integer; fp32 rounding of a value < 2^10 is far below)
+struct PoolRows {
+    long long g0;
+    int s0, S;
+    float invS;
+    __device__ PoolRows(long long row0, int S_) : S(S_) {
+        g0 = (long long)((unsigned long long)row0 / (unsigned)S_);
+        s0 = (int)(row0 - g0 * S_);
+        invS = 1.0f / (float)S_;
+    }
+    __device__ void split(int r, long long glast, long long &g, unsigned &s) const {
+        const int t = s0 + r;
+        const int dg = (int)(((float)t + 0.5f) * invS);
+        s = (unsigned)(t - dg * S);
+        g = g0 + dg;
+        g = g < glast ? g : glast;            // rows beyond M (masked by the caller) stay inside gpool / argmax
+    }
+};
+
+template <int NT, int AM, int EM, int KC, int WAVES, int EH, bool POOL>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs a) {
     // WAVES waves per workgroup (4: one per SIMD, 8: two per SIMD so that one wave's staging / epilogue hides under
     // its partner's MFMA phase); EH: the epilogue transposes the accumulator tile in EH column passes so that the
@@ -376,6 +405,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (n < N) {
                 if (EM == E_FWD && a.bias) e0 = a.bias[n];
                 if (EM == E_MASK) { e0 = a.msc[n]; e1 = a.msh[n]; }
+                if (POOL) e1 = a.pgamma[n] < 0.f ? -1.f : 1.f;
             }
             ecoef[e] = e0;
             ecoef[BN + e] = e1;
@@ -400,17 +430,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const unsigned xvoff = (unsigned)((lane / C4) * a.ldx + (lane % C4) * 4) * 4u;
     const unsigned xrowstep = (unsigned)(64 / C4) * (unsigned)a.ldx * 4u;          // bytes per j
     const unsigned yrowstep = (unsigned)(64 / O4) * (unsigned)a.ldy * 4u;
+    const long long glast = AM == A_DYPOOL ? ((long long)M - 1) / a.S : 0;
     auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
         if (AM == A_DYPOOL) {
+            const PoolRows pr(row0, a.S);
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int e = lane + 64 * j;
                 int c = (e % C4) * 4 + kc * KC;
                 c = c < K ? c : K - 4;
-                long long row = row0 + e / C4;
-                row = row < M ? row : M - 1;
-                const long long gi = row / a.S;
+                long long gi;
+                unsigned sdummy;
+                pr.split(e / C4, glast, gi, sdummy);
                 pa[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
                 pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
             }
@@ -427,6 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     };
     auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
         const long long row0 = tile * 32;
+        const PoolRows prs(AM == A_DYPOOL ? row0 : 0, AM == A_DYPOOL ? a.S : 1);
         const int cl = (lane % C4) * 4;              // fixed per lane (64 % C4 == 0)
         const int c = cl + kc * KC;
         float4 c0, c1, c2, c3, c4;
@@ -453,8 +486,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 const float4 y = pb[j];
                 float4 g = x;
                 if (AM == A_DYPOOL) {
-                    const long long row = row0 + r;
-                    const int s = (int)(row % a.S);
+                    long long gdummy;
+                    unsigned s;
+                    prs.split(r, glast, gdummy, s);
                     const unsigned am = pm[j];
                     g.x = ((am & 0xffu) == (unsigned)s && fmaf(y.x, c3.x, c4.x) > 0.f) ? x.x : 0.f;
                     g.y = (((am >> 8) & 0xffu) == (unsigned)s && fmaf(y.y, c3.y, c4.y) > 0.f) ? x.y : 0.f;
@@ -471,15 +505,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         }
     };
 
-    long long tile = (long long)rowgrp * WAVES + wave;
-    if (tile < ntiles) issue(tile, 0);
-    for (; tile < ntiles; tile += tstride) {
+    // a wave walks whole pooling groups: SUB consecutive 32-row tiles (SUB = 1 without pooling)
+    const int SUB = POOL ? a.pool_sub : 1;
+    const long long nsuper = (ntiles + SUB - 1) / SUB;
+    float pmx[EH][4];                                // running max of sign(gamma) * y over the group, and its row
+    int pax[EH][4];
+#pragma unroll
+    for (int h = 0; h < EH; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
+    long long st = (long long)rowgrp * WAVES + wave;
+    int sub = 0;
+    if (st < nsuper) issue(st * SUB, 0);
+    while (st < nsuper) {
+        const long long tile = st * SUB + sub;
+        long long nst = st;
+        int nsub = sub + 1;
+        if (nsub == SUB) { nsub = 0; nst = st + tstride; }
+        const bool more = nst < nsuper;
+        const long long next_tile = nst * SUB + nsub;
         f32x16 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
-        const bool more = tile + tstride < ntiles;
 
         for (int kc = 0; kc < nchunk; ++kc) {
             __builtin_amdgcn_wave_barrier();
@@ -488,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             __builtin_amdgcn_wave_barrier();
             // next stripe: the next K chunk of this tile, or chunk 0 of this wave's next tile
             if (kc + 1 < nchunk) issue(tile, kc + 1);
-            else if (more) issue(tile + tstride, 0);
+            else if (more) issue(next_tile, 0);
 
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
             const float *bcol = &Ws[(kc * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
@@ -562,6 +611,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         s1[h][0] += o.x; s1[h][1] += o.y; s1[h][2] += o.z; s1[h][3] += o.w;
                         s2[h][0] = fmaf(o.x, o.x, s2[h][0]); s2[h][1] = fmaf(o.y, o.y, s2[h][1]);
                         s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
+                        if (POOL) {   // rows arrive in ascending order: a strict comparison keeps the first extremum
+                            const int sr = sub * 32 + r;
+                            const float ov[4] = {o.x * em.x, o.y * em.y, o.z * em.z, o.w * em.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ov[e] > pmx[h][e]) { pmx[h][e] = ov[e]; pax[h][e] = sr; }
+                        }
                     } else if (EM == E_MASK) {
                         const float4 yp = py[j];
                         o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
@@ -576,7 +632,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (POOL && sub == SUB - 1) {
+                // group complete: combine the 64/O4 lanes that own this column quad (larger key, then lower row)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int off = 32; off >= O4; off >>= 1) {
+                        const float ov = __shfl_xor(pmx[h][e], off, 64);
+                        const int oa = __shfl_xor(pax[h][e], off, 64);
+                        if (ov > pmx[h][e] || (ov == pmx[h][e] && oa < pax[h][e])) { pmx[h][e] = ov; pax[h][e] = oa; }
+                    }
+                }
+                if (lane < O4 && ocin) {
+                    const long long o4 = st * N + n0 + ocq;
+                    *reinterpret_cast<float4 *>(a.ysel + o4) =
+                        make_float4(pmx[h][0] * em.x, pmx[h][1] * em.y, pmx[h][2] * em.z, pmx[h][3] * em.w);
+                    uchar4 qa;
+                    qa.x = (unsigned char)pax[h][0]; qa.y = (unsigned char)pax[h][1];
+                    qa.z = (unsigned char)pax[h][2]; qa.w = (unsigned char)pax[h][3];
+                    *reinterpret_cast<uchar4 *>(a.psel + o4) = qa;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
+            }
         }
+        st = nst;
+        sub = nsub;
     }
 
     if (EM != E_PLAIN && a.stats) {
@@ -640,7 +721,8 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
     if (pl->lds > 160 * 1024) return false;
     pl->ncb = (a.N + pl->bn - 1) / pl->bn;
-    const long long ntiles = ((long long)a.M + 31) / 32;
+    const long long ntiles = (((long long)a.M + 31) / 32 + (a.pool_sub > 1 ? a.pool_sub - 1 : 0)) /
+                             (a.pool_sub > 1 ? a.pool_sub : 1);   // units a wave walks: tiles, or pooling groups
     long long want = 256 / pl->ncb;                          // one persistent workgroup per CU over the whole grid
     if (want < 1) want = 1;
     const long long maxg = (ntiles + pl->waves - 1) / pl->waves;
@@ -653,11 +735,11 @@ template <int AM, int EM>
 int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
 #define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
-        auto kern = gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_>;                                          \
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),            \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                                     160 * 1024);                                     \
-        (void)once;                                                                                   \
+        auto kern = (EM == E_FWD && a.pool_sub > 0) ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (EM == E_FWD)>  \
+                                                    : gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, false>; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+            return PCOPS_ERR_LAUNCH;                                                                  \
         hipLaunchKernelGGL(kern, dim3(pl.gy, pl.ncb), dim3(512), pl.lds, st, a);                      \
     } while (0)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
@@ -799,7 +881,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int S
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift,
                                                               float *__restrict__ out,
-                                                              unsigned char *__restrict__ argmax) {
+                                                              unsigned char *__restrict__ argmax,
+                                                              float *__restrict__ ysel) {
     const int c4n = C / 4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < G * c4n; e += (long long)gridDim.x * 256) {
         const long long g = e / c4n;
@@ -807,16 +890,17 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int S
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
         const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
         float m[4] = {-1.f, -1.f, -1.f, -1.f};
+        float ys[4] = {0.f, 0.f, 0.f, 0.f};
         int am[4] = {0, 0, 0, 0};
         const float *base = Y + (g * S) * C + c;
         for (int s = 0; s < S; ++s) {
             const float4 y = *reinterpret_cast<const float4 *>(base + (long long)s * C);
             const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
             const float a2 = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
-            if (a0 > m[0]) { m[0] = a0; am[0] = s; }
-            if (a1 > m[1]) { m[1] = a1; am[1] = s; }
-            if (a2 > m[2]) { m[2] = a2; am[2] = s; }
-            if (a3 > m[3]) { m[3] = a3; am[3] = s; }
+            if (a0 > m[0]) { m[0] = a0; am[0] = s; ys[0] = y.x; }
+            if (a1 > m[1]) { m[1] = a1; am[1] = s; ys[1] = y.y; }
+            if (a2 > m[2]) { m[2] = a2; am[2] = s; ys[2] = y.z; }
+            if (a3 > m[3]) { m[3] = a3; am[3] = s; ys[3] = y.w; }
         }
         *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(m[0], m[1], m[2], m[3]);
         if (argmax) {
@@ -825,6 +909,39 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int S
             q.z = (unsigned char)am[2]; q.w = (unsigned char)am[3];
             *reinterpret_cast<uchar4 *>(argmax + g * C + c) = q;
         }
+        if (ysel) *reinterpret_cast<float4 *>(ysel + g * C + c) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    }
+}
+
+// pooled output from the fused epilogue's selected raw values: out = relu(scale * ysel + shift)
+__global__ __launch_bounds__(256) void pool_select_kernel(long long total, int C, const float *__restrict__ ysel,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        out[e] = fmaxf(fmaf(ysel[e], scale[c], shift[c]), 0.f);
+    }
+}
+
+// the two BN-backward sums of a max-pooled layer from (gpool, y at the selected row): stats [P][2][C]
+__global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long G, int C, const float *__restrict__ gpool,
+                                                                 const float *__restrict__ ysel,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 float *__restrict__ stats, int groups_per_block) {
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    const long long g1 = min(G, g0 + groups_per_block);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sc = scale[c], sh = shift[c];
+        float a1 = 0.f, a2 = 0.f;
+        for (long long g = g0; g < g1; ++g) {
+            const float y = ysel[g * C + c];
+            const float gm = fmaf(y, sc, sh) > 0.f ? gpool[g * C + c] : 0.f;
+            a1 += gm;
+            a2 = fmaf(gm, y, a2);
+        }
+        stats[((long long)blockIdx.x * 2 + 0) * C + c] = a1;
+        stats[((long long)blockIdx.x * 2 + 1) * C + c] = a2;
     }
 }
 
@@ -895,32 +1012,6 @@ __global__ __launch_bounds__(256) void relu_mask_stats_kernel(long long R, int C
         float t = 0.f;
         for (int l = 0; l < rl; ++l) t += sm[(l * 2 + which) * C + c];
         stats[((long long)blockIdx.x * 2 + which) * C + c] = t;
-    }
-}
-
-// backward of the max-pool + relu + bn for the pooled upstream grad: partial sums over groups of
-// Gm = gpool*[a_argmax>0] and Gm*Y_argmax; stats [P][2][C], one block per `groups_per_block` groups
-__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(long long G, int S, int C,
-                                                             const float *__restrict__ gpool,
-                                                             const unsigned char *__restrict__ argmax,
-                                                             const float *__restrict__ Y,
-                                                             const float *__restrict__ scale,
-                                                             const float *__restrict__ shift,
-                                                             float *__restrict__ stats, int groups_per_block) {
-    const long long g0 = (long long)blockIdx.x * groups_per_block;
-    const long long g1 = min(G, g0 + groups_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float sc = scale[c], sh = shift[c];
-        float a1 = 0.f, a2 = 0.f;
-        for (long long g = g0; g < g1; ++g) {
-            const int s = argmax[g * C + c];
-            const float y = Y[(g * S + s) * C + c];
-            const float gm = fmaf(y, sc, sh) > 0.f ? gpool[g * C + c] : 0.f;
-            a1 += gm;
-            a2 = fmaf(gm, y, a2);
-        }
-        stats[((long long)blockIdx.x * 2 + 0) * C + c] = a1;
-        stats[((long long)blockIdx.x * 2 + 1) * C + c] = a2;
     }
 }
 
@@ -1010,8 +1101,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 if (a.dmode == A_DY) {
                     gm = a.G[r * a.ldy + n];
                 } else {
-                    const long long g = r / a.S;
-                    const int s = (int)(r - g * a.S);
+                    const long long g = (long long)((unsigned)r / (unsigned)a.S);   // rows < 2^31 (launcher)
+                    const int s = (int)((unsigned)r - (unsigned)g * (unsigned)a.S);
                     gm = (a.argmax[g * N + n] == s && fmaf(y, dsc[e], dsh[e]) > 0.f) ? a.gpool[g * N + n] : 0.f;
                 }
                 d = fmaf(cp[e], gm, fmaf(cq[e], y, ct[e]));
@@ -1135,6 +1226,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     const unsigned xvoff = ain ? (unsigned)((lane / A4) * a.ldx + acl) * 4u : kOOB;
     const unsigned dvoff = din ? (unsigned)((lane / D4) * a.ldy + dcl) * 4u : kOOB;
     const unsigned xstep = (unsigned)(64 / A4) * (unsigned)a.ldx * 4u, dstep = (unsigned)(64 / D4) * (unsigned)a.ldy * 4u;
+    const long long glast = DMODE == A_DYPOOL ? (M - 1) / a.S : 0;
     auto issue = [&](long long stripe) {
         const long long row0 = stripe * RS;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
@@ -1142,13 +1234,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
         const __amdgpu_buffer_rsrc_t rg = make_rsrc((DMODE == A_DYPOOL ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
 #pragma unroll
         for (int j = 0; j < NA; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+        const PoolRows pr(DMODE == A_DYPOOL ? row0 : 0, DMODE == A_DYPOOL ? a.S : 1);
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
             py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
             if (DMODE == A_DYPOOL) {
-                long long row = row0 + (lane + 64 * j) / D4;
-                row = row < M ? row : M - 1;
-                const long long gi = row / a.S;
+                long long gi;
+                unsigned sdummy;
+                pr.split((lane + 64 * j) / D4, glast, gi, sdummy);
                 pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
                 pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
             } else {
@@ -1158,6 +1251,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     };
     auto stage = [&](long long stripe) {
         const long long row0 = stripe * RS;
+        const PoolRows prs(DMODE == A_DYPOOL ? row0 : 0, DMODE == A_DYPOOL ? a.S : 1);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int r = (lane + 64 * j) / A4;
@@ -1177,7 +1271,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
             const float4 y = py[j];
             float4 g = pg[j];
             if (DMODE == A_DYPOOL) {
-                const unsigned s = (unsigned)((row0 + r) % a.S);
+                long long gdummy;
+                unsigned s;
+                prs.split(r, glast, gdummy, s);
                 const unsigned am = pm[j];
                 g.x = ((am & 0xffu) == s && fmaf(y.x, cds.x, cdh.x) > 0.f) ? g.x : 0.f;
                 g.y = (((am >> 8) & 0xffu) == s && fmaf(y.y, cds.y, cdh.y) > 0.f) ? g.y : 0.f;
@@ -1360,6 +1456,47 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
     return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));
 }
 
+static bool fwd_pool_shape_ok(int M, int K, int N, int S) {
+    if (S < 32 || S > 256 || S % 32 != 0 || M % S != 0) return false;
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.ldx = K; a.ldy = N; a.pool_sub = S / 32;
+    WsPlan pl;
+    return ws_enabled() && ws_plan(a, A_BNRELU, &pl);
+}
+
+int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S) { return fwd_pool_shape_ok(M, K, N, S) ? 1 : 0; }
+
+int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx, const float *pro_scale,
+                            const float *pro_shift, const float *W, const float *bias, const float *gamma,
+                            float *Y, float *stats_partial, float *ysel, unsigned char *argsel,
+                            pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K && S >= 1);
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(pro_scale);
+    PCOPS_REQUIRE_PTR(pro_shift); PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(argsel);
+    if (!fwd_pool_shape_ok(M, K, N, S) || ldx != K) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(ysel) & 15) || (reinterpret_cast<uintptr_t>(argsel) & 3))
+        return PCOPS_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.pool_sub = S / 32; a.pgamma = gamma; a.ysel = ysel; a.psel = argsel;
+    WsPlan pl;
+    if (!ws_plan(a, A_BNRELU, &pl)) return PCOPS_ERR_UNSUPPORTED;   // pointer alignment
+    return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
+}
+
+int pcops_mlp_pool_select(long long G, int C, const float *ysel, const float *scale, const float *shift,
+                          float *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && C >= 1);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
+    const long long total = G * C;
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(pool_select_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, C, ysel, scale,
+                       shift, out);
+    return pcops_launch_status();
+}
+
 int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
                           const float *gamma, const float *beta, float eps, float decay,
                           int unbiased_moving_var, float *moving_mean, float *moving_var, float *mean,
@@ -1390,7 +1527,7 @@ int pcops_mlp_bn_eval_coeffs(int N, const float *gamma, const float *beta, const
 }
 
 int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const float *scale,
-                              const float *shift, float *out, unsigned char *argmax,
+                              const float *shift, float *out, unsigned char *argmax, float *ysel,
                               pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(G >= 0 && S >= 1 && S <= 256 && C >= 4 && C % 4 == 0);
     if (G == 0) return PCOPS_OK;
@@ -1398,7 +1535,7 @@ int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const f
     const long long total = G * (C / 4);
     const unsigned grid = cdiv(total, 256) < 32768u ? cdiv(total, 256) : 32768u;
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(256), 0, as_stream(stream), G, S, C, Y, scale,
-                       shift, out, argmax);
+                       shift, out, argmax, ysel);
     return pcops_launch_status();
 }
 
@@ -1434,14 +1571,13 @@ int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float
     return pcops_launch_status();
 }
 
-int pcops_mlp_pool_bwd_stats(long long G, int S, int C, const float *gpool, const unsigned char *argmax,
-                             const float *Y, const float *scale, const float *shift, float *stats_partial,
-                             pcops_stream_t stream) {
-    PCOPS_REQUIRE_SHAPE(G >= 1 && S >= 1 && C >= 1);
-    PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale);
+int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
+                             const float *shift, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 1 && C >= 1);
+    PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(scale);
     PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(stats_partial);
-    hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), 0,
-                       as_stream(stream), G, S, C, gpool, argmax, Y, scale, shift, stats_partial, 64);
+    hipLaunchKernelGGL(pool_bwd_stats_sel_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), 0,
+                       as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 64);
     return pcops_launch_status();
 }
 

@@ -24,9 +24,19 @@ def _f32(n, dev):
     return torch.empty(n, dtype=torch.float32, device=dev)
 
 
-def _vec(n, dev):
-    """per-channel vector, padded to a multiple of 4 floats (kernels read them 16 bytes at a time)"""
-    return torch.zeros((n + 3) // 4 * 4, dtype=torch.float32, device=dev)
+class _VecArena:
+    """per-channel vectors, zero-filled and padded to a multiple of 4 floats (kernels read them 16 bytes at a
+    time), carved from ONE zeroed allocation per pass instead of one fill launch per vector"""
+
+    def __init__(self, widths, per_width, dev):
+        self.buf = torch.zeros(sum(((n + 3) // 4 * 4) * per_width for n in widths), dtype=torch.float32, device=dev)
+        self.off = 0
+
+    def take(self, n):
+        n4 = (n + 3) // 4 * 4
+        v = self.buf[self.off:self.off + n4]
+        self.off += n4
+        return v
 
 
 def _workspace(n, dev):
@@ -62,6 +72,9 @@ class FusedMLPStack(torch.autograd.Function):
             R, K0 = a0.shape
         Ys, means, rstds, scales, shifts, Ws = [], [], [], [], [], []
         src, ld, sc_prev, sh_prev, K = a0, K0, None, None, K0
+        vecs = _VecArena([l[2].shape[0] for l in layers], 4, dev)
+        ws = _workspace(max(l[2].shape[0] for l in layers), dev) if training else None
+        pooled_raw = None
         for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
             if li == 0 and gather:
                 N = C1
@@ -78,12 +91,20 @@ class FusedMLPStack(torch.autograd.Function):
                 Y = _f32((R, N), dev)
                 P = lib.pcops_mlp_stats_rows(R)
                 part = _f32((P, 2, N), dev) if training else None
-                _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
-                          W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
-            scale, shift = _vec(N, dev), _vec(N, dev)
+                if (pool and li == L - 1 and sc_prev is not None and ld == K
+                        and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)):
+                    # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics)
+                    G = R // S
+                    pooled_raw = (_f32((G, N), dev), torch.empty((G, N), dtype=torch.uint8, device=dev))
+                    _lib.call("pcops_mlp_gemm_fwd_pool", R, K, N, S, src.data_ptr(), ld, sc_prev.data_ptr(),
+                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), Y.data_ptr(),
+                              _p(part), pooled_raw[0].data_ptr(), pooled_raw[1].data_ptr())
+                else:
+                    _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
+                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
+            scale, shift = vecs.take(N), vecs.take(N)
             if training:
-                mean, rstd = _vec(N, dev), _vec(N, dev)
-                ws = _workspace(N, dev)
+                mean, rstd = vecs.take(N), vecs.take(N)
                 _lib.call("pcops_mlp_bn_finalize", P, N, R, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                           beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
@@ -99,27 +120,33 @@ class FusedMLPStack(torch.autograd.Function):
             src, ld, sc_prev, sh_prev, K = Y, N, scale, shift, N
 
         C = K
-        argmax = None
+        argmax = ysel = None
         if pool:
             G = R // S
             out = _f32((G, C), dev)
-            argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if training else None
-            _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
-                      shifts[-1].data_ptr(), out.data_ptr(), _p(argmax))
+            if pooled_raw is not None:
+                ysel, argmax = pooled_raw
+                _lib.call("pcops_mlp_pool_select", G, C, ysel.data_ptr(), scales[-1].data_ptr(),
+                          shifts[-1].data_ptr(), out.data_ptr())
+            else:
+                argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if training else None
+                ysel = _f32((G, C), dev) if training else None
+                _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                          shifts[-1].data_ptr(), out.data_ptr(), _p(argmax), _p(ysel))
         else:
             out = _f32((R, C), dev)
             _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
                       shifts[-1].data_ptr(), out.data_ptr())
         if training:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
-                         [l[2] for l in layers], argmax)
+                         [l[2] for l in layers], argmax, ysel)
             ctx.meta = (S, pool, L, R, K0, gather)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax = ctx.saved
+        a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax, ysel = ctx.saved
         S, pool, L, R, K0, gather = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
@@ -129,12 +156,13 @@ class FusedMLPStack(torch.autograd.Function):
         # ---- top of the stack: statistics of the masked upstream gradient
         C = Ys[-1].shape[1]
         ws = _workspace(max(y.shape[1] for y in Ys), dev)
+        vecs = _VecArena([y.shape[1] for y in Ys], 3, dev)
         if pool:
             G = R // S
             P = lib.pcops_mlp_bwd_pool_stats_rows(G)
             part = _f32((P, 2, C), dev)
-            _lib.call("pcops_mlp_pool_bwd_stats", G, S, C, grad_out.data_ptr(), argmax.data_ptr(),
-                      Ys[-1].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(), part.data_ptr())
+            _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(),
+                      scales[-1].data_ptr(), shifts[-1].data_ptr(), part.data_ptr())
             Gm = None
         else:
             P = lib.pcops_mlp_bwd_stats_rows(R)
@@ -146,7 +174,7 @@ class FusedMLPStack(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             N = Ys[l].shape[1]
             dgamma, dbeta = _f32(N, dev), _f32(N, dev)
-            p, q, t = _vec(N, dev), _vec(N, dev), _vec(N, dev)
+            p, q, t = vecs.take(N), vecs.take(N), vecs.take(N)
             _lib.call("pcops_mlp_bn_bwd_coeffs", P, N, R, part.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
                       means[l].data_ptr(), rstds[l].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                       p.data_ptr(), q.data_ptr(), t.data_ptr())

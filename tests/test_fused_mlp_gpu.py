@@ -18,7 +18,8 @@ def make_layers(k0, widths, seed, dtype=torch.float32):
     for w in widths:
         W = (torch.randn(cin, w, generator=g) / cin ** 0.5).to(DEV)
         b = (0.1 * torch.randn(w, generator=g)).to(DEV)
-        gamma = (0.5 + torch.rand(w, generator=g)).to(DEV)
+        # every third channel gets a negative gamma: the fused max-pool then has to pick the group MINIMUM
+        gamma = ((0.5 + torch.rand(w, generator=g)) * (1.0 - 2.0 * (torch.arange(w) % 3 == 2))).to(DEV)
         beta = (0.2 * torch.randn(w, generator=g)).to(DEV)
         mm = (0.1 * torch.randn(w, generator=g)).to(DEV)
         mv = (0.5 + torch.rand(w, generator=g)).to(DEV)
@@ -53,6 +54,9 @@ CASES = [  # (R, S, K0, widths, pool)
     (512 * 64 + 37, 1, 128, [128, 256], False),    # KC=128, N=256 (two column blocks), ragged tail rows
     (128 * 64 * 4, 64, 132, [128, 128, 256], True),  # pooled backward through the wave-stream dgrad (K=256 in 2 chunks)
     (40000, 1, 256, [64], False),                  # K=256 chunked, N=64
+    (400 * 96, 96, 64, [64, 128], True),           # pooling fused into the GEMM epilogue, 3 tiles per group
+    (130 * 256, 256, 32, [128, 64], True),         # ... 8 tiles per group (largest 8-bit arg index)
+    (1100 * 32, 32, 16, [32, 32], True),           # ... N=32: half-empty column block
 ]
 
 
