@@ -219,13 +219,18 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
 /* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
  * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
  * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.
- * wpartial: caller scratch of pcops_sa_scatter_rows(b*m) * 4 * c floats (needed for dWxyz / dbias). */
-int pcops_sa_scatter_rows(long long groups);
+ * wpartial: caller scratch of pcops_sa_scatter_rows(b, m) * 4 * c floats (needed for dWxyz / dbias).
+ * workspace (may be NULL): pcops_sa_scatter_workspace_bytes(b,n,m,s) bytes, 16-byte aligned; with it the feature
+ * gradient is computed as a GATHER over a per-cloud inverse index (counting sort of idx) -- one wave per source
+ * point, no float atomics; without it (or when dCtr / the pooled form is requested) dQ is accumulated with atomics
+ * in an LDS-resident slice per cloud. */
+int pcops_sa_scatter_rows(int b, int m);
+unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s);
 int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                          const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
-                         float *dbias, pcops_stream_t stream);
+                         float *dbias, void *workspace, pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
     "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 17, True),
+    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 18, True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
@@ -59,7 +59,8 @@ PLAIN = {
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
-    "pcops_sa_scatter_rows": ([_LL], _I),
+    "pcops_sa_scatter_rows": ([_I, _I], _I),
+    "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
 }
 
 _lib = None

@@ -199,6 +199,346 @@ __global__ __launch_bounds__(256) void sa_scatter_bwd_kernel(long long G, int n,
     }
 }
 
+// backward, LDS-accumulating variant (the default).  One workgroup owns ONE cloud b and a slice of CS channels:
+// the cloud's slice of dQ (n x CS floats) lives in LDS, every row's dY is added there with LDS atomics (no
+// same-address traffic to L2 at all), and the slice leaves once, with plain coalesced stores.  A wave walks whole
+// groups (so dCtr is a register sum + lane reduction), lanes = (row, column quad) with 16-byte loads, U row
+// chunks in flight.  The cloud's xyz sits in LDS too (the offsets of the inline coordinate term).
+// Workgroups of the same cloud are spaced 8 apart in the launch order: same XCD, so the 128-byte lines two
+// slices share are fetched from HBM once.   wpart [b][4][C]: per-cloud partial (dWxyz rows 0..2, dbias).
+struct ScatterArgs {
+    int b, n, m, S, C, nsl;
+    const float *Gm, *Y, *p, *q, *t, *gpool;
+    const unsigned char *argmax;
+    const float *psc, *psh;
+    const int *idx;
+    const float *xyz, *new_xyz;
+    float *dQ, *dCtr, *wpart;
+};
+
+template <bool POOLED, int CS>
+__global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
+    constexpr int LPR = CS / 4;        // lanes per row (one float4 each)
+    constexpr int RW = 64 / LPR;       // rows per wave instruction
+    constexpr int U = 4;               // row chunks in flight
+    constexpr int NW = 16;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // launch order -> (cloud, slice): ids 8 apart share a cloud
+    const int L = blockIdx.x;
+    const int blo = L & 7, rest = L >> 3;
+    const int sl = rest % a.nsl, b = (rest / a.nsl) * 8 + blo;
+    if (b >= a.b) return;
+    const int n = a.n, m = a.m, S = a.S, C = a.C;
+    float *acc = sm;                                            // [n][CS]   (dQ slice)  | reduction scratch
+    const int accn = a.dQ ? n * CS : NW * 4 * CS;
+    float *sx = sm + (accn > NW * 4 * CS ? accn : NW * 4 * CS);  // [n][3]
+    if (a.dQ)
+        for (int e = tid; e < n * CS / 4; e += 1024)
+            reinterpret_cast<float4 *>(acc)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.xyz)
+        for (int e = tid; e < n * 3; e += 1024) sx[e] = a.xyz[(long long)b * n * 3 + e];
+    __syncthreads();
+
+    const int rsub = lane / LPR, quad = lane % LPR;
+    const int c0 = sl * CS + quad * 4;
+    const float4 cp = *reinterpret_cast<const float4 *>(a.p + c0);
+    const float4 cq = *reinterpret_cast<const float4 *>(a.q + c0);
+    const float4 ct = *reinterpret_cast<const float4 *>(a.t + c0);
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f), ch4 = cs4;
+    if (POOLED) {
+        cs4 = *reinterpret_cast<const float4 *>(a.psc + c0);
+        ch4 = *reinterpret_cast<const float4 *>(a.psh + c0);
+    }
+    float aw[4][4];                    // [x, y, z, 1][channel of the quad]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
+
+    for (int j = wave; j < m; j += NW) {
+        const long long g = (long long)b * m + j;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (a.xyz) { cx = a.new_xyz[g * 3 + 0]; cy = a.new_xyz[g * 3 + 1]; cz = a.new_xyz[g * 3 + 2]; }
+        float4 gp = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned am = 0;
+        if (POOLED) {
+            gp = *reinterpret_cast<const float4 *>(a.gpool + g * C + c0);
+            am = *reinterpret_cast<const unsigned *>(a.argmax + g * C + c0);
+        }
+        float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += RW * U) {
+            int ii[U];
+            float4 yy[U], gg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = s0 + u * RW + rsub;
+                const long long r = g * S + (s < S ? s : S - 1);
+                ii[u] = a.idx[r];
+                yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
+                if (!POOLED) gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = s0 + u * RW + rsub;
+                const float4 y = yy[u];
+                float4 gm;
+                if (POOLED) {
+                    const unsigned us = (unsigned)s;
+                    gm.x = ((am & 0xffu) == us && fmaf(y.x, cs4.x, ch4.x) > 0.f) ? gp.x : 0.f;
+                    gm.y = (((am >> 8) & 0xffu) == us && fmaf(y.y, cs4.y, ch4.y) > 0.f) ? gp.y : 0.f;
+                    gm.z = (((am >> 16) & 0xffu) == us && fmaf(y.z, cs4.z, ch4.z) > 0.f) ? gp.z : 0.f;
+                    gm.w = ((am >> 24) == us && fmaf(y.w, cs4.w, ch4.w) > 0.f) ? gp.w : 0.f;
+                } else {
+                    gm = gg[u];
+                }
+                float d[4];
+                d[0] = fmaf(cp.x, gm.x, fmaf(cq.x, y.x, ct.x));
+                d[1] = fmaf(cp.y, gm.y, fmaf(cq.y, y.y, ct.y));
+                d[2] = fmaf(cp.z, gm.z, fmaf(cq.z, y.z, ct.z));
+                d[3] = fmaf(cp.w, gm.w, fmaf(cq.w, y.w, ct.w));
+                if (s >= S) d[0] = d[1] = d[2] = d[3] = 0.f;
+                dsum.x += d[0]; dsum.y += d[1]; dsum.z += d[2]; dsum.w += d[3];
+                const int i = ii[u];
+                if (a.xyz) {
+                    const float ox = sx[i * 3 + 0] - cx, oy = sx[i * 3 + 1] - cy, oz = sx[i * 3 + 2] - cz;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        aw[0][e] = fmaf(ox, d[e], aw[0][e]);
+                        aw[1][e] = fmaf(oy, d[e], aw[1][e]);
+                        aw[2][e] = fmaf(oz, d[e], aw[2][e]);
+                    }
+                }
+                if (a.dQ && s < S) {
+                    float *dst = acc + i * CS + quad * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, d[e]);
+                }
+            }
+        }
+        aw[3][0] += dsum.x; aw[3][1] += dsum.y; aw[3][2] += dsum.z; aw[3][3] += dsum.w;
+        if (a.dCtr) {
+#pragma unroll
+            for (int off = 32; off >= LPR; off >>= 1) {
+                dsum.x += __shfl_xor(dsum.x, off, 64); dsum.y += __shfl_xor(dsum.y, off, 64);
+                dsum.z += __shfl_xor(dsum.z, off, 64); dsum.w += __shfl_xor(dsum.w, off, 64);
+            }
+            if (rsub == 0) *reinterpret_cast<float4 *>(a.dCtr + g * C + c0) = dsum;
+        }
+    }
+    __syncthreads();
+    if (a.dQ) {
+        for (int e = tid; e < n * LPR; e += 1024) {
+            const int i = e / LPR, qd = e % LPR;
+            *reinterpret_cast<float4 *>(a.dQ + ((long long)b * n + i) * C + sl * CS + qd * 4) =
+                *reinterpret_cast<const float4 *>(acc + i * CS + qd * 4);
+        }
+        __syncthreads();
+    }
+    if (a.wpart) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = aw[i][e];
+#pragma unroll
+                for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (rsub == 0) acc[(wave * 4 + i) * CS + quad * 4 + e] = v;
+            }
+        __syncthreads();
+        for (int e = tid; e < 4 * CS; e += 1024) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += acc[w * 4 * CS + e];
+            a.wpart[((long long)b * 4 + e / CS) * C + sl * CS + e % CS] = v;
+        }
+    }
+}
+
+template <bool POOLED, int CS>
+static int launch_scatter_lds(const ScatterArgs &a, size_t lds, hipStream_t st) {
+    auto kern = sa_scatter_lds_kernel<POOLED, CS>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    const unsigned grid = (unsigned)((a.b + 7) / 8 * 8 * a.nsl);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, a);
+    return pcops_launch_status();
+}
+
+// slice width: the widest of 64/32/16/8 that divides C and whose LDS footprint fits; 0 = none (fallback kernel)
+static int scatter_lds_slice(int n, int C, bool has_dq, bool has_xyz, size_t *lds) {
+    for (int cs = 64; cs >= 8; cs >>= 1) {
+        if (C % cs) continue;
+        const size_t red = (size_t)16 * 4 * cs;
+        size_t fl = has_dq ? (size_t)n * cs : 0;
+        if (fl < red) fl = red;
+        if (has_xyz) fl += (size_t)n * 3;
+        if (fl * sizeof(float) <= 156 * 1024) { *lds = fl * sizeof(float); return cs; }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward as a GATHER: the scatter-add turned inside out.  A counting sort per cloud (LDS histogram of idx, scan,
+// slot assignment) gives for every source point the list of (group, sample) rows that reference it; then one
+// wave per source point sums those rows of dY in registers and writes dQ[b, i, :] once -- no float atomics, no
+// memset, every row of G / Y read once with 16-byte loads, dWxyz / dbias partial sums in the same pass.
+//   order [b][m*S] int32 : row-in-cloud (j*S + s) sorted by idx      start [b][n+1] int32 : list boundaries
+__global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const int *__restrict__ idx,
+                                                            int *__restrict__ order, int *__restrict__ start) {
+    extern __shared__ int si[];                 // cnt[n] | cursor[n] | scan scratch [1024]
+    int *cnt = si, *cursor = si + n, *sc = si + 2 * n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int *ib = idx + (long long)b * mS;
+    for (int i = tid; i < n; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < mS; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+    __syncthreads();
+    // exclusive scan: each thread owns a contiguous run of bins
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; ++i) local += cnt[i];
+    sc[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? sc[tid - off] : 0;
+        __syncthreads();
+        sc[tid] += v;
+        __syncthreads();
+    }
+    int run = sc[tid] - local;
+    int *sb = start + (long long)b * (n + 1);
+    for (int i = i0; i < i1; ++i) {
+        cursor[i] = run;
+        sb[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 0) sb[n] = mS;
+    __syncthreads();
+    int *ob = order + (long long)b * mS;
+    for (int e = tid; e < mS; e += 1024) ob[atomicAdd(&cursor[ib[e]], 1)] = e;
+}
+
+struct CsrArgs {
+    int b, n, m, S, C;
+    const float *Gm, *Y, *p, *q, *t;
+    const float *xyz, *new_xyz;
+    const int *idx, *order;
+    float *dQ, *wpart;
+};
+
+template <int LPR>     // lanes per row: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256 channels
+__global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
+    // Work is dealt out in CHUNKS of the sorted row list, not per source point: ball query pads short
+    // neighbourhoods with their first index and prefers low indices, so a few points own very long lists.  A wave
+    // walks its chunk in sorted order, keeps the running sum of the current point in registers and flushes it
+    // with ONE global atomic per channel when the point changes -- (points + chunks) x C atomics instead of
+    // rows x C, and dQ is zeroed by the launcher.
+    constexpr int RW = 64 / LPR, U = 4, CH = 64;
+    __shared__ float red[4][4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rsub = lane / LPR, quad = lane % LPR;
+    const int n = a.n, m = a.m, S = a.S, C = a.C, mS = m * S;
+    const int nch = (mS + CH - 1) / CH;
+    const long long nchunks = (long long)a.b * nch;
+    const long long wstride = (long long)gridDim.x * 4;
+    for (int cb = 0; cb < C; cb += 4 * LPR) {
+        const int c0 = cb + quad * 4;
+        const float4 cp = *reinterpret_cast<const float4 *>(a.p + c0);
+        const float4 cq = *reinterpret_cast<const float4 *>(a.q + c0);
+        const float4 ct = *reinterpret_cast<const float4 *>(a.t + c0);
+        float aw[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
+        for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += wstride) {
+            const int b = (int)(ch / nch);
+            const int kb = (int)(ch - (long long)b * nch) * CH, ke = min(mS, kb + CH);
+            const int *ob = a.order + (long long)b * mS;
+            const int *ib = a.idx + (long long)b * mS;
+            int cur = -1;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            auto flush = [&]() {
+                float *dst = a.dQ + ((long long)b * n + cur) * C + c0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[e]);
+            };
+            // each row-lane set owns a CONTIGUOUS run of CH / RW sorted rows (interleaving would cut every
+            // point's list into RW pieces and multiply the flushes)
+            const int ks = kb + rsub * (CH / RW), kse = min(ke, ks + CH / RW);
+            for (int k0 = 0; k0 < CH / RW; k0 += U) {
+                if (kb + k0 >= ke) break;               // wave-uniform: nothing left for any lane set
+                int ee[U], ii[U];
+                float4 yy[U], gg[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = ks + k0 + u;
+                    ee[u] = ob[k < kse ? k : kb];
+                    ii[u] = ib[ee[u]];
+                    const long long r = (long long)b * mS + ee[u];
+                    yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
+                    gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = ks + k0 + u;
+                    if (k >= kse) continue;
+                    const float4 y = yy[u], gm = gg[u];
+                    float d[4];
+                    d[0] = fmaf(cp.x, gm.x, fmaf(cq.x, y.x, ct.x));
+                    d[1] = fmaf(cp.y, gm.y, fmaf(cq.y, y.y, ct.y));
+                    d[2] = fmaf(cp.z, gm.z, fmaf(cq.z, y.z, ct.z));
+                    d[3] = fmaf(cp.w, gm.w, fmaf(cq.w, y.w, ct.w));
+                    const int i = ii[u];
+                    if (i != cur) {
+                        if (cur >= 0) flush();
+                        cur = i;
+                        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += d[e];
+                    if (a.wpart) {
+                        if (a.xyz) {
+                            const int j = (int)((unsigned)ee[u] / (unsigned)S);
+                            const float *px = a.xyz + ((long long)b * n + i) * 3;
+                            const float *cx = a.new_xyz + ((long long)b * m + j) * 3;
+                            const float ox = px[0] - cx[0], oy = px[1] - cx[1], oz = px[2] - cx[2];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                aw[0][e] = fmaf(ox, d[e], aw[0][e]);
+                                aw[1][e] = fmaf(oy, d[e], aw[1][e]);
+                                aw[2][e] = fmaf(oz, d[e], aw[2][e]);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) aw[3][e] += d[e];
+                    }
+                }
+            }
+            if (cur >= 0) flush();
+        }
+        if (a.wpart) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = aw[i][e];
+#pragma unroll
+                    for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (rsub == 0) red[wave][i][quad * 4 + e] = v;
+                }
+            __syncthreads();
+            for (int e = tid; e < 4 * 4 * LPR; e += 256) {
+                const int i = e / (4 * LPR), c = e % (4 * LPR);
+                a.wpart[((long long)blockIdx.x * 4 + i) * C + cb + c] =
+                    red[0][i][c] + red[1][i][c] + red[2][i][c] + red[3][i][c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int kCsrGrid = 1024;      // persistent workgroups of the gather pass (= rows of its wpart)
+
 // out[L] = sum_p part[p][L] in double (deterministic)
 __global__ __launch_bounds__(256) void sum_rows_kernel(int P, int L, const float *__restrict__ part,
                                                        float *__restrict__ out) {
@@ -217,10 +557,35 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(int P, int L, const float
 
 }  // namespace
 
+static bool scatter_csr_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_SCATTER_CSR");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+static bool scatter_lds_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_SCATTER_LDS");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 extern "C" {
 
 int pcops_sa_gather_stats_rows(long long G) { return (int)((G + 7) / 8); }
-int pcops_sa_scatter_rows(long long G) { return (int)((G + 15) / 16); }
+int pcops_sa_scatter_rows(int b, int m) {
+    // rows of the caller's weight-gradient scratch: one per cloud (LDS kernel) or per 16 groups (fallback kernel)
+    const long long fb = ((long long)b * m + 15) / 16;
+    const long long r = fb > b ? fb : b;
+    return (int)(r > kCsrGrid ? r : kCsrGrid);
+}
+
+unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) {
+    return sizeof(int) * ((unsigned long long)b * m * s + (unsigned long long)b * (n + 1));
+}
 
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
@@ -243,22 +608,87 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                          const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
-                         float *dbias, pcops_stream_t stream) {
+                         float *dbias, void *workspace, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
     PCOPS_REQUIRE_SHAPE(c <= 1024 && (c >= 256 || 256 % c == 0));
     const long long Gn = (long long)b * m;
     hipStream_t st = as_stream(stream);
-    if (dQ && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
-    if (Gn == 0) return PCOPS_OK;
+    if (Gn == 0) {
+        if (dQ && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
+        return PCOPS_OK;
+    }
     PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(idx);
     if (xyz) { PCOPS_REQUIRE_PTR(new_xyz); }
     if (dWxyz || dbias) PCOPS_REQUIRE_PTR(wpartial);
+    float *wp = (dWxyz || dbias) ? wpartial : nullptr;
+    if (gpool) {
+        PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
+        PCOPS_REQUIRE_SHAPE(s <= 256);
+    } else {
+        PCOPS_REQUIRE_PTR(G);
+    }
+    // gather formulation: feature gradient wanted, G materialised, no per-group output
+    const int lpr = c <= 256 ? c / 4 : 64;
+    const bool csr_shape = (c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384 &&
+                           (long long)m * s < (1ll << 30) && 2 * (size_t)n * 4 + 4096 <= 160 * 1024;
+    if (scatter_csr_enabled() && workspace && dQ && !dCtr && !gpool && csr_shape) {
+        int *order = static_cast<int *>(workspace);
+        int *start = order + (size_t)b * m * s;
+        const size_t blds = (2 * (size_t)n + 1024) * sizeof(int);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
+        if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
+        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, idx, order, dQ, wp};
+        switch (lpr) {
+            case 8: hipLaunchKernelGGL(sa_scatter_csr_kernel<8>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL(sa_scatter_csr_kernel<16>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+            case 32: hipLaunchKernelGGL(sa_scatter_csr_kernel<32>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(sa_scatter_csr_kernel<64>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+        }
+        int rc = pcops_launch_status();
+        if (rc) return rc;
+        if (wp) {
+            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, kCsrGrid, 4 * c, wp, dWxyz);
+            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, kCsrGrid, 4 * c, wp + 3 * c, dbias);
+            rc = pcops_launch_status();
+        }
+        return rc;
+    }
+    size_t lds_bytes = 0;
+    const int cs = scatter_lds_enabled() ? scatter_lds_slice(n, c, dQ != nullptr, xyz != nullptr, &lds_bytes) : 0;
+    if (cs) {
+        ScatterArgs a = {b, n, m, s, c, c / cs, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx, xyz,
+                         new_xyz, dQ, dCtr, wp};
+        int rc;
+#define PCOPS_SCATTER_CASE(CS_)                                                                   \
+    case CS_:                                                                                     \
+        rc = gpool ? launch_scatter_lds<true, CS_>(a, lds_bytes, st) : launch_scatter_lds<false, CS_>(a, lds_bytes, st); \
+        break;
+        switch (cs) {
+            PCOPS_SCATTER_CASE(64)
+            PCOPS_SCATTER_CASE(32)
+            PCOPS_SCATTER_CASE(16)
+            PCOPS_SCATTER_CASE(8)
+            default: rc = PCOPS_ERR_UNSUPPORTED;
+        }
+#undef PCOPS_SCATTER_CASE
+        if (rc) return rc;
+        if (wp) {
+            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, b, 4 * c, wp, dWxyz);
+            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, b, 4 * c, wp + 3 * c, dbias);
+            rc = pcops_launch_status();
+        }
+        return rc;
+    }
+    // fallback: global atomics (clouds too large for an LDS-resident slice)
+    if (dQ && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
     const int rl = c >= 256 ? 1 : 256 / c;
     const size_t lds = (size_t)rl * 6 * c * sizeof(float);
     const int gpb = 16;
-    const unsigned grid = pcops_sa_scatter_rows(Gn);
-    float *wp = (dWxyz || dbias) ? wpartial : nullptr;
+    const unsigned grid = (unsigned)((Gn + 15) / 16);
     if (gpool) {
         PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
         PCOPS_REQUIRE_SHAPE(s <= 256);

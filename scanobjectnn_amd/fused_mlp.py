@@ -194,11 +194,15 @@ class FusedMLPStack(torch.autograd.Function):
                 d1 = _f32((B, M, N), dev) if ctr is not None else None
                 dwxyz = _f32((3, N), dev) if wxyz is not None else None
                 dbias = _f32(N, dev) if bias is not None else None
-                wpart = _f32(lib.pcops_sa_scatter_rows(B * M) * 4 * N, dev) if (wxyz is not None or bias is not None) else None
+                wpart = _f32(lib.pcops_sa_scatter_rows(B, M) * 4 * N, dev) if (wxyz is not None or bias is not None) else None
+                wsp = None
+                if d0 is not None and d1 is None and not pooled:   # gather formulation over an inverse index
+                    wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,
+                                      dtype=torch.int32, device=dev)
                 _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
                           q.data_ptr(), t.data_ptr(), gp, am, psc, psh, idx.data_ptr(),
                           _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
-                          _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias))
+                          _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(wsp))
                 break
 
             K = Ws[l].shape[0]
