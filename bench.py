@@ -253,14 +253,14 @@ def main():
         s = state["step"]
         lr = TU.get_learning_rate(s, global_batch)
         bn_decay = TU.get_bn_decay(s, global_batch)
-        fp.zero_grad()
+        fp.begin_step()
         out = net(x, is_training=True, bn_decay=bn_decay)
         if has_mask:
             loss = mod.get_loss(out[0], out[1], y, mask)[0]
         else:
             loss = mod.get_loss(out[0], y, out[1])
         loss.backward()
-        D.allreduce_mean_(fp.grad, world)
+        D.allreduce_mean_(fp.collect(), world)
         opt.step(lr)
         state["step"] = s + 1
         return loss

@@ -207,13 +207,15 @@ __global__ __launch_bounds__(256) void sa_scatter_bwd_kernel(long long G, int n,
 // Workgroups of the same cloud are spaced 8 apart in the launch order: same XCD, so the 128-byte lines two
 // slices share are fetched from HBM once.   wpart [b][4][C]: per-cloud partial (dWxyz rows 0..2, dbias).
 struct ScatterArgs {
-    int b, n, m, S, C, nsl;
+    int b, n, m, S, C, nsl, gsplit;     // gsplit > 1 (streaming use only, dQ == NULL): groups of a cloud dealt to
+                                        // several workgroups; wpart rows are then [b * gsplit]
     const float *Gm, *Y, *p, *q, *t, *gpool;
     const unsigned char *argmax;
     const float *psc, *psh;
     const int *idx;
     const float *xyz, *new_xyz;
     float *dQ, *dCtr, *wpart;
+    float *dQarg;                       // pooled form: global dQ receiving p.gpool at the arg-max rows (atomics)
 };
 
 template <bool POOLED, int CS>
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // launch order -> (cloud, slice): ids 8 apart share a cloud
-    const int L = blockIdx.x;
+    const int L = blockIdx.x / a.gsplit, part = blockIdx.x % a.gsplit;
     const int blo = L & 7, rest = L >> 3;
     const int sl = rest % a.nsl, b = (rest / a.nsl) * 8 + blo;
     if (b >= a.b) return;
@@ -254,7 +256,9 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
 
-    for (int j = wave; j < m; j += NW) {
+    const int jper = (m + a.gsplit - 1) / a.gsplit;
+    const int jbeg = part * jper, jend = min(m, jbeg + jper);
+    for (int j = jbeg + wave; j < jend; j += NW) {
         const long long g = (long long)b * m + j;
         float cx = 0.f, cy = 0.f, cz = 0.f;
         if (a.xyz) { cx = a.new_xyz[g * 3 + 0]; cy = a.new_xyz[g * 3 + 1]; cz = a.new_xyz[g * 3 + 2]; }
@@ -287,6 +291,13 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
                     gm.y = (((am >> 8) & 0xffu) == us && fmaf(y.y, cs4.y, ch4.y) > 0.f) ? gp.y : 0.f;
                     gm.z = (((am >> 16) & 0xffu) == us && fmaf(y.z, cs4.z, ch4.z) > 0.f) ? gp.z : 0.f;
                     gm.w = ((am >> 24) == us && fmaf(y.w, cs4.w, ch4.w) > 0.f) ? gp.w : 0.f;
+                    if (a.dQarg && s < S) {      // one atomic per (group, channel): the sparse part of the pooled dY
+                        float *dst = a.dQarg + ((long long)b * n + ii[u]) * C + c0;
+                        if (gm.x != 0.f) atomicAdd(dst + 0, cp.x * gm.x);
+                        if (gm.y != 0.f) atomicAdd(dst + 1, cp.y * gm.y);
+                        if (gm.z != 0.f) atomicAdd(dst + 2, cp.z * gm.z);
+                        if (gm.w != 0.f) atomicAdd(dst + 3, cp.w * gm.w);
+                    }
                 } else {
                     gm = gg[u];
                 }
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += acc[w * 4 * CS + e];
-            a.wpart[((long long)b * 4 + e / CS) * C + sl * CS + e % CS] = v;
+            a.wpart[(((long long)b * a.gsplit + part) * 4 + e / CS) * C + sl * CS + e % CS] = v;
         }
     }
 }
@@ -359,7 +370,7 @@ static int launch_scatter_lds(const ScatterArgs &a, size_t lds, hipStream_t st) 
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
         return PCOPS_ERR_LAUNCH;
-    const unsigned grid = (unsigned)((a.b + 7) / 8 * 8 * a.nsl);
+    const unsigned grid = (unsigned)((a.b + 7) / 8 * 8 * a.nsl * a.gsplit);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, st, a);
     return pcops_launch_status();
 }
@@ -382,9 +393,9 @@ static int scatter_lds_slice(int n, int C, bool has_dq, bool has_xyz, size_t *ld
 // slot assignment) gives for every source point the list of (group, sample) rows that reference it; then one
 // wave per source point sums those rows of dY in registers and writes dQ[b, i, :] once -- no float atomics, no
 // memset, every row of G / Y read once with 16-byte loads, dWxyz / dbias partial sums in the same pass.
-//   order [b][m*S] int32 : row-in-cloud (j*S + s) sorted by idx      start [b][n+1] int32 : list boundaries
+//   order [b][m*S] int2 : (row-in-cloud j*S + s, idx) sorted by idx      start [b][n+1] int32 : list boundaries
 __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const int *__restrict__ idx,
-                                                            int *__restrict__ order, int *__restrict__ start) {
+                                                            int2 *__restrict__ order, int *__restrict__ start) {
     extern __shared__ int si[];                 // cnt[n] | cursor[n] | scan scratch [1024]
     int *cnt = si, *cursor = si + n, *sc = si + 2 * n;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -415,19 +426,24 @@ __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const
     }
     if (tid == 0) sb[n] = mS;
     __syncthreads();
-    int *ob = order + (long long)b * mS;
-    for (int e = tid; e < mS; e += 1024) ob[atomicAdd(&cursor[ib[e]], 1)] = e;
+    int2 *ob = order + (long long)b * mS;
+    for (int e = tid; e < mS; e += 1024) {
+        const int i = ib[e];
+        ob[atomicAdd(&cursor[i], 1)] = make_int2(e, i);
+    }
 }
 
 struct CsrArgs {
     int b, n, m, S, C;
     const float *Gm, *Y, *p, *q, *t;
     const float *xyz, *new_xyz;
-    const int *idx, *order;
+    const int2 *order;
     float *dQ, *wpart;
 };
 
-template <int LPR>     // lanes per row: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256 channels
+// YONLY: the pooled form -- dY = q.Y + t everywhere plus p.gpool at the arg-max rows, which the streaming
+// kernel adds with one atomic per (group, channel) (G is never materialised there)
+template <int LPR, bool YONLY>     // lanes per row: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
 __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
     // Work is dealt out in CHUNKS of the sorted row list, not per source point: ball query pads short
     // neighbourhoods with their first index and prefers low indices, so a few points own very long lists.  A wave
@@ -453,8 +469,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
         for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += wstride) {
             const int b = (int)(ch / nch);
             const int kb = (int)(ch - (long long)b * nch) * CH, ke = min(mS, kb + CH);
-            const int *ob = a.order + (long long)b * mS;
-            const int *ib = a.idx + (long long)b * mS;
+            const int2 *ob = a.order + (long long)b * mS;
             int cur = -1;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             auto flush = [&]() {
@@ -472,17 +487,19 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int k = ks + k0 + u;
-                    ee[u] = ob[k < kse ? k : kb];
-                    ii[u] = ib[ee[u]];
+                    const int2 oe = ob[k < kse ? k : kb];
+                    ee[u] = oe.x;
+                    ii[u] = oe.y;
                     const long long r = (long long)b * mS + ee[u];
                     yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
-                    gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
+                    if (!YONLY) gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int k = ks + k0 + u;
                     if (k >= kse) continue;
-                    const float4 y = yy[u], gm = gg[u];
+                    const float4 y = yy[u];
+                    const float4 gm = YONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : gg[u];
                     float d[4];
                     d[0] = fmaf(cp.x, gm.x, fmaf(cq.x, y.x, ct.x));
                     d[1] = fmaf(cp.y, gm.y, fmaf(cq.y, y.y, ct.y));
@@ -584,7 +601,7 @@ int pcops_sa_scatter_rows(int b, int m) {
 }
 
 unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) {
-    return sizeof(int) * ((unsigned long long)b * m * s + (unsigned long long)b * (n + 1));
+    return sizeof(int) * (2ull * b * m * s + (unsigned long long)b * (n + 1));
 }
 
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
@@ -632,27 +649,61 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
     const int lpr = c <= 256 ? c / 4 : 64;
     const bool csr_shape = (c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384 &&
                            (long long)m * s < (1ll << 30) && 2 * (size_t)n * 4 + 4096 <= 160 * 1024;
-    if (scatter_csr_enabled() && workspace && dQ && !dCtr && !gpool && csr_shape) {
-        int *order = static_cast<int *>(workspace);
-        int *start = order + (size_t)b * m * s;
+    if (scatter_csr_enabled() && workspace && dQ && csr_shape) {
+        const bool split = dCtr || gpool;        // per-group outputs / pooled form: streaming pass first
+        if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
+        if (split) {
+            size_t lb = 0;
+            const int cs0 = scatter_lds_slice(n, c, false, xyz != nullptr, &lb);
+            if (!cs0) return PCOPS_ERR_UNSUPPORTED;
+            const int nsl = c / cs0;
+            int gsplit = kCsrGrid / ((b + 7) / 8 * 8 * nsl);        // enough workgroups to fill the chip
+            if (gsplit > (m + 15) / 16) gsplit = (m + 15) / 16;
+            if (gsplit < 1) gsplit = 1;
+            ScatterArgs sa = {b, n, m, s, c, nsl, gsplit, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx,
+                              xyz, new_xyz, nullptr, dCtr, wp, gpool ? dQ : nullptr};
+            int rc0 = PCOPS_ERR_UNSUPPORTED;
+            switch (cs0) {
+                case 64: rc0 = gpool ? launch_scatter_lds<true, 64>(sa, lb, st) : launch_scatter_lds<false, 64>(sa, lb, st); break;
+                case 32: rc0 = gpool ? launch_scatter_lds<true, 32>(sa, lb, st) : launch_scatter_lds<false, 32>(sa, lb, st); break;
+                case 16: rc0 = gpool ? launch_scatter_lds<true, 16>(sa, lb, st) : launch_scatter_lds<false, 16>(sa, lb, st); break;
+                case 8: rc0 = gpool ? launch_scatter_lds<true, 8>(sa, lb, st) : launch_scatter_lds<false, 8>(sa, lb, st); break;
+            }
+            if (rc0) return rc0;
+            if (wp) {
+                const int rows = b * gsplit;
+                if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, rows, 4 * c, wp, dWxyz);
+                if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, rows, 4 * c, wp + 3 * c, dbias);
+            }
+        }
+        int2 *order = static_cast<int2 *>(workspace);
+        int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
         const size_t blds = (2 * (size_t)n + 1024) * sizeof(int);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PCOPS_ERR_LAUNCH;
         hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
-        if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
-        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, idx, order, dQ, wp};
+        float *wp2 = split ? nullptr : wp;
+        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2};
+#define PCOPS_CSR_CASE(LPR_)                                                                                    \
+    case LPR_:                                                                                                  \
+        if (gpool) hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, true>), dim3(kCsrGrid), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, false>), dim3(kCsrGrid), dim3(256), 0, st, a);      \
+        break;
         switch (lpr) {
-            case 8: hipLaunchKernelGGL(sa_scatter_csr_kernel<8>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
-            case 16: hipLaunchKernelGGL(sa_scatter_csr_kernel<16>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
-            case 32: hipLaunchKernelGGL(sa_scatter_csr_kernel<32>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL(sa_scatter_csr_kernel<64>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+            PCOPS_CSR_CASE(8)
+            PCOPS_CSR_CASE(16)
+            PCOPS_CSR_CASE(32)
+            default:
+                if (gpool) hipLaunchKernelGGL((sa_scatter_csr_kernel<64, true>), dim3(kCsrGrid), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((sa_scatter_csr_kernel<64, false>), dim3(kCsrGrid), dim3(256), 0, st, a);
         }
+#undef PCOPS_CSR_CASE
         int rc = pcops_launch_status();
         if (rc) return rc;
-        if (wp) {
-            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, kCsrGrid, 4 * c, wp, dWxyz);
-            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, kCsrGrid, 4 * c, wp + 3 * c, dbias);
+        if (wp2) {
+            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, kCsrGrid, 4 * c, wp2, dWxyz);
+            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, kCsrGrid, 4 * c, wp2 + 3 * c, dbias);
             rc = pcops_launch_status();
         }
         return rc;
@@ -660,8 +711,14 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
     size_t lds_bytes = 0;
     const int cs = scatter_lds_enabled() ? scatter_lds_slice(n, c, dQ != nullptr, xyz != nullptr, &lds_bytes) : 0;
     if (cs) {
-        ScatterArgs a = {b, n, m, s, c, c / cs, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx, xyz,
-                         new_xyz, dQ, dCtr, wp};
+        int gsplit = 1;
+        if (!dQ) {                               // pure streaming: deal a cloud's groups to several workgroups
+            gsplit = kCsrGrid / ((b + 7) / 8 * 8 * (c / cs));
+            if (gsplit > (m + 15) / 16) gsplit = (m + 15) / 16;
+            if (gsplit < 1) gsplit = 1;
+        }
+        ScatterArgs a = {b, n, m, s, c, c / cs, gsplit, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx,
+                         xyz, new_xyz, dQ, dCtr, wp, nullptr};
         int rc;
 #define PCOPS_SCATTER_CASE(CS_)                                                                   \
     case CS_:                                                                                     \
@@ -677,8 +734,9 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
 #undef PCOPS_SCATTER_CASE
         if (rc) return rc;
         if (wp) {
-            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, b, 4 * c, wp, dWxyz);
-            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, b, 4 * c, wp + 3 * c, dbias);
+            const int rows = b * gsplit;
+            if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, rows, 4 * c, wp, dWxyz);
+            if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, rows, 4 * c, wp + 3 * c, dbias);
             rc = pcops_launch_status();
         }
         return rc;

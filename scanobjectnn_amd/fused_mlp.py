@@ -196,7 +196,7 @@ class FusedMLPStack(torch.autograd.Function):
                 dbias = _f32(N, dev) if bias is not None else None
                 wpart = _f32(lib.pcops_sa_scatter_rows(B, M) * 4 * N, dev) if (wxyz is not None or bias is not None) else None
                 wsp = None
-                if d0 is not None and d1 is None and not pooled:   # gather formulation over an inverse index
+                if d0 is not None:   # gather formulation over an inverse index
                     wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,
                                       dtype=torch.int32, device=dev)
                 _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
@@ -242,6 +242,54 @@ class FusedMLPStack(torch.autograd.Function):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
         return tuple(out)
+
+
+class _RowsLinear(torch.autograd.Function):
+    """Y = X W + b on (rows, K) through the libpcops GEMMs, backward included.  Exists for the per-source-point
+    contraction of a grouped first layer (Q = points W_f + b): rows = B*N is large and the weight gradient is a
+    (K, N) = (128, 128)-sized reduction over all rows, a shape the library GEMM runs on a handful of CUs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        R, K = x.shape
+        N = w.shape[1]
+        y = _f32((R, N), x.device)
+        _lib.call("pcops_mlp_gemm_fwd", R, K, N, x.data_ptr(), K, None, None, w.data_ptr(), _p(b), y.data_ptr(), None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        R, K = x.shape
+        N = w.shape[1]
+        dev = g.device
+        g = g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = _f32((N, K), dev)
+            _lib.call("pcops_mlp_transpose", K, N, w.data_ptr(), wt.data_ptr())
+            dx = _f32((R, K), dev)
+            _lib.call("pcops_mlp_gemm_fwd", R, N, K, g.data_ptr(), N, None, None, wt.data_ptr(), None, dx.data_ptr(), None)
+        if ctx.needs_input_grad[1] or ctx.has_bias:
+            n4 = (N + 3) // 4 * 4
+            coef = torch.zeros(3 * n4, dtype=torch.float32, device=dev)     # p = 1, q = 0, t = 0: dY = G
+            coef[:n4] = 1.0
+            scratch = _f32(lib.pcops_mlp_wgrad_splits(R, K, N) * (K * N + N), dev)
+            dw, db = _f32((K, N), dev), _f32(N, dev)
+            _lib.call("pcops_mlp_wgrad", R, K, N, x.data_ptr(), K, None, None, g.data_ptr(), g.data_ptr(),
+                      coef.data_ptr(), coef[n4:].data_ptr(), coef[2 * n4:].data_ptr(), None, None, 1, None, None,
+                      scratch.data_ptr(), dw.data_ptr(), db.data_ptr())
+            if not ctx.has_bias:
+                db = None
+        return dx, dw, db
+
+
+def rows_linear(x2d, w, b=None):
+    """x2d (R, K) @ w (K, N) + b through libpcops (forward and backward); K % 4 == 0 and N % 4 == 0"""
+    return _RowsLinear.apply(x2d.contiguous(), w.contiguous(), b)
 
 
 def fused_supported(x, widths, bn, activation_relu):

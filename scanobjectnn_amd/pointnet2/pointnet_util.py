@@ -85,11 +85,12 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
     else:
         cf = points.shape[-1]
         pts2d = points.reshape(b * n, cf)
+        lin = fused_mlp.rows_linear if cf % 4 == 0 else (lambda x, w, bias: torch.addmm(bias, x, w))
         if use_xyz:
             w_xyz, w_f = (w1[:3], w1[3:]) if xyz_first else (w1[cf:], w1[:cf])
-            kw = dict(Q=torch.addmm(b1, pts2d, w_f).view(b, n, c1), xyz=xyz, new_xyz=new_xyz, wxyz=w_xyz)
+            kw = dict(Q=lin(pts2d, w_f, b1).view(b, n, c1), xyz=xyz, new_xyz=new_xyz, wxyz=w_xyz)
         else:
-            kw = dict(Q=torch.addmm(b1, pts2d, w1).view(b, n, c1))
+            kw = dict(Q=lin(pts2d, w1, b1).view(b, n, c1))
     decay = bn_decay if bn_decay is not None else 0.9
     out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers, **kw)
     return out.view(b, m, 1 if pool_max else s, widths[-1])

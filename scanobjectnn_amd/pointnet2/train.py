@@ -96,7 +96,7 @@ def train(args):
             y = torch.as_tensor(lab[sl], device=dev)
             lr = TU.get_learning_rate(step, args.batch_size, args.learning_rate, args.decay_step, args.decay_rate)
             bn_decay = TU.get_bn_decay(step, args.batch_size, float(args.decay_step))
-            fp.zero_grad()
+            fp.begin_step()
             out = net(x, is_training=True, bn_decay=bn_decay)
             if with_mask:
                 m = torch.as_tensor(msk[sl], device=dev)
@@ -104,7 +104,7 @@ def train(args):
             else:
                 loss = mod.get_loss(out[0], y, out[1])
             loss.backward()
-            D.allreduce_mean_(fp.grad, world)
+            D.allreduce_mean_(fp.collect(), world)
             opt.step(lr)
             step += 1
             loss_sum += float(loss)

@@ -38,17 +38,37 @@ class FlatParams:
         dev = self.params[0].device
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self._gviews = []
         off = 0
         for p in self.params:
             k = p.numel()
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
+            self._gviews.append(p.grad)
             off += k
         self.numel = n
 
     def zero_grad(self):
         self.grad.zero_()
+        for p, v in zip(self.params, self._gviews):
+            p.grad = v
+
+    def begin_step(self):
+        """Drop the gradient views: autograd then hands each parameter its freshly computed gradient instead of
+        adding it into a zeroed buffer (one fill + one add launch per parameter saved); `collect()` re-homes them."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """after backward(): pack the per-parameter gradients into the flat bucket with ONE concatenation and make
+        p.grad a view of it again (parameters the loss did not reach contribute zeros)"""
+        pieces = [(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()]) for p in self.params]
+        torch.cat(pieces, out=self.grad)
+        for p, v in zip(self.params, self._gviews):
+            p.grad = v
+        return self.grad
 
 
 class TFAdam:

@@ -261,3 +261,25 @@ def test_gather_stack_forward_backward(B, N, M, S, widths, pool, form):
             continue          # analytically zero gradient (a bias in front of the batch norm): noise only
         err, err_plain = (a - b).abs().max().item(), (c - b).abs().max().item()
         assert err <= 1e-3 * scale + 1e-5 or err <= 2.0 * err_plain, (i, err, err_plain, scale)
+
+
+@pytest.mark.parametrize("R,K,N,bias", [(256 * 512, 128, 128, True), (3000, 64, 96, False), (70000, 32, 64, True)])
+def test_rows_linear(R, K, N, bias):
+    """Y = X W + b through libpcops (the per-source-point contraction of a grouped first layer) against torch in
+    float64, forward and all three gradients"""
+    g = torch.Generator().manual_seed(R + K)
+    x = torch.randn(R, K, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True) if bias else None
+    y = fused_mlp.rows_linear(x, w, b)
+    go = torch.randn(R, N, generator=g).to(DEV)
+    y.backward(go)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    bd = b.detach().double().requires_grad_(True) if bias else None
+    yd = xd @ wd + (bd if bias else 0.0)
+    yd.backward(go.double())
+    assert (y.double() - yd).abs().max().item() < 1e-4
+    assert (x.grad.double() - xd.grad).abs().max().item() < 1e-4 * max(1.0, xd.grad.abs().max().item())
+    assert (w.grad.double() - wd.grad).abs().max().item() < 1e-4 * wd.grad.abs().max().item()
+    if bias:
+        assert (b.grad.double() - bd.grad).abs().max().item() < 1e-4 * bd.grad.abs().max().item()

@@ -65,6 +65,27 @@ def test_flat_params_gradients_accumulate_in_place():
     assert all(p.grad.abs().sum() == 0 for p in net.parameters())
 
 
+def test_flat_params_collect_matches_in_place_accumulation():
+    """begin_step()/collect(): gradients handed over by autograd and packed with one concatenation are the same
+    flat bucket the in-place path produces; an unreached parameter contributes zeros"""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2))
+    extra = torch.nn.Parameter(torch.randn(7))          # never touched by the loss
+    net.register_parameter("unused", extra)
+    fp = TU.FlatParams(net)
+    x = torch.randn(5, 3)
+    fp.zero_grad()
+    net(x).sum().backward()
+    want = fp.grad.clone()
+    fp.begin_step()
+    assert all(p.grad is None for p in net.parameters())
+    net(x).sum().backward()
+    got = fp.collect()
+    assert got is fp.grad and torch.equal(got, want)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(fp.params, fp._gviews))
+    assert extra.grad.abs().sum() == 0 and extra.grad.numel() == 7
+
+
 def test_center_and_normalize():
     """data_utils.py:133-143,162-168"""
     rng = np.random.default_rng(0)
