@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -35,7 +36,10 @@ constexpr int kBM = 128;   // rows per tile (4 waves x 32)
 constexpr int kBK = 32;    // K chunk
 constexpr int kLdA = 36;   // A tile row stride in floats (16 B aligned, conflict-free b128 reads)
 
-enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3 };
+enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3, A_DYPOOLU = 4 };
+// A_DYPOOLU: A_DYPOOL with S % 32 == 0 -- a 32-row tile / stripe lies inside ONE pooling group, so its gpool / arg-max
+// quad is loaded once per tile and the row-in-group is (row0 % S) + r (wave-stream kernels only)
+constexpr bool is_pool(int am) { return am == A_DYPOOL || am == A_DYPOOLU; }
 
 // ---- buffer-resource addressing (gfx950): ONE 32-bit VGPR offset per lane + a scalar offset per access, and the
 // hardware bounds check (offset >= num_records -> loads return 0, stores are dropped) replaces every row guard.
@@ -424,25 +428,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const long long tstride = (long long)nrowgrp * WAVES;
     float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
     float4 pb[(AM >= A_DY) ? NLD : 1];               // A_DY*: raw Y
-    unsigned pm[(AM == A_DYPOOL) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
+    unsigned pm[(is_pool(AM)) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
 
     // per-lane byte offsets inside a tile (the row part of element e = lane + 64 j is added as a SCALAR offset)
     const unsigned xvoff = (unsigned)((lane / C4) * a.ldx + (lane % C4) * 4) * 4u;
     const unsigned xrowstep = (unsigned)(64 / C4) * (unsigned)a.ldx * 4u;          // bytes per j
     const unsigned yrowstep = (unsigned)(64 / O4) * (unsigned)a.ldy * 4u;
-    const long long glast = AM == A_DYPOOL ? ((long long)M - 1) / a.S : 0;
+    const long long glast = is_pool(AM) ? ((long long)M - 1) / a.S : 0;
+    constexpr bool U_ = AM == A_DYPOOLU;             // one pooling group per tile
     auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
-        if (AM == A_DYPOOL) {
+        if (is_pool(AM)) {
             const PoolRows pr(row0, a.S);
 #pragma unroll
-            for (int j = 0; j < NLD; ++j) {
+            for (int j = 0; j < (U_ ? 1 : NLD); ++j) {
                 const int e = lane + 64 * j;
                 int c = (e % C4) * 4 + kc * KC;
                 c = c < K ? c : K - 4;
                 long long gi;
                 unsigned sdummy;
-                pr.split(e / C4, glast, gi, sdummy);
+                if (U_) gi = pr.g0 < glast ? pr.g0 : glast;
+                else pr.split(e / C4, glast, gi, sdummy);
                 pa[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
                 pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
             }
@@ -453,13 +459,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const unsigned kbytes = (unsigned)(kc * KC) * 4u;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            if (AM != A_DYPOOL) pa[j] = buf_load4(rx, xvoff, kbytes + (unsigned)j * xrowstep);
+            if (!is_pool(AM)) pa[j] = buf_load4(rx, xvoff, kbytes + (unsigned)j * xrowstep);
             if (AM >= A_DY) pb[j] = buf_load4(rx2, xvoff, kbytes + (unsigned)j * xrowstep);
         }
     };
     auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
         const long long row0 = tile * 32;
-        const PoolRows prs(AM == A_DYPOOL ? row0 : 0, AM == A_DYPOOL ? a.S : 1);
+        const PoolRows prs(is_pool(AM) ? row0 : 0, is_pool(AM) ? a.S : 1);
         const int cl = (lane % C4) * 4;              // fixed per lane (64 % C4 == 0)
         const int c = cl + kc * KC;
         float4 c0, c1, c2, c3, c4;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
             const bool in = (row0 + r < M) && (c < K);
-            float4 x = pa[j];
+            float4 x = pa[U_ ? 0 : j];
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
                 x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
@@ -485,11 +491,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             } else if (AM >= A_DY) {
                 const float4 y = pb[j];
                 float4 g = x;
-                if (AM == A_DYPOOL) {
+                if (is_pool(AM)) {
                     long long gdummy;
                     unsigned s;
-                    prs.split(r, glast, gdummy, s);
-                    const unsigned am = pm[j];
+                    if (U_) s = (unsigned)(prs.s0 + r);
+                    else prs.split(r, glast, gdummy, s);
+                    const unsigned am = pm[U_ ? 0 : j];
                     g.x = ((am & 0xffu) == (unsigned)s && fmaf(y.x, c3.x, c4.x) > 0.f) ? x.x : 0.f;
                     g.y = (((am >> 8) & 0xffu) == (unsigned)s && fmaf(y.y, c3.y, c4.y) > 0.f) ? x.y : 0.f;
                     g.z = (((am >> 16) & 0xffu) == (unsigned)s && fmaf(y.z, c3.z, c4.z) > 0.f) ? x.z : 0.f;
@@ -504,7 +511,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
         }
     };
-
     // a wave walks whole pooling groups: SUB consecutive 32-row tiles (SUB = 1 without pooling)
     const int SUB = POOL ? a.pool_sub : 1;
     const long long nsuper = (ntiles + SUB - 1) / SUB;
@@ -709,7 +715,7 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
-    if (am == A_DYPOOL && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
+    if (is_pool(am) && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
         return false;
     // 8 waves (two per SIMD) with 64-wide stripes; 128 output columns when the resident weight tile fits
     pl->kc = 64;
@@ -764,7 +770,9 @@ template <int AM, int EM>
 int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
     if (ws_enabled() && ws_plan(a, AM, &pl)) {
-        int rc = launch_gemm_ws<AM, EM>(a, pl, st);
+        int rc;
+        if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
+        else rc = launch_gemm_ws<AM, EM>(a, pl, st);
         if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
             const int P = pcops_mlp_stats_rows(a.M);
             if (pl.gy < P && hipMemsetAsync(a.stats + (size_t)pl.gy * 2 * a.N, 0,
@@ -1362,6 +1370,274 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
             if (n0 + i < N) a.dbpart[(long long)grp * N + n0 + i] = red[KB * NB + i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// wgrad, producer / consumer variant (the default for large M).  The single-role kernel above alternates between
+// rebuilding operands (VALU + LDS writes) and MFMAs inside one wave per SIMD, so the matrix pipe idles while
+// operands are staged.  Here a workgroup is 8 waves = 2 per SIMD with fixed roles:
+//   waves 4..7  PRODUCERS: HBM -> registers (one stripe ahead) -> BN/ReLU resp. dY rebuild -> LDS stripe [RS][KB+NB]
+//   waves 0..3  CONSUMERS: LDS fragments -> MFMA, nothing else; consumer (ck, cn) owns the (TK x TN) x 32x32 sub-block
+//               (ck, cn) of the workgroup's KB x NB output tile, so no cross-wave reduction is needed at the end
+// Stripes are double buffered and handed over with ONE workgroup barrier per stripe.  Per 32-row stripe a consumer
+// issues 16 TK TN MFMAs (64 cycles each) while the producers need a few hundred VALU cycles: the kernel is MFMA
+// bound for K >= 128 and HBM bound for the 64-wide layers.
+template <int TK, int TN, int AMODE, int DMODE>
+__global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
+    constexpr int KB = 64 * TK, NB = 64 * TN, RS = 32, LD = KB + NB;
+    constexpr int A4 = KB / 4, D4 = NB / 4;                   // float4 per stripe row
+    constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;     // float4 per producer lane per stripe
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, N = a.N;
+    const long long M = a.M;
+    const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
+    float *coefA = lds;                        // [2][KB]
+    float *coefD = coefA + 2 * KB;             // [5][NB]
+    float *buf = coefD + 5 * NB;               // [2][RS][LD]   | afterwards: db scratch [256][4]
+
+    for (int e = tid; e < KB; e += 512) {
+        const int k = k0 + e;
+        const bool in = k < K;
+        coefA[e] = (AMODE == A_BNRELU && in) ? a.asc[k] : 0.f;
+        coefA[KB + e] = (AMODE == A_BNRELU && in) ? a.ash[k] : 0.f;
+    }
+    for (int e = tid; e < NB; e += 512) {
+        const int n = n0 + e;
+        const bool in = n < N;
+        coefD[e] = in ? a.p[n] : 0.f;
+        coefD[NB + e] = in ? a.q[n] : 0.f;
+        coefD[2 * NB + e] = in ? a.t[n] : 0.f;
+        coefD[3 * NB + e] = (is_pool(DMODE) && in) ? a.dsc[n] : 0.f;
+        coefD[4 * NB + e] = (is_pool(DMODE) && in) ? a.dsh[n] : 0.f;
+    }
+    __syncthreads();
+
+    const long long nstripes = (M + RS - 1) / RS;
+    const long long cnt = grp < nstripes ? (nstripes - grp + ngrp - 1) / ngrp : 0;   // stripes of this workgroup
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const int acq = (pt % A4) * 4, dcq = (pt % D4) * 4;
+        const bool ain = k0 + acq < K, din = n0 + dcq < N;    // K % 4 == 0 and N % 4 == 0 (launcher)
+        const int acl = ain ? k0 + acq : 0, dcl = din ? n0 + dcq : 0;
+        const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
+        const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+        const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
+        const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
+        const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
+        const float4 cds = *reinterpret_cast<const float4 *>(&coefD[3 * NB + dcq]);
+        const float4 cdh = *reinterpret_cast<const float4 *>(&coefD[4 * NB + dcq]);
+        float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 px[NA], pg[ND], py[ND];
+        unsigned pm[(is_pool(DMODE)) ? ND : 1];
+        const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acl) * 4u : kOOB;
+        const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcl) * 4u : kOOB;
+        const unsigned xstep = (unsigned)(256 / A4) * (unsigned)a.ldx * 4u;
+        const unsigned dstep = (unsigned)(256 / D4) * (unsigned)a.ldy * 4u;
+        const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
+        constexpr bool U_ = DMODE == A_DYPOOLU;                // one pooling group per stripe
+        auto issue = [&](long long stripe) {
+            const long long row0 = stripe * RS;
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            const __amdgpu_buffer_rsrc_t rg =
+                make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
+                if (is_pool(DMODE)) {
+                    if (U_) {
+                        if (j == 0) {
+                            const long long gi = pr.g0 < glast ? pr.g0 : glast;
+                            pg[0] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                            pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                        }
+                    } else {
+                        long long gi;
+                        unsigned sdummy;
+                        pr.split(pt / D4 + j * (256 / D4), glast, gi, sdummy);
+                        pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                        pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                    }
+                } else {
+                    pg[j] = buf_load4(rg, dvoff, (unsigned)j * dstep);
+                }
+            }
+        };
+        auto stage = [&](long long stripe, float *dst) {
+            const long long row0 = stripe * RS;
+            const PoolRows prs(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int r = pt / A4 + j * (256 / A4);
+                float4 x = px[j];
+                if (AMODE == A_BNRELU) {
+                    x.x = fmaxf(fmaf(x.x, casc.x, cash.x), 0.f);
+                    x.y = fmaxf(fmaf(x.y, casc.y, cash.y), 0.f);
+                    x.z = fmaxf(fmaf(x.z, casc.z, cash.z), 0.f);
+                    x.w = fmaxf(fmaf(x.w, casc.w, cash.w), 0.f);
+                }
+                if (!(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&dst[r * LD + acq]) = x;
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int r = pt / D4 + j * (256 / D4);
+                const float4 y = py[j];
+                float4 g = pg[U_ ? 0 : j];
+                if (is_pool(DMODE)) {
+                    long long gdummy;
+                    unsigned s;
+                    if (U_) s = (unsigned)(prs.s0 + r);
+                    else prs.split(r, glast, gdummy, s);
+                    const unsigned am = pm[U_ ? 0 : j];
+                    g.x = ((am & 0xffu) == s && fmaf(y.x, cds.x, cdh.x) > 0.f) ? g.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == s && fmaf(y.y, cds.y, cdh.y) > 0.f) ? g.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == s && fmaf(y.z, cds.z, cdh.z) > 0.f) ? g.z : 0.f;
+                    g.w = ((am >> 24) == s && fmaf(y.w, cds.w, cdh.w) > 0.f) ? g.w : 0.f;
+                }
+                float4 d;
+                d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
+                d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
+                d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
+                d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+                if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
+                *reinterpret_cast<float4 *>(&dst[r * LD + KB + dcq]) = d;
+            }
+        };
+        if (cnt > 0) {
+            issue(grp);
+            stage(grp, buf);
+            if (cnt > 1) issue(grp + ngrp);
+        }
+        __syncthreads();                                       // stripe 0 is in buf[0]
+        for (long long i = 0; i < cnt; ++i) {
+            if (i + 1 < cnt) {
+                stage(grp + (i + 1) * ngrp, buf + ((i + 1) & 1) * RS * LD);
+                if (i + 2 < cnt) issue(grp + (i + 2) * ngrp);
+            }
+            __syncthreads();
+        }
+        // column sums of dY: lanes pt, pt + D4, ... own the same 4 columns
+        float *sdb = buf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sdb[pt * 4 + e] = dbs[e];
+        __syncthreads();
+    } else {
+        // ------------------------------------------------------------------ consumers
+        constexpr int CN = 2;
+        const int ck = wave / CN, cn = wave % CN;
+        const int half = lane >> 5, li = lane & 31;
+        f32x16 acc[TK][TN];
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        const int aoff = half * LD + ck * TK * 32 + li;
+        const int doff = half * LD + KB + cn * TN * 32 + li;
+        __syncthreads();
+        for (long long i = 0; i < cnt; ++i) {
+            const float *sb = buf + (i & 1) * RS * LD;
+            float av_n[TK], dv_n[TN];
+#pragma unroll
+            for (int x = 0; x < TK; ++x) av_n[x] = sb[aoff + 32 * x];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 32 * y];
+#pragma unroll
+            for (int it = 0; it < RS / 2; ++it) {
+                float av[TK], dv[TN];
+#pragma unroll
+                for (int x = 0; x < TK; ++x) av[x] = av_n[x];
+#pragma unroll
+                for (int y = 0; y < TN; ++y) dv[y] = dv_n[y];
+                if (it + 1 < RS / 2) {
+#pragma unroll
+                    for (int x = 0; x < TK; ++x) av_n[x] = sb[aoff + 2 * (it + 1) * LD + 32 * x];
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
+                }
+                // the next row pair's fragments are REQUESTED before this pair's MFMAs issue (the scheduler would
+                // otherwise sink the reads to just in front of their first use and expose the LDS latency)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int x = 0; x < TK; ++x)
+#pragma unroll
+                    for (int y = 0; y < TN; ++y)
+                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], dv[y], acc[x][y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+        // acc[x][y][v]: A channel 32 x + (v&3) + 8 (v>>2) + 4 half, dY channel 32 y + li  (of this consumer's block)
+        float *out = a.part + (long long)grp * K * N;
+#pragma unroll
+        for (int x = 0; x < TK; ++x)
+#pragma unroll
+            for (int y = 0; y < TN; ++y) {
+                const int nn = n0 + (cn * TN + y) * 32 + li;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int kk = k0 + (ck * TK + x) * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+                    if (kk < K && nn < N) out[(long long)kk * N + nn] = acc[x][y][v];
+                }
+            }
+        __syncthreads();                                       // matches the producers' db hand-over
+        if (blockIdx.y == 0 && a.dbpart) {
+            const float *sdb = buf;
+            for (int c = tid; c < NB; c += 256) {
+                const int quad = c >> 2, e = c & 3;
+                float sum = 0.f;
+                for (int r = quad; r < 256; r += D4) sum += sdb[r * 4 + e];
+                if (n0 + c < N) a.dbpart[(long long)grp * N + n0 + c] = sum;
+            }
+        }
+    }
+}
+
+struct PcWgradPlan {
+    int tk, tn, kblocks, nblocks, groups;
+    size_t lds;
+};
+
+static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
+                          const void *gpool, const void *argmax, PcWgradPlan *pl) {
+    if (M < 16 * 1024) return false;
+    if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
+        (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return false;
+    pl->tk = K <= 64 ? 1 : 2;
+    pl->tn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+    const int KB = 64 * pl->tk, NB = 64 * pl->tn;
+    pl->kblocks = (K + KB - 1) / KB;
+    pl->nblocks = (N + NB - 1) / NB;
+    int groups = 256 / (pl->kblocks * pl->nblocks);    // one persistent workgroup per CU over the whole grid
+    if (groups < 1) groups = 1;
+    const long long maxg = (M + 31) / 32;
+    if (groups > maxg) groups = (int)maxg;
+    if (groups >= 8) groups &= ~7;
+    pl->groups = groups;
+    pl->lds = (size_t)(2 * KB + 5 * NB + 2 * 32 * (KB + NB)) * sizeof(float);
+    return pl->lds <= 160 * 1024;
+}
+
+static bool wgrad_pc_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_WGRAD_PC");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 struct WsWgradPlan {
     int tk, tn, rs, kblocks, nblocks, groups;
     size_t lds;
@@ -1670,7 +1946,40 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     int splits;
     WsWgradPlan pl;
-    if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
+    PcWgradPlan pc;
+    // producer/consumer kernel for the pooled forms and the widest tile; the single-role kernel (256 accumulator
+    // registers per wave) is ahead on the narrow materialised-G shapes
+    if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc) &&
+        (gpool || pc.tn == 4 || !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
+        splits = pc.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
+#define PCOPS_PC_LAUNCH(TK_, TN_, AM_, DM_)                                                                \
+    do {                                                                                                   \
+        auto kern = wgrad_pc_kernel<TK_, TN_, AM_, DM_>;                                                   \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(512), pc.lds, st, a);                                          \
+    } while (0)
+#define PCOPS_PC_MODES(TK_, TN_)                                                                           \
+    do {                                                                                                   \
+        if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);             \
+        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLU);     \
+        else if (a.amode == A_BNRELU) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOL);                       \
+        else if (a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DY);                                \
+        else if (a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLU);                             \
+        else PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOL);                                                 \
+    } while (0)
+        if (pc.tk == 1 && pc.tn == 1) PCOPS_PC_MODES(1, 1);
+        else if (pc.tk == 1 && pc.tn == 2) PCOPS_PC_MODES(1, 2);
+        else if (pc.tk == 1) PCOPS_PC_MODES(1, 4);
+        else if (pc.tn == 1) PCOPS_PC_MODES(2, 1);
+        else if (pc.tn == 2) PCOPS_PC_MODES(2, 2);
+        else PCOPS_PC_MODES(2, 4);
+#undef PCOPS_PC_MODES
+#undef PCOPS_PC_LAUNCH
+    } else if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
         splits = pl.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
         const dim3 grid(pl.groups, pl.kblocks, pl.nblocks);

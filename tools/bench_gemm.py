@@ -7,6 +7,7 @@ from scanobjectnn_amd import _lib
 lib = _lib.load()
 dev = "cuda:0"
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
+POOLED = "--pooled" in sys.argv   # wgrad: dY rebuilt from (gpool, argmax, Y) with S=64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 def vec(n): return (torch.randn((n + 3) // 4 * 4, device=dev) * 0.1 + 1.0)
 if "--shape" in sys.argv:
@@ -46,7 +47,14 @@ for (M, K, N) in SHAPES:
         p, q, t = vec(N), vec(N), vec(N)
         splits = lib.pcops_mlp_wgrad_splits(M, K, N); scratch = torch.empty(splits * (K * N + N), device=dev)
         dW = torch.empty(K, N, device=dev); db = torch.empty(N, device=dev)
-        ms = timeit(lambda: _lib.call("pcops_mlp_wgrad", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), G.data_ptr(), Yl.data_ptr(),
+        if POOLED:
+            S = 64
+            gp = torch.randn(M // S, N, device=dev); am = torch.randint(0, S, (M // S, N), device=dev, dtype=torch.int32).to(torch.uint8)
+            ms = timeit(lambda: _lib.call("pcops_mlp_wgrad", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), None, Yl.data_ptr(),
+                                          p.data_ptr(), q.data_ptr(), t.data_ptr(), gp.data_ptr(), am.data_ptr(), S, p.data_ptr(), q.data_ptr(),
+                                          scratch.data_ptr(), dW.data_ptr(), db.data_ptr()))
+        else:
+            ms = timeit(lambda: _lib.call("pcops_mlp_wgrad", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), G.data_ptr(), Yl.data_ptr(),
                                       p.data_ptr(), q.data_ptr(), t.data_ptr(), None, None, 1, None, None, scratch.data_ptr(), dW.data_ptr(), db.data_ptr()))
         gb = (M * K + 2 * M * N) * 4 / 1e9; gf = 2.0 * M * K * N / 1e9
         print("wgrad M=%8d K=%4d N=%4d  %8.3f ms  %7.1f GB/s  %6.1f TF/s" % (M, K, N, ms, gb / ms * 1e3, gf / ms))
