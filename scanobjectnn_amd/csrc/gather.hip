@@ -443,14 +443,14 @@ struct CsrArgs {
 
 // YONLY: the pooled form -- dY = q.Y + t everywhere plus p.gpool at the arg-max rows, which the streaming
 // kernel adds with one atomic per (group, channel) (G is never materialised there)
-template <int LPR, bool YONLY>     // lanes per row: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
+template <int LPR, bool YONLY, int CH = 64>   // lanes per row: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
 __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
     // Work is dealt out in CHUNKS of the sorted row list, not per source point: ball query pads short
     // neighbourhoods with their first index and prefers low indices, so a few points own very long lists.  A wave
     // walks its chunk in sorted order, keeps the running sum of the current point in registers and flushes it
     // with ONE global atomic per channel when the point changes -- (points + chunks) x C atomics instead of
     // rows x C, and dQ is zeroed by the launcher.
-    constexpr int RW = 64 / LPR, U = 4, CH = 64;
+    constexpr int RW = 64 / LPR, U = (CH / RW) < 4 ? (CH / RW) : 4;   // CH: sorted rows per chunk (16 for small problems)
     __shared__ float red[4][4][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rsub = lane / LPR, quad = lane % LPR;
@@ -592,7 +592,11 @@ static bool scatter_lds_enabled() {
 
 extern "C" {
 
-int pcops_sa_gather_stats_rows(long long G) { return (int)((G + 7) / 8); }
+static int gather_groups_per_block(long long G) { return G >= 8192 ? 8 : 1; }   // few groups: one workgroup each
+int pcops_sa_gather_stats_rows(long long G) {
+    const int gpb = gather_groups_per_block(G);
+    return (int)((G + gpb - 1) / gpb);
+}
 int pcops_sa_scatter_rows(int b, int m) {
     // rows of the caller's weight-gradient scratch: one per cloud (LDS kernel) or per 16 groups (fallback kernel)
     const long long fb = ((long long)b * m + 15) / 16;
@@ -617,7 +621,7 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
     const int rl = 256 / (c / 4);
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        (size_t)rl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
-                       Wxyz, bias, idx, Y, stats_partial, 8);
+                       Wxyz, bias, idx, Y, stats_partial, gather_groups_per_block(G));
     return pcops_launch_status();
 }
 
@@ -685,19 +689,27 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
         float *wp2 = split ? nullptr : wp;
         CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2};
-#define PCOPS_CSR_CASE(LPR_)                                                                                    \
-    case LPR_:                                                                                                  \
-        if (gpool) hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, true>), dim3(kCsrGrid), dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, false>), dim3(kCsrGrid), dim3(256), 0, st, a);      \
+        const bool small = (long long)b * ((m * s + 63) / 64) < 4 * kCsrGrid;   // fewer 64-row chunks than waves
+#define PCOPS_CSR_LAUNCH(LPR_, Y_, CH_) \
+    hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, Y_, CH_>), dim3(kCsrGrid), dim3(256), 0, st, a)
+#define PCOPS_CSR_CASE(LPR_)                                             \
+    case LPR_:                                                           \
+        if (gpool) {                                                     \
+            if (small) PCOPS_CSR_LAUNCH(LPR_, true, 16);                 \
+            else PCOPS_CSR_LAUNCH(LPR_, true, 64);                       \
+        } else {                                                         \
+            if (small) PCOPS_CSR_LAUNCH(LPR_, false, 16);                \
+            else PCOPS_CSR_LAUNCH(LPR_, false, 64);                      \
+        }                                                                \
         break;
         switch (lpr) {
             PCOPS_CSR_CASE(8)
             PCOPS_CSR_CASE(16)
             PCOPS_CSR_CASE(32)
-            default:
-                if (gpool) hipLaunchKernelGGL((sa_scatter_csr_kernel<64, true>), dim3(kCsrGrid), dim3(256), 0, st, a);
-                else hipLaunchKernelGGL((sa_scatter_csr_kernel<64, false>), dim3(kCsrGrid), dim3(256), 0, st, a);
+            PCOPS_CSR_CASE(64)
+            default: return PCOPS_ERR_UNSUPPORTED;
         }
+#undef PCOPS_CSR_LAUNCH
 #undef PCOPS_CSR_CASE
         int rc = pcops_launch_status();
         if (rc) return rc;

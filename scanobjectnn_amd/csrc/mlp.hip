@@ -931,25 +931,50 @@ __global__ __launch_bounds__(256) void pool_select_kernel(long long total, int C
     }
 }
 
-// the two BN-backward sums of a max-pooled layer from (gpool, y at the selected row): stats [P][2][C]
+// the two BN-backward sums of a max-pooled layer from (gpool, y at the selected row): stats [P][2][C];
+// one workgroup per `groups_per_block` groups, threads = (row lane, column quad), 16-byte loads
 __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long G, int C, const float *__restrict__ gpool,
                                                                  const float *__restrict__ ysel,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
                                                                  float *__restrict__ stats, int groups_per_block) {
+    extern __shared__ float sm[];                     // [RL][2][C]
+    const int c4n = C / 4;
+    const int RL = c4n >= 256 ? 1 : 256 / c4n;
+    const int rl = c4n >= 256 ? 0 : threadIdx.x / c4n;
     const long long g0 = (long long)blockIdx.x * groups_per_block;
     const long long g1 = min(G, g0 + groups_per_block);
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float sc = scale[c], sh = shift[c];
-        float a1 = 0.f, a2 = 0.f;
-        for (long long g = g0; g < g1; ++g) {
-            const float y = ysel[g * C + c];
-            const float gm = fmaf(y, sc, sh) > 0.f ? gpool[g * C + c] : 0.f;
-            a1 += gm;
-            a2 = fmaf(gm, y, a2);
+    for (int cq = threadIdx.x % (c4n >= 256 ? 256 : c4n); cq < c4n; cq += 256) {
+        const int c = cq * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl < RL)
+            for (long long g = g0 + rl; g < g1; g += RL) {
+                const float4 y = *reinterpret_cast<const float4 *>(ysel + g * C + c);
+                const float4 gp = *reinterpret_cast<const float4 *>(gpool + g * C + c);
+                const float gm0 = fmaf(y.x, sc.x, sh.x) > 0.f ? gp.x : 0.f;
+                const float gm1 = fmaf(y.y, sc.y, sh.y) > 0.f ? gp.y : 0.f;
+                const float gm2 = fmaf(y.z, sc.z, sh.z) > 0.f ? gp.z : 0.f;
+                const float gm3 = fmaf(y.w, sc.w, sh.w) > 0.f ? gp.w : 0.f;
+                a1[0] += gm0; a1[1] += gm1; a1[2] += gm2; a1[3] += gm3;
+                a2[0] = fmaf(gm0, y.x, a2[0]); a2[1] = fmaf(gm1, y.y, a2[1]);
+                a2[2] = fmaf(gm2, y.z, a2[2]); a2[3] = fmaf(gm3, y.w, a2[3]);
+            }
+        if (rl < RL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sm[(rl * 2 + 0) * C + c + e] = a1[e];
+                sm[(rl * 2 + 1) * C + c + e] = a2[e];
+            }
         }
-        stats[((long long)blockIdx.x * 2 + 0) * C + c] = a1;
-        stats[((long long)blockIdx.x * 2 + 1) * C + c] = a2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        float t = 0.f;
+        for (int l = 0; l < RL; ++l) t += sm[(l * 2 + which) * C + c];
+        stats[((long long)blockIdx.x * 2 + which) * C + c] = t;
     }
 }
 
@@ -1829,7 +1854,7 @@ int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *sca
 
 // ---- backward ---------------------------------------------------------------------------------
 int pcops_mlp_bwd_stats_rows(long long R) { return (int)((R + 511) / 512); }
-int pcops_mlp_bwd_pool_stats_rows(long long G) { return (int)((G + 63) / 64); }
+int pcops_mlp_bwd_pool_stats_rows(long long G) { return (int)((G + 15) / 16); }
 
 /* Gm = Gout * [relu(bn(Y)) > 0]; partial sums (sum Gm, sum Gm*Y) -> stats [pcops_mlp_bwd_stats_rows(R)][2][C] */
 int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float *Y, const float *scale,
@@ -1849,11 +1874,15 @@ int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float
 
 int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
                              const float *shift, float *stats_partial, pcops_stream_t stream) {
-    PCOPS_REQUIRE_SHAPE(G >= 1 && C >= 1);
+    PCOPS_REQUIRE_SHAPE(G >= 1 && C >= 4 && C % 4 == 0);
     PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(scale);
     PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(stats_partial);
-    hipLaunchKernelGGL(pool_bwd_stats_sel_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), 0,
-                       as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 64);
+    const int c4n = C / 4;
+    const int rl = c4n >= 256 ? 1 : 256 / c4n;        // threads beyond rl * c4n idle when c4n does not divide 256
+    const size_t lds = (size_t)rl * 2 * C * sizeof(float);
+    if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pool_bwd_stats_sel_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), lds,
+                       as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 16);
     return pcops_launch_status();
 }
 

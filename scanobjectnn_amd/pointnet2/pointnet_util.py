@@ -111,20 +111,28 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     # the flag changes nothing numerically (the reference transposes in and out, :116-123).
     with variable_scope(scope):
         pool_max = pooling == 'max'
-        if (not group_all and pooling in ('max', 'avg', 'max_and_avg') and xyz.is_cuda
+        if group_all:
+            nsample = xyz.shape[1]
+        if (pooling in ('max', 'avg', 'max_and_avg') and xyz.is_cuda and (points is not None or not group_all)
                 and _gather_fusable(points, mlp, bn, nsample, pool_max)):
             # fast path: sample -> query -> [first conv before grouping] -> gather+add -> fused stack
-            new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
-            if knn:
-                _, idx = knn_point(nsample, xyz, new_xyz)
+            if group_all:
+                # one group holding the whole cloud around the origin (:59-84): idx = 0..n-1, so the "gather" is
+                # the identity and the K = 3 + C first layer becomes an aligned K = C contraction + 3 inline terms
+                b, n, _ = xyz.shape
+                new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+                idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).expand(b, 1, n).contiguous()
             else:
-                idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+                new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+                if knn:
+                    _, idx = knn_point(nsample, xyz, new_xyz)
+                else:
+                    idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
             new_points = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp, 'conv%d', is_training, bn_decay,
                                             use_xyz, True, pool_max)
             grouped_xyz = None
         else:
             if group_all:
-                nsample = xyz.shape[1]
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
             else:
                 new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz,
