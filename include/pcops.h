@@ -220,6 +220,10 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
  * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
  * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.
  * wpartial: caller scratch of pcops_sa_scatter_rows(b, m) * 4 * c floats (needed for dWxyz / dbias).
+ * fwd_Q / fwd_Ctr / fwd_Wxyz / fwd_bias (all may be NULL): the arguments pcops_sa_gather_fwd was called with.  When
+ * the forward had no Q / Ctr term (Y = (xyz[idx]-new_xyz) Wxyz + bias) the streaming kernel REBUILDS Y in the
+ * forward's own operation order instead of reading it (bit-identical, one (b,m,s,c) tensor less to stream); Y may
+ * be NULL only in that case with dQ == NULL.
  * workspace (may be NULL): pcops_sa_scatter_workspace_bytes(b,n,m,s) bytes, 16-byte aligned; with it the feature
  * gradient is computed as a GATHER over a per-cloud inverse index (counting sort of idx) -- one wave per source
  * point, no float atomics; without it (or when dCtr / the pooled form is requested) dQ is accumulated with atomics
@@ -230,7 +234,8 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                          const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
-                         float *dbias, void *workspace, pcops_stream_t stream);
+                         float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
+                         const float *fwd_bias, void *workspace, pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

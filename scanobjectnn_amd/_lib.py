@@ -46,7 +46,7 @@ SIGNATURES = {
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
     "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 18, True),
+    "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),

@@ -19,6 +19,22 @@
 
 namespace {
 
+// one quad of Y[b,j,s,:] in the forward's own operation order -- the backward kernels REBUILD the first layer's
+// output with it instead of reading it back (bit-identical, and one (b,m,s,c) tensor less to stream from HBM):
+//   y = (bias + Ctr) + Q;  y = fma(dz, w2, fma(dy, w1, fma(dx, w0, y)))
+__device__ __forceinline__ float4 first_layer_quad(float4 ctr, bool has_q, float4 q, bool has_w, float dx, float dy,
+                                                   float dz, float4 w0, float4 w1, float4 w2) {
+    float4 y = ctr;
+    if (has_q) { y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w; }
+    if (has_w) {
+        y.x = fmaf(dz, w2.x, fmaf(dy, w1.x, fmaf(dx, w0.x, y.x)));
+        y.y = fmaf(dz, w2.y, fmaf(dy, w1.y, fmaf(dx, w0.y, y.y)));
+        y.z = fmaf(dz, w2.z, fmaf(dy, w1.z, fmaf(dx, w0.z, y.z)));
+        y.w = fmaf(dz, w2.w, fmaf(dy, w1.w, fmaf(dx, w0.w, y.w)));
+    }
+    return y;
+}
+
 // Y[b,j,s,:] = Q[b,idx,:] + Ctr[b,j,:] + (xyz[b,idx,:] - new_xyz[b,j,:]) Wxyz + bias      (every term optional)
 // The coordinate term is evaluated INLINE on the centred offsets -- exactly the reference's arithmetic for those
 // three channels -- because pushing it through Q/Ctr would subtract two O(1) numbers to get an O(radius) one.
@@ -59,19 +75,14 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
             for (int s = rl; s < S; s += RL) {
                 const long long r = g * S + s;
                 const int i = idx[r];
-                float4 y = ctr;
-                if (Q) {
-                    const float4 q = *reinterpret_cast<const float4 *>(Q + (b * n + i) * (long long)C + cq);
-                    y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
-                }
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Q) q = *reinterpret_cast<const float4 *>(Q + (b * n + i) * (long long)C + cq);
+                float dx = 0.f, dy = 0.f, dz = 0.f;
                 if (Wxyz) {
                     const float *px = xyz + (b * n + i) * 3;
-                    const float dx = px[0] - cx, dy = px[1] - cy, dz = px[2] - cz;
-                    y.x = fmaf(dz, w2.x, fmaf(dy, w1.x, fmaf(dx, w0.x, y.x)));
-                    y.y = fmaf(dz, w2.y, fmaf(dy, w1.y, fmaf(dx, w0.y, y.y)));
-                    y.z = fmaf(dz, w2.z, fmaf(dy, w1.z, fmaf(dx, w0.z, y.z)));
-                    y.w = fmaf(dz, w2.w, fmaf(dy, w1.w, fmaf(dx, w0.w, y.w)));
+                    dx = px[0] - cx; dy = px[1] - cy; dz = px[2] - cz;
                 }
+                const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, dx, dy, dz, w0, w1, w2);
                 *reinterpret_cast<float4 *>(Y + r * C + cq) = y;
                 s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
                 s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
@@ -216,9 +227,10 @@ struct ScatterArgs {
     const float *xyz, *new_xyz;
     float *dQ, *dCtr, *wpart;
     float *dQarg;                       // pooled form: global dQ receiving p.gpool at the arg-max rows (atomics)
+    const float *fQ, *fCtr, *fW, *fbias;    // RC kernels: the forward's sources, Y is rebuilt instead of read
 };
 
-template <bool POOLED, int CS>
+template <bool POOLED, int CS, bool RC>
 __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
     constexpr int LPR = CS / 4;        // lanes per row (one float4 each)
     constexpr int RW = 64 / LPR;       // rows per wave instruction
@@ -255,6 +267,15 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
     float aw[4][4];                    // [x, y, z, 1][channel of the quad]
 #pragma unroll
     for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
+    float4 fw0 = make_float4(0.f, 0.f, 0.f, 0.f), fw1 = fw0, fw2 = fw0, fbb = fw0;
+    if (RC) {
+        if (a.fW) {
+            fw0 = *reinterpret_cast<const float4 *>(a.fW + 0 * C + c0);
+            fw1 = *reinterpret_cast<const float4 *>(a.fW + 1 * C + c0);
+            fw2 = *reinterpret_cast<const float4 *>(a.fW + 2 * C + c0);
+        }
+        if (a.fbias) fbb = *reinterpret_cast<const float4 *>(a.fbias + c0);
+    }
 
     const int jper = (m + a.gsplit - 1) / a.gsplit;
     const int jbeg = part * jper, jend = min(m, jbeg + jper);
@@ -269,6 +290,11 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
             am = *reinterpret_cast<const unsigned *>(a.argmax + g * C + c0);
         }
         float4 dsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 fctr = fbb;
+        if (RC && a.fCtr) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(a.fCtr + g * C + c0);
+            fctr.x += c4.x; fctr.y += c4.y; fctr.z += c4.z; fctr.w += c4.w;
+        }
         for (int s0 = 0; s0 < S; s0 += RW * U) {
             int ii[U];
             float4 yy[U], gg[U];
@@ -277,13 +303,23 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
                 const int s = s0 + u * RW + rsub;
                 const long long r = g * S + (s < S ? s : S - 1);
                 ii[u] = a.idx[r];
-                yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
+                if (!RC) yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
                 if (!POOLED) gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
+            }
+            if (RC && a.fQ) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    yy[u] = *reinterpret_cast<const float4 *>(a.fQ + ((long long)b * n + ii[u]) * C + c0);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = s0 + u * RW + rsub;
-                const float4 y = yy[u];
+                float4 y = yy[u];
+                if (RC) {
+                    float dx = 0.f, dy = 0.f, dz = 0.f;
+                    if (a.fW) { dx = sx[ii[u] * 3 + 0] - cx; dy = sx[ii[u] * 3 + 1] - cy; dz = sx[ii[u] * 3 + 2] - cz; }
+                    y = first_layer_quad(fctr, a.fQ != nullptr, y, a.fW != nullptr, dx, dy, dz, fw0, fw1, fw2);
+                }
                 float4 gm;
                 if (POOLED) {
                     const unsigned us = (unsigned)s;
@@ -366,7 +402,10 @@ __global__ __launch_bounds__(1024) void sa_scatter_lds_kernel(ScatterArgs a) {
 
 template <bool POOLED, int CS>
 static int launch_scatter_lds(const ScatterArgs &a, size_t lds, hipStream_t st) {
-    auto kern = sa_scatter_lds_kernel<POOLED, CS>;
+    // rebuilding Y pays when it costs arithmetic only (coordinate term + bias); a Q / Ctr row gathered per grouped
+    // row is slower than streaming the stored Y
+    const bool rc = (a.fW || a.fbias) && !a.fQ && !a.fCtr;
+    auto kern = rc ? sa_scatter_lds_kernel<POOLED, CS, true> : sa_scatter_lds_kernel<POOLED, CS, false>;
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
         return PCOPS_ERR_LAUNCH;
@@ -629,8 +668,11 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                          const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
-                         float *dbias, void *workspace, pcops_stream_t stream) {
+                         float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
+                         const float *fwd_bias, void *workspace, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
+    const bool rc_fwd = (fwd_Wxyz || fwd_bias) && !fwd_Q && !fwd_Ctr && !dQ;   // Y rebuilt, never read
+    if (fwd_Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     PCOPS_REQUIRE_SHAPE(c <= 1024 && (c >= 256 || 256 % c == 0));
     const long long Gn = (long long)b * m;
     hipStream_t st = as_stream(stream);
@@ -638,7 +680,8 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         if (dQ && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
         return PCOPS_OK;
     }
-    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    if (!rc_fwd) PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(idx);
     if (xyz) { PCOPS_REQUIRE_PTR(new_xyz); }
     if (dWxyz || dbias) PCOPS_REQUIRE_PTR(wpartial);
@@ -665,7 +708,8 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
             if (gsplit > (m + 15) / 16) gsplit = (m + 15) / 16;
             if (gsplit < 1) gsplit = 1;
             ScatterArgs sa = {b, n, m, s, c, nsl, gsplit, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx,
-                              xyz, new_xyz, nullptr, dCtr, wp, gpool ? dQ : nullptr};
+                              xyz, new_xyz, nullptr, dCtr, wp, gpool ? dQ : nullptr, fwd_Q, fwd_Ctr, fwd_Wxyz,
+                              fwd_bias};
             int rc0 = PCOPS_ERR_UNSUPPORTED;
             switch (cs0) {
                 case 64: rc0 = gpool ? launch_scatter_lds<true, 64>(sa, lb, st) : launch_scatter_lds<false, 64>(sa, lb, st); break;
@@ -690,7 +734,7 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         float *wp2 = split ? nullptr : wp;
         CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2};
         const bool small = (long long)b * ((m * s + 63) / 64) < 4 * kCsrGrid;   // fewer 64-row chunks than waves
-#define PCOPS_CSR_LAUNCH(LPR_, Y_, CH_) \
+#define PCOPS_CSR_LAUNCH(LPR_, Y_, CH_)                                                                            \
     hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, Y_, CH_>), dim3(kCsrGrid), dim3(256), 0, st, a)
 #define PCOPS_CSR_CASE(LPR_)                                             \
     case LPR_:                                                           \
@@ -730,7 +774,7 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
             if (gsplit < 1) gsplit = 1;
         }
         ScatterArgs a = {b, n, m, s, c, c / cs, gsplit, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx,
-                         xyz, new_xyz, dQ, dCtr, wp, nullptr};
+                         xyz, new_xyz, dQ, dCtr, wp, nullptr, fwd_Q, fwd_Ctr, fwd_Wxyz, fwd_bias};
         int rc;
 #define PCOPS_SCATTER_CASE(CS_)                                                                   \
     case CS_:                                                                                     \
@@ -753,7 +797,8 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         }
         return rc;
     }
-    // fallback: global atomics (clouds too large for an LDS-resident slice)
+    // fallback: global atomics (clouds too large for an LDS-resident slice); reads the stored Y
+    PCOPS_REQUIRE_PTR(Y);
     if (dQ && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
     const int rl = c >= 256 ? 1 : 256 / c;
     const size_t lds = (size_t)rl * 6 * c * sizeof(float);

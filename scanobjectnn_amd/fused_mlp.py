@@ -202,7 +202,8 @@ class FusedMLPStack(torch.autograd.Function):
                 _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
                           q.data_ptr(), t.data_ptr(), gp, am, psc, psh, idx.data_ptr(),
                           _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
-                          _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(wsp))
+                          _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(a0), _p(ctr), _p(wxyz), _p(bias),
+                          _p(wsp))
                 break
 
             K = Ws[l].shape[0]

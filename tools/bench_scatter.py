@@ -40,7 +40,7 @@ for (b, n, m, S, C, has_dq, has_xyz, pooled) in CASES:
                   q.data_ptr(), t.data_ptr(), gpool.data_ptr() if pooled else None, argmax.data_ptr() if pooled else None,
                   p.data_ptr() if pooled else None, q.data_ptr() if pooled else None, idx.data_ptr(),
                   P(xyz) if has_xyz else None, P(new_xyz) if has_xyz else None, P(dQ), P(dCtr), wpart.data_ptr(),
-                  dW.data_ptr() if has_xyz else None, db.data_ptr(), wsp.data_ptr())
+                  dW.data_ptr() if has_xyz else None, db.data_ptr(), None, None, None, None, wsp.data_ptr())
     run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
