@@ -76,6 +76,15 @@ def _algo(name, a):
     if name == "pcops_mlp_gemm_fwd":          # Y[M,N] = f(X)[M,K] W
         M, K, N = a[:3]
         return 4 * (M * K + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_gemm_fwd_xyz":      # operand rebuilt from 16 bytes per row
+        M, K, N = a[:3]
+        return 4 * (4 * M + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_gemm_dgrad_xyz":    # reads G?, Y (K wide) + 16 bytes per row; writes Gprev
+        M, K, Nout = a[:3]
+        return 4 * ((1 if a[3] is None else 2) * M * K + 4 * M + M * Nout), 2 * M * K * Nout, "flop"
+    if name == "pcops_mlp_wgrad_xyz":         # reads 16 bytes per row + G?, Y
+        M, K, N = a[:3]
+        return 4 * (4 * M + (1 if a[7] is None else 2) * M * N), 2 * M * K * N, "flop"
     if name == "pcops_mlp_gemm_fwd_pool":     # + raw extrema per group
         M, K, N, S = a[:4]
         return 4 * (M * K + M * N) + 5 * (M // S) * N, 2 * M * K * N, "flop"
@@ -103,7 +112,8 @@ def _algo(name, a):
         return 8 * G * C, 0, ""
     if name == "pcops_sa_gather_fwd":         # Y (b,m,s,c) written once; Q read once (algorithmically), idx
         b, n, m, s, c = a[:5]
-        return 4 * (b * m * s * c + (b * n * c if a[5] is not None else 0) + b * m * s), 0, ""
+        wr = (b * m * s * c if a[12] is not None else 0) + (4 * b * m * s if a[13] is not None else 0)
+        return 4 * (wr + (b * n * c if a[5] is not None else 0) + b * m * s), 0, ""
     if name == "pcops_sa_scatter_bwd":        # reads G?,Y (b,m,s,c), idx; writes dQ (b,n,c)
         b, n, m, s, c = a[:5]
         return 4 * ((1 if a[5] is None else 2) * b * m * s * c + b * m * s + (b * n * c if a[17] is not None else 0)), 0, ""

@@ -203,6 +203,27 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
                     const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                     pcops_stream_t stream);
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
+/* The layer that FOLLOWS an arithmetic first layer  y1[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))
+ * (grouped xyz offsets only: the first set-abstraction level, pointnet_util.py:44-54 with points == None).  y1 is
+ * rebuilt from off4 [M][4] = (dx, dy, dz, 0) and xyzw [4][C1] (rows w0, w1, w2, b) wherever the plain entry points
+ * would read it -- as the forward operand, as the weight gradient's A side, and in the data gradient's ReLU mask and
+ * BN-backward statistics -- so the (rows, C1) first-layer tensor never exists.  Same arguments as the plain
+ * functions otherwise.  Wave-stream shapes only: check pcops_mlp_xyz_supported(M, C1, N2) first
+ * (PCOPS_ERR_UNSUPPORTED otherwise). */
+int pcops_mlp_xyz_supported(int M, int C1, int N2);
+int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
+                           const float *pro_shift, const float *W, const float *bias, float *Y,
+                           float *stats_partial, pcops_stream_t stream);
+int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                             const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                             int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                             const float *off4, const float *xyzw, const float *prev_scale,
+                             const float *prev_shift, float *Gprev, float *stats_partial, pcops_stream_t stream);
+int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                        const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                        const float *t, const float *gpool, const unsigned char *argmax, int S,
+                        const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                        pcops_stream_t stream);
 
 /* --------------------------------------------- first grouped layer in front of the grouping (gather.hip)
  * A 1x1 conv is linear: concat(xyz[idx] - new_xyz, points[idx]) W = (points W_f)[idx] + (xyz[idx] - new_xyz) W_xyz
@@ -211,11 +232,14 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
  *     Y[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] + (xyz[b,idx,:] - new_xyz[b,j,:]) Wxyz + bias
  * Q (b,n,c), Ctr (b,m,c), xyz (b,n,3), new_xyz (b,m,3), Wxyz (3,c), bias (c), idx (b,m,s); Q, Ctr, the coordinate
  * term and bias are each optional (NULL); the coordinate term is evaluated on the centred offsets (no cancellation).
- * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y). */
+ * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y).
+ * Y may be NULL (statistics only) and off4 (may be NULL; needs the coordinate term) receives the centred offsets
+ * (dx, dy, dz, 0) per grouped row, float [b*m*s][4]: when the layer has NO Q / Ctr term it is arithmetic in those
+ * three numbers, and the pcops_mlp_*_xyz entry points rebuild it on the fly instead of reading a (b,m,s,c) tensor. */
 int pcops_sa_gather_stats_rows(long long groups);
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *stats_partial, pcops_stream_t stream);
+                        float *off4, float *stats_partial, pcops_stream_t stream);
 /* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
  * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
  * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.

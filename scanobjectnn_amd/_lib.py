@@ -45,7 +45,10 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
-    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_wgrad_xyz": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
 }
 PLAIN = {
@@ -55,6 +58,7 @@ PLAIN = {
     "pcops_mlp_stats_rows": ([_I], _I),
     "pcops_mlp_reduce_workspace_bytes": ([_I], _U64),
     "pcops_mlp_gemm_fwd_pool_supported": ([_I, _I, _I, _I], _I),
+    "pcops_mlp_xyz_supported": ([_I, _I, _I], _I),
     "pcops_mlp_bwd_stats_rows": ([_LL], _I),
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ Wxyz,
                                                             const float *__restrict__ bias,
                                                             const int *__restrict__ idx, float *__restrict__ Y,
-                                                            float *__restrict__ stats, int groups_per_block) {
+                                                            float *__restrict__ off4, float *__restrict__ stats,
+                                                            int groups_per_block) {
     extern __shared__ float sm[];  // [RL][2][C]
     const int c4n = C / 4;
     const int RL = 256 / c4n;
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                     dx = px[0] - cx; dy = px[1] - cy; dz = px[2] - cz;
                 }
                 const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, dx, dy, dz, w0, w1, w2);
-                *reinterpret_cast<float4 *>(Y + r * C + cq) = y;
+                if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
+                if (off4 && cq == 0) *reinterpret_cast<float4 *>(off4 + r * 4) = make_float4(dx, dy, dz, 0.f);
                 s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
                 s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
                 s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
@@ -649,18 +651,20 @@ unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) 
 
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *stats_partial, pcops_stream_t stream) {
+                        float *off4, float *stats_partial, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
     PCOPS_REQUIRE_SHAPE(c <= 1024 && 256 % (c / 4) == 0);
     const long long G = (long long)b * m;
     if (G == 0) return PCOPS_OK;
-    PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(idx);
+    PCOPS_REQUIRE_ARG(Y != nullptr || stats_partial != nullptr || off4 != nullptr);
     PCOPS_REQUIRE_ARG(Q != nullptr || Wxyz != nullptr);
+    if (off4) PCOPS_REQUIRE_PTR(Wxyz);
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     const int rl = 256 / (c / 4);
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        (size_t)rl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
-                       Wxyz, bias, idx, Y, stats_partial, gather_groups_per_block(G));
+                       Wxyz, bias, idx, Y, off4, stats_partial, gather_groups_per_block(G));
     return pcops_launch_status();
 }
 

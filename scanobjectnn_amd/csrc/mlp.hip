@@ -40,6 +40,14 @@ enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3, A_DYPOOLU = 4 };
 // A_DYPOOLU: A_DYPOOL with S % 32 == 0 -- a 32-row tile / stripe lies inside ONE pooling group, so its gpool / arg-max
 // quad is loaded once per tile and the row-in-group is (row0 % S) + r (wave-stream kernels only)
 constexpr bool is_pool(int am) { return am == A_DYPOOL || am == A_DYPOOLU; }
+// A_XYZ: the operand is the BN+ReLU of a first layer that is ARITHMETIC in three per-row offsets,
+//   y[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))      (csrc/gather.hip first_layer_quad order)
+// rebuilt from off4[row] = (dx, dy, dz, 0) instead of being read: 16 bytes per row instead of 4 K (wave-stream only)
+constexpr int A_XYZ = 5;
+constexpr bool is_dy(int am) { return am == A_DY || is_pool(am); }
+__device__ __forceinline__ float xyz_y(float4 o, float w0, float w1, float w2, float b) {
+    return fmaf(o.z, w2, fmaf(o.y, w1, fmaf(o.x, w0, b)));
+}
 
 // ---- buffer-resource addressing (gfx950): ONE 32-bit VGPR offset per lane + a scalar offset per access, and the
 // hardware bounds check (offset >= num_records -> loads return 0, stores are dropped) replaces every row guard.
@@ -58,7 +66,8 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // a voffset no tensor reaches: forces the bounds check to fail
-enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2 };
+enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2, E_MASKX = 3 };   // E_MASKX: E_MASK with the previous layer in xyz form
+constexpr bool is_mask(int em) { return em == E_MASK || em == E_MASKX; }
 
 struct GemmArgs {
     int M, K, N;
@@ -81,6 +90,9 @@ struct GemmArgs {
     const float *bias;   // E_FWD (may be null)
     float *Y;            // output [M][N]
     int ldy;
+    const float *off4;   // A_XYZ / E_MASKX: per-row offsets [M][4]
+    const float *xw;     // A_XYZ / E_MASKX: [4][xw_ld] rows w0, w1, w2, b of the arithmetic first layer
+    int xw_ld;
     const float *Yprev;  // E_MASK: raw Y of the previous layer [M][N]
     const float *msc;    // E_MASK: bn scale / shift of the previous layer
     const float *msh;
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     constexpr int NLD = KC / 8;                    // float4 per lane per 32 x KC operand stripe
     constexpr int O4 = BNH / 4;                    // float4 per output row per pass
     constexpr int NST = BNH / 8;                   // float4 per lane per pass
-    constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : 5));
+    constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : (AM == A_XYZ ? 6 : 5)));
     constexpr int NTHR = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -370,10 +382,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const int nchunk = (K + KC - 1) / KC;
     const int Kp = nchunk * KC;
     float *Ws = lds;                                        // [Kp][BN]
-    float *coef = Ws + (size_t)Kp * BN;                     // [5][Kp]
-    float *ecoef = coef + 5 * Kp;                           // [2][BN]: bias | (mask scale, mask shift)
-    float *Aw = ecoef + 2 * BN + wave * 32 * LDW;           // [32][LDW] per wave
-    float *red = ecoef + 2 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
+    float *coef = Ws + (size_t)Kp * BN;                     // [6][Kp]
+    float *ecoef = coef + 6 * Kp;                           // [6][BN]: bias | (mask scale, mask shift) | xyz-form w0 w1 w2 b
+    float *Aw = ecoef + 6 * BN + wave * 32 * LDW;           // [32][LDW] per wave
+    float *red = ecoef + 6 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
     // grid = (row groups, column blocks): the column blocks of one row group have linear ids that differ by a
     // multiple of 8, i.e. they run on the SAME XCD and the second reader of a stripe hits that XCD's L2
     const int n0 = blockIdx.y * BN;
@@ -398,7 +410,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         *reinterpret_cast<float4 *>(&Ws[k * BN + nq]) = w;
     }
     {
-        const float *vs[5] = {a.v0, a.v1, a.v2, a.v3, a.v4};
+        const float *vs[6] = {a.v0, a.v1, a.v2, a.v3, a.v4, nullptr};
+        if (AM == A_XYZ) {
+            vs[2] = a.xw; vs[3] = a.xw + a.xw_ld; vs[4] = a.xw + 2 * a.xw_ld; vs[5] = a.xw + 3 * a.xw_ld;
+        }
         for (int e = tid; e < NCOEF * Kp; e += NTHR) {
             const int which = e / Kp, k = e % Kp;
             coef[which * Kp + k] = k < K ? vs[which][k] : 0.f;
@@ -408,11 +423,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             float e0 = 0.f, e1 = 0.f;
             if (n < N) {
                 if (EM == E_FWD && a.bias) e0 = a.bias[n];
-                if (EM == E_MASK) { e0 = a.msc[n]; e1 = a.msh[n]; }
+                if (is_mask(EM)) { e0 = a.msc[n]; e1 = a.msh[n]; }
                 if (POOL) e1 = a.pgamma[n] < 0.f ? -1.f : 1.f;
             }
             ecoef[e] = e0;
             ecoef[BN + e] = e1;
+            if (EM == E_MASKX) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ecoef[(2 + i) * BN + e] = n < N ? a.xw[i * a.xw_ld + n] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const long long ntiles = ((long long)M + 31) / 32;
     const long long tstride = (long long)nrowgrp * WAVES;
     float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
-    float4 pb[(AM >= A_DY) ? NLD : 1];               // A_DY*: raw Y
+    float4 pb[is_dy(AM) ? NLD : 1];                  // A_DY*: raw Y
     unsigned pm[(is_pool(AM)) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
 
     // per-lane byte offsets inside a tile (the row part of element e = lane + 64 j is added as a SCALAR offset)
@@ -455,12 +474,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         }
         const long long left = ((long long)M - row0) * a.ldx * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, left);
-        const __amdgpu_buffer_rsrc_t rx2 = make_rsrc((AM >= A_DY ? a.X2 : a.X) + row0 * a.ldx, left);
+        const __amdgpu_buffer_rsrc_t rx2 = make_rsrc((is_dy(AM) ? a.X2 : a.X) + row0 * a.ldx, left);
         const unsigned kbytes = (unsigned)(kc * KC) * 4u;
+        if (AM == A_XYZ) {       // 16 bytes per ROW (broadcast over the C4 lanes of a row)
+            const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, ((long long)M - row0) * 16);
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) pa[j] = buf_load4(ro, (unsigned)(lane / C4) * 16u, (unsigned)j * (64 / C4) * 16u);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             if (!is_pool(AM)) pa[j] = buf_load4(rx, xvoff, kbytes + (unsigned)j * xrowstep);
-            if (AM >= A_DY) pb[j] = buf_load4(rx2, xvoff, kbytes + (unsigned)j * xrowstep);
+            if (is_dy(AM)) pb[j] = buf_load4(rx2, xvoff, kbytes + (unsigned)j * xrowstep);
         }
     };
     auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
@@ -468,7 +493,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const PoolRows prs(is_pool(AM) ? row0 : 0, is_pool(AM) ? a.S : 1);
         const int cl = (lane % C4) * 4;              // fixed per lane (64 % C4 == 0)
         const int c = cl + kc * KC;
-        float4 c0, c1, c2, c3, c4;
+        float4 c0, c1, c2, c3, c4, c5;
+        if (NCOEF >= 6) c5 = *reinterpret_cast<const float4 *>(&coef[5 * Kp + c]);
         if (NCOEF >= 2) {
             c0 = *reinterpret_cast<const float4 *>(&coef[0 * Kp + c]);
             c1 = *reinterpret_cast<const float4 *>(&coef[1 * Kp + c]);
@@ -488,7 +514,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
                 x.z = fmaxf(fmaf(x.z, c0.z, c1.z), 0.f);
                 x.w = fmaxf(fmaf(x.w, c0.w, c1.w), 0.f);
-            } else if (AM >= A_DY) {
+            } else if (AM == A_XYZ) {
+                const float4 o = x;
+                x.x = fmaxf(fmaf(xyz_y(o, c2.x, c3.x, c4.x, c5.x), c0.x, c1.x), 0.f);
+                x.y = fmaxf(fmaf(xyz_y(o, c2.y, c3.y, c4.y, c5.y), c0.y, c1.y), 0.f);
+                x.z = fmaxf(fmaf(xyz_y(o, c2.z, c3.z, c4.z, c5.z), c0.z, c1.z), 0.f);
+                x.w = fmaxf(fmaf(xyz_y(o, c2.w, c3.w, c4.w, c5.w), c0.w, c1.w), 0.f);
+            } else if (is_dy(AM)) {
                 const float4 y = pb[j];
                 float4 g = x;
                 if (is_pool(AM)) {
@@ -589,7 +621,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             const int ocq = h * BNH + ocl;                   // this lane's column quad in the BN-wide tile
             const bool ocin = n0 + ocq < N;                  // N % 4 == 0 (launcher)
             const unsigned yvoff = ocin ? (unsigned)((lane / O4) * a.ldy + n0 + ocq) * 4u : kOOB;
-            float4 py[(EM == E_MASK) ? NST : 1];
+            float4 py[is_mask(EM) ? NST : 1];
+            if (EM == E_MASKX) {   // the previous layer's raw output rebuilt from the row offsets
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, ((long long)M - row0) * 16);
+                const float4 xw0 = *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq]);
+                const float4 xw1 = *reinterpret_cast<const float4 *>(&ecoef[3 * BN + ocq]);
+                const float4 xw2 = *reinterpret_cast<const float4 *>(&ecoef[4 * BN + ocq]);
+                const float4 xb = *reinterpret_cast<const float4 *>(&ecoef[5 * BN + ocq]);
+#pragma unroll
+                for (int j = 0; j < NST; ++j) {
+                    const float4 o = buf_load4(ro, (unsigned)(lane / O4) * 16u, (unsigned)j * (64 / O4) * 16u);
+                    py[j] = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
+                                        xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
+                }
+            }
             if (EM == E_MASK) {
                 // the mask tensor is requested HERE (not a tile ahead): it would cost NST more live float4 across the
                 // whole MFMA phase, and with two waves per SIMD the partner wave covers this latency
@@ -624,7 +669,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                             for (int e = 0; e < 4; ++e)
                                 if (ov[e] > pmx[h][e]) { pmx[h][e] = ov[e]; pax[h][e] = sr; }
                         }
-                    } else if (EM == E_MASK) {
+                    } else if (is_mask(EM)) {
                         const float4 yp = py[j];
                         o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
                         o.y = fmaf(yp.y, eb.y, em.y) > 0.f ? o.y : 0.f;
@@ -707,7 +752,7 @@ struct WsPlan {
 static size_t ws_lds_bytes(int Kp, int kc, int bn, int waves, int eh) {
     // weights + 5 coefficient vectors + 2 epilogue vectors + wave stripes + statistics scratch
     const int ldw = (kc > bn / eh ? kc : bn / eh) + 4;
-    return (size_t)(Kp * bn + 5 * Kp + 2 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
+    return (size_t)(Kp * bn + 6 * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
 }
 
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
@@ -1056,8 +1101,9 @@ struct WgradArgs {
     long long M;
     int K, N;
     int rows_per_block;
-    int amode;               // A_PLAIN | A_BNRELU for the A^T side
+    int amode;               // A_PLAIN | A_BNRELU | A_XYZ for the A^T side
     const float *X; int ldx; const float *asc; const float *ash;
+    const float *off4; const float *xw; int xw_ld;   // A_XYZ: see the GEMM's A_XYZ
     int dmode;               // A_DY | A_DYPOOL for the dY side
     const float *G; const float *Y; int ldy;
     const float *p; const float *q; const float *t;
@@ -1407,7 +1453,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
 // bound for K >= 128 and HBM bound for the 64-wide layers.
 template <int TK, int TN, int AMODE, int DMODE>
 __global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
-    constexpr int KB = 64 * TK, NB = 64 * TN, RS = 32, LD = KB + NB;
+    constexpr int KB = 64 * TK, NB = 64 * TN, LD = KB + NB;
+    // rows per stripe: the small tiles get longer stripes (fewer barriers) unless the pooled form wants stripes that
+    // stay inside one 32-row-aligned group
+    constexpr int RS = (TK * TN <= 2 && !is_pool(DMODE)) ? 64 : 32;
     constexpr int A4 = KB / 4, D4 = NB / 4;                   // float4 per stripe row
     constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;     // float4 per producer lane per stripe
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1417,15 +1466,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
     const long long M = a.M;
     const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
     const int grp = blockIdx.x, ngrp = gridDim.x;
-    float *coefA = lds;                        // [2][KB]
-    float *coefD = coefA + 2 * KB;             // [5][NB]
+    float *coefA = lds;                        // [6][KB]  scale, shift | xyz-form w0 w1 w2 b
+    float *coefD = coefA + 6 * KB;             // [5][NB]
     float *buf = coefD + 5 * NB;               // [2][RS][LD]   | afterwards: db scratch [256][4]
 
     for (int e = tid; e < KB; e += 512) {
         const int k = k0 + e;
         const bool in = k < K;
-        coefA[e] = (AMODE == A_BNRELU && in) ? a.asc[k] : 0.f;
-        coefA[KB + e] = (AMODE == A_BNRELU && in) ? a.ash[k] : 0.f;
+        coefA[e] = (AMODE != A_PLAIN && in) ? a.asc[k] : 0.f;
+        coefA[KB + e] = (AMODE != A_PLAIN && in) ? a.ash[k] : 0.f;
+        if (AMODE == A_XYZ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) coefA[(2 + i) * KB + e] = in ? a.xw[i * a.xw_ld + k] : 0.f;
+        }
     }
     for (int e = tid; e < NB; e += 512) {
         const int n = n0 + e;
@@ -1449,6 +1502,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
         const int acl = ain ? k0 + acq : 0, dcl = din ? n0 + dcq : 0;
         const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
         const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+        float4 xw0 = make_float4(0.f, 0.f, 0.f, 0.f), xw1 = xw0, xw2 = xw0, xb = xw0;
+        if (AMODE == A_XYZ) {
+            xw0 = *reinterpret_cast<const float4 *>(&coefA[2 * KB + acq]);
+            xw1 = *reinterpret_cast<const float4 *>(&coefA[3 * KB + acq]);
+            xw2 = *reinterpret_cast<const float4 *>(&coefA[4 * KB + acq]);
+            xb = *reinterpret_cast<const float4 *>(&coefA[5 * KB + acq]);
+        }
         const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
         const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
         const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
@@ -1469,8 +1529,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
             const __amdgpu_buffer_rsrc_t rg =
                 make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            if (AMODE == A_XYZ) {     // 16 bytes per ROW, broadcast over the A4 lanes of a row
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, (M - row0) * 16);
 #pragma unroll
-            for (int j = 0; j < NA; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+                for (int j = 0; j < NA; ++j) px[j] = buf_load4(ro, (unsigned)(pt / A4) * 16u, (unsigned)j * (256 / A4) * 16u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NA; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            }
             const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
@@ -1501,7 +1567,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
             for (int j = 0; j < NA; ++j) {
                 const int r = pt / A4 + j * (256 / A4);
                 float4 x = px[j];
-                if (AMODE == A_BNRELU) {
+                if (AMODE == A_XYZ) {
+                    const float4 o = x;
+                    x = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
+                                    xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
+                }
+                if (AMODE != A_PLAIN) {
                     x.x = fmaxf(fmaf(x.x, casc.x, cash.x), 0.f);
                     x.y = fmaxf(fmaf(x.y, casc.y, cash.y), 0.f);
                     x.z = fmaxf(fmaf(x.z, casc.z, cash.z), 0.f);
@@ -1651,7 +1722,8 @@ static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, con
     if (groups > maxg) groups = (int)maxg;
     if (groups >= 8) groups &= ~7;
     pl->groups = groups;
-    pl->lds = (size_t)(2 * KB + 5 * NB + 2 * 32 * (KB + NB)) * sizeof(float);
+    const int rs = pl->tk * pl->tn <= 2 ? 64 : 32;
+    pl->lds = (size_t)(6 * KB + 5 * NB + 2 * rs * (KB + NB)) * sizeof(float);
     return pl->lds <= 160 * 1024;
 }
 
@@ -1727,6 +1799,23 @@ int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
 }  // namespace
 
 // ============================================================================ C ABI
+// wave-stream kernel or nothing (the xyz-form modes have no tiled fallback)
+template <int AM, int EM>
+static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
+    WsPlan pl;
+    if (!(ws_enabled() && ws_plan(a, AM, &pl))) return PCOPS_ERR_UNSUPPORTED;
+    int rc;
+    if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
+    else rc = launch_gemm_ws<AM, EM>(a, pl, st);
+    if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
+        const int P = pcops_mlp_stats_rows(a.M);
+        if (pl.gy < P && hipMemsetAsync(a.stats + (size_t)pl.gy * 2 * a.N, 0,
+                                        sizeof(float) * (size_t)(P - pl.gy) * 2 * a.N, st) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+    }
+    return rc;
+}
+
 extern "C" {
 
 int pcops_mlp_stats_rows(int M) {
@@ -1932,6 +2021,63 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
     return launch_gemm<A_DY, E_PLAIN>(a, st);
 }
 
+int pcops_mlp_xyz_supported(int M, int C1, int N2) {
+    // second layer (C1 -> N2) forward / weight gradient with an A_XYZ operand, and its data gradient (N2 -> C1) with
+    // the E_MASKX epilogue, all on the wave-stream kernels
+    GemmArgs f = {};
+    f.M = M; f.K = C1; f.N = N2; f.ldx = C1; f.ldy = N2;
+    GemmArgs d = {};
+    d.M = M; d.K = N2; d.N = C1; d.ldx = N2; d.ldy = C1;
+    WsPlan pl;
+    PcWgradPlan pc;
+    return ws_enabled() && wgrad_pc_enabled() && C1 % 4 == 0 && ws_plan(f, A_XYZ, &pl) && ws_plan(d, A_DY, &pl) &&
+           wgrad_pc_plan(M, C1, N2, C1, nullptr, nullptr, nullptr, nullptr, nullptr, &pc) ? 1 : 0;
+}
+
+/* forward of the layer FOLLOWING an arithmetic first layer: X = relu(pro_scale * y + pro_shift), y rebuilt from
+ * off4 [M][4] and xyzw [4][K]; otherwise pcops_mlp_gemm_fwd */
+int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
+                           const float *pro_shift, const float *W, const float *bias, float *Y,
+                           float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && N >= 1);
+    PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(pro_scale); PCOPS_REQUIRE_PTR(pro_shift);
+    PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
+    if (reinterpret_cast<uintptr_t>(off4) & 15) return PCOPS_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.X = nullptr; a.ldx = K; a.v0 = pro_scale; a.v1 = pro_shift;
+    a.off4 = off4; a.xw = xyzw; a.xw_ld = K;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    return launch_gemm_ws_only<A_XYZ, E_FWD>(a, as_stream(stream));
+}
+
+/* pcops_mlp_gemm_dgrad whose PREVIOUS layer is the arithmetic first layer: the ReLU mask and the (sum G, sum G*Y)
+ * statistics use y rebuilt from off4 [M][4] and xyzw [4][Nout] instead of a stored Yprev */
+int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                             const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                             int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                             const float *off4, const float *xyzw, const float *prev_scale,
+                             const float *prev_shift, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && Nout >= 1);
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(Gprev); PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw);
+    PCOPS_REQUIRE_PTR(prev_scale); PCOPS_REQUIRE_PTR(prev_shift);
+    if (reinterpret_cast<uintptr_t>(off4) & 15) return PCOPS_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = Nout; a.X = G; a.X2 = Y; a.ldx = K; a.v0 = p; a.v1 = q; a.v2 = t;
+    a.v3 = pool_scale; a.v4 = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    a.W = Wt; a.Y = Gprev; a.ldy = Nout; a.msc = prev_scale; a.msh = prev_shift;
+    a.off4 = off4; a.xw = xyzw; a.xw_ld = Nout;
+    a.stats = stats_partial;
+    hipStream_t st = as_stream(stream);
+    if (gpool) {
+        PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
+        a.X = Y;  // alignment probe only
+        return launch_gemm_ws_only<A_DYPOOL, E_MASKX>(a, st);
+    }
+    PCOPS_REQUIRE_PTR(G);
+    return launch_gemm_ws_only<A_DY, E_MASKX>(a, st);
+}
+
 int pcops_mlp_wgrad_splits(long long M, int K, int N) {
     // upper bound of the partial copies either wgrad kernel writes (scratch is sized with it)
     const int kb = (K + 63) / 64, nb = (N + 127) / 128;
@@ -1958,28 +2104,18 @@ static int wgrad_legacy_splits(long long M, int K, int N) {
 
 /* dW[K][N] = A^T dY, db[N] = 1^T dY;  A = X (a_scale==NULL) or relu(X*a_scale + a_shift);
  * dY as in pcops_mlp_gemm_dgrad.  partial: float [splits][K][N] + [splits][N] scratch (caller). */
-int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
-                    const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
-                    const float *t, const float *gpool, const unsigned char *argmax, int S,
-                    const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
-                    pcops_stream_t stream) {
-    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
-    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
-    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
-    hipStream_t st = as_stream(stream);
-    if (!gpool) PCOPS_REQUIRE_PTR(G);
-    WgradArgs a = {};
-    a.M = M; a.K = K; a.N = N;
-    a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = X; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
-    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
-    a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t st) {
+    const long long M = a.M;
+    const int K = a.K, N = a.N, ldx = a.ldx;
+    const float *X = a.X, *G = a.G, *Y = a.Y, *gpool = a.gpool;
+    const unsigned char *argmax = a.argmax;
     int splits;
     WsWgradPlan pl;
     PcWgradPlan pc;
     // producer/consumer kernel for the pooled forms and the widest tile; the single-role kernel (256 accumulator
     // registers per wave) is ahead on the narrow materialised-G shapes
     if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc) &&
-        (gpool || pc.tn == 4 || !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
+        (gpool || pc.tn == 4 || a.amode == A_XYZ || !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
         splits = pc.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
         const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
@@ -1993,7 +2129,10 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     } while (0)
 #define PCOPS_PC_MODES(TK_, TN_)                                                                           \
     do {                                                                                                   \
-        if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);             \
+        if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);                   \
+        else if (a.amode == A_XYZ && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLU);           \
+        else if (a.amode == A_XYZ) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOL);                             \
+        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);        \
         else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLU);     \
         else if (a.amode == A_BNRELU) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOL);                       \
         else if (a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DY);                                \
@@ -2008,6 +2147,8 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
         else PCOPS_PC_MODES(2, 4);
 #undef PCOPS_PC_MODES
 #undef PCOPS_PC_LAUNCH
+    } else if (a.amode == A_XYZ) {
+        return PCOPS_ERR_UNSUPPORTED;
     } else if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
         splits = pl.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
@@ -2046,6 +2187,45 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
         hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, splits, (long long)N,
                            a.dbpart, db);
     return pcops_launch_status();
+}
+
+int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
+                    const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                    const float *t, const float *gpool, const unsigned char *argmax, int S,
+                    const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                    pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = X; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    return wgrad_impl(a, partial, dW, db, as_stream(stream));
+}
+
+/* A = relu(a_scale * y + a_shift) with y the ARITHMETIC first layer rebuilt from off4 [M][4] and xyzw [4][K]
+ * (rows w0, w1, w2, b): the grouped first-layer tensor is never read.  Wave-stream shapes only. */
+int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                        const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                        const float *t, const float *gpool, const unsigned char *argmax, int S,
+                        const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                        pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1);
+    PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift);
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
+    if (reinterpret_cast<uintptr_t>(off4) & 15) return PCOPS_ERR_UNSUPPORTED;
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_XYZ; a.X = nullptr; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
+    a.off4 = off4; a.xw = xyzw; a.xw_ld = K;
+    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    return wgrad_impl(a, partial, dW, db, as_stream(stream));
 }
 
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream) {

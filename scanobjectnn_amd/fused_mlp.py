@@ -75,14 +75,23 @@ class FusedMLPStack(torch.autograd.Function):
         vecs = _VecArena([l[2].shape[0] for l in layers], 4, dev)
         ws = _workspace(max(l[2].shape[0] for l in layers), dev) if training else None
         pooled_raw = None
+        # a first layer with only the coordinate term is ARITHMETIC in three offsets per row: it is never stored, the
+        # next layer and the whole backward rebuild it from off4 (16 bytes per row instead of 4 C1)
+        virt = (gather and a0 is None and ctr is None and wxyz is not None and (L >= 3 or (L == 2 and not pool))
+                and bool(lib.pcops_mlp_xyz_supported(R, C1, layers[1][0].shape[-1])))
+        off4 = xyzw = None
+        if virt:
+            off4 = _f32((R, 4), dev)
+            xyzw = torch.cat([wxyz.detach(), (bias.detach() if bias is not None
+                                              else torch.zeros(C1, dtype=torch.float32, device=dev)).view(1, C1)]).contiguous()
         for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
             if li == 0 and gather:
                 N = C1
-                Y = _f32((R, N), dev)
+                Y = None if virt else _f32((R, N), dev)
                 P = lib.pcops_sa_gather_stats_rows(B * M)
                 part = _f32((P, 2, N), dev) if training else None
                 _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
-                          _p(wxyz), _p(bias), idx.data_ptr(), Y.data_ptr(), _p(part))
+                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part))
                 W2 = None
             else:
                 N = w.shape[-1]
@@ -91,7 +100,10 @@ class FusedMLPStack(torch.autograd.Function):
                 Y = _f32((R, N), dev)
                 P = lib.pcops_mlp_stats_rows(R)
                 part = _f32((P, 2, N), dev) if training else None
-                if (pool and li == L - 1 and sc_prev is not None and ld == K
+                if li == 1 and virt:
+                    _lib.call("pcops_mlp_gemm_fwd_xyz", R, K, N, off4.data_ptr(), xyzw.data_ptr(), sc_prev.data_ptr(),
+                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
+                elif (pool and li == L - 1 and sc_prev is not None and ld == K
                         and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)):
                     # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics)
                     G = R // S
@@ -139,14 +151,17 @@ class FusedMLPStack(torch.autograd.Function):
                       shifts[-1].data_ptr(), out.data_ptr())
         if training:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
-                         [l[2] for l in layers], argmax, ysel)
+                         [l[2] for l in layers], argmax, ysel, off4, xyzw)
             ctx.meta = (S, pool, L, R, K0, gather)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax, ysel = ctx.saved
+        (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax, ysel, off4,
+         xyzw) = ctx.saved
+        virt = off4 is not None
+        widths = [g.shape[0] for g in gammas]
         S, pool, L, R, K0, gather = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
@@ -155,8 +170,8 @@ class FusedMLPStack(torch.autograd.Function):
 
         # ---- top of the stack: statistics of the masked upstream gradient
         C = Ys[-1].shape[1]
-        ws = _workspace(max(y.shape[1] for y in Ys), dev)
-        vecs = _VecArena([y.shape[1] for y in Ys], 3, dev)
+        ws = _workspace(max(widths), dev)
+        vecs = _VecArena(widths, 3, dev)
         if pool:
             G = R // S
             P = lib.pcops_mlp_bwd_pool_stats_rows(G)
@@ -172,7 +187,7 @@ class FusedMLPStack(torch.autograd.Function):
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), Gm.data_ptr(), part.data_ptr())
 
         for l in range(L - 1, -1, -1):
-            N = Ys[l].shape[1]
+            N = widths[l]
             dgamma, dbeta = _f32(N, dev), _f32(N, dev)
             p, q, t = vecs.take(N), vecs.take(N), vecs.take(N)
             _lib.call("pcops_mlp_bn_bwd_coeffs", P, N, R, part.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
@@ -199,7 +214,7 @@ class FusedMLPStack(torch.autograd.Function):
                 if d0 is not None:   # gather formulation over an inverse index
                     wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,
                                       dtype=torch.int32, device=dev)
-                _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(),
+                _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, _p(Ys[0]), p.data_ptr(),
                           q.data_ptr(), t.data_ptr(), gp, am, psc, psh, idx.data_ptr(),
                           _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
                           _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(a0), _p(ctr), _p(wxyz), _p(bias),
@@ -207,23 +222,35 @@ class FusedMLPStack(torch.autograd.Function):
                 break
 
             K = Ws[l].shape[0]
+            xyz_prev = virt and l == 1          # the layer below is the arithmetic first layer (never stored)
             if l == 0:
                 src, ld, asc, ash = a0, K0, None, None
-            else:
+            elif not xyz_prev:
                 src, ld, asc, ash = Ys[l - 1], Ys[l - 1].shape[1], scales[l - 1].data_ptr(), shifts[l - 1].data_ptr()
             splits = lib.pcops_mlp_wgrad_splits(R, K, N)
             scratch = _f32(splits * (K * N + N), dev)
             dW, db = _f32((K, N), dev), _f32(N, dev)
-            _lib.call("pcops_mlp_wgrad", R, K, N, src.data_ptr(), ld, asc, ash, Gptr, Ys[l].data_ptr(),
-                      p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S, psc, psh, scratch.data_ptr(),
-                      dW.data_ptr(), db.data_ptr())
+            if xyz_prev:
+                _lib.call("pcops_mlp_wgrad_xyz", R, K, N, off4.data_ptr(), xyzw.data_ptr(), scales[0].data_ptr(),
+                          shifts[0].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am,
+                          S, psc, psh, scratch.data_ptr(), dW.data_ptr(), db.data_ptr())
+            else:
+                _lib.call("pcops_mlp_wgrad", R, K, N, src.data_ptr(), ld, asc, ash, Gptr, Ys[l].data_ptr(),
+                          p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S, psc, psh, scratch.data_ptr(),
+                          dW.data_ptr(), db.data_ptr())
             grads[6 * l + 0] = dW
             grads[6 * l + 1] = db
             if l > 0 or ctx.needs_input_grad[0]:
                 Wt = _f32((N, K), dev)
                 _lib.call("pcops_mlp_transpose", K, N, Ws[l].data_ptr(), Wt.data_ptr())
                 Gprev = _f32((R, K), dev)
-                if l > 0:
+                if xyz_prev:
+                    P = lib.pcops_mlp_stats_rows(R)
+                    part = _f32((P, 2, K), dev)
+                    _lib.call("pcops_mlp_gemm_dgrad_xyz", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
+                              t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), off4.data_ptr(), xyzw.data_ptr(),
+                              scales[0].data_ptr(), shifts[0].data_ptr(), Gprev.data_ptr(), part.data_ptr())
+                elif l > 0:
                     P = lib.pcops_mlp_stats_rows(R)
                     part = _f32((P, 2, K), dev)
                     _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),

@@ -172,6 +172,11 @@ GATHER_CASES = [  # (B, N, M, S, widths, pool)
     (2, 128, 128, 20, [64], True),              # EdgeConv: single pooled layer
     (2, 90, 30, 8, [32, 32, 64], True),         # MSG scale 0 widths
     (2, 64, 16, 4, [64, 128], False),           # un-pooled output
+    # >= 32768 grouped rows: wave-stream kernels; in the xyz_bias form the first layer is never stored (rebuilt from
+    # the row offsets in the next layer's forward, weight gradient and data-gradient mask)
+    (8, 512, 256, 32, [64, 64, 128], True),
+    (4, 512, 128, 64, [64, 128], False),
+    (3, 700, 130, 96, [32, 64, 64], True),      # ragged tail tile, 3 tiles per pooling group
 ]
 
 
