@@ -312,7 +312,7 @@ int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
     // enough row-tile groups to fill the chip a few times over, few enough that the partial-statistics
     // buffer stays small
     int tpb = 1;
-    while (tiles / tpb > 4096) tpb *= 2;
+    while (tiles / tpb > 512) tpb *= 2;
     a.tiles_per_block = tpb;
     const int gy = (tiles + tpb - 1) / tpb;
     if (a.N <= 64) {
@@ -1778,6 +1778,27 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, c
     if (pl == 0 && i < L) out[i] = (float)((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
 }
 
+// two adjacent reductions in one launch: blocks [0, ceil(L/64)) sum part -> out, the rest sum part2 -> out2
+__global__ __launch_bounds__(256) void sum_partials2_kernel(int P, long long L, const float *__restrict__ part,
+                                                            float *__restrict__ out, long long L2,
+                                                            const float *__restrict__ part2,
+                                                            float *__restrict__ out2) {
+    __shared__ double sm[4][64];
+    const long long nb1 = (L + 63) / 64;
+    const bool second = (long long)blockIdx.x >= nb1;
+    const long long len = second ? L2 : L;
+    const float *src = second ? part2 : part;
+    float *dst = second ? out2 : out;
+    const int c = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const long long i = ((long long)blockIdx.x - (second ? nb1 : 0)) * 64 + c;
+    double s = 0.0;
+    if (i < len)
+        for (int p = pl; p < P; p += 4) s += (double)src[(long long)p * len + i];
+    sm[pl][c] = s;
+    __syncthreads();
+    if (pl == 0 && i < len) dst[i] = (float)((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+}
+
 // Wt[n][k] = W[k][n]
 __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const float *__restrict__ W,
                                                         float *__restrict__ Wt) {
@@ -1789,6 +1810,83 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
         if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
+}
+
+// few partial rows (P <= kFusedRows): column reduction and the per-channel finalisation in ONE launch.
+// block = 32 columns x 8 row lanes; the row-lane totals meet in LDS in a fixed order (deterministic)
+constexpr int kFusedRows = 1024;
+
+__device__ __forceinline__ bool fused_col_sums(int P, int N, const float *__restrict__ part, double &s1, double &s2,
+                                               int &c) {
+    __shared__ double sm[2][8][32];
+    c = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int g = threadIdx.x >> 5;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < N)
+        for (int p = g; p < P; p += 8) {
+            a1 += (double)part[((long long)p * 2 + 0) * N + c];
+            a2 += (double)part[((long long)p * 2 + 1) * N + c];
+        }
+    sm[0][g][threadIdx.x & 31] = a1;
+    sm[1][g][threadIdx.x & 31] = a2;
+    __syncthreads();
+    if (g != 0 || c >= N) return false;
+    s1 = s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1 += sm[0][i][threadIdx.x]; s2 += sm[1][i][threadIdx.x]; }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(int P, int N, double R, const float *__restrict__ part,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, float eps,
+                                                                float decay, int unbiased,
+                                                                float *__restrict__ moving_mean,
+                                                                float *__restrict__ moving_var,
+                                                                float *__restrict__ mean_o,
+                                                                float *__restrict__ rstd_o,
+                                                                float *__restrict__ scale_o,
+                                                                float *__restrict__ shift_o) {
+    double s1, s2;
+    int c;
+    if (!fused_col_sums(P, N, part, s1, s2, c)) return;
+    const double mean = s1 / R;
+    double var = s2 / R - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    mean_o[c] = (float)mean;
+    rstd_o[c] = rstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)mean * sc;
+    if (moving_mean) {
+        const double uv = (unbiased && R > 1.0) ? var * (R / (R - 1.0)) : var;
+        moving_mean[c] = decay * moving_mean[c] + (1.f - decay) * (float)mean;
+        moving_var[c] = decay * moving_var[c] + (1.f - decay) * (float)uv;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_fused_kernel(int P, int N, double R,
+                                                                  const float *__restrict__ part,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd,
+                                                                  float *__restrict__ dgamma,
+                                                                  float *__restrict__ dbeta, float *__restrict__ p_o,
+                                                                  float *__restrict__ q_o, float *__restrict__ t_o) {
+    double sg, sgy;
+    int c;
+    if (!fused_col_sums(P, N, part, sg, sgy, c)) return;
+    const double mu = mean[c], rs = rstd[c], g = gamma[c];
+    const double dga = (sgy - mu * sg) * rs;
+    const double p = g * rs;
+    const double q = -p * rs * dga / R;
+    const double t = -p * sg / R - q * mu;
+    dgamma[c] = (float)dga;
+    dbeta[c] = (float)sg;
+    p_o[c] = (float)p;
+    q_o[c] = (float)q;
+    t_o[c] = (float)t;
 }
 
 int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
@@ -1823,7 +1921,7 @@ int pcops_mlp_stats_rows(int M) {
     // it; kernels that launch fewer row groups leave the tail ZERO -- see zero_stats_tail)
     const int tiles = (M + kBM - 1) / kBM;
     int tpb = 1;
-    while (tiles / tpb > 4096) tpb *= 2;
+    while (tiles / tpb > 512) tpb *= 2;
     return (tiles + tpb - 1) / tpb;
 }
 
@@ -1897,6 +1995,12 @@ int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial,
     PCOPS_REQUIRE_PTR(shift);
     PCOPS_REQUIRE_ARG((moving_mean == nullptr) == (moving_var == nullptr));
     hipStream_t st = as_stream(stream);
+    if (P <= kFusedRows) {
+        hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((N + 31) / 32), dim3(256), 0, st, P, N, (double)R,
+                           stats_partial, gamma, beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean,
+                           rstd, scale, shift);
+        return pcops_launch_status();
+    }
     double *ws = static_cast<double *>(workspace);
     int rc = reduce_stats(P, N, stats_partial, ws, st);
     if (rc) return rc;
@@ -1983,6 +2087,11 @@ int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partia
     PCOPS_REQUIRE_PTR(mean); PCOPS_REQUIRE_PTR(rstd); PCOPS_REQUIRE_PTR(dgamma); PCOPS_REQUIRE_PTR(dbeta);
     PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     hipStream_t st = as_stream(stream);
+    if (P <= kFusedRows) {
+        hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3((N + 31) / 32), dim3(256), 0, st, P, N, (double)R,
+                           stats_partial, gamma, mean, rstd, dgamma, dbeta, p, q, t);
+        return pcops_launch_status();
+    }
     double *ws = static_cast<double *>(workspace);
     int rc = reduce_stats(P, N, stats_partial, ws, st);
     if (rc) return rc;
@@ -2181,11 +2290,10 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     }
     int rc = pcops_launch_status();
     if (rc) return rc;
+    // dW and db partials are adjacent ([splits][K*N] then [splits][N]): one launch sums both
     const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(L, 64)), dim3(256), 0, st, splits, L, partial, dW);
-    if (db)
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, splits, (long long)N,
-                           a.dbpart, db);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(256), 0, st, splits, L,
+                       partial, dW, (long long)N, a.dbpart, db);
     return pcops_launch_status();
 }
 
