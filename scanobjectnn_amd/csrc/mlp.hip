@@ -358,11 +358,17 @@ struct PoolRows {
     }
 };
 
-template <int NT, int AM, int EM, int KC, int WAVES, int EH, bool POOL>
+template <int NT, int AM, int EM, int KC, int WAVES, int EH, int VAR>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs a) {
     // WAVES waves per workgroup (4: one per SIMD, 8: two per SIMD so that one wave's staging / epilogue hides under
     // its partner's MFMA phase); EH: the epilogue transposes the accumulator tile in EH column passes so that the
     // wave stripe only needs max(KC, BN/EH) columns.
+    // VAR 0: weights resident in LDS for the life of the workgroup (K <= 256)
+    //     1: + neighbourhood pooling fused into the forward epilogue
+    //     2: weights STREAMED -- K chunks of KC rows double-buffered in LDS, refilled from L2 by the whole workgroup
+    //        while the MFMAs of the current chunk run; all waves then walk the chunks in lockstep (one workgroup
+    //        barrier per chunk), which is what K > 256 costs
+    constexpr bool POOL = VAR == 1, WST = VAR == 2;
     constexpr int BN = NT * 32;
     constexpr int NTH = NT / EH;                   // accumulator tiles per epilogue pass
     constexpr int BNH = BN / EH;                   // columns per epilogue pass
@@ -381,9 +387,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const int M = a.M, K = a.K, N = a.N;
     const int nchunk = (K + KC - 1) / KC;
     const int Kp = nchunk * KC;
-    float *Ws = lds;                                        // [Kp][BN]
-    float *coef = Ws + (size_t)Kp * BN;                     // [6][Kp]
-    float *ecoef = coef + 6 * Kp;                           // [6][BN]: bias | (mask scale, mask shift) | xyz-form w0 w1 w2 b
+    constexpr int CROWS = WST ? (NCOEF > 0 ? NCOEF : 1) : 6;
+    float *Ws = lds;                                        // [Kp][BN], or [2][KC][BN] when streamed
+    float *coef = Ws + (size_t)(WST ? 2 * KC : Kp) * BN;    // [CROWS][Kp]
+    float *ecoef = coef + CROWS * Kp;                       // [6][BN]: bias | (mask scale, mask shift) | xyz-form w0 w1 w2 b
     float *Aw = ecoef + 6 * BN + wave * 32 * LDW;           // [32][LDW] per wave
     float *red = ecoef + 6 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
     // grid = (row groups, column blocks): the column blocks of one row group have linear ids that differ by a
@@ -391,8 +398,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const int n0 = blockIdx.y * BN;
     const int rowgrp = blockIdx.x, nrowgrp = gridDim.x;
 
+    // ---- streamed weights: KC x BN chunk = WPT float4 per thread, global (L2) -> registers -> LDS buffer
+    constexpr int WPT = (KC * (BN / 4) + NTHR - 1) / NTHR;
+    float4 wreg[WST ? WPT : 1];
+    auto wload = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + NTHR * j;
+            const int k = kc * KC + e / (BN / 4), n = n0 + (e % (BN / 4)) * 4;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < KC * (BN / 4) && k < K && n < N) w = *reinterpret_cast<const float4 *>(a.W + (long long)k * N + n);
+            wreg[j] = w;
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + NTHR * j;
+            if (e < KC * (BN / 4))
+                *reinterpret_cast<float4 *>(&Ws[(buf * KC + e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = wreg[j];
+        }
+    };
     // ---- resident data: weights + coefficient vectors, loaded once per workgroup
-    for (int e = tid; e < Kp * (BN / 4); e += NTHR) {
+    if (WST) {
+        wload(0);
+        wstore(0);
+    }
+    for (int e = tid; e < (WST ? 0 : Kp * (BN / 4)); e += NTHR) {
         const int k = e / (BN / 4), nq = (e % (BN / 4)) * 4;
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
@@ -555,7 +587,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     long long st = (long long)rowgrp * WAVES + wave;
     int sub = 0;
     if (st < nsuper) issue(st * SUB, 0);
-    while (st < nsuper) {
+    // streamed weights: every wave runs the workgroup's number of rounds (the chunk barriers are workgroup-wide);
+    // a wave without a tile in the last round only helps refilling the weight buffers
+    const long long st0 = (long long)rowgrp * WAVES;
+    const long long nrounds = st0 < nsuper ? (nsuper - st0 + tstride - 1) / tstride : 0;
+    long long round = 0;
+    int wt = 0;                                      // streamed chunks consumed so far (buffer = wt & 1)
+    while (WST ? round < nrounds : st < nsuper) {
+        const bool active = !WST || st < nsuper;
         const long long tile = st * SUB + sub;
         long long nst = st;
         int nsub = sub + 1;
@@ -569,6 +608,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
 
         for (int kc = 0; kc < nchunk; ++kc) {
+            if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
+            if (active) {
             __builtin_amdgcn_wave_barrier();
             stage(tile, kc);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -578,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             else if (more) issue(next_tile, 0);
 
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
-            const float *bcol = &Ws[(kc * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
+            const float *bcol = &Ws[((WST ? (wt & 1) : kc) * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
             // software pipeline: the fragments of step it+1 are requested from LDS before the 4*NT MFMAs of step
             // it are issued
             float4 av_n = *reinterpret_cast<const float4 *>(arow);
@@ -609,8 +650,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv[t][nt], acc[nt], 0, 0, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (WST) {      // refill the other buffer (last read one chunk ago, before the previous barrier)
+                wstore((wt + 1) & 1);
+                __syncthreads();
+                ++wt;
+            }
         }
-
+        if (active) {
         // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
@@ -707,8 +754,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
             }
         }
+        }
         st = nst;
         sub = nsub;
+        ++round;
     }
 
     if (EM != E_PLAIN && a.stats) {
@@ -746,8 +795,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 
 struct WsPlan {
     int kc, bn, waves, eh, ncb, gy;
+    bool wst;        // weights streamed (K > 256)
     size_t lds;
 };
+
+static int ws_ncoef(int am) { return am == A_PLAIN ? 0 : (am == A_BNRELU ? 2 : (am == A_DY ? 3 : (am == A_XYZ ? 6 : 5))); }
+
+static size_t ws_lds_bytes_streamed(int Kp, int kc, int bn, int waves, int eh, int ncoef) {
+    const int ldw = (kc > bn / eh ? kc : bn / eh) + 4;
+    const int crows = ncoef > 0 ? ncoef : 1;
+    return (size_t)(2 * kc * bn + crows * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
+}
 
 static size_t ws_lds_bytes(int Kp, int kc, int bn, int waves, int eh) {
     // weights + 5 coefficient vectors + 2 epilogue vectors + wave stripes + statistics scratch
@@ -757,7 +815,8 @@ static size_t ws_lds_bytes(int Kp, int kc, int bn, int waves, int eh) {
 
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
-    if (a.K % 8 != 0 || a.K > 256 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
+    if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
+    if (a.K > 256 && (a.pool_sub > 0 || am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
     if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
     if (is_pool(am) && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
@@ -768,8 +827,15 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     const int Kp = (a.K + 63) / 64 * 64;
     pl->bn = 64;
     pl->eh = 1;
-    if (a.N > 64 && ws_lds_bytes(Kp, 64, 128, 8, 2) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
-    pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
+    pl->wst = a.K > 256;
+    if (pl->wst) {
+        const int nc = ws_ncoef(am);
+        if (a.N > 64 && ws_lds_bytes_streamed(Kp, 64, 128, 8, 2, nc) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
+        pl->lds = ws_lds_bytes_streamed(Kp, pl->kc, pl->bn, pl->waves, pl->eh, nc);
+    } else {
+        if (a.N > 64 && ws_lds_bytes(Kp, 64, 128, 8, 2) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
+        pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
+    }
     if (pl->lds > 160 * 1024) return false;
     pl->ncb = (a.N + pl->bn - 1) / pl->bn;
     const long long ntiles = (((long long)a.M + 31) / 32 + (a.pool_sub > 1 ? a.pool_sub - 1 : 0)) /
@@ -786,8 +852,9 @@ template <int AM, int EM>
 int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
 #define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
-        auto kern = (EM == E_FWD && a.pool_sub > 0) ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (EM == E_FWD)>  \
-                                                    : gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, false>; \
+        auto kern = pl.wst ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (AM == A_XYZ ? 0 : 2)>            \
+                    : (EM == E_FWD && a.pool_sub > 0) ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (EM == E_FWD ? 1 : 0)> \
+                                                      : gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, 0>;   \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
             return PCOPS_ERR_LAUNCH;                                                                  \

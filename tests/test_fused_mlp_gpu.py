@@ -57,6 +57,9 @@ CASES = [  # (R, S, K0, widths, pool)
     (400 * 96, 96, 64, [64, 128], True),           # pooling fused into the GEMM epilogue, 3 tiles per group
     (130 * 256, 256, 32, [128, 64], True),         # ... 8 tiles per group (largest 8-bit arg index)
     (1100 * 32, 32, 16, [32, 32], True),           # ... N=32: half-empty column block
+    # K > 256: weights streamed through LDS in 64-row chunks (one workgroup barrier per chunk)
+    (256 * 128, 128, 260, [256, 512, 1024], True),  # SA3 of the SSG config at B=256 (pooled 1024-wide last layer)
+    (33000, 1, 320, [1024, 64], False),            # DGCNN aggregation shapes, ragged tail, N=64 behind K=1024
 ]
 
 
