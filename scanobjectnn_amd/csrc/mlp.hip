@@ -813,6 +813,14 @@ static size_t ws_lds_bytes(int Kp, int kc, int bn, int waves, int eh) {
     return (size_t)(Kp * bn + 6 * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
 }
 
+static bool ws_stream256_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_WS_STREAM256");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
@@ -828,6 +836,11 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     pl->bn = 64;
     pl->eh = 1;
     pl->wst = a.K > 256;
+    // K = 193..256 with more than 64 output columns: resident weights would only fit 64 columns at a time, i.e. the
+    // operand would be streamed from HBM once per 64-column block; streaming the WEIGHTS (from L2) keeps 128 columns
+    if (!pl->wst && a.N > 64 && a.pool_sub == 0 && am != A_XYZ && !(reinterpret_cast<uintptr_t>(a.W) & 15) &&
+        ws_lds_bytes(Kp, 64, 128, 8, 2) > 160 * 1024 && ws_stream256_enabled())
+        pl->wst = true;
     if (pl->wst) {
         const int nc = ws_ncoef(am);
         if (a.N > 64 && ws_lds_bytes_streamed(Kp, 64, 128, 8, 2, nc) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
