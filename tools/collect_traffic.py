@@ -1,50 +1,67 @@
 #!/usr/bin/env python3
-"""Runs ON THE GPU BOX (via gpurun): HBM traffic of the big MLP kernels from the PMC counters, collected the way
-MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (they do not fit
-one pass), no tracing flags next to --pmc, FETCH_SIZE doubled (gfx950 tallies 128-byte requests at 64 bytes for
-wide coalesced reads), both counters in KiB.  Writes gpurun_out/pmc_traffic.json:
-    {"pcops_mlp_gemm_dgrad(2097152, 256, 128)": bytes_per_launch, ...}
-keys are the C-ABI name + the leading shape arguments, as bench.py's kernel table prints them."""
-import csv, glob, json, os, subprocess, sys
+"""Runs ON THE GPU BOX (via gpurun): HBM traffic per launch of the kernels of the REAL bench step, from the PMC
+counters collected the way MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc
+passes (they do not fit one pass), no tracing flags next to --pmc, FETCH_SIZE doubled (gfx950 tallies 128-byte
+requests at 64 bytes for wide coalesced reads), both counters in KiB.
+
+  python tools/collect_traffic.py            -> gpurun_out/pmc_traffic.json         {C-ABI key: bytes per launch}
+                                                gpurun_out/pmc_traffic_detail.json  per (kernel, grid) averages
+
+A dispatch is identified by (kernel name, grid size); KEYS maps the (name fragment, grid) pairs of the SSG bench's
+biggest kernels to the C-ABI call + leading shape arguments bench.py prints in its kernel table."""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-CASES = [  # (kind, M, K, N) in tools/bench_gemm.py's convention (dgrad of the K->N layer: dY is M x N)
-    ("fwd", 2097152, 128, 256), ("dgrad", 2097152, 128, 256), ("wgrad", 2097152, 128, 256),
-    ("fwd", 4194304, 64, 128), ("dgrad", 4194304, 64, 128), ("wgrad", 4194304, 64, 128),
-    ("fwd", 2097152, 128, 128), ("dgrad", 2097152, 128, 128), ("wgrad", 2097152, 128, 128),
-    ("fwd", 4194304, 64, 64), ("dgrad", 4194304, 64, 64), ("wgrad", 4194304, 64, 64),
+# (kernel-name fragment, total grid threads or None) -> bench.py key.  Template arguments:
+# gemm_ws_kernel<NT, AM, EM, KC, WAVES, EH, VAR>, wgrad_pc_kernel<TK, TN, AMODE, DMODE>
+KEYS = [
+    ("gemm_ws_kernel<4, 4, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128)"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", None, "pcops_mlp_gemm_fwd_pool(2097152, 128, 256, 64)"),
+    ("wgrad_pc_kernel<2, 4, 1, 4>", 256 * 512, "pcops_mlp_wgrad(2097152, 128, 256)"),
+    ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),
+    ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
+    ("gemm_ws_kernel<2, 2, 3, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad_xyz(4194304, 64, 64)"),
 ]
-KERNEL_OF = {"fwd": ("gemm_ws_kernel", "gemm_rt_kernel"), "dgrad": ("gemm_ws_kernel", "gemm_rt_kernel"),
-             "wgrad": ("wgrad_ws_kernel", "wgrad_kernel")}
-ABI = {"fwd": "pcops_mlp_gemm_fwd", "dgrad": "pcops_mlp_gemm_dgrad", "wgrad": "pcops_mlp_wgrad"}
 
 
-def one_pass(counter, kind, M, K, N):
+def one_pass(counter):
     d = os.path.join(OUT, "pmc_%s" % counter)
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
-           sys.executable, os.path.join(ROOT, "tools", "bench_gemm.py"), kind, "3", "--shape", str(M), str(K), str(N)]
-    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp")
-    vals = []
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp",
+                   env=dict(os.environ, TMPDIR="/tmp"))
+    agg = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in KERNEL_OF[kind]):
-                vals.append(float(r["Counter_Value"]))
-    return sum(vals) / len(vals) if vals else None
+            if r["Counter_Name"] == counter:
+                agg[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    fetch, nf = one_pass("FETCH_SIZE")
+    write, _ = one_pass("WRITE_SIZE")
     table, detail = {}, {}
-    for kind, M, K, N in CASES:
-        f, w = one_pass("FETCH_SIZE", kind, M, K, N), one_pass("WRITE_SIZE", kind, M, K, N)
-        if f is None or w is None:
-            continue
-        shape = (M, N, K) if kind == "dgrad" else (M, K, N)     # C-ABI order of pcops_mlp_gemm_dgrad: (M, K=N_l, Nout)
-        key = "%s%s" % (ABI[kind], shape)
-        table[key] = int((2.0 * f + w) * 1024)
-        detail[key] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_correction": 2.0}
-        print(key, "traffic %.3f GB (fetch raw %.3f GiB x2, write %.3f GiB)" % (table[key] / 1e9, f / 2**20, w / 2**20), flush=True)
+    for (name, grid), f in sorted(fetch.items(), key=lambda kv: -kv[1]):
+        w = write.get((name, grid), 0.0)
+        total = int((2.0 * f + w) * 1024)
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        detail["%s|grid=%d" % (short, grid)] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_correction": 2.0,
+                                                "bytes_per_launch": total, "launches": nf[(name, grid)]}
+        for frag, g, key in KEYS:
+            if frag in name and (g is None or g == grid) and key not in table:
+                table[key] = total
+                print("%-52s %7.3f GB per launch (fetch raw %.3f GiB x2, write %.3f GiB)" % (
+                    key, total / 1e9, f / 2 ** 20, w / 2 ** 20), flush=True)
     json.dump(table, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
     json.dump(detail, open(os.path.join(OUT, "pmc_traffic_detail.json"), "w"), indent=1)
 
