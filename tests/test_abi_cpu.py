@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu():
     assert lib.pcops_farthest_point_sample(1, 8, 0, None, None, None, None) == -3
     assert lib.pcops_knn_graph(1, 8, 3, 9, None, None, None) == -3          # k > n
     assert lib.pcops_farthest_point_sample_workspace_bytes(32, 2048) == 0
-    assert lib.pcops_mlp_stats_rows(4194304) == 4096 and lib.pcops_mlp_stats_rows(100) == 1
+    assert lib.pcops_mlp_stats_rows(4194304) == 512 and lib.pcops_mlp_stats_rows(100) == 1
 
 
 def test_no_cpu_fallback():
