@@ -156,6 +156,19 @@ def pointnet2_cls_bga(point_cloud, P, training):
     return class_pred, dense(net, P, "seg_fc2", training, use_bn=False, act=False)
 
 
+def pointnet2_cls_partseg(point_cloud, P, training):
+    """pointnet2/models/pointnet2_cls_partseg.py:20-45 -> seg_pred (B,N,6)"""
+    l0_xyz = point_cloud[:, :, :3]
+    l1_xyz, l1 = sa_module(l0_xyz, None, 512, 0.2, 64, [64, 64, 128], P, "layer1", training)
+    l2_xyz, l2 = sa_module(l1_xyz, l1, 128, 0.4, 64, [128, 128, 256], P, "layer2", training)
+    l3_xyz, l3 = sa_module(l2_xyz, l2, None, None, None, [256, 512, 1024], P, "layer3", training, group_all=True)
+    l2p = fp_module(l2_xyz, l3_xyz, l2, l3, [256, 256], P, "fa_layer1", training)
+    l1p = fp_module(l1_xyz, l2_xyz, l1, l2p, [256, 128], P, "fa_layer2", training)
+    l0p = fp_module(l0_xyz, l1_xyz, None, l1p, [128, 128, 128], P, "fa_layer3", training)
+    net = dense(l0p, P, "seg_fc1", training)
+    return dense(net, P, "seg_fc2", training, use_bn=False, act=False)
+
+
 # ------------------------------------------------------------------------------- DGCNN
 def _edge_features(x, k, nn=None):
     """dgcnn/utils/tf_util.py:638-706 via the fused oracle graph.  `nn` overrides the graph (tests feed

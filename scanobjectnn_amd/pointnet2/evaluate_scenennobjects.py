@@ -65,3 +65,23 @@ def eval_seg_one_epoch(net, data, labels, masks, batch_size, device="cuda:0"):
     acc, mean_class_acc, per_class = accuracy_summary(pred, lab)
     return {"accuracy": acc, "avg_class_acc": mean_class_acc, "per_class": per_class,
             "seg_accuracy": seg_correct / float(n_pts)}
+
+
+def eval_partseg_one_epoch(net, data, parts, batch_size, num_classes=6, device="cuda:0"):
+    """part segmentation (`train_partseg.py:251-303`, `evaluate_partseg.py`): point accuracy = correct points /
+    seen points; avg class acc = mean over the part classes that occur of (correct points of the class / points of it)"""
+    seen_c = np.zeros(num_classes, dtype=np.int64)
+    corr_c = np.zeros(num_classes, dtype=np.int64)
+    for b in range(data.shape[0] // batch_size):
+        sl = slice(b * batch_size, (b + 1) * batch_size)
+        pts = torch.as_tensor(data[sl], dtype=torch.float32, device=device)
+        pred = net(pts.contiguous(), is_training=False).argmax(dim=2).cpu().numpy()
+        gt = np.asarray(parts[sl])
+        for c in range(num_classes):
+            seen_c[c] += int((gt == c).sum())
+            corr_c[c] += int(((gt == c) & (pred == c)).sum())
+    occurs = seen_c > 0
+    per_class = np.where(occurs, corr_c / np.maximum(seen_c, 1), 0.0)
+    return {"accuracy": float(corr_c.sum()) / max(int(seen_c.sum()), 1),
+            "avg_class_acc": float(per_class[occurs].mean()) if occurs.any() else 0.0,
+            "per_class": per_class.tolist()}

@@ -108,3 +108,18 @@ def test_pointnet_cls_config1_cpu_plumbing():
     z = torch.zeros(2, 15)
     lab = torch.zeros(2, dtype=torch.long)
     assert torch.isclose(pointnet_cls.get_loss(z, lab, eye), torch.tensor(math.log(15.0)))
+
+
+def test_get_current_data_parts_keeps_points_and_part_labels_aligned():
+    """data_utils.get_current_data_parts_h5 (:212-229): the epoch's point subset is applied to the clouds AND the
+    per-point part labels, the cloud permutation to all three arrays"""
+    from scanobjectnn_amd import data_utils as DU
+    rng = np.random.RandomState(3)
+    pcs = rng.rand(5, 40, 3).astype(np.float32)
+    parts = (pcs[:, :, 0] * 6).astype(np.int32)             # label is a function of the point -> checkable after shuffling
+    labels = np.arange(5, dtype=np.int32)
+    cur, lab, prt = DU.get_current_data_parts_h5(pcs, labels, parts, 16, rng=np.random.RandomState(0))
+    assert cur.shape == (5, 16, 3) and prt.shape == (5, 16) and sorted(lab.tolist()) == [0, 1, 2, 3, 4]
+    assert np.array_equal(prt, (cur[:, :, 0] * 6).astype(np.int32))
+    for row, l in enumerate(lab):                            # every sampled point belongs to the cloud its label names
+        assert all(any(np.array_equal(pt, q) for q in pcs[l]) for pt in cur[row])

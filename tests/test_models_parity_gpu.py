@@ -89,6 +89,25 @@ def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     assert (seg.cpu().double() - ws).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("training", [False, True])
+def test_pointnet2_partseg_logits(training, monkeypatch):
+    """pointnet2_cls_partseg: the SA + FP stacks with the global feature propagated from the single l3
+    point; per-point part logits against the float64 restatement"""
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_partseg as m
+    _no_dropout(monkeypatch)
+    c = synth_clouds(16, 1024, seed=9)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(m.get_model, device=DEV, seed=4).build(x)
+    _randomise(net, 10)
+    P = R.params_from_state_dict(net.state_dict(), dtype=torch.float64)
+    with torch.no_grad():
+        seg = net(x, is_training=training, bn_decay=0.9)
+        want = R.pointnet2_cls_partseg(torch.from_numpy(c).double(), P, training)
+    assert seg.shape == (16, 1024, 6)
+    tol = 2.5e-4 if training else TOL          # same allowance as the BGA mask branch with batch statistics
+    assert (seg.cpu().double() - want).abs().max().item() <= tol
+
+
 def test_pointnet2_ssg_training_gradients(monkeypatch):
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg as m
     _no_dropout(monkeypatch)
