@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
 // issues 16 TK TN MFMAs (64 cycles each) while the producers need a few hundred VALU cycles: the kernel is MFMA
 // bound for K >= 128 and HBM bound for the 64-wide layers.
 template <int TK, int TN, int AMODE, int DMODE>
-__global__ __launch_bounds__(512, 1) void wgrad_pc_kernel(WgradArgs a) {
+__global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(WgradArgs a) {
     constexpr int KB = 64 * TK, NB = 64 * TN, LD = KB + NB;
     // rows per stripe: the small tiles get longer stripes (fewer barriers) unless the pooled form wants stripes that
     // stay inside one 32-row-aligned group
@@ -1796,7 +1796,9 @@ static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, con
     const int KB = 64 * pl->tk, NB = 64 * pl->tn;
     pl->kblocks = (K + KB - 1) / KB;
     pl->nblocks = (N + NB - 1) / NB;
-    int groups = 256 / (pl->kblocks * pl->nblocks);    // one persistent workgroup per CU over the whole grid
+    // one persistent workgroup per CU over the whole grid; two for the 64x64 tile (its LDS and register footprints
+    // allow it, and one workgroup's stripe barrier then hides under the other's MFMAs; measured slower for 64x128)
+    int groups = (pl->tk * pl->tn == 1 ? 512 : 256) / (pl->kblocks * pl->nblocks);
     if (groups < 1) groups = 1;
     const long long maxg = (M + 31) / 32;
     if (groups > maxg) groups = (int)maxg;
