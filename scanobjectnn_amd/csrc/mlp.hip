@@ -97,6 +97,7 @@ struct GemmArgs {
     const float *msc;    // E_MASK: bn scale / shift of the previous layer
     const float *msh;
     float *stats;        // [gridDim.y][2][N] partial column sums (null: none)
+    int nrowgrp;         // wave-stream kernel: row groups that own tiles; workgroups beyond only zero their statistics row
     // fused neighbourhood pooling of the RAW outputs (forward, wave-stream kernel only): BN+ReLU is monotone per
     // channel -- increasing for gamma >= 0, decreasing otherwise (scale = gamma * rstd) -- so per group of
     // 32*pool_sub rows the pooled activation is relu(scale * ysel + shift) with ysel the max (gamma >= 0) or min
@@ -396,7 +397,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // grid = (row groups, column blocks): the column blocks of one row group have linear ids that differ by a
     // multiple of 8, i.e. they run on the SAME XCD and the second reader of a stripe hits that XCD's L2
     const int n0 = blockIdx.y * BN;
-    const int rowgrp = blockIdx.x, nrowgrp = gridDim.x;
+    const int rowgrp = blockIdx.x, nrowgrp = a.nrowgrp;
+    if (rowgrp >= nrowgrp) {
+        // padding workgroup: the statistics buffer has a fixed number of partial rows (pcops_mlp_stats_rows), the rows
+        // no tile owner writes are zeroed here instead of by a separate memset launch
+        if (EM != E_PLAIN && a.stats)
+            for (int i = tid; i < 2 * BN; i += NTHR)
+                if (n0 + i % BN < N) a.stats[((long long)rowgrp * 2 + i / BN) * N + n0 + i % BN] = 0.f;
+        return;
+    }
 
     // ---- streamed weights: KC x BN chunk = WPT float4 per thread, global (L2) -> registers -> LDS buffer
     constexpr int WPT = (KC * (BN / 4) + NTHR - 1) / NTHR;
@@ -871,7 +880,9 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
             return PCOPS_ERR_LAUNCH;                                                                  \
-        hipLaunchKernelGGL(kern, dim3(pl.gy, pl.ncb), dim3(512), pl.lds, st, a);                      \
+        a.nrowgrp = pl.gy;                                                                            \
+        const int P_ = (a.stats && EM != E_PLAIN) ? pcops_mlp_stats_rows(a.M) : 0;                    \
+        hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
     else PCOPS_WS_LAUNCH(2, 1);
@@ -898,12 +909,6 @@ int launch_gemm(GemmArgs &a, hipStream_t st) {
         int rc;
         if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
         else rc = launch_gemm_ws<AM, EM>(a, pl, st);
-        if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
-            const int P = pcops_mlp_stats_rows(a.M);
-            if (pl.gy < P && hipMemsetAsync(a.stats + (size_t)pl.gy * 2 * a.N, 0,
-                                            sizeof(float) * (size_t)(P - pl.gy) * 2 * a.N, st) != hipSuccess)
-                return PCOPS_ERR_LAUNCH;
-        }
         return rc;
     }
     return launch_gemm_rt<AM, EM>(a, st);
@@ -1861,11 +1866,11 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, c
 }
 
 // two adjacent reductions in one launch: blocks [0, ceil(L/64)) sum part -> out, the rest sum part2 -> out2
-__global__ __launch_bounds__(256) void sum_partials2_kernel(int P, long long L, const float *__restrict__ part,
-                                                            float *__restrict__ out, long long L2,
-                                                            const float *__restrict__ part2,
-                                                            float *__restrict__ out2) {
-    __shared__ double sm[4][64];
+__global__ __launch_bounds__(1024) void sum_partials2_kernel(int P, long long L, const float *__restrict__ part,
+                                                             float *__restrict__ out, long long L2,
+                                                             const float *__restrict__ part2,
+                                                             float *__restrict__ out2) {
+    __shared__ double sm[16][64];
     const long long nb1 = (L + 63) / 64;
     const bool second = (long long)blockIdx.x >= nb1;
     const long long len = second ? L2 : L;
@@ -1875,10 +1880,15 @@ __global__ __launch_bounds__(256) void sum_partials2_kernel(int P, long long L, 
     const long long i = ((long long)blockIdx.x - (second ? nb1 : 0)) * 64 + c;
     double s = 0.0;
     if (i < len)
-        for (int p = pl; p < P; p += 4) s += (double)src[(long long)p * len + i];
+        for (int p = pl; p < P; p += 16) s += (double)src[(long long)p * len + i];
     sm[pl][c] = s;
     __syncthreads();
-    if (pl == 0 && i < len) dst[i] = (float)((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+    if (pl == 0 && i < len) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][c];
+        dst[i] = (float)t;
+    }
 }
 
 // Wt[n][k] = W[k][n]
@@ -1895,17 +1905,17 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
 }
 
 // few partial rows (P <= kFusedRows): column reduction and the per-channel finalisation in ONE launch.
-// block = 32 columns x 8 row lanes; the row-lane totals meet in LDS in a fixed order (deterministic)
+// block = 32 columns x 32 row lanes; the row-lane totals meet in LDS in a fixed order (deterministic)
 constexpr int kFusedRows = 1024;
 
 __device__ __forceinline__ bool fused_col_sums(int P, int N, const float *__restrict__ part, double &s1, double &s2,
                                                int &c) {
-    __shared__ double sm[2][8][32];
+    __shared__ double sm[2][32][32];
     c = blockIdx.x * 32 + (threadIdx.x & 31);
     const int g = threadIdx.x >> 5;
     double a1 = 0.0, a2 = 0.0;
     if (c < N)
-        for (int p = g; p < P; p += 8) {
+        for (int p = g; p < P; p += 32) {
             a1 += (double)part[((long long)p * 2 + 0) * N + c];
             a2 += (double)part[((long long)p * 2 + 1) * N + c];
         }
@@ -1915,11 +1925,11 @@ __device__ __forceinline__ bool fused_col_sums(int P, int N, const float *__rest
     if (g != 0 || c >= N) return false;
     s1 = s2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1 += sm[0][i][threadIdx.x]; s2 += sm[1][i][threadIdx.x]; }
+    for (int i = 0; i < 32; ++i) { s1 += sm[0][i][threadIdx.x]; s2 += sm[1][i][threadIdx.x]; }
     return true;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(int P, int N, double R, const float *__restrict__ part,
+__global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(int P, int N, double R, const float *__restrict__ part,
                                                                 const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, float eps,
                                                                 float decay, int unbiased,
@@ -1948,7 +1958,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fused_kernel(int P, int N, do
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_coeffs_fused_kernel(int P, int N, double R,
+__global__ __launch_bounds__(1024) void bn_bwd_coeffs_fused_kernel(int P, int N, double R,
                                                                   const float *__restrict__ part,
                                                                   const float *__restrict__ gamma,
                                                                   const float *__restrict__ mean,
@@ -1987,12 +1997,6 @@ static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     int rc;
     if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
     else rc = launch_gemm_ws<AM, EM>(a, pl, st);
-    if (rc == PCOPS_OK && a.stats && EM != E_PLAIN) {
-        const int P = pcops_mlp_stats_rows(a.M);
-        if (pl.gy < P && hipMemsetAsync(a.stats + (size_t)pl.gy * 2 * a.N, 0,
-                                        sizeof(float) * (size_t)(P - pl.gy) * 2 * a.N, st) != hipSuccess)
-            return PCOPS_ERR_LAUNCH;
-    }
     return rc;
 }
 
@@ -2078,7 +2082,7 @@ int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial,
     PCOPS_REQUIRE_ARG((moving_mean == nullptr) == (moving_var == nullptr));
     hipStream_t st = as_stream(stream);
     if (P <= kFusedRows) {
-        hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((N + 31) / 32), dim3(256), 0, st, P, N, (double)R,
+        hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, P, N, (double)R,
                            stats_partial, gamma, beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean,
                            rstd, scale, shift);
         return pcops_launch_status();
@@ -2170,7 +2174,7 @@ int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partia
     PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     hipStream_t st = as_stream(stream);
     if (P <= kFusedRows) {
-        hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3((N + 31) / 32), dim3(256), 0, st, P, N, (double)R,
+        hipLaunchKernelGGL(bn_bwd_coeffs_fused_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, P, N, (double)R,
                            stats_partial, gamma, mean, rstd, dgamma, dbeta, p, q, t);
         return pcops_launch_status();
     }
@@ -2374,7 +2378,7 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     if (rc) return rc;
     // dW and db partials are adjacent ([splits][K*N] then [splits][N]): one launch sums both
     const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(256), 0, st, splits, L,
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, splits, L,
                        partial, dW, (long long)N, a.dbpart, db);
     return pcops_launch_status();
 }
