@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const int *__restrict__ idx, float *__restrict__ Y,
                                                             float *__restrict__ off4, float *__restrict__ stats,
                                                             int groups_per_block) {
-    extern __shared__ float sm[];  // [RL][2][C]
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [RL][2][C] statistics scratch | staged rows
     const int c4n = C / 4;
     const int RL = 256 / c4n;
     const int cq = (threadIdx.x % c4n) * 4, rl = threadIdx.x / c4n;
@@ -63,34 +63,50 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
         w2 = *reinterpret_cast<const float4 *>(Wxyz + 2 * C + cq);
     }
     if (bias) bb = *reinterpret_cast<const float4 *>(bias + cq);
-    if (rl < RL) {
-        for (long long g = g0; g < g1; ++g) {
+    // rows are staged first, ONE thread per grouped row: index + centred offsets go to LDS (and to off4), so the
+    // C/4 lanes that then share a row read them as an LDS broadcast instead of each issuing its own global loads
+    float4 *st4 = reinterpret_cast<float4 *>(sm + RL * 2 * C);        // (dx, dy, dz, index bits) per staged row
+    const int gch = S >= 1024 ? 1 : 1024 / S;                         // groups per staging chunk
+    for (long long gb = g0; gb < g1; gb += gch) {
+        const long long ge = min(g1, gb + gch);
+        const int nrows = (int)(ge - gb) * S;
+        for (int t = threadIdx.x; t < nrows; t += 256) {
+            const long long r = gb * S + t;
+            const long long g = gb + t / S;
             const long long b = g / m;
-            float4 ctr = bb;
-            if (Ctr) {
-                const float4 c4 = *reinterpret_cast<const float4 *>(Ctr + g * C + cq);
-                ctr.x += c4.x; ctr.y += c4.y; ctr.z += c4.z; ctr.w += c4.w;
+            const int i = idx[r];
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (Wxyz) {
+                const float *px = xyz + (b * n + i) * 3;
+                dx = px[0] - new_xyz[g * 3 + 0]; dy = px[1] - new_xyz[g * 3 + 1]; dz = px[2] - new_xyz[g * 3 + 2];
             }
-            float cx = 0.f, cy = 0.f, cz = 0.f;
-            if (Wxyz) { cx = new_xyz[g * 3 + 0]; cy = new_xyz[g * 3 + 1]; cz = new_xyz[g * 3 + 2]; }
-            for (int s = rl; s < S; s += RL) {
-                const long long r = g * S + s;
-                const int i = idx[r];
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (Q) q = *reinterpret_cast<const float4 *>(Q + (b * n + i) * (long long)C + cq);
-                float dx = 0.f, dy = 0.f, dz = 0.f;
-                if (Wxyz) {
-                    const float *px = xyz + (b * n + i) * 3;
-                    dx = px[0] - cx; dy = px[1] - cy; dz = px[2] - cz;
+            st4[t] = make_float4(dx, dy, dz, __int_as_float(i));
+            if (off4) *reinterpret_cast<float4 *>(off4 + r * 4) = make_float4(dx, dy, dz, 0.f);
+        }
+        __syncthreads();
+        if (rl < RL) {
+            for (long long g = gb; g < ge; ++g) {
+                const long long b = g / m;
+                float4 ctr = bb;
+                if (Ctr) {
+                    const float4 c4 = *reinterpret_cast<const float4 *>(Ctr + g * C + cq);
+                    ctr.x += c4.x; ctr.y += c4.y; ctr.z += c4.z; ctr.w += c4.w;
                 }
-                const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, dx, dy, dz, w0, w1, w2);
-                if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
-                if (off4 && cq == 0) *reinterpret_cast<float4 *>(off4 + r * 4) = make_float4(dx, dy, dz, 0.f);
-                s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
-                s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
-                s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+                const float4 *sg = st4 + (g - gb) * S;
+                for (int s = rl; s < S; s += RL) {
+                    const long long r = g * S + s;
+                    const float4 e = sg[s];
+                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (Q) q = *reinterpret_cast<const float4 *>(Q + (b * n + __float_as_int(e.w)) * (long long)C + cq);
+                    const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, e.x, e.y, e.z, w0, w1, w2);
+                    if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
+                    s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
+                    s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
+                    s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+                }
             }
         }
+        __syncthreads();
     }
     if (stats == nullptr) return;
     if (rl < RL)
@@ -662,8 +678,10 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
     if (off4) PCOPS_REQUIRE_PTR(Wxyz);
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     const int rl = 256 / (c / 4);
+    const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
+    if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
-                       (size_t)rl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
+                       ((size_t)rl * 2 * c + staged) * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
                        Wxyz, bias, idx, Y, off4, stats_partial, gather_groups_per_block(G));
     return pcops_launch_status();
 }
