@@ -81,7 +81,7 @@ def _algo(name, a):
         return 4 * (4 * M + M * N), 2 * M * K * N, "flop"
     if name == "pcops_mlp_gemm_dgrad_xyz":    # reads G?, Y (K wide) + 16 bytes per row; writes Gprev
         M, K, Nout = a[:3]
-        return 4 * ((1 if a[3] is None else 2) * M * K + 4 * M + M * Nout), 2 * M * K * Nout, "flop"
+        return 4 * ((1 if a[3] is None else 2) * M * K + 4 * M + (M * Nout if a[18] is not None else 0)), 2 * M * K * Nout, "flop"
     if name == "pcops_mlp_wgrad_xyz":         # reads 16 bytes per row + G?, Y
         M, K, N = a[:3]
         return 4 * (4 * M + (1 if a[7] is None else 2) * M * N), 2 * M * K * N, "flop"
@@ -127,7 +127,7 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_sa_gather_fwd": 5, "pcops_sa_scatter_bwd": 5, "pcops_mlp_bn_finalize": 3,
            "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
            "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
-           "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2}
+           "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1}
 
 
 class KernelTimer:

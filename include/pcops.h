@@ -209,7 +209,12 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
  * would read it -- as the forward operand, as the weight gradient's A side, and in the data gradient's ReLU mask and
  * BN-backward statistics -- so the (rows, C1) first-layer tensor never exists.  Same arguments as the plain
  * functions otherwise.  Wave-stream shapes only: check pcops_mlp_xyz_supported(M, C1, N2) first
- * (PCOPS_ERR_UNSUPPORTED otherwise). */
+ * (PCOPS_ERR_UNSUPPORTED otherwise).
+ * pcops_mlp_gemm_dgrad_xyz: xyz_stats (may be NULL) = float [pcops_mlp_stats_rows(M)][3][Nout] partial sums of
+ * off[row][i] * Gprev[row][c].  The first layer's gradients are LINEAR in a handful of such sums,
+ *   dWxyz[i][c] = p[c] A[i][c] + q[c] B[i][c] + t[c] S[i],   dbias[c] = p[c] sumG[c] + q[c] sumY[c] + t[c] rows
+ * (A = these sums, sumG / sumGY = stats_partial, B = M33 Wxyz + S^T b and S from the offset moments the forward
+ * gather emits), so with xyz_stats Gprev may be NULL: the (rows, C1) gradient is neither written nor scattered. */
 int pcops_mlp_xyz_supported(int M, int C1, int N2);
 int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                            const float *pro_shift, const float *W, const float *bias, float *Y,
@@ -218,7 +223,8 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                              int S, const float *pool_scale, const float *pool_shift, const float *Wt,
                              const float *off4, const float *xyzw, const float *prev_scale,
-                             const float *prev_shift, float *Gprev, float *stats_partial, pcops_stream_t stream);
+                             const float *prev_shift, float *Gprev, float *stats_partial, float *xyz_stats,
+                             pcops_stream_t stream);
 int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
                         const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
                         const float *t, const float *gpool, const unsigned char *argmax, int S,
@@ -235,11 +241,13 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
  * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y).
  * Y may be NULL (statistics only) and off4 (may be NULL; needs the coordinate term) receives the centred offsets
  * (dx, dy, dz, 0) per grouped row, float [b*m*s][4]: when the layer has NO Q / Ctr term it is arithmetic in those
- * three numbers, and the pcops_mlp_*_xyz entry points rebuild it on the fly instead of reading a (b,m,s,c) tensor. */
+ * three numbers, and the pcops_mlp_*_xyz entry points rebuild it on the fly instead of reading a (b,m,s,c) tensor.
+ * moments (may be NULL; needs the coordinate term): float [pcops_sa_gather_stats_rows(b*m)][9] partial sums of
+ * (dx dx, dx dy, dx dz, dy dy, dy dz, dz dz, dx, dy, dz) -- see pcops_mlp_gemm_dgrad_xyz. */
 int pcops_sa_gather_stats_rows(long long groups);
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *off4, float *stats_partial, pcops_stream_t stream);
+                        float *off4, float *stats_partial, float *moments, pcops_stream_t stream);
 /* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
  * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
  * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.
@@ -260,6 +268,14 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
                          float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
                          const float *fwd_bias, void *workspace, pcops_stream_t stream);
+
+/* dWxyz (3,c) and dbias (c, may be NULL) of an arithmetic first layer from the sums described at
+ * pcops_mlp_gemm_dgrad_xyz: xyz_stats [P1][3][c], moments [P2][9] (pcops_sa_gather_fwd), p/q/t and sumG (= dbeta) from
+ * pcops_mlp_bn_bwd_coeffs, mean from pcops_mlp_bn_finalize, rows = b*m*s. */
+int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const float *moments, int C,
+                                const float *Wxyz, const float *bias, const float *p, const float *q, const float *t,
+                                const float *sumG, const float *mean, long long rows, float *dWxyz, float *dbias,
+                                pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -45,10 +45,11 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
-    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
+    "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
 }
 PLAIN = {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ bias,
                                                             const int *__restrict__ idx, float *__restrict__ Y,
                                                             float *__restrict__ off4, float *__restrict__ stats,
-                                                            int groups_per_block) {
+                                                            float *__restrict__ moments, int groups_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [RL][2][C] statistics scratch | staged rows
     const int c4n = C / 4;
     const int RL = 256 / c4n;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
     // C/4 lanes that then share a row read them as an LDS broadcast instead of each issuing its own global loads
     float4 *st4 = reinterpret_cast<float4 *>(sm + RL * 2 * C);        // (dx, dy, dz, index bits) per staged row
     const int gch = S >= 1024 ? 1 : 1024 / S;                         // groups per staging chunk
+    float mo[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // offset moments: xx xy xz yy yz zz | x y z
     for (long long gb = g0; gb < g1; gb += gch) {
         const long long ge = min(g1, gb + gch);
         const int nrows = (int)(ge - gb) * S;
@@ -82,6 +83,11 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
             }
             st4[t] = make_float4(dx, dy, dz, __int_as_float(i));
             if (off4) *reinterpret_cast<float4 *>(off4 + r * 4) = make_float4(dx, dy, dz, 0.f);
+            if (moments) {
+                mo[0] = fmaf(dx, dx, mo[0]); mo[1] = fmaf(dx, dy, mo[1]); mo[2] = fmaf(dx, dz, mo[2]);
+                mo[3] = fmaf(dy, dy, mo[3]); mo[4] = fmaf(dy, dz, mo[4]); mo[5] = fmaf(dz, dz, mo[5]);
+                mo[6] += dx; mo[7] += dy; mo[8] += dz;
+            }
         }
         __syncthreads();
         if (rl < RL) {
@@ -105,6 +111,18 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                     s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
                 }
             }
+        }
+        __syncthreads();
+    }
+    if (moments) {          // block sums of the nine offset moments (the staging area is free again)
+        float *mm = reinterpret_cast<float *>(st4);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mm[k * 256 + threadIdx.x] = mo[k];
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            float t = 0.f;
+            for (int j = 0; j < 256; ++j) t += mm[threadIdx.x * 256 + j];
+            moments[(long long)blockIdx.x * 9 + threadIdx.x] = t;
         }
         __syncthreads();
     }
@@ -613,6 +631,63 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
 
 constexpr int kCsrGrid = 1024;      // persistent workgroups of the gather pass (= rows of its wpart)
 
+// gradients of an ARITHMETIC first layer from a handful of sums (see pcops_mlp_gemm_dgrad_xyz in pcops.h):
+//   dWxyz[i][c] = p[c] A[i][c] + q[c] B[i][c] + t[c] S[i],   B = M33 Wxyz + S^T b,   dbias[c] = p sumG + q sumY + t rows
+// block = 32 channels x 32 row lanes; all sums in double, fixed order
+__global__ __launch_bounds__(1024) void xyz_first_layer_grads_kernel(int P1, const float *__restrict__ xstats, int P2,
+                                                                     const float *__restrict__ moments, int C,
+                                                                     const float *__restrict__ Wxyz,
+                                                                     const float *__restrict__ bias,
+                                                                     const float *__restrict__ p,
+                                                                     const float *__restrict__ q,
+                                                                     const float *__restrict__ t,
+                                                                     const float *__restrict__ sumG,
+                                                                     const float *__restrict__ mean, double rows,
+                                                                     float *__restrict__ dWxyz,
+                                                                     float *__restrict__ dbias) {
+    __shared__ double smA[3][32][32];
+    __shared__ double smM[9][112];
+    __shared__ double mom[9];
+    const int tid = threadIdx.x, cl = tid & 31, g = tid >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    // offset moments: 9 sums over P2 partial rows; thread = (row lane l < 112, moment k) reads element r*9 + k, so a
+    // wave reads consecutive floats
+    if (tid < 9 * 112) {
+        const int l = tid / 9, k = tid % 9;
+        double a = 0.0;
+        for (int r = l; r < P2; r += 112) a += (double)moments[(long long)r * 9 + k];
+        smM[k][l] = a;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int r = g; r < P1; r += 32) {
+            a0 += (double)xstats[((long long)r * 3 + 0) * C + c];
+            a1 += (double)xstats[((long long)r * 3 + 1) * C + c];
+            a2 += (double)xstats[((long long)r * 3 + 2) * C + c];
+        }
+    smA[0][g][cl] = a0; smA[1][g][cl] = a1; smA[2][g][cl] = a2;
+    __syncthreads();
+    if (tid < 9) {
+        double a = 0.0;
+        for (int l = 0; l < 112; ++l) a += smM[tid][l];
+        mom[tid] = a;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    double A[3] = {0.0, 0.0, 0.0};
+    for (int l = 0; l < 32; ++l) { A[0] += smA[0][l][cl]; A[1] += smA[1][l][cl]; A[2] += smA[2][l][cl]; }
+    const double M33[3][3] = {{mom[0], mom[1], mom[2]}, {mom[1], mom[3], mom[4]}, {mom[2], mom[4], mom[5]}};
+    const double S[3] = {mom[6], mom[7], mom[8]};
+    const double w[3] = {(double)Wxyz[0 * C + c], (double)Wxyz[1 * C + c], (double)Wxyz[2 * C + c]};
+    const double b = bias ? (double)bias[c] : 0.0;
+    const double pc = p[c], qc = q[c], tc = t[c];
+    for (int i = 0; i < 3; ++i) {
+        const double B = M33[i][0] * w[0] + M33[i][1] * w[1] + M33[i][2] * w[2] + S[i] * b;
+        dWxyz[i * C + c] = (float)(pc * A[i] + qc * B + tc * S[i]);
+    }
+    if (dbias) dbias[c] = (float)(pc * (double)sumG[c] + qc * ((double)mean[c] * rows) + tc * rows);
+}
+
 // out[L] = sum_p part[p][L] in double (deterministic)
 __global__ __launch_bounds__(256) void sum_rows_kernel(int P, int L, const float *__restrict__ part,
                                                        float *__restrict__ out) {
@@ -667,7 +742,7 @@ unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) 
 
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *off4, float *stats_partial, pcops_stream_t stream) {
+                        float *off4, float *stats_partial, float *moments, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
     PCOPS_REQUIRE_SHAPE(c <= 1024 && 256 % (c / 4) == 0);
     const long long G = (long long)b * m;
@@ -675,14 +750,14 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
     PCOPS_REQUIRE_PTR(idx);
     PCOPS_REQUIRE_ARG(Y != nullptr || stats_partial != nullptr || off4 != nullptr);
     PCOPS_REQUIRE_ARG(Q != nullptr || Wxyz != nullptr);
-    if (off4) PCOPS_REQUIRE_PTR(Wxyz);
+    if (off4 || moments) PCOPS_REQUIRE_PTR(Wxyz);
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     const int rl = 256 / (c / 4);
     const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        ((size_t)rl * 2 * c + staged) * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
-                       Wxyz, bias, idx, Y, off4, stats_partial, gather_groups_per_block(G));
+                       Wxyz, bias, idx, Y, off4, stats_partial, moments, gather_groups_per_block(G));
     return pcops_launch_status();
 }
 
@@ -845,6 +920,18 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         rc = pcops_launch_status();
     }
     return rc;
+}
+
+int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const float *moments, int C,
+                                const float *Wxyz, const float *bias, const float *p, const float *q, const float *t,
+                                const float *sumG, const float *mean, long long rows, float *dWxyz, float *dbias,
+                                pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(P1 >= 1 && P2 >= 1 && C >= 1 && rows >= 1);
+    PCOPS_REQUIRE_PTR(xyz_stats); PCOPS_REQUIRE_PTR(moments); PCOPS_REQUIRE_PTR(Wxyz); PCOPS_REQUIRE_PTR(p);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(sumG); PCOPS_REQUIRE_PTR(mean); PCOPS_REQUIRE_PTR(dWxyz);
+    hipLaunchKernelGGL(xyz_first_layer_grads_kernel, dim3((C + 31) / 32), dim3(1024), 0, as_stream(stream), P1,
+                       xyz_stats, P2, moments, C, Wxyz, bias, p, q, t, sumG, mean, (double)rows, dWxyz, dbias);
+    return pcops_launch_status();
 }
 
 }  // extern "C"

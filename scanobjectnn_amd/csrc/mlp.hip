@@ -98,6 +98,8 @@ struct GemmArgs {
     const float *msh;
     float *stats;        // [gridDim.y][2][N] partial column sums (null: none)
     int nrowgrp;         // wave-stream kernel: row groups that own tiles; workgroups beyond only zero their statistics row
+    float *xstats;       // E_MASKX: [rows of stats][3][N] partial sums of off (x) Gprev -- with them the arithmetic first
+                         // layer's weight gradient needs neither Gprev nor a pass over it (Y may then be NULL)
     // fused neighbourhood pooling of the RAW outputs (forward, wave-stream kernel only): BN+ReLU is monotone per
     // channel -- increasing for gamma >= 0, decreasing otherwise (scale = gamma * rstd) -- so per group of
     // 32*pool_sub rows the pooled activation is relu(scale * ysel + shift) with ysel the max (gamma >= 0) or min
@@ -404,6 +406,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         if (EM != E_PLAIN && a.stats)
             for (int i = tid; i < 2 * BN; i += NTHR)
                 if (n0 + i % BN < N) a.stats[((long long)rowgrp * 2 + i / BN) * N + n0 + i % BN] = 0.f;
+        if (EM == E_MASKX && a.xstats)
+            for (int i = tid; i < 3 * BN; i += NTHR)
+                if (n0 + i % BN < N) a.xstats[((long long)rowgrp * 3 + i / BN) * N + n0 + i % BN] = 0.f;
         return;
     }
 
@@ -478,10 +483,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     __syncthreads();
 
     float s1[EH][4], s2[EH][4];                      // statistics of this lane's 4 columns, per epilogue pass
+    float sx[(EM == E_MASKX) ? EH : 1][3][4];        // E_MASKX: sums of offset (x) masked gradient
 #pragma unroll
     for (int h = 0; h < EH; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[h][e] = s2[h][e] = 0.f;
+#pragma unroll
+    for (int h = 0; h < ((EM == E_MASKX) ? EH : 1); ++h)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sx[h][i][e] = 0.f;
     const int ocl = (lane % O4) * 4;                 // column quad inside a pass (fixed: 64 % O4 == 0)
 
     const long long ntiles = ((long long)M + 31) / 32;
@@ -678,6 +690,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             const bool ocin = n0 + ocq < N;                  // N % 4 == 0 (launcher)
             const unsigned yvoff = ocin ? (unsigned)((lane / O4) * a.ldy + n0 + ocq) * 4u : kOOB;
             float4 py[is_mask(EM) ? NST : 1];
+            float4 po[(EM == E_MASKX) ? NST : 1];
             if (EM == E_MASKX) {   // the previous layer's raw output rebuilt from the row offsets
                 const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, ((long long)M - row0) * 16);
                 const float4 xw0 = *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq]);
@@ -687,6 +700,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
                 for (int j = 0; j < NST; ++j) {
                     const float4 o = buf_load4(ro, (unsigned)(lane / O4) * 16u, (unsigned)j * (64 / O4) * 16u);
+                    po[j] = o;
                     py[j] = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
                                         xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
                 }
@@ -734,9 +748,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         s1[h][0] += o.x; s1[h][1] += o.y; s1[h][2] += o.z; s1[h][3] += o.w;
                         s2[h][0] = fmaf(o.x, yp.x, s2[h][0]); s2[h][1] = fmaf(o.y, yp.y, s2[h][1]);
                         s2[h][2] = fmaf(o.z, yp.z, s2[h][2]); s2[h][3] = fmaf(o.w, yp.w, s2[h][3]);
+                        if (EM == E_MASKX) {
+                            const float4 of = po[j];
+                            const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                sx[h][0][e] = fmaf(of.x, ov[e], sx[h][0][e]);
+                                sx[h][1][e] = fmaf(of.y, ov[e], sx[h][1][e]);
+                                sx[h][2][e] = fmaf(of.z, ov[e], sx[h][2][e]);
+                            }
+                        }
                     }
                 }
-                buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
+                if (EM != E_MASKX || a.Y)
+                    buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (POOL && sub == SUB - 1) {
@@ -797,6 +822,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
                 for (int w = 0; w < WAVES; ++w) v += red[(w * 2 + which) * BN + c];
                 a.stats[((long long)rowgrp * 2 + which) * N + n0 + c] = v;
+            }
+        }
+    }
+    if (EM == E_MASKX && a.xstats) {
+        // the three offset sums go through the same scratch, one at a time
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < EH; ++h) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = sx[h][i][e];
+#pragma unroll
+                    for (int off = 32; off >= O4; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (lane < O4) red[wave * BN + h * BNH + ocl + e] = v;
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NTHR) {
+                if (n0 + c < N) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) v += red[w * BN + c];
+                    a.xstats[((long long)rowgrp * 3 + i) * N + n0 + c] = v;
+                }
             }
         }
     }
@@ -2251,10 +2302,13 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                              int S, const float *pool_scale, const float *pool_shift, const float *Wt,
                              const float *off4, const float *xyzw, const float *prev_scale,
-                             const float *prev_shift, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+                             const float *prev_shift, float *Gprev, float *stats_partial, float *xyz_stats,
+                             pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && Nout >= 1);
     PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
-    PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(Gprev); PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw);
+    PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw);
+    PCOPS_REQUIRE_ARG(Gprev != nullptr || xyz_stats != nullptr);
+    if (xyz_stats) PCOPS_REQUIRE_PTR(stats_partial);
     PCOPS_REQUIRE_PTR(prev_scale); PCOPS_REQUIRE_PTR(prev_shift);
     if (reinterpret_cast<uintptr_t>(off4) & 15) return PCOPS_ERR_UNSUPPORTED;
     GemmArgs a = {};
@@ -2262,7 +2316,7 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
     a.v3 = pool_scale; a.v4 = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     a.W = Wt; a.Y = Gprev; a.ldy = Nout; a.msc = prev_scale; a.msh = prev_shift;
     a.off4 = off4; a.xw = xyzw; a.xw_ld = Nout;
-    a.stats = stats_partial;
+    a.stats = stats_partial; a.xstats = xyz_stats;
     hipStream_t st = as_stream(stream);
     if (gpool) {
         PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);

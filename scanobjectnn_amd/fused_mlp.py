@@ -79,9 +79,10 @@ class FusedMLPStack(torch.autograd.Function):
         # next layer and the whole backward rebuild it from off4 (16 bytes per row instead of 4 C1)
         virt = (gather and a0 is None and ctr is None and wxyz is not None and (L >= 3 or (L == 2 and not pool))
                 and bool(lib.pcops_mlp_xyz_supported(R, C1, layers[1][0].shape[-1])))
-        off4 = xyzw = None
+        off4 = xyzw = mom = None
         if virt:
             off4 = _f32((R, 4), dev)
+            mom = _f32((lib.pcops_sa_gather_stats_rows(B * M), 9), dev) if training else None
             xyzw = torch.cat([wxyz.detach(), (bias.detach() if bias is not None
                                               else torch.zeros(C1, dtype=torch.float32, device=dev)).view(1, C1)]).contiguous()
         for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
@@ -91,7 +92,7 @@ class FusedMLPStack(torch.autograd.Function):
                 P = lib.pcops_sa_gather_stats_rows(B * M)
                 part = _f32((P, 2, N), dev) if training else None
                 _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
-                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part))
+                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), _p(mom))
                 W2 = None
             else:
                 N = w.shape[-1]
@@ -151,7 +152,7 @@ class FusedMLPStack(torch.autograd.Function):
                       shifts[-1].data_ptr(), out.data_ptr())
         if training:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
-                         [l[2] for l in layers], argmax, ysel, off4, xyzw)
+                         [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
             ctx.meta = (S, pool, L, R, K0, gather)
         return out
 
@@ -159,7 +160,8 @@ class FusedMLPStack(torch.autograd.Function):
     def backward(ctx, grad_out):
         lib = _lib.load()
         (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws, gammas, argmax, ysel, off4,
-         xyzw) = ctx.saved
+         xyzw, mom) = ctx.saved
+        xstats = None
         virt = off4 is not None
         widths = [g.shape[0] for g in gammas]
         S, pool, L, R, K0, gather = ctx.meta
@@ -200,8 +202,16 @@ class FusedMLPStack(torch.autograd.Function):
             am = argmax.data_ptr() if pooled else None
             psc = scales[l].data_ptr() if pooled else None
             psh = shifts[l].data_ptr() if pooled else None
-            Gptr = None if pooled else Gm.data_ptr()
+            Gptr = None if (pooled or Gm is None) else Gm.data_ptr()
 
+            if l == 0 and gather and virt:
+                # arithmetic first layer: its gradients are linear in sums the layer above already produced
+                dwxyz = _f32((3, N), dev)
+                dbias = _f32(N, dev) if bias is not None else None
+                _lib.call("pcops_xyz_first_layer_grads", xstats.shape[0], xstats.data_ptr(), mom.shape[0], mom.data_ptr(),
+                          N, wxyz.data_ptr(), _p(bias), p.data_ptr(), q.data_ptr(), t.data_ptr(), dbeta.data_ptr(),
+                          means[0].data_ptr(), R, dwxyz.data_ptr(), _p(dbias))
+                break
             if l == 0 and gather:
                 B, M, _ = idx.shape
                 Nsrc = a0.shape[1] if a0 is not None else xyz.shape[1]
@@ -243,13 +253,14 @@ class FusedMLPStack(torch.autograd.Function):
             if l > 0 or ctx.needs_input_grad[0]:
                 Wt = _f32((N, K), dev)
                 _lib.call("pcops_mlp_transpose", K, N, Ws[l].data_ptr(), Wt.data_ptr())
-                Gprev = _f32((R, K), dev)
-                if xyz_prev:
+                Gprev = None if xyz_prev else _f32((R, K), dev)
+                if xyz_prev:     # the first layer's masked gradient is reduced in the epilogue, never written
                     P = lib.pcops_mlp_stats_rows(R)
                     part = _f32((P, 2, K), dev)
+                    xstats = _f32((P, 3, K), dev)
                     _lib.call("pcops_mlp_gemm_dgrad_xyz", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
                               t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), off4.data_ptr(), xyzw.data_ptr(),
-                              scales[0].data_ptr(), shifts[0].data_ptr(), Gprev.data_ptr(), part.data_ptr())
+                              scales[0].data_ptr(), shifts[0].data_ptr(), None, part.data_ptr(), xstats.data_ptr())
                 elif l > 0:
                     P = lib.pcops_mlp_stats_rows(R)
                     part = _f32((P, 2, K), dev)
