@@ -60,6 +60,8 @@ class FusedMLPStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased, L, *tensors):
         lib = _lib.load()
+        identity = bool(int(pool) & 2)      # gather stack whose idx is 0..n-1 per cloud (group_all): scatter = reshape
+        pool = bool(int(pool) & 1)
         gather = idx is not None
         dev = idx.device if gather else a0.device
         layers = [tensors[6 * i:6 * i + 6] for i in range(L)]
@@ -153,7 +155,7 @@ class FusedMLPStack(torch.autograd.Function):
         if training:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
                          [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
-            ctx.meta = (S, pool, L, R, K0, gather)
+            ctx.meta = (S, pool, L, R, K0, gather, identity)
         return out
 
     @staticmethod
@@ -164,7 +166,7 @@ class FusedMLPStack(torch.autograd.Function):
         xstats = None
         virt = off4 is not None
         widths = [g.shape[0] for g in gammas]
-        S, pool, L, R, K0, gather = ctx.meta
+        S, pool, L, R, K0, gather, identity = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grads = [None] * (6 * L)
@@ -221,6 +223,11 @@ class FusedMLPStack(torch.autograd.Function):
                 dbias = _f32(N, dev) if bias is not None else None
                 wpart = _f32(lib.pcops_sa_scatter_rows(B, M) * 4 * N, dev) if (wxyz is not None or bias is not None) else None
                 wsp = None
+                d0_out = d0
+                if d0 is not None and identity and not pooled:
+                    # idx = 0..n-1: the scatter-add is the identity map, dQ = dY row for row
+                    d0_out = torch.addcmul(t[:N], Gm, p[:N]).addcmul_(Ys[0], q[:N]).view(B, Nsrc, N)
+                    d0 = None                # the kernel below then only reduces dWxyz / dbias / dCtr
                 if d0 is not None:   # gather formulation over an inverse index
                     wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,
                                       dtype=torch.int32, device=dev)
@@ -229,6 +236,7 @@ class FusedMLPStack(torch.autograd.Function):
                           _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
                           _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(a0), _p(ctr), _p(wxyz), _p(bias),
                           _p(wsp))
+                d0 = d0_out
                 break
 
             K = Ws[l].shape[0]
@@ -358,14 +366,16 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
 
 
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
-                     new_xyz=None, wxyz=None, bias=None):
+                     new_xyz=None, wxyz=None, bias=None, identity_idx=False):
     """Grouped stack whose first conv was applied before the grouping:
          Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
     idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
-    layer_tensors[0] supplies only the BN variables of layer 1.  Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
+    layer_tensors[0] supplies only the BN variables of layer 1.  identity_idx: the caller guarantees
+    idx[b, 0, s] = s with M = 1 and S = N (group_all), which turns the backward scatter into a reshape.
+    Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
     c = lambda t: t.contiguous() if t is not None else None   # noqa: E731
     S = idx.shape[2]
     return FusedMLPStack.apply(c(Q), c(Ctr), idx.contiguous(), c(xyz.detach()) if xyz is not None else None,
                                c(new_xyz.detach()) if new_xyz is not None else None, c(wxyz), c(bias), int(S),
-                               bool(pool), bool(training), float(decay), float(eps), bool(unbiased),
-                               len(layer_tensors), *_flat(layer_tensors, True))
+                               int(bool(pool)) | (2 if identity_idx else 0), bool(training), float(decay), float(eps),
+                               bool(unbiased), len(layer_tensors), *_flat(layer_tensors, True))

@@ -66,7 +66,7 @@ def _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_for
 
 
 def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training, bn_decay, use_xyz,
-                       xyz_first, pool_max):
+                       xyz_first, pool_max, identity_idx=False):
     """Grouped shared MLP without ever building the grouped input.  The first 1x1 conv is linear, so
          concat(xyz[idx] - new_xyz, points[idx]) W + b  =  (points W_f + b)[idx] + (xyz[idx] - new_xyz) W_xyz :
     the feature part runs once per SOURCE point (B*N rows through a library GEMM instead of B*M*S) and the
@@ -92,7 +92,8 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
         else:
             kw = dict(Q=lin(pts2d, w1, b1).view(b, n, c1))
     decay = bn_decay if bn_decay is not None else 0.9
-    out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers, **kw)
+    out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers,
+                                     identity_idx=identity_idx, **kw)
     return out.view(b, m, 1 if pool_max else s, widths[-1])
 
 
@@ -129,7 +130,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 else:
                     idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
             new_points = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp, 'conv%d', is_training, bn_decay,
-                                            use_xyz, True, pool_max)
+                                            use_xyz, True, pool_max, identity_idx=group_all)
             grouped_xyz = None
         else:
             if group_all:
