@@ -222,6 +222,40 @@ def dgcnn_bga(point_cloud, P, training, nn_list=None):
     return class_pred, dense(s, P, "seg/conv3", training, use_bn=False, act=False)
 
 
+def spidercnn_cls_xyz(point_cloud, P, training):
+    """SpiderCNN/models/spidercnn_cls_xyz.py:20-71 with SpiderCNN/utils/tf_util.py:127-236,363-377,407-429"""
+    xyz = point_cloud[:, :, :3]
+    b, n, _ = xyz.shape
+    k, G, T = 20, 16, 5
+    _, idx = O.knn_point(k, _np(xyz), _np(xyz))
+    idx = _idx(idx)
+    delta = batch_gather(xyz, idx) - xyz.unsqueeze(2)
+    X, Y, Z = delta[..., 0:1], delta[..., 1:2], delta[..., 2:3]
+    feats, feat = [], xyz
+    for li, width in enumerate((32, 64, 128, 256)):
+        s = "fanConv%d/taylor/" % (li + 1)
+        w = lambda name: P[s + "weight_" + name]          # noqa: E731
+        g_d = (w("x") * X + w("y") * Y + w("z") * Z + w("xyz") * X * Y * Z) \
+            + (w("xy") * X * Y + w("yz") * Y * Z + w("xz") * X * Z + P[s + "biases"]) \
+            + (w("xx") * X * X + w("yy") * Y * Y + w("zz") * Z * Z) \
+            + (w("xxy") * X * X * Y + w("xyy") * X * Y * Y + w("xxz") * X * X * Z) \
+            + (w("xzz") * X * Z * Z + w("yyz") * Y * Y * Z + w("yzz") * Y * Z * Z) \
+            + (w("xxx") * X * X * X + w("yyy") * Y * Y * Y + w("zzz") * Z * Z * Z)
+        grouped = batch_gather(feat, idx)                                    # (B,N,k,C)
+        c = grouped.shape[-1]
+        x = (grouped.unsqueeze(-1) * g_d.unsqueeze(3)).reshape(b * n, k * c * T)
+        out = x @ P[s + "conv/weights"].reshape(k * c * T, width) + P[s + "conv/biases"]
+        og = out.reshape(b, n, min(G, width), width // min(G, width)).permute(0, 2, 3, 1)   # (B,G,C/G,N)
+        var, mean = torch.var_mean(og, dim=(2, 3), unbiased=False, keepdim=True)
+        og = ((og - mean) / torch.sqrt(var + 1e-6)).permute(0, 3, 1, 2).reshape(b, n, width)
+        feat = torch.relu(og * P[s + "conv/gn/gamma"] + P[s + "conv/gn/beta"])
+        feats.append(feat)
+    net = torch.topk(torch.cat(feats, 2).permute(0, 2, 1), 2, dim=2).values.reshape(b, -1)
+    net = dense(net, P, "fc1", training)
+    net = dense(net, P, "fc2", training)
+    return dense(net, P, "fc3", training, use_bn=False, act=False)
+
+
 def params_from_state_dict(sd, prefix="graph.", dtype=torch.float32):
     """product Model.state_dict() -> {tf_scope_name: cpu tensor}.  dtype=torch.float64 gives the
     high-precision "truth" the fp32 paths are judged against (every function here follows its inputs'
