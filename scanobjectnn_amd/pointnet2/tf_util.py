@@ -68,6 +68,17 @@ def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format):
 
 
 def _dense(x2d, kernel2d, biases):
+    """X W + b.  Many rows into a few output columns (the per-point heads: 262 144 x 128 -> 2) is a shape the
+    library GEMM runs on a handful of CUs, forward and weight gradient alike: those go through the libpcops GEMMs
+    with the output padded to 4 columns."""
+    rows, k = x2d.shape
+    n = kernel2d.shape[1]
+    if x2d.is_cuda and rows >= 32768 and k % 8 == 0 and n <= 64:
+        pad = (-n) % 4
+        w = F.pad(kernel2d, (0, pad)) if pad else kernel2d
+        b = F.pad(biases, (0, pad)) if pad else biases
+        out = fused_mlp.rows_linear(x2d, w, b)
+        return out[:, :n] if pad else out
     return torch.addmm(biases, x2d, kernel2d)
 
 
@@ -157,6 +168,18 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
         kernel = _variable_with_weight_decay('weights', [kernel_size, cin, num_output_channels],
                                              stddev=stddev, wd=weight_decay, use_xavier=use_xavier)
         biases = get_variable('biases', [num_output_channels], constant_initializer(0.0))
+        if (bn and activation_fn is relu and FUSED_MLP and data_format == 'NHWC'
+                and fused_mlp.fused_supported(x, [num_output_channels], True, True)):
+            # conv + bias + BN + ReLU over B*L rows: one single-layer fused stack (same variables as below)
+            with variable_scope('bn'):
+                beta = get_variable('beta', [num_output_channels], constant_initializer(0.0))
+                gamma = get_variable('gamma', [num_output_channels], constant_initializer(1.0))
+                mm = get_variable('moving_mean', [num_output_channels], constant_initializer(0.0), trainable=False)
+                mv = get_variable('moving_variance', [num_output_channels], constant_initializer(1.0), trainable=False)
+            decay = bn_decay if bn_decay is not None else 0.9
+            out = fused_mlp.mlp_stack(x, 1, False, is_training, decay, BN_EPS, True,
+                                      [(kernel.view(cin, num_output_channels), biases, gamma, beta, mm, mv)])
+            return out.view(x.shape[0], x.shape[1], num_output_channels)
         out = _dense(x.reshape(-1, cin), kernel.view(cin, num_output_channels), biases)
         out = out.view(x.shape[0], x.shape[1], num_output_channels)
         if data_format == 'NCHW':

@@ -49,7 +49,8 @@ def _worker(rank, world, port, q):
         opt.step(TU.get_learning_rate(step, 8))
     D.barrier()
     t = D.max_over_ranks(float(rank), torch.device("cpu"))
-    q.put((rank, fp.flat.clone(), fp.grad.clone(), t))
+    # plain Python lists: a torch tensor travels as a shared-memory handle that dies with this process
+    q.put((rank, fp.flat.tolist(), fp.grad.tolist(), t))
     dist.destroy_process_group()
 
 
@@ -61,6 +62,7 @@ def test_two_rank_gloo_equals_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    res = [(r, torch.tensor(a), torch.tensor(b), t) for r, a, b, t in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
