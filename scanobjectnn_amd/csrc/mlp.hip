@@ -882,7 +882,7 @@ static bool ws_stream256_enabled() {
 }
 
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
-    if (a.M < 32 * 1024) return false;                       // small problems: the tiled kernel is fine
+    if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
     if (a.K > 256 && (a.pool_sub > 0 || am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
     if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
@@ -1841,7 +1841,7 @@ struct PcWgradPlan {
 
 static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
                           const void *gpool, const void *argmax, PcWgradPlan *pl) {
-    if (M < 16 * 1024) return false;
+    if (M < 8 * 1024) return false;
     if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
         (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
@@ -1880,7 +1880,7 @@ struct WsWgradPlan {
 
 static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
                           const void *gpool, const void *argmax, WsWgradPlan *pl) {
-    if (M < 16 * 1024) return false;
+    if (M < 8 * 1024) return false;
     if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
         (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
