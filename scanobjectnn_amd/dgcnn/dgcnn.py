@@ -29,7 +29,8 @@ def _edge_conv(x, width, scope, k, is_training, bn_decay):
 
 
 def backbone(point_cloud, is_training, bn_decay, k=20):
-    """shared by dgcnn / dgcnn_bga: returns (net1..net4, agg) with agg (B,N,1,1024)"""
+    """shared by dgcnn / dgcnn_bga: returns (net1..net4, out_max) with out_max (B,1,1,1024) = the max over the points
+    of the 1024-wide `agg` layer (both models only ever use that max, dgcnn.py:79-84 / dgcnn_bga.py)"""
     nn_idx = tf_util.knn_graph(point_cloud, k=k)
     with variable_scope('transform_net1'):
         if tf_util.fused_ok(point_cloud, [64, 128]):
@@ -44,19 +45,20 @@ def backbone(point_cloud, is_training, bn_decay, k=20):
     net4 = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay)
     cat = torch.cat([net1, net2, net3, net4], dim=-1)
     if tf_util.fused_ok(cat, [1024]):
-        agg = tf_util.conv2d_stack(cat, [1024], ['agg'], is_training, bn_decay)
+        out_max = tf_util.conv2d_stack_global_max(cat, [1024], ['agg'], is_training, bn_decay)
     else:
         agg = tf_util.conv2d(cat, 1024, [1, 1], padding='VALID', stride=[1, 1], bn=True, is_training=is_training,
                              scope='agg', bn_decay=bn_decay)
-    return net1, net2, net3, net4, agg
+        out_max = tf_util.max_pool2d(agg, [agg.shape[1], 1], padding='VALID', scope='maxpool')
+    return net1, net2, net3, net4, out_max
 
 
 def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
     """point_cloud (B,N,3) -> logits (B,num_class), end_points"""
     batch_size = point_cloud.shape[0]
     end_points = {}
-    *_, agg = backbone(point_cloud, is_training, bn_decay)
-    net = agg.amax(dim=1, keepdim=True).reshape(batch_size, -1)
+    *_, out_max = backbone(point_cloud, is_training, bn_decay)
+    net = out_max.reshape(batch_size, -1)
     net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='fc1', bn_decay=bn_decay)
     net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp1')
     net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='fc2', bn_decay=bn_decay)

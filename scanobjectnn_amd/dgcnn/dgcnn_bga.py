@@ -20,8 +20,7 @@ def placeholder_inputs(batch_size, num_point, device=None):
 def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
     """point_cloud (B,N,3) -> class_pred (B,num_class), seg_pred (B,N,2)"""
     batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
-    net1, net2, net3, net4, agg = backbone(point_cloud, is_training, bn_decay)
-    out_max = tf_util.max_pool2d(agg, [num_point, 1], padding='VALID', scope='maxpool')   # (B,1,1,1024)
+    net1, net2, net3, net4, out_max = backbone(point_cloud, is_training, bn_decay)        # out_max (B,1,1,1024)
     expand = out_max.expand(batch_size, num_point, 1, 1024)
 
     net = out_max.reshape(batch_size, -1)

@@ -198,16 +198,35 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
     w1, b1 = layers[0][0], layers[0][1]
     w_a, w_b = w1[:c], w1[c:]
     x2d = x.reshape(b * n, c)
-    q = (x2d @ w_b).view(b, n, widths[0])                       # neighbour term, gathered by nn_idx
-    ctr = torch.addmm(b1, x2d, w_a - w_b).view(b, n, widths[0])  # centre term + bias
+    if c % 8 == 0 and b * n >= 8192 and widths[0] % 4 == 0:
+        # B*N rows into a C x C' weight: the libpcops GEMMs (the library picks a few-CU kernel for these weight gradients)
+        q = fused_mlp.rows_linear(x2d, w_b).view(b, n, widths[0])
+        ctr = fused_mlp.rows_linear(x2d, w_a - w_b, b1).view(b, n, widths[0])
+    else:
+        q = (x2d @ w_b).view(b, n, widths[0])                       # neighbour term, gathered by nn_idx
+        ctr = torch.addmm(b1, x2d, w_a - w_b).view(b, n, widths[0])  # centre term + bias
     decay = bn_decay if bn_decay is not None else 0.9
     out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, Q=q, Ctr=ctr)
     return out.view(b, n, 1, widths[-1])
 
 
-def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False):
+def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False, pool_max=False):
     """len(widths) x conv2d([1,1], bn, relu) on a channel-last (B,H,W,C) tensor through the fused MLP stack
-    (this module's BN flavour: biased variance in the moving statistics)."""
+    (this module's BN flavour: biased variance in the moving statistics); pool_max: + max over axis 2."""
     names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
-    return _pn2.conv2d_stack(inputs, widths, list(scopes), is_training, bn_decay, unbiased_moving_var=False,
-                             mov_names=names)
+    return _pn2.conv2d_stack(inputs, widths, list(scopes), is_training, bn_decay, pool_max=pool_max,
+                             unbiased_moving_var=False, mov_names=names)
+
+
+def conv2d_stack_global_max(inputs, widths, scopes, is_training, bn_decay, is_dist=False):
+    """conv stack on (B,N,1,C) followed by the max over ALL points (the reference's `agg` conv + max_pool2d over
+    [num_point,1], dgcnn.py:79-84): the max is associative, so it is taken inside the fused stack over chunks of 256
+    points (8-bit arg-max) and finished over the N/256 chunk maxima -- the (B,N,1,C') activation and its dense
+    gradient never exist.  Returns (B,1,1,widths[-1])."""
+    b, n, _, c = inputs.shape
+    chunk = 256 if n % 256 == 0 else (n if n <= 256 else 0)
+    if chunk == 0:
+        return conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist).amax(dim=1, keepdim=True)
+    part = conv2d_stack(inputs.reshape(b, n // chunk, chunk, c), widths, scopes, is_training, bn_decay, is_dist,
+                        pool_max=True)                               # (B, N/chunk, 1, C')
+    return part.amax(dim=1, keepdim=True)

@@ -13,7 +13,9 @@ def input_transform_net(edge_feature, is_training, bn_decay=None, K=3, is_dist=F
         batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
         net = tf_util.edge_conv_stack(point_cloud, nn_idx, [64, 128], ['tconv1', 'tconv2'], is_training, bn_decay,
                                       is_dist=is_dist)                                  # (B,N,1,128)
-        net = tf_util.conv2d_stack(net, [1024], ['tconv3'], is_training, bn_decay, is_dist=is_dist)
+        # tconv3 + the max over all points (tmaxpool) inside the fused stack
+        net = tf_util.conv2d_stack_global_max(net, [1024], ['tconv3'], is_training, bn_decay, is_dist=is_dist)
+        num_point = 1
     else:
         batch_size, num_point = edge_feature.shape[0], edge_feature.shape[1]
         net = tf_util.conv2d(edge_feature, 64, [1, 1], padding='VALID', stride=[1, 1], bn=True,
