@@ -187,6 +187,9 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
 
     TopK<KL> top;
     top.init();
+    float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};   // parked candidates (arrival order) and their count
+    int bj[4] = {0, 0, 0, 0};
+    int nb = 0;
 
     for (int j0 = 0; j0 < n; j0 += CH) {
         const int tn = min(CH, n - j0);
@@ -211,15 +214,36 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
             for (int kk = 0; kk < NKK; ++kk)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], bq[kk], acc, 0, 0, 0);
             // acc[v]: candidate row 32 t + (v&3) + 8 (v>>2) + 4 half, query li
+            // candidates that beat the lane's current k-th distance are parked in a 4-slot register buffer; the
+            // (expensive, wave-wide) sorted insertion runs only when SOME lane's buffer is full -- about 5x fewer
+            // insertion passes than inserting whenever any lane has a hit.  Arrival order is kept, and the
+            // insertion re-checks against the up-to-date k-th value, so the result is unchanged.
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int row = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * half;
                 const int j = j0 + row;
                 float d = (sq + (-2.f * acc[v])) + sc[row];
                 if (!(j < n)) d = INFINITY;
-                if (__any(d < top.v[KL - 1])) top.insert_ascending(d, j);
+                const bool hit = d < top.v[KL - 1];
+                bd[3] = (hit && nb == 3) ? d : bd[3]; bj[3] = (hit && nb == 3) ? j : bj[3];
+                bd[2] = (hit && nb == 2) ? d : bd[2]; bj[2] = (hit && nb == 2) ? j : bj[2];
+                bd[1] = (hit && nb == 1) ? d : bd[1]; bj[1] = (hit && nb == 1) ? j : bj[1];
+                bd[0] = (hit && nb == 0) ? d : bd[0]; bj[0] = (hit && nb == 0) ? j : bj[0];
+                nb += hit ? 1 : 0;
+                if (__any(nb == 4)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        top.insert_ascending(u < nb ? bd[u] : INFINITY, bj[u]);
+                        bd[u] = INFINITY;
+                    }
+                    nb = 0;
+                }
             }
         }
+    }
+    if (__any(nb > 0)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) top.insert_ascending(u < nb ? bd[u] : INFINITY, bj[u]);
     }
 
     // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
