@@ -42,10 +42,10 @@ def _worker(rank, world, port, q):
     opt = TU.TFAdam(fp)
     lo, hi = D.shard_range(8, rank, world)
     for step in range(3):
-        fp.zero_grad()
+        fp.begin_step()                          # exactly bench.py's / train.py's step: fresh grads, one cat, one all-reduce
         # per-rank mean loss; mean over ranks of equal shards == mean over the global batch
         torch.nn.functional.cross_entropy(net(x[lo:hi]), y[lo:hi]).backward()
-        D.allreduce_mean_(fp.grad, world)
+        D.allreduce_mean_(fp.collect(), world)
         opt.step(TU.get_learning_rate(step, 8))
     D.barrier()
     t = D.max_over_ranks(float(rank), torch.device("cpu"))
