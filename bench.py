@@ -110,6 +110,12 @@ def _algo(name, a):
     if name == "pcops_mlp_pool_bwd_stats":
         G, C = a[:2]
         return 8 * G * C, 0, ""
+    if name == "pcops_edge_pool_fwd":         # Q, Ctr, idx read once (algorithmically); SQ, qsel, arg written
+        b, n, m, s_, c = a[:5]
+        return 4 * (b * n * c + b * m * c + b * m * s_) + 9 * b * m * c, 0, ""
+    if name == "pcops_edge_pool_bwd":         # + gpool, ysel, SQ, arg read; dQ, dCtr written
+        b, n, m, s_, c = a[:5]
+        return 4 * (2 * b * n * c + 2 * b * m * c + b * m * s_) + 13 * b * m * c, 0, ""
     if name == "pcops_sa_gather_fwd":         # Y (b,m,s,c) written once; Q read once (algorithmically), idx
         b, n, m, s, c = a[:5]
         wr = (b * m * s * c if a[12] is not None else 0) + (4 * b * m * s if a[13] is not None else 0)
@@ -127,7 +133,8 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_sa_gather_fwd": 5, "pcops_sa_scatter_bwd": 5, "pcops_mlp_bn_finalize": 3,
            "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
            "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
-           "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1}
+           "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1,
+           "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2}
 
 
 class KernelTimer:

@@ -269,6 +269,27 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
                          const float *fwd_bias, void *workspace, pcops_stream_t stream);
 
+/* EdgeConv as ONE pooled layer without the (b,n,k,c) tensor in either direction (dgcnn/models/dgcnn.py:39-48 with the
+ * first-layer restructuring above):  y[g,s,:] = Q[idx[g,s],:] + Ctr[g,:] -> BN -> ReLU -> max over s.  Ctr is constant
+ * inside a group and BN+ReLU is monotone per channel, so
+ *   forward : qsel[g,c] = max_s (gamma[c] >= 0) | min_s (gamma[c] < 0) of Q[idx[g,s],c], arg = first s attaining it,
+ *             SQ[g,c] = sum_s Q[idx[g,s],c];  stats_partial [pcops_edge_pool_stats_rows(b*m)][2][c] = partial
+ *             (sum y, sum y^2) = (SQ + k Ctr, SQ2 + 2 Ctr SQ + k Ctr^2)  -> pcops_mlp_bn_finalize
+ *   out     : out = relu(scale (qsel + Ctr) + shift), ysel = qsel + Ctr
+ *   backward: with (p, q, t) from pcops_mlp_pool_bwd_stats(gpool, ysel) + pcops_mlp_bn_bwd_coeffs,
+ *             dCtr[g] = q (SQ + k Ctr) + k t + a[g],  a = p gpool [relu(bn(ysel)) > 0],
+ *             dQ[i] = cnt_i (q Q[i] + t) + q sum_{(g,s)->i} Ctr[g] + sum_{g: arg row -> i} a[g]   (inverse index of idx)
+ * workspace: pcops_sa_scatter_workspace_bytes(b,n,m,s) bytes.  s <= 256. */
+int pcops_edge_pool_stats_rows(long long groups);
+int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
+                        const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,
+                        pcops_stream_t stream);
+int pcops_edge_pool_out(long long groups, int c, const float *qsel, const float *Ctr, const float *scale,
+                        const float *shift, float *out, float *ysel, pcops_stream_t stream);
+int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
+                        const float *gpool, const float *ysel, const float *SQ, const unsigned char *arg,
+                        const float *scale, const float *shift, const float *p, const float *q, const float *t,
+                        float *dQ, float *dCtr, void *workspace, pcops_stream_t stream);
 /* dWxyz (3,c) and dbias (c, may be NULL) of an arithmetic first layer from the sums described at
  * pcops_mlp_gemm_dgrad_xyz: xyz_stats [P1][3][c], moments [P2][9] (pcops_sa_gather_fwd), p/q/t and sumG (= dbeta) from
  * pcops_mlp_bn_bwd_coeffs, mean from pcops_mlp_bn_finalize, rows = b*m*s. */

@@ -49,6 +49,9 @@ SIGNATURES = {
     "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
+    "pcops_edge_pool_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_edge_pool_out": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_edge_pool_bwd": ([_I, _I, _I, _I, _I] + [_P] * 15, True),
     "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
 }
@@ -65,6 +68,7 @@ PLAIN = {
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_rows": ([_I, _I], _I),
+    "pcops_edge_pool_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
 }
 

@@ -688,6 +688,195 @@ __global__ __launch_bounds__(1024) void xyz_first_layer_grads_kernel(int P1, con
     if (dbias) dbias[c] = (float)(pc * (double)sumG[c] + qc * ((double)mean[c] * rows) + tc * rows);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// EdgeConv as a single pooled layer, WITHOUT the (b, n, k, c) tensor in either direction.
+//   y[g, s, :] = Q[idx[g, s], :] + Ctr[g, :]   ->  BN  ->  ReLU  ->  max over s                (dgcnn.py:39-48)
+// Ctr is constant inside a group and BN + ReLU is monotone per channel (increasing for gamma >= 0), so
+//   * the pooled value only needs  qsel = max_s (or min_s) Q[idx[g, s]]  and the first s attaining it,
+//   * the batch statistics only need  SQ = sum_s Q[idx]  and  sum_s Q[idx]^2:
+//       sum y = SQ + k Ctr,    sum y^2 = SQ2 + 2 Ctr SQ + k Ctr^2,
+//   * the backward needs no y either:  dY = q y + t (+ p gpool at the arg row), so
+//       dCtr[g] = q (SQ + k Ctr) + k t + a[g],   a = p gpool [relu(bn(ysel)) > 0]
+//       dQ[i]   = cnt_i (q Q[i] + t) + q sum_{(g, s) -> i} Ctr[g] + sum_{g: arg row -> i} a[g]
+//     where the middle sum walks the inverse index of idx (csr build above) over the L2-resident Ctr rows.
+// thread = (group lane, column quad): one thread reduces the k neighbours of one (group, quad)
+__global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, int m, int S, int C,
+                                                            const float *__restrict__ Q,
+                                                            const float *__restrict__ Ctr,
+                                                            const int *__restrict__ idx,
+                                                            const float *__restrict__ gamma,
+                                                            float *__restrict__ SQ, float *__restrict__ qsel,
+                                                            unsigned char *__restrict__ arg,
+                                                            float *__restrict__ stats, int groups_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [GL][2][C] statistics scratch
+    const int c4n = C / 4;
+    const int GL = 256 / c4n;                                    // groups in flight per block
+    const int cq = (threadIdx.x % c4n) * 4, gl = threadIdx.x / c4n;
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    const long long g1 = min(G, g0 + groups_per_block);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + cq);
+    const bool up[4] = {!(ga.x < 0.f), !(ga.y < 0.f), !(ga.z < 0.f), !(ga.w < 0.f)};
+    if (gl < GL) {
+        for (long long g = g0 + gl; g < g1; g += GL) {
+            const long long b = g / m;
+            const float4 ct = *reinterpret_cast<const float4 *>(Ctr + g * C + cq);
+            float sq[4] = {0.f, 0.f, 0.f, 0.f}, sq2[4] = {0.f, 0.f, 0.f, 0.f};
+            float ex[4];
+            int ea[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[e] = up[e] ? -INFINITY : INFINITY;
+            for (int s = 0; s < S; ++s) {
+                const int i = idx[g * S + s];
+                const float4 q = *reinterpret_cast<const float4 *>(Q + (b * n + i) * (long long)C + cq);
+                const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sq[e] += qv[e];
+                    sq2[e] = fmaf(qv[e], qv[e], sq2[e]);
+                    const bool better = up[e] ? qv[e] > ex[e] : qv[e] < ex[e];    // strict: first extremum wins
+                    ex[e] = better ? qv[e] : ex[e];
+                    ea[e] = better ? s : ea[e];
+                }
+            }
+            *reinterpret_cast<float4 *>(SQ + g * C + cq) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+            *reinterpret_cast<float4 *>(qsel + g * C + cq) = make_float4(ex[0], ex[1], ex[2], ex[3]);
+            uchar4 a4;
+            a4.x = (unsigned char)ea[0]; a4.y = (unsigned char)ea[1]; a4.z = (unsigned char)ea[2]; a4.w = (unsigned char)ea[3];
+            *reinterpret_cast<uchar4 *>(arg + g * C + cq) = a4;
+            const float cv[4] = {ct.x, ct.y, ct.z, ct.w};
+            const float kf = (float)S;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += fmaf(kf, cv[e], sq[e]);
+                s2[e] += fmaf(cv[e], fmaf(kf, cv[e], 2.f * sq[e]), sq2[e]);
+            }
+        }
+    }
+    if (stats == nullptr) return;
+    if (gl < GL)
+        for (int e = 0; e < 4; ++e) {
+            sm[(gl * 2 + 0) * C + cq + e] = s1[e];
+            sm[(gl * 2 + 1) * C + cq + e] = s2[e];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        float t = 0.f;
+        for (int l = 0; l < GL; ++l) t += sm[(l * 2 + which) * C + c];
+        stats[((long long)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
+// out = relu(scale (qsel + Ctr) + shift), ysel = qsel + Ctr   (the same sum the forward of a stored y would hold)
+__global__ __launch_bounds__(256) void edge_pool_out_kernel(long long total, int C, const float *__restrict__ qsel,
+                                                            const float *__restrict__ Ctr,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift,
+                                                            float *__restrict__ out, float *__restrict__ ysel) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float y = qsel[e] + Ctr[e];
+        out[e] = fmaxf(fmaf(y, scale[c], shift[c]), 0.f);
+        if (ysel) ysel[e] = y;
+    }
+}
+
+// dCtr and the arg-row part of dQ (one atomic per (group, channel))
+__global__ __launch_bounds__(256) void edge_pool_bwd_ctr_kernel(long long total, int n, int m, int S, int C,
+                                                                const float *__restrict__ gpool,
+                                                                const float *__restrict__ ysel,
+                                                                const float *__restrict__ SQ,
+                                                                const float *__restrict__ Ctr,
+                                                                const unsigned char *__restrict__ arg,
+                                                                const int *__restrict__ idx,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift,
+                                                                const float *__restrict__ p,
+                                                                const float *__restrict__ q,
+                                                                const float *__restrict__ t,
+                                                                float *__restrict__ dCtr, float *__restrict__ dQ) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long g = e / C;
+        const int c = (int)(e - g * C);
+        const float a = fmaf(ysel[e], scale[c], shift[c]) > 0.f ? p[c] * gpool[e] : 0.f;
+        const float kf = (float)S;
+        dCtr[e] = fmaf(q[c], fmaf(kf, Ctr[e], SQ[e]), fmaf(kf, t[c], a));
+        if (a != 0.f) {
+            const long long b = g / m;
+            atomicAdd(dQ + (b * n + idx[g * S + arg[e]]) * (long long)C + c, a);
+        }
+    }
+}
+
+// dense part of dQ over the inverse index: waves walk chunks of the sorted row list, sum the Ctr rows of the current
+// point in registers and flush  q (cnt Q[i] + sum Ctr) + cnt t  with one atomic per channel when the point changes
+template <int LPR>
+__global__ __launch_bounds__(256) void edge_pool_bwd_q_kernel(int B, int n, int m, int S, int C,
+                                                              const float *__restrict__ Q,
+                                                              const float *__restrict__ Ctr,
+                                                              const float *__restrict__ qv,
+                                                              const float *__restrict__ tv,
+                                                              const int2 *__restrict__ order,
+                                                              float *__restrict__ dQ) {
+    constexpr int RW = 64 / LPR, U = 4, CH = 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rsub = lane / LPR, quad = lane % LPR;
+    const int mS = m * S;
+    const int nch = (mS + CH - 1) / CH;
+    const long long nchunks = (long long)B * nch;
+    const long long wstride = (long long)gridDim.x * 4;
+    for (int cb = 0; cb < C; cb += 4 * LPR) {
+        const int c0 = cb + quad * 4;
+        const float4 cq = *reinterpret_cast<const float4 *>(qv + c0);
+        const float4 ct = *reinterpret_cast<const float4 *>(tv + c0);
+        for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += wstride) {
+            const int b = (int)(ch / nch);
+            const int kb = (int)(ch - (long long)b * nch) * CH, ke = min(mS, kb + CH);
+            const int2 *ob = order + (long long)b * mS;
+            int cur = -1, cnt = 0;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            auto flush = [&]() {
+                const float4 qi = *reinterpret_cast<const float4 *>(Q + ((long long)b * n + cur) * C + c0);
+                const float kf = (float)cnt;
+                float *dst = dQ + ((long long)b * n + cur) * C + c0;
+                atomicAdd(dst + 0, fmaf(cq.x, fmaf(kf, qi.x, acc[0]), kf * ct.x));
+                atomicAdd(dst + 1, fmaf(cq.y, fmaf(kf, qi.y, acc[1]), kf * ct.y));
+                atomicAdd(dst + 2, fmaf(cq.z, fmaf(kf, qi.z, acc[2]), kf * ct.z));
+                atomicAdd(dst + 3, fmaf(cq.w, fmaf(kf, qi.w, acc[3]), kf * ct.w));
+            };
+            const int ks = kb + rsub * (CH / RW), kse = min(ke, ks + CH / RW);
+            for (int k0 = 0; k0 < CH / RW; k0 += U) {
+                if (kb + k0 >= ke) break;
+                int ii[U];
+                float4 cc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = ks + k0 + u;
+                    const int2 oe = ob[k < kse ? k : kb];
+                    ii[u] = oe.y;
+                    const int j = (int)((unsigned)oe.x / (unsigned)S);
+                    cc[u] = *reinterpret_cast<const float4 *>(Ctr + ((long long)b * m + j) * C + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = ks + k0 + u;
+                    if (k >= kse) continue;
+                    if (ii[u] != cur) {
+                        if (cur >= 0) flush();
+                        cur = ii[u];
+                        cnt = 0;
+                        acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+                    }
+                    acc[0] += cc[u].x; acc[1] += cc[u].y; acc[2] += cc[u].z; acc[3] += cc[u].w;
+                    ++cnt;
+                }
+            }
+            if (cur >= 0) flush();
+        }
+    }
+}
+
 // out[L] = sum_p part[p][L] in double (deterministic)
 __global__ __launch_bounds__(256) void sum_rows_kernel(int P, int L, const float *__restrict__ part,
                                                        float *__restrict__ out) {
@@ -920,6 +1109,72 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         rc = pcops_launch_status();
     }
     return rc;
+}
+
+int pcops_edge_pool_stats_rows(long long G) { return (int)((G + 63) / 64); }
+
+int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
+                        const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,
+                        pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && s <= 256 && c >= 4 && c % 4 == 0);
+    PCOPS_REQUIRE_SHAPE(c <= 1024 && 256 % (c / 4) == 0);
+    const long long G = (long long)b * m;
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gamma);
+    PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(arg);
+    const int gl = 256 / (c / 4);
+    hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3(pcops_edge_pool_stats_rows(G)), dim3(256),
+                       (size_t)gl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel,
+                       arg, stats_partial, 64);
+    return pcops_launch_status();
+}
+
+int pcops_edge_pool_out(long long G, int c, const float *qsel, const float *Ctr, const float *scale,
+                        const float *shift, float *out, float *ysel, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && c >= 1);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift);
+    PCOPS_REQUIRE_PTR(out);
+    const long long total = G * c;
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(edge_pool_out_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, c, qsel, Ctr, scale,
+                       shift, out, ysel);
+    return pcops_launch_status();
+}
+
+int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
+                        const float *gpool, const float *ysel, const float *SQ, const unsigned char *arg,
+                        const float *scale, const float *shift, const float *p, const float *q, const float *t,
+                        float *dQ, float *dCtr, void *workspace, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && s <= 256 && c >= 4);
+    PCOPS_REQUIRE_SHAPE((c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384);
+    PCOPS_REQUIRE_PTR(dQ);
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    const long long G = (long long)b * m;
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
+    PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
+    int2 *order = static_cast<int2 *>(workspace);
+    int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
+    const size_t blds = (2 * (size_t)n + 1024) * sizeof(int);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
+    const long long total = G * c;
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(edge_pool_bwd_ctr_kernel, dim3(grid), dim3(256), 0, st, total, n, m, s, c, gpool, ysel, SQ, Ctr,
+                       arg, idx, scale, shift, p, q, t, dCtr, dQ);
+    const int lpr = c <= 256 ? c / 4 : 64;
+    switch (lpr) {
+        case 8: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<8>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        case 16: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<16>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        case 32: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<32>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        default: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<64>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+    }
+    return pcops_launch_status();
 }
 
 int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const float *moments, int C,

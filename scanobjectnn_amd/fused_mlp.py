@@ -339,6 +339,77 @@ def rows_linear(x2d, w, b=None):
     return _RowsLinear.apply(x2d.contiguous(), w.contiguous(), b)
 
 
+class EdgeConvPool(torch.autograd.Function):
+    """apply(Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased) -> (B*M, C)
+    One pooled layer  y = Q[idx] + Ctr -> BN -> ReLU -> max over the neighbours  without the (B,M,S,C) tensor in either
+    direction (csrc/gather.hip, edge_pool_*): the statistics, the pooled value and both gradients are functions of
+    per-group sums / extrema of the gathered Q rows."""
+
+    @staticmethod
+    def forward(ctx, Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased):
+        lib = _lib.load()
+        B, M, S = idx.shape
+        Nsrc, C = Q.shape[1], Q.shape[2]
+        dev = Q.device
+        G = B * M
+        SQ, qsel = _f32((G, C), dev), _f32((G, C), dev)
+        arg = torch.empty((G, C), dtype=torch.uint8, device=dev)
+        P = lib.pcops_edge_pool_stats_rows(G)
+        part = _f32((P, 2, C), dev) if training else None
+        _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
+                  gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part))
+        vecs = _VecArena([C], 4, dev)
+        scale, shift = vecs.take(C), vecs.take(C)
+        mean = rstd = None
+        if training:
+            mean, rstd = vecs.take(C), vecs.take(C)
+            ws = _workspace(C, dev)
+            _lib.call("pcops_mlp_bn_finalize", P, C, G * S, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                      beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
+                      mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
+        else:
+            _lib.call("pcops_mlp_bn_eval_coeffs", C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                      float(eps), scale.data_ptr(), shift.data_ptr())
+        out = _f32((G, C), dev)
+        ysel = _f32((G, C), dev) if training else None
+        _lib.call("pcops_edge_pool_out", G, C, qsel.data_ptr(), Ctr.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  out.data_ptr(), _p(ysel))
+        if training:
+            ctx.saved = (Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift = ctx.saved
+        B, M, S = idx.shape
+        Nsrc, C = Q.shape[1], Q.shape[2]
+        dev = Q.device
+        G = B * M
+        grad_out = grad_out.contiguous()
+        P = lib.pcops_mlp_bwd_pool_stats_rows(G)
+        part = _f32((P, 2, C), dev)
+        _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), part.data_ptr())
+        vecs = _VecArena([C], 3, dev)
+        p, q, t = vecs.take(C), vecs.take(C), vecs.take(C)
+        dgamma, dbeta = _f32(C, dev), _f32(C, dev)
+        ws = _workspace(C, dev)
+        _lib.call("pcops_mlp_bn_bwd_coeffs", P, C, G * S, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                  mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), p.data_ptr(), q.data_ptr(),
+                  t.data_ptr())
+        dQ, dCtr = _f32((B, Nsrc, C), dev), _f32((B, M, C), dev)
+        wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4, dtype=torch.int32, device=dev)
+        _lib.call("pcops_edge_pool_bwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
+                  grad_out.data_ptr(), ysel.data_ptr(), SQ.data_ptr(), arg.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  p.data_ptr(), q.data_ptr(), t.data_ptr(), dQ.data_ptr(), dCtr.data_ptr(), wsp.data_ptr())
+        return dQ, dCtr, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def edge_conv_pool_supported(C, S):
+    return C in (32, 64, 128) or C % 256 == 0 and S <= 256
+
+
 def fused_supported(x, widths, bn, activation_relu):
     if not (bn and activation_relu and x.is_cuda and x.dtype == torch.float32):
         return False
@@ -375,6 +446,12 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
     Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
     c = lambda t: t.contiguous() if t is not None else None   # noqa: E731
     S = idx.shape[2]
+    if (len(layer_tensors) == 1 and pool and Q is not None and Ctr is not None and xyz is None and wxyz is None
+            and bias is None and S <= 256 and edge_conv_pool_supported(Q.shape[-1], S)
+            and 256 % (Q.shape[-1] // 4) == 0 and Q.shape[1] <= 16384):
+        _w, _b, gamma, beta, mm, mv = layer_tensors[0]
+        return EdgeConvPool.apply(c(Q), c(Ctr), idx.contiguous(), gamma, beta, mm, mv, bool(training), float(decay),
+                                  float(eps), bool(unbiased))
     return FusedMLPStack.apply(c(Q), c(Ctr), idx.contiguous(), c(xyz.detach()) if xyz is not None else None,
                                c(new_xyz.detach()) if new_xyz is not None else None, c(wxyz), c(bias), int(S),
                                int(bool(pool)) | (2 if identity_idx else 0), bool(training), float(decay), float(eps),
