@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     //     2: weights STREAMED -- K chunks of KC rows double-buffered in LDS, refilled from L2 by the whole workgroup
     //        while the MFMAs of the current chunk run; all waves then walk the chunks in lockstep (one workgroup
     //        barrier per chunk), which is what K > 256 costs
-    constexpr bool POOL = VAR == 1, WST = VAR == 2;
+    constexpr bool POOL = VAR == 1 || VAR == 3, WST = VAR == 2 || VAR == 3;   // 3: pooled epilogue AND streamed weights
     constexpr int BN = NT * 32;
     constexpr int NTH = NT / EH;                   // accumulator tiles per epilogue pass
     constexpr int BNH = BN / EH;                   // columns per epilogue pass
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // streamed weights: every wave runs the workgroup's number of rounds (the chunk barriers are workgroup-wide);
     // a wave without a tile in the last round only helps refilling the weight buffers
     const long long st0 = (long long)rowgrp * WAVES;
-    const long long nrounds = st0 < nsuper ? (nsuper - st0 + tstride - 1) / tstride : 0;
+    const long long nrounds = st0 < nsuper ? (nsuper - st0 + tstride - 1) / tstride * SUB : 0;   // SUB tiles per group
     long long round = 0;
     int wt = 0;                                      // streamed chunks consumed so far (buffer = wt & 1)
     while (WST ? round < nrounds : st < nsuper) {
@@ -884,7 +884,7 @@ static bool ws_stream256_enabled() {
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
-    if (a.K > 256 && (a.pool_sub > 0 || am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
+    if (a.K > 256 && (am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
     if ((reinterpret_cast<uintptr_t>(a.X) & 15) || (reinterpret_cast<uintptr_t>(a.X2) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
     if (is_pool(am) && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
@@ -898,7 +898,7 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     pl->wst = a.K > 256;
     // K = 193..256 with more than 64 output columns: resident weights would only fit 64 columns at a time, i.e. the
     // operand would be streamed from HBM once per 64-column block; streaming the WEIGHTS (from L2) keeps 128 columns
-    if (!pl->wst && a.N > 64 && a.pool_sub == 0 && am != A_XYZ && !(reinterpret_cast<uintptr_t>(a.W) & 15) &&
+    if (!pl->wst && a.N > 64 && am != A_XYZ && !(reinterpret_cast<uintptr_t>(a.W) & 15) &&
         ws_lds_bytes(Kp, 64, 128, 8, 2) > 160 * 1024 && ws_stream256_enabled())
         pl->wst = true;
     if (pl->wst) {
@@ -925,9 +925,11 @@ template <int AM, int EM>
 int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
 #define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
-        auto kern = pl.wst ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (AM == A_XYZ ? 0 : 2)>            \
-                    : (EM == E_FWD && a.pool_sub > 0) ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (EM == E_FWD ? 1 : 0)> \
-                                                      : gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, 0>;   \
+        const bool pool_ = EM == E_FWD && a.pool_sub > 0;                                             \
+        auto kern = (pl.wst && pool_) ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, ((AM == A_XYZ || EM != E_FWD) ? 0 : 3)> \
+                    : pl.wst ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (AM == A_XYZ ? 0 : 2)>            \
+                    : pool_ ? gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, (EM == E_FWD ? 1 : 0)>              \
+                            : gemm_ws_kernel<NT_, AM, EM, 64, 8, EH_, 0>;                                 \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
             return PCOPS_ERR_LAUNCH;                                                                  \
