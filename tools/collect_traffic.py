@@ -23,7 +23,10 @@ OUT = os.path.join(ROOT, "gpurun_out")
 # gemm_ws_kernel<NT, AM, EM, KC, WAVES, EH, VAR>, wgrad_pc_kernel<TK, TN, AMODE, DMODE>
 KEYS = [
     ("gemm_ws_kernel<4, 4, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128)"),
-    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", None, "pcops_mlp_gemm_fwd_pool(2097152, 128, 256, 64)"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 1024 * 512, "pcops_mlp_gemm_fwd_pool(2097152, 128, 256, 64)"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", None, "pcops_mlp_gemm_fwd(2097152, 128, 128)"),
+    ("gemm_ws_kernel<4, 2, 1, 64, 8, 2, 0>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128)"),
     ("wgrad_pc_kernel<2, 4, 1, 4>", 256 * 512, "pcops_mlp_wgrad(2097152, 128, 256)"),
     ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),
     ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
@@ -46,8 +49,40 @@ def one_pass(counter):
     return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
 
 
+def mfma_pass():
+    """third pass: matrix-pipe busy cycles and active GPU cycles per dispatch -> MFMA utilisation and effective clock.
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts per-SIMD busy cycles (1024 SIMDs)."""
+    d = os.path.join(OUT, "pmc_MFMA")
+    subprocess.run(["rm", "-rf", d])
+    cmd = ["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "-d", d, "-o", "p", "--output-format", "csv",
+           "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp",
+                   env=dict(os.environ, TMPDIR="/tmp"))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    # largest launches first: a template instantiation shared by several shapes is keyed by its biggest user
+    for (name, grid), c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0])) /
+                                  max(1, len(kv[1].get("GRBM_GUI_ACTIVE", [0])))):
+        busy = sum(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])) / max(1, len(c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0])))
+        act = sum(c.get("GRBM_GUI_ACTIVE", [0])) / max(1, len(c.get("GRBM_GUI_ACTIVE", [0])))
+        if busy <= 0 or act <= 0:
+            continue
+        for frag, g, key in KEYS:
+            if frag in name and (g is None or g == grid) and key not in out:
+                out[key] = {"mfma_busy_cycles_per_simd": busy / 1024.0, "gpu_active_cycles": act / 8.0,
+                            "mfma_utilisation": busy / 1024.0 / (act / 8.0)}
+                print("%-52s MFMA pipe busy %.1f %% of the active cycles" % (key, 100 * out[key]["mfma_utilisation"]),
+                      flush=True)
+    json.dump(out, open(os.path.join(OUT, "pmc_mfma.json"), "w"), indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--mfma" in sys.argv:
+        return mfma_pass()
     fetch, nf = one_pass("FETCH_SIZE")
     write, _ = one_pass("WRITE_SIZE")
     table, detail = {}, {}
