@@ -2,7 +2,12 @@
 """Throughput harness for the hot path: PointNet++ SSG (BASELINE config 2), forward + backward + Adam,
 point-clouds/sec on synthetic B x 2048 x 3 clouds resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1 is launched by torchrun, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are
+already there (RANK / WORLD_SIZE in the environment); started bare (`python bench.py --gpus N`) the script
+launches the N ranks itself through torch.distributed.run on 127.0.0.1.  Either way the run FAILS if the world
+size it ends up with is not --gpus.
 
 A "step" = one training step of `pointnet2_cls_ssg` on one batch of 256 clouds per GPU (weak scaling):
 geometry (FPS / ball query / grouping) -> shared MLPs + BN + max-pool -> FC head -> loss -> backward ->
@@ -28,6 +33,10 @@ from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks  # no
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3   # f32 vector == f32-input MFMA peak
+MEASURED_F32_MFMA_TFLOPS = 155.0   # tools/ubench/mfma_peak.hip on this chip (operands in registers, 2.37 GHz)
+MEASURED_HBM_GBS = 6290.0          # MI355X_MICROARCH.md: float4 copy, 79 % of spec
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9    # 256 CUs x 4 SIMD-32 at 2.4 GHz = 78.6 T fp32 lane-ops/s
+QBP_VALU_OPS_PER_PAIR = 9          # 3 sub, 3 mul, 2 add (uncontracted) + 1 compare
 
 MODELS = {
     "pointnet2_cls_ssg": ("scanobjectnn_amd.pointnet2.pointnet2_cls_ssg", False, 256, 2048),
@@ -193,6 +202,35 @@ def _measured_traffic(dom):
     return None
 
 
+def _ball_query_fractions(x, kernels):
+    """SA1 ball query of the SSG config on the bench's own clouds: pair tests actually executed, fp32-VALU fraction
+    and HBM fraction.  The kernel scans a query's dataset in slabs of 64 points and stops at the slab holding the
+    nsample-th hit, so executed pairs = 64 * slabs scanned (computed here from idx / pts_cnt, outside the timed
+    region); `pairs_nominal` = b*m*n is what a full scan would test."""
+    from scanobjectnn_amd.pointnet2 import tf_grouping, tf_sampling
+    out = {}
+    for d in kernels:
+        if d["kernel"] != "pcops_query_ball_point":
+            continue
+        b, n, m, r, s = d["shape"][:5]
+        if (b, n) != (x.shape[0], x.shape[1]):
+            continue        # only the level whose inputs can be rebuilt here (SA1)
+        with torch.no_grad():
+            q = tf_sampling.gather_point(x, tf_sampling.farthest_point_sample(m, x))
+            idx, cnt = tf_grouping.query_ball_point(float(r), int(s), x, q)
+            last = idx[:, :, s - 1].long()
+            slabs = torch.where(cnt >= s, last // 64 + 1, torch.full_like(last, (n + 63) // 64))
+            executed = int(slabs.sum().item()) * 64
+        t = d["avg_us"] * 1e-6
+        out = {"shape": d["shape"], "avg_us": d["avg_us"], "pairs_nominal": b * m * n, "pairs_executed": executed,
+               "pair_tests_per_s": executed / t,
+               "valu_frac": executed * QBP_VALU_OPS_PER_PAIR / t / VALU_LANE_OPS_PER_S,
+               "hbm_frac": d["bytes"] / t / 1e9 / HBM_PEAK_GBS,
+               "bound": "fp32 VALU (brute-force scan: %d lane-ops per pair test)" % QBP_VALU_OPS_PER_PAIR,
+               "padding_frac": float(1.0 - cnt.float().mean().item() / s)}
+    return out
+
+
 def cpu_baseline(model_name, n_points, seconds_budget=15.0):
     """The CPU restatement (oracle/ref_models.py + the C oracle for the geometry) of the SAME step
     (forward + backward, training-mode BN, no optimiser), timed on the host cores of this box."""
@@ -228,48 +266,154 @@ def cpu_baseline(model_name, n_points, seconds_budget=15.0):
                       % (done, n_points, model_name, cores, el)}
 
 
+def cpu_ops_baseline(seconds_budget=6.0):
+    """the op-level CPU figures.  The reference's own CPU twins (query_ball_point_cpu,
+    group_point_cpu, group_point_grad_cpu, threenn_cpu, threeinterpolate_cpu, threeinterpolate_grad_cpu) at the
+    reference's own bench sizes (tf_ops/grouping/test/query_ball_point.cpp:86-119: b=32 n=512 m=128 nsample=64 c=64
+    r=0.1; 3d_interpolation/interpolate.cpp:132-169: b=32 n=512 m=128 c=64), timed (a) on one core as they are and
+    (b) sharded by cloud over the host cores (one process per shard, no code change).  `kind` says what ran:
+    "reference" = oracle/_ref (the reference sources compiled in the build container, prebuilt .so shipped),
+    "port" = oracle/pcops_oracle.c (validated bit-exact against them by tests/test_oracle_golden.py)."""
+    import multiprocessing as mp
+    from oracle import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    rng = np.random.default_rng(5)
+    b, n, m, s, c, r = 32, 512, 128, 64, 64, 0.1
+    xyz1 = rng.random((b, n, 3), dtype=np.float32)
+    xyz2 = rng.random((b, m, 3), dtype=np.float32)
+    pts = rng.random((b, n, c), dtype=np.float32)
+    idx = O.query_ball_point(r, s, xyz1, xyz2)[0]
+    gout = rng.random((b, m, s, c), dtype=np.float32)
+    w = rng.random((b, n, 3), dtype=np.float32)
+    i3 = rng.integers(0, m, (b, n, 3)).astype(np.int32)
+    p2 = rng.random((b, m, c), dtype=np.float32)
+    g2 = rng.random((b, n, c), dtype=np.float32)
+    R = kind == "reference"
+    ops = {
+        "query_ball_point": ((lambda sl: (O.ref_query_ball_point if R else (lambda *a: O.query_ball_point(*a)[0]))(r, s, xyz1[sl], xyz2[sl]))),
+        "group_point": (lambda sl: (O.ref_group_point if R else O.group_point)(pts[sl], idx[sl])),
+        "group_point_grad": (lambda sl: (O.ref_group_point_grad if R else O.group_point_grad)(pts[sl].shape, idx[sl], gout[sl])),
+        "three_nn": (lambda sl: (O.ref_three_nn if R else O.three_nn)(xyz1[sl], xyz2[sl])),
+        "three_interpolate": (lambda sl: (O.ref_three_interpolate if R else O.three_interpolate)(p2[sl], i3[sl], w[sl])),
+        "three_interpolate_grad": (lambda sl: (O.ref_three_interpolate_grad if R else O.three_interpolate_grad)(p2[sl].shape, i3[sl], w[sl], g2[sl])),
+    }
+    cores = min(b, os.cpu_count() or 1)
+    per = max(1, b // cores)
+    shards = [slice(i, min(b, i + per)) for i in range(0, b, per)]
+    out = {}
+    t_all = time.perf_counter()
+    for name, fn in ops.items():
+        fn(slice(0, 1))
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            fn(slice(0, b))
+            reps += 1
+            if time.perf_counter() - t0 > seconds_budget / (2 * len(ops)) or reps >= 20:
+                break
+        one = (time.perf_counter() - t0) / reps
+        # batch-sharded: fork one worker per shard (the closures and arrays are inherited, nothing is pickled)
+        t0 = time.perf_counter()
+        procs = []
+        for sl in shards:
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    fn(sl)
+                finally:
+                    os._exit(0)
+            procs.append(pid)
+        for pid in procs:
+            os.waitpid(pid, 0)
+        sharded = time.perf_counter() - t0
+        out[name] = {"ms_1core": one * 1e3, "clouds_per_s_1core": b / one,
+                     "ms_sharded": sharded * 1e3, "clouds_per_s_sharded": b / sharded}
+    return {"kind": kind, "cores_sharded": len(shards), "shape": {"b": b, "n": n, "m": m, "nsample": s, "c": c, "radius": r},
+            "ops": out, "seconds": time.perf_counter() - t_all,
+            "note": "sharded = one forked process per cloud shard incl. fork cost; reference bench sizes"}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks through torch.distributed.run."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="pointnet2_cls_ssg", choices=sorted(MODELS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--num_point", type=int, default=0)
     ap.add_argument("--kind", default="surface", choices=["surface", "ball"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="eval-mode forward throughput (not the metric)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (eval forward, kind=ball, rotate+jitter in the step)")
+    ap.add_argument("--augment", action="store_true",
+                    help="put the device-side rotate + jitter of the input pipeline (provider.py) inside the timed step")
+    ap.add_argument("--sync_bn", action="store_true", help="all-reduce the BN batch statistics over the ranks")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s); refusing to "
+                         "report a number for a different world size" % (args.gpus, world, os.environ.get("WORLD_SIZE")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     _lib.load()
 
+    import gc
     import importlib
+    from scanobjectnn_amd import provider
     modpath, has_mask, cfg_batch, cfg_n = MODELS[args.model]
     mod = importlib.import_module(modpath)
     B = args.batch or cfg_batch
     N = args.num_point or cfg_n
+    D.SYNC_BN = bool(args.sync_bn) and world > 1
 
-    x = torch.from_numpy(synth_clouds(B, N, seed=1234 + rank, kind=args.kind)).to(dev)
-    y = torch.from_numpy(synth_labels(B, seed=1234 + rank)).to(dev)
-    mask = torch.from_numpy(synth_masks(B, N, seed=1234 + rank)).to(dev) if has_mask else None
+    def make_inputs(kind):
+        xx = torch.from_numpy(synth_clouds(B, N, seed=1234 + rank, kind=kind)).to(dev)
+        yy = torch.from_numpy(synth_labels(B, seed=1234 + rank)).to(dev)
+        mm = torch.from_numpy(synth_masks(B, N, seed=1234 + rank)).to(dev) if has_mask else None
+        return xx, yy, mm
 
-    net = Model(mod.get_model, device=dev, seed=0).build(x[:2].contiguous())
+    inputs = {"x": None}
+    inputs["x"], y, mask = make_inputs(args.kind)
+
+    net = Model(mod.get_model, device=dev, seed=0).build(inputs["x"][:2].contiguous())
     fp = TU.FlatParams(net)
     D.broadcast_(fp.flat)                       # identical replicas
     opt = TU.TFAdam(fp)
     global_batch = B * world
-    state = {"step": 0}
+    state = {"step": 0, "augment": bool(args.augment)}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    ar_events = []                              # (start, end) HIP events around the gradient all-reduce
 
     def train_step():
         s = state["step"]
         lr = TU.get_learning_rate(s, global_batch)
         bn_decay = TU.get_bn_decay(s, global_batch)
+        x = inputs["x"]
+        if state["augment"]:                    # §8f-1: the reference's per-batch rotate + jitter, on the device
+            x = provider.jitter_point_cloud(provider.rotate_point_cloud(x, generator=gen), generator=gen).contiguous()
         fp.begin_step()
         out = net(x, is_training=True, bn_decay=bn_decay)
         if has_mask:
@@ -277,50 +421,95 @@ def main():
         else:
             loss = mod.get_loss(out[0], y, out[1])
         loss.backward()
-        D.allreduce_mean_(fp.collect(), world)
+        g = fp.collect()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            D.allreduce_mean_(g, world)
+            e1.record()
+            ar_events.append((e0, e1))
         opt.step(lr)
         state["step"] = s + 1
         return loss
 
     def fwd_step():
         with torch.no_grad():
-            return net(x, is_training=False)
+            return net(inputs["x"], is_training=False)
+
+    def measure(step, steps, warmup, with_kernels):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(warmup):
+            step()
+        # the host only has to stay ahead of the GPU: a generation-2 garbage collection in the middle of the timed
+        # region (tens of ms with the autograd graphs of a step alive) would let the device queue run dry
+        gc.collect()
+        gc.disable()
+        timer = KernelTimer() if with_kernels else None
+        if timer:
+            _lib._hooks.append(timer)
+        del ar_events[:]
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        host_elapsed = time.perf_counter() - t0      # all launches of the K steps enqueued (GPU still running)
+        torch.cuda.synchronize()
+        local_elapsed = time.perf_counter() - t0
+        D.barrier()
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+        if timer:
+            _lib._hooks.remove(timer)
+        return D.max_over_ranks(elapsed, dev), local_elapsed, host_elapsed, (timer.summary() if timer else [])
 
     step = fwd_step if args.forward_only else train_step
+    elapsed, local_elapsed, host_elapsed, kernels = measure(step, args.steps, args.warmup, True)
+    ar_ms = [a.elapsed_time(b) for a, b in ar_events]
+    per_rank = D.gather_floats(B * args.steps / local_elapsed, dev)      # every rank's own clouds/s
+    ar_all = D.gather_floats(sum(ar_ms) / max(len(ar_ms), 1), dev)
+    rccl_ranks = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
-    for _ in range(args.warmup):
-        step()
-    # the host only has to stay ahead of the GPU: a generation-2 garbage collection in the middle of the timed
-    # region (tens of ms with the autograd graphs of a step alive) would let the device queue run dry
-    import gc
-    gc.collect()
-    gc.disable()
-    timer = KernelTimer()
-    _lib._hooks.append(timer)
-    D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    host_elapsed = time.perf_counter() - t0          # all launches of the K steps enqueued (GPU still running)
-    torch.cuda.synchronize()
-    D.barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    _lib._hooks.remove(timer)
-    elapsed = D.max_over_ranks(elapsed, dev)
-    kernels = timer.summary()
+    # ---- secondary measurements (single GPU only; never part of `value`)
+    extras = {}
+    if world == 1 and not args.no_extras and not args.forward_only:
+        k2 = max(5, min(20, args.steps))
+        e, _, _, _ = measure(fwd_step, k2, 3, False)
+        extras["forward_eval_clouds_per_s"] = B * k2 / e
+        other = "ball" if args.kind == "surface" else "surface"
+        keep = inputs["x"]
+        inputs["x"] = make_inputs(other)[0]
+        e, _, _, _ = measure(train_step, k2, 3, False)
+        extras["train_clouds_per_s_kind_%s" % other] = B * k2 / e
+        e, _, _, _ = measure(fwd_step, k2, 3, False)
+        extras["forward_eval_clouds_per_s_kind_%s" % other] = B * k2 / e
+        inputs["x"] = keep
+        if not state["augment"]:
+            state["augment"] = True
+            e, _, _, _ = measure(train_step, k2, 3, False)
+            extras["train_clouds_per_s_with_rotate_jitter"] = B * k2 / e
+            state["augment"] = False
+        extras["steps_each"] = k2
+
+    # ---- ball query: the pair tests the kernel actually executes (it stops a query at its nsample-th hit) and the
+    # fp32-VALU bound next to the HBM figure (SURVEY.md §8d: brute force is VALU bound, both are reported)
+    qbp = None
+    if rank == 0 and args.model.startswith("pointnet2_cls_ssg"):
+        qbp = _ball_query_fractions(inputs["x"], kernels)
 
     if rank != 0:
         return
     value = global_batch * args.steps / elapsed
+    for d in kernels:
+        d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
+        d["mfma_frac"] = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
+        d["bound_frac"] = max(d["hbm_frac"], d["mfma_frac"])
     dom = kernels[0] if kernels else None
     roofline = None
     if dom is not None:
         # the binding roofline of the dominant kernel = the one it sits closer to: HBM for the streaming
         # kernels; for the MFMA GEMMs whichever of (algorithmic bytes / 8 TB/s, flops / 157.3 TF/s) is larger
-        hbm_frac = dom["gbs"] / HBM_PEAK_GBS
-        mfma_frac = dom["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if dom["work_unit"] == "flop" else 0.0
+        hbm_frac, mfma_frac = dom["hbm_frac"], dom["mfma_frac"]
         traffic = _measured_traffic(dom)
         if mfma_frac > hbm_frac:
             roofline = {"bound": "mfma", "achieved": dom["gwork_s"] / 1e3, "peak": F32_PEAK_TFLOPS,
@@ -332,7 +521,11 @@ def main():
                          "launches": dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"],
                          "algorithmic_flops_per_launch": dom["work"] if dom["work_unit"] == "flop" else None,
                          "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
-                         "share_of_step": dom["ms"] / (elapsed * 1e3)})
+                         "share_of_step": dom["ms"] / (elapsed * 1e3),
+                         # ceilings measured on this chip (tools/ubench, MI355X_MICROARCH.md): what `peak` is in practice
+                         "peak_measured": {"mfma_f32_tflops": MEASURED_F32_MFMA_TFLOPS, "hbm_gbs": MEASURED_HBM_GBS},
+                         "frac_of_measured_peak": (dom["gwork_s"] / 1e3 / MEASURED_F32_MFMA_TFLOPS
+                                                   if mfma_frac > hbm_frac else dom["gbs"] / MEASURED_HBM_GBS)})
     line = {
         "metric": "point-clouds/sec fwd+bwd at B×2048×3, 15-cls" if not args.forward_only
                   else "point-clouds/sec forward (eval) at B×2048×3, 15-cls",
@@ -341,14 +534,28 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s PB_T50_RS-shaped synthetic clouds (%s), %d pts, batch %d per GPU, "
-                               "train step = fwd+bwd+allreduce+Adam" % (args.model, args.kind, N, B),
-                   "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world},
+                               "train step = %sfwd+bwd+allreduce+Adam"
+                               % (args.model, args.kind, N, B, "rotate+jitter+" if args.augment else ""),
+                   "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world,
+                   "sync_bn": bool(D.SYNC_BN)},
+        "rccl_ranks": rccl_ranks,
+        "per_rank_clouds_per_s": per_rank,
+        "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,
+        "allreduce_share_of_step": (max(ar_all) / (elapsed / args.steps * 1e3)) if world > 1 else 0.0,
         "roofline": roofline,
-        "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit")}
-                    for d in kernels[:24]],
+        "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit",
+                                        "hbm_frac", "mfma_frac", "bound_frac")} for d in kernels[:24]],
     }
+    if extras:
+        line["extras"] = extras
+    if qbp:
+        line["ball_query"] = qbp
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.model, N)
+        try:
+            line["cpu_baseline"]["ops"] = cpu_ops_baseline()
+        except Exception as ex:       # the op leg is a reported extra: never lose the bench line over it
+            line["cpu_baseline"]["ops"] = {"error": repr(ex)}
     print(json.dumps(line))
 
 

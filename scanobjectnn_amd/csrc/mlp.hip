@@ -2329,17 +2329,31 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
     return launch_gemm_ws_only<A_DY, E_MASKX>(a, st);
 }
 
+static int wgrad_legacy_splits(long long M, int K, int N);
+
 int pcops_mlp_wgrad_splits(long long M, int K, int N) {
-    // upper bound of the partial copies either wgrad kernel writes (scratch is sized with it)
-    const int kb = (K + 63) / 64, nb = (N + 127) / 128;
-    long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    long long rows = (M + want - 1) / want;
-    rows = ((rows + 7) / 8) * 8;
-    if (rows < 8) rows = 8;
-    int legacy = (int)((M + rows - 1) / rows);
-    return legacy < 512 ? 512 : legacy;
+    // upper bound of the partial copies ANY of the three wgrad kernels writes for this shape (the scratch is sized
+    // with it): the group counts of wgrad_pc_plan / wgrad_ws_plan before their M clamp, and the legacy split count.
+    // (It used to be a flat 512, i.e. 1 GiB of scratch for the 512 -> 1024 layer whose kernels write 16 partials.)
+    int best = wgrad_legacy_splits(M, K, N);
+    {   // wgrad_pc_plan
+        const int tk = K <= 64 ? 1 : 2, tn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+        const int kb = (K + 64 * tk - 1) / (64 * tk), nb = (N + 64 * tn - 1) / (64 * tn);
+        int g = (tk * tn == 1 ? 512 : 256) / (kb * nb);
+        if (g < 1) g = 1;
+        if (g > best) best = g;
+    }
+    {   // wgrad_ws_plan
+        int tk, tn;
+        if (K <= 64 && N <= 64) { tk = 2; tn = 2; }
+        else if (K <= 64) { tk = 2; tn = 4; }
+        else { tk = 4; tn = 4; }
+        const int kb = (K + 32 * tk - 1) / (32 * tk), nb = (N + 32 * tn - 1) / (32 * tn);
+        int g = 256 / (kb * nb);
+        if (g < 1) g = 1;
+        if (g > best) best = g;
+    }
+    return best;
 }
 
 static int wgrad_legacy_splits(long long M, int K, int N) {

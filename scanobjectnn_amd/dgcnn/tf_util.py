@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib, fused_mlp
+from .. import dist as _dist
 from ..graph import constant_initializer, get_variable, variable_scope
 from ..pointnet2 import tf_util as _pn2
 from ..pointnet2.tf_util import (_dense, _variable_with_weight_decay, avg_pool2d, dropout,  # noqa: F401
@@ -33,7 +34,10 @@ def _batch_norm(inputs, is_training, scope, bn_decay, names):
         mov_var = get_variable(names[1], [c], constant_initializer(1.0), trainable=False)
     flat = inputs.reshape(-1, c)
     if is_training:
-        var, mean = torch.var_mean(flat, dim=0, unbiased=False)
+        if _dist.sync_bn_active():
+            mean, var, _ = _dist.sync_batch_stats(flat)
+        else:
+            var, mean = torch.var_mean(flat, dim=0, unbiased=False)
         with torch.no_grad():
             mov_mean.mul_(decay).add_(mean.detach(), alpha=1.0 - decay)
             mov_var.mul_(decay).add_(var.detach(), alpha=1.0 - decay)

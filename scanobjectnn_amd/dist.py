@@ -8,6 +8,25 @@ import os
 import torch
 import torch.distributed as dist
 
+# Optional SyncBN: when True and a process group with more than one rank exists, every BatchNorm
+# layer all-reduces its per-channel batch statistics (forward: sum, sum of squares; backward: the two BN-backward
+# sums) so that training normalises with the statistics of the GLOBAL batch, i.e. reproduces single-device batch
+# statistics at the global batch size.  Off: statistics are per rank (plain data parallelism) and the moving
+# averages differ between ranks until `broadcast_buffers_` is called (the trainers do so before every checkpoint).
+SYNC_BN = False
+
+
+def sync_bn_active():
+    return SYNC_BN and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_stat_partials(part, rows):
+    """(P, 2, C) fp32 partial column sums of this rank -> ((1, 2, C) global sums, global row count).
+    The P partials are added in float64 (as the finalisation kernels do) before the all-reduce."""
+    tot = part.double().sum(dim=0, keepdim=True)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return tot.float().contiguous(), rows * dist.get_world_size()
+
 
 def init_from_env(backend=None):
     """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).  Returns (rank, world, local)."""
@@ -60,3 +79,45 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sync_batch_stats(flat):
+    """(rows, C) -> per-channel (mean, biased variance, global row count) over the rows of ALL ranks, differentiable:
+    the all-reduce of (sum, sum of squares) is autograd-aware (its backward is the all-reduce of the incoming
+    gradients), which yields exactly the cross-rank terms of the SyncBN backward.  For the layers that do not go
+    through the fused kernels (FC head, small stacks)."""
+    import torch.distributed.nn.functional as dfn
+    n = flat.shape[0]
+    s = torch.stack([flat.sum(dim=0), (flat * flat).sum(dim=0)])
+    s = dfn.all_reduce(s, op=dist.ReduceOp.SUM)
+    total = n * dist.get_world_size()
+    mean = s[0] / total
+    var = (s[1] / total - mean * mean).clamp_min(0.0)
+    return mean, var, total
+
+
+def gather_floats(value, device):
+    """[value on rank 0, value on rank 1, ...] on every rank"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def broadcast_buffers_(module, src=0):
+    """Make the non-trainable state (BN moving mean / variance) of every replica that of rank `src`: without SyncBN
+    each rank tracks the statistics of its own shard, and a checkpoint must not depend on which rank wrote it."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for b in bufs:
+        k = b.numel()
+        b.copy_(flat[off:off + k].view_as(b))
+        off += k

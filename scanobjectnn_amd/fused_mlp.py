@@ -18,6 +18,7 @@ Two kinds of first layer:
 import torch
 
 from . import _lib
+from . import dist as _dist
 
 
 def _f32(n, dev):
@@ -63,6 +64,8 @@ class FusedMLPStack(torch.autograd.Function):
         identity = bool(int(pool) & 2)      # gather stack whose idx is 0..n-1 per cloud (group_all): scatter = reshape
         pool = bool(int(pool) & 1)
         gather = idx is not None
+        need_grad = any(ctx.needs_input_grad)
+        sync = training and _dist.sync_bn_active()
         dev = idx.device if gather else a0.device
         layers = [tensors[6 * i:6 * i + 6] for i in range(L)]
         if gather:
@@ -79,7 +82,10 @@ class FusedMLPStack(torch.autograd.Function):
         pooled_raw = None
         # a first layer with only the coordinate term is ARITHMETIC in three offsets per row: it is never stored, the
         # next layer and the whole backward rebuild it from off4 (16 bytes per row instead of 4 C1)
+        # (with SyncBN, or a backward through eval-mode BN, the layer is materialised: its gradient shortcut assumes
+        # rank-local batch statistics)
         virt = (gather and a0 is None and ctr is None and wxyz is not None and (L >= 3 or (L == 2 and not pool))
+                and not sync and (training or not need_grad)
                 and bool(lib.pcops_mlp_xyz_supported(R, C1, layers[1][0].shape[-1])))
         off4 = xyzw = mom = None
         if virt:
@@ -120,7 +126,11 @@ class FusedMLPStack(torch.autograd.Function):
             scale, shift = vecs.take(N), vecs.take(N)
             if training:
                 mean, rstd = vecs.take(N), vecs.take(N)
-                _lib.call("pcops_mlp_bn_finalize", P, N, R, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                Pf, Rf = P, R
+                if sync:        # SyncBN: the statistics of the global batch
+                    part, Rf = _dist.allreduce_stat_partials(part, R)
+                    Pf = 1
+                _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                           beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
                 means.append(mean)
@@ -128,6 +138,9 @@ class FusedMLPStack(torch.autograd.Function):
             else:
                 _lib.call("pcops_mlp_bn_eval_coeffs", N, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(),
                           mv.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr())
+                if need_grad:   # backward through frozen statistics: y_bn = scale*y + shift with constants
+                    means.append(mm.detach().clone())
+                    rstds.append(torch.rsqrt(mv.detach() + float(eps)))
             Ys.append(Y)
             scales.append(scale)
             shifts.append(shift)
@@ -144,18 +157,18 @@ class FusedMLPStack(torch.autograd.Function):
                 _lib.call("pcops_mlp_pool_select", G, C, ysel.data_ptr(), scales[-1].data_ptr(),
                           shifts[-1].data_ptr(), out.data_ptr())
             else:
-                argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if training else None
-                ysel = _f32((G, C), dev) if training else None
+                argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if (training or need_grad) else None
+                ysel = _f32((G, C), dev) if (training or need_grad) else None
                 _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
                           shifts[-1].data_ptr(), out.data_ptr(), _p(argmax), _p(ysel))
         else:
             out = _f32((R, C), dev)
             _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
                       shifts[-1].data_ptr(), out.data_ptr())
-        if training:
+        if training or need_grad:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
                          [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
-            ctx.meta = (S, pool, L, R, K0, gather, identity)
+            ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
         return out
 
     @staticmethod
@@ -166,7 +179,7 @@ class FusedMLPStack(torch.autograd.Function):
         xstats = None
         virt = off4 is not None
         widths = [g.shape[0] for g in gammas]
-        S, pool, L, R, K0, gather, identity = ctx.meta
+        S, pool, L, R, K0, gather, identity, training, sync = ctx.meta
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grads = [None] * (6 * L)
@@ -197,6 +210,17 @@ class FusedMLPStack(torch.autograd.Function):
             _lib.call("pcops_mlp_bn_bwd_coeffs", P, N, R, part.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
                       means[l].data_ptr(), rstds[l].data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                       p.data_ptr(), q.data_ptr(), t.data_ptr())
+            if sync:
+                # SyncBN: dgamma / dbeta stay rank-local sums (the gradient all-reduce adds the ranks up); the
+                # dY = p G + q Y + t coefficients come from the sums over the GLOBAL batch
+                gpart, Rg = _dist.allreduce_stat_partials(part, R)
+                junk = _f32(2 * N, dev)
+                _lib.call("pcops_mlp_bn_bwd_coeffs", 1, N, Rg, gpart.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
+                          means[l].data_ptr(), rstds[l].data_ptr(), junk.data_ptr(), junk[N:].data_ptr(),
+                          p.data_ptr(), q.data_ptr(), t.data_ptr())
+            if not training:    # frozen statistics: no mean / variance terms in the BN backward
+                q.zero_()
+                t.zero_()
             grads[6 * l + 2] = dgamma
             grads[6 * l + 3] = dbeta
             pooled = pool and l == L - 1
@@ -352,6 +376,8 @@ class EdgeConvPool(torch.autograd.Function):
         Nsrc, C = Q.shape[1], Q.shape[2]
         dev = Q.device
         G = B * M
+        need_grad = any(ctx.needs_input_grad)
+        sync = training and _dist.sync_bn_active()
         SQ, qsel = _f32((G, C), dev), _f32((G, C), dev)
         arg = torch.empty((G, C), dtype=torch.uint8, device=dev)
         P = lib.pcops_edge_pool_stats_rows(G)
@@ -364,24 +390,32 @@ class EdgeConvPool(torch.autograd.Function):
         if training:
             mean, rstd = vecs.take(C), vecs.take(C)
             ws = _workspace(C, dev)
-            _lib.call("pcops_mlp_bn_finalize", P, C, G * S, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+            Pf, Rf = P, G * S
+            if sync:
+                part, Rf = _dist.allreduce_stat_partials(part, G * S)
+                Pf = 1
+            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                       beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                       mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         else:
             _lib.call("pcops_mlp_bn_eval_coeffs", C, gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
                       float(eps), scale.data_ptr(), shift.data_ptr())
+            if need_grad:
+                mean, rstd = mm.detach().clone(), torch.rsqrt(mv.detach() + float(eps))
         out = _f32((G, C), dev)
-        ysel = _f32((G, C), dev) if training else None
+        ysel = _f32((G, C), dev) if (training or need_grad) else None
         _lib.call("pcops_edge_pool_out", G, C, qsel.data_ptr(), Ctr.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   out.data_ptr(), _p(ysel))
-        if training:
+        if training or need_grad:
             ctx.saved = (Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift)
+            ctx.flags = (bool(training), bool(sync))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
         Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift = ctx.saved
+        training, sync = ctx.flags
         B, M, S = idx.shape
         Nsrc, C = Q.shape[1], Q.shape[2]
         dev = Q.device
@@ -398,6 +432,15 @@ class EdgeConvPool(torch.autograd.Function):
         _lib.call("pcops_mlp_bn_bwd_coeffs", P, C, G * S, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                   mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), p.data_ptr(), q.data_ptr(),
                   t.data_ptr())
+        if sync:        # see FusedMLPStack.backward
+            gpart, Rg = _dist.allreduce_stat_partials(part, G * S)
+            junk = _f32(2 * C, dev)
+            _lib.call("pcops_mlp_bn_bwd_coeffs", 1, C, Rg, gpart.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                      mean.data_ptr(), rstd.data_ptr(), junk.data_ptr(), junk[C:].data_ptr(), p.data_ptr(),
+                      q.data_ptr(), t.data_ptr())
+        if not training:
+            q.zero_()
+            t.zero_()
         dQ, dCtr = _f32((B, Nsrc, C), dev), _f32((B, M, C), dev)
         wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4, dtype=torch.int32, device=dev)
         _lib.call("pcops_edge_pool_bwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
@@ -446,6 +489,11 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
     Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
     c = lambda t: t.contiguous() if t is not None else None   # noqa: E731
     S = idx.shape[2]
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xyz, new_xyz)):
+        # the fused path has no d(loss)/d(coordinates) (the reference has one through GroupPoint / GatherPoint and
+        # the centring subtraction): the callers take the unfused path then -- never detach silently
+        raise RuntimeError("gather_mlp_stack: xyz / new_xyz require grad; use the unfused grouped path "
+                           "(pointnet_util falls back to it automatically)")
     if (len(layer_tensors) == 1 and pool and Q is not None and Ctr is not None and xyz is None and wxyz is None
             and bias is None and S <= 256 and edge_conv_pool_supported(Q.shape[-1], S)
             and 256 % (Q.shape[-1] // 4) == 0 and Q.shape[1] <= 16384):

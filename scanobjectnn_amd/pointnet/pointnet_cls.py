@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from ..graph import variable_scope
-from ..pointnet2 import tf_util
+from . import tf_util
 from .transform_nets import feature_transform_net, input_transform_net
 
 NUM_CLASSES = 15

@@ -3,7 +3,7 @@ feature_transform_net :53-95).  Pure dense layers (no custom kernel), runs on an
 import torch
 
 from ..graph import constant_initializer, get_variable, variable_scope
-from ..pointnet2 import tf_util
+from . import tf_util
 
 
 def _trunk(net, num_point, is_training, bn_decay, first_kernel):

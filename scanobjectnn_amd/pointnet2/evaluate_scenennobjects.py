@@ -13,6 +13,11 @@ from .. import provider
 NUM_CLASSES = 15
 
 
+def _host(a):
+    """labels / masks may live on the device (the trainer keeps the whole set resident): metrics are host NumPy"""
+    return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
+
 def vote_logits(predict, points, num_votes):
     """sum over votes of predict(rotated points); predict: (B,N,3) tensor -> (B,C) logits"""
     total = None
@@ -39,6 +44,7 @@ def eval_one_epoch(net, data, labels, batch_size, num_votes=1, device="cuda:0"):
     """net: graph.Model of a classifier get_model; data (K,N,3), labels (K,).  Whole batches only (like the
     reference: num_batches = K // BATCH_SIZE)."""
     preds, seen = [], []
+    labels = _host(labels)
     for b in range(data.shape[0] // batch_size):
         pts = torch.as_tensor(data[b * batch_size:(b + 1) * batch_size], dtype=torch.float32, device=device)
         logits = vote_logits(lambda p: net(p.contiguous(), is_training=False)[0], pts, num_votes)
@@ -53,6 +59,7 @@ def eval_one_epoch(net, data, labels, batch_size, num_votes=1, device="cuda:0"):
 def eval_seg_one_epoch(net, data, labels, masks, batch_size, device="cuda:0"):
     """BGA models: class accuracy + mask accuracy = correct points / (seen clouds * points)"""
     cls_pred, seen, seg_correct, n_pts = [], [], 0, 0
+    labels, masks = _host(labels), _host(masks)
     for b in range(data.shape[0] // batch_size):
         sl = slice(b * batch_size, (b + 1) * batch_size)
         pts = torch.as_tensor(data[sl], dtype=torch.float32, device=device)
@@ -67,11 +74,13 @@ def eval_seg_one_epoch(net, data, labels, masks, batch_size, device="cuda:0"):
             "seg_accuracy": seg_correct / float(n_pts)}
 
 
+@torch.no_grad()
 def eval_partseg_one_epoch(net, data, parts, batch_size, num_classes=6, device="cuda:0"):
     """part segmentation (`train_partseg.py:251-303`, `evaluate_partseg.py`): point accuracy = correct points /
     seen points; avg class acc = mean over the part classes that occur of (correct points of the class / points of it)"""
     seen_c = np.zeros(num_classes, dtype=np.int64)
     corr_c = np.zeros(num_classes, dtype=np.int64)
+    parts = _host(parts)
     for b in range(data.shape[0] // batch_size):
         sl = slice(b * batch_size, (b + 1) * batch_size)
         pts = torch.as_tensor(data[sl], dtype=torch.float32, device=device)

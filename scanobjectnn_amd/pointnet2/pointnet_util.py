@@ -97,8 +97,13 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
     return out.view(b, m, 1 if pool_max else s, widths[-1])
 
 
-def _gather_fusable(points, widths, bn, nsample, pool_max):
+def _gather_fusable(points, widths, bn, nsample, pool_max, xyz=None):
     c1 = widths[0]
+    if xyz is not None and torch.is_grad_enabled() and xyz.requires_grad:
+        # coordinates carry gradient (a T-Net in front, input saliency, adversarial perturbation): only the unfused
+        # path differentiates w.r.t. xyz -- group_point / gather_point / the centring subtraction, as in the
+        # reference (tf_grouping.py:43-47, tf_sampling.py:44-48)
+        return False
     return (tf_util.FUSED_MLP and bn and all(w % 32 == 0 for w in widths) and 256 % (c1 // 4) == 0
             and (c1 >= 256 or 256 % c1 == 0) and c1 <= 1024 and (not pool_max or nsample <= 256))
 
@@ -115,7 +120,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         if group_all:
             nsample = xyz.shape[1]
         if (pooling in ('max', 'avg', 'max_and_avg') and xyz.is_cuda and (points is not None or not group_all)
-                and _gather_fusable(points, mlp, bn, nsample, pool_max)):
+                and _gather_fusable(points, mlp, bn, nsample, pool_max, xyz)):
             # fast path: sample -> query -> [first conv before grouping] -> gather+add -> fused stack
             if group_all:
                 # one group holding the whole cloud around the origin (:59-84): idx = 0..n-1, so the "gather" is
@@ -171,7 +176,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
         outs = []
         for i, (idx, _cnt) in enumerate(scales):
             fmt = 'conv%d_' % i + '%d'
-            if xyz.is_cuda and _gather_fusable(points, mlp_list[i], bn, idx.shape[2], True):
+            if xyz.is_cuda and _gather_fusable(points, mlp_list[i], bn, idx.shape[2], True, xyz):
                 grouped = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp_list[i], fmt, is_training, bn_decay,
                                              use_xyz, False, True)          # [feats | xyz] order (:184)
             else:

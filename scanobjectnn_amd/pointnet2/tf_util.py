@@ -18,6 +18,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+from .. import dist as _dist
 from .. import fused_mlp
 from ..graph import (constant_initializer, get_variable, truncated_normal_initializer,
                      variable_scope, xavier_initializer, get_default_graph)
@@ -46,6 +47,18 @@ def batch_norm_template(inputs, is_training, scope, moments_dims_unused, bn_deca
         gamma = get_variable('gamma', [c], constant_initializer(1.0))
         moving_mean = get_variable('moving_mean', [c], constant_initializer(0.0), trainable=False)
         moving_var = get_variable('moving_variance', [c], constant_initializer(1.0), trainable=False)
+    if is_training and _dist.sync_bn_active():
+        # SyncBN: batch statistics of the global batch (all-reduced sums), same moving-average rule as the local path
+        x = inputs.movedim(ch_axis, -1) if ch_axis != inputs.dim() - 1 else inputs
+        flat = x.reshape(-1, c)
+        mean, var, total = _dist.sync_batch_stats(flat)
+        with torch.no_grad():
+            d = float(bn_decay)
+            moving_mean.mul_(d).add_(mean.detach(), alpha=1.0 - d)
+            moving_var.mul_(d).add_(var.detach() * (total / max(total - 1, 1)), alpha=1.0 - d)
+        scale = gamma * torch.rsqrt(var + BN_EPS)
+        out = (flat * scale + (beta - mean * scale)).reshape(x.shape)
+        return out.movedim(-1, ch_axis) if ch_axis != inputs.dim() - 1 else out
     if ch_axis == 1:
         return F.batch_norm(inputs, moving_mean, moving_var, gamma, beta, bool(is_training),
                             1.0 - float(bn_decay), BN_EPS)

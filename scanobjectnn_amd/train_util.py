@@ -89,3 +89,27 @@ class TFAdam:
         self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
         lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         self.fp.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr_t)
+
+
+class TFMomentum:
+    """tf.train.MomentumOptimizer(lr, momentum) (`pointnet2/train.py:165-166`): accum <- momentum*accum + g;
+    p <- p - lr*accum (no Nesterov, no dampening) on the flat buffers."""
+
+    def __init__(self, flat, momentum=0.9):
+        self.fp = flat
+        self.momentum = momentum
+        self.accum = torch.zeros_like(flat.flat)
+
+    @torch.no_grad()
+    def step(self, lr):
+        self.accum.mul_(self.momentum).add_(self.fp.grad)
+        self.fp.flat.add_(self.accum, alpha=-lr)
+
+
+def make_optimizer(name, flat, momentum=0.9):
+    """`--optimizer adam|momentum` of the reference trainers (`pointnet2/train.py:41-42,165-168`)"""
+    if name == "adam":
+        return TFAdam(flat)
+    if name == "momentum":
+        return TFMomentum(flat, momentum)
+    raise ValueError("optimizer must be 'adam' or 'momentum', got %r" % (name,))

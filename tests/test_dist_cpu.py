@@ -86,3 +86,100 @@ def test_shard_range_partitions_the_batch():
     spans = [D.shard_range(1024, r, 8) for r in range(8)]
     assert spans[0] == (0, 128) and spans[-1] == (896, 1024)
     assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The PRODUCT model object (graph.Model + FlatParams + TFAdam) under data parallelism: BASELINE config 1 (PointNet,
+# pure dense layers, runs on the host) on 2 and 4 gloo ranks.
+def _pointnet_setup(batch, npts):
+    import numpy as np
+    from scanobjectnn_amd.graph import Model
+    from scanobjectnn_amd.pointnet import pointnet_cls
+    from scanobjectnn_amd.synth import synth_clouds, synth_labels
+    pointnet_cls.tf_util.dropout = lambda x, *a, **k: x            # dropout draws per-rank random masks: off
+    x = torch.from_numpy(synth_clouds(batch, npts, seed=11))
+    y = torch.from_numpy(synth_labels(batch, seed=11))
+    net = Model(pointnet_cls.get_model, seed=0).build(x[:2])
+    return pointnet_cls, net, x, y
+
+
+def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    D.init_from_env(backend="gloo")
+    D.SYNC_BN = sync_bn
+    mod, net, x, y = _pointnet_setup(batch, npts)
+    fp = TU.FlatParams(net)
+    D.broadcast_(fp.flat)
+    opt = TU.TFAdam(fp)
+    lo, hi = D.shard_range(batch, rank, world)
+    for step in range(steps):
+        fp.begin_step()
+        logits, ep = net(x[lo:hi], is_training=True, bn_decay=0.5)
+        mod.get_loss(logits, y[lo:hi], ep, reg_weight=0.0).backward()
+        D.allreduce_mean_(fp.collect(), world)
+        if step == 0:
+            grad0 = fp.grad.tolist()
+        opt.step(1e-3)
+    bufs_before = torch.cat([b.reshape(-1) for b in net.buffers()]).tolist()
+    D.broadcast_buffers_(net)                                      # what the trainers do before a checkpoint
+    bufs_after = torch.cat([b.reshape(-1) for b in net.buffers()]).tolist()
+    q.put((rank, fp.flat.tolist(), bufs_before, bufs_after, grad0))
+    dist.destroy_process_group()
+
+
+def _run_model_dp(world, sync_bn, batch=8, npts=32, steps=2):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, sync_bn, batch, npts, steps))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [(torch.tensor(a), torch.tensor(b), torch.tensor(c), torch.tensor(d)) for _, a, b, c, d in res]
+
+
+def _single_process(batch=8, npts=32, steps=2):
+    mod, net, x, y = _pointnet_setup(batch, npts)
+    fp = TU.FlatParams(net)
+    opt = TU.TFAdam(fp)
+    for step in range(steps):
+        fp.begin_step()
+        logits, ep = net(x, is_training=True, bn_decay=0.5)
+        mod.get_loss(logits, y, ep, reg_weight=0.0).backward()
+        fp.collect()
+        if step == 0:
+            grad0 = fp.grad.clone()
+        opt.step(1e-3)
+    return fp.flat.clone(), torch.cat([b.reshape(-1) for b in net.buffers()]), grad0
+
+
+def test_model_data_parallel_sync_bn_equals_single_process():
+    """graph.Model + FlatParams + TFAdam on 2 and 4 ranks with SyncBN == one process on the whole batch: parameters
+    after two Adam steps and the BN moving statistics (global-batch statistics on every rank)."""
+    want_flat, want_bufs, want_grad0 = _single_process()
+    for world in (2, 4):
+        res = _run_model_dp(world, sync_bn=True)
+        for flat, bufs, _, _ in res:
+            assert torch.equal(flat, res[0][0])                              # replicas identical
+            assert torch.allclose(bufs, res[0][1], atol=1e-6)                # and so are their moving statistics
+        # the all-reduced gradient of the first step IS the gradient of the whole batch
+        assert (res[0][3] - want_grad0).abs().max().item() <= 1e-5 * max(1.0, want_grad0.abs().max().item())
+        # parameters after two Adam steps: Adam moves every parameter by ~lr whatever the gradient magnitude, so a
+        # parameter whose gradient sits at rounding level may differ by O(lr); the bulk must agree
+        assert (res[0][0] - want_flat).abs().mean().item() < 2e-5
+        assert torch.allclose(res[0][1], want_bufs, atol=1e-3, rtol=1e-3)     # statistics of the global batch
+
+
+def test_model_data_parallel_local_bn_and_buffer_broadcast():
+    """without SyncBN: one all-reduce keeps the PARAMETERS of the replicas identical, the BN moving statistics are
+    per rank (each saw its own shard) until broadcast_buffers_ makes them rank 0's"""
+    res = _run_model_dp(2, sync_bn=False)
+    assert torch.equal(res[0][0], res[1][0])
+    assert not torch.allclose(res[0][1], res[1][1], atol=1e-6)               # shards differ -> statistics differ
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][2], res[0][1])

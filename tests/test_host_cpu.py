@@ -2,6 +2,8 @@
 schedules, TF-flavoured Adam on flat buffers, the synthetic-cloud normalisation, and the TF1-style variable store."""
 import math
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -119,3 +121,85 @@ def test_variable_store_scopes_and_reuse():
     limit = math.sqrt(6.0 / (3 + 64))
     assert w.abs().max().item() <= limit and w.abs().max().item() > 0.5 * limit and b.abs().sum() == 0
     assert not mm.requires_grad
+
+
+def test_momentum_optimizer_matches_hand_computation():
+    """tf.train.MomentumOptimizer (`pointnet2/train.py:165-166`): accum = m*accum + g; p -= lr*accum"""
+    import torch
+    from scanobjectnn_amd import train_util as TU
+    lin = torch.nn.Linear(2, 1, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(torch.tensor([[1.0, -2.0]]))
+    fp = TU.FlatParams(lin)
+    opt = TU.make_optimizer("momentum", fp, 0.9)
+    p, acc = np.array([1.0, -2.0]), np.zeros(2)
+    for g in ([0.5, 0.25], [-1.0, 2.0], [0.125, 0.0]):
+        fp.grad.copy_(torch.tensor(g))
+        opt.step(0.1)
+        acc = 0.9 * acc + np.array(g)
+        p = p - 0.1 * acc
+    assert np.allclose(fp.flat.numpy(), p, atol=1e-6)
+    assert isinstance(TU.make_optimizer("adam", fp), TU.TFAdam)
+    with pytest.raises(ValueError):
+        TU.make_optimizer("sgd", fp)
+
+
+def test_device_side_centre_normalise_equal_the_host_formulas():
+    """data_utils.center_data_device / normalize_data_device (torch) == center_data / normalize_data (NumPy,
+    `data_utils.py:133-143,162-168`) on un-normalised clouds"""
+    import torch
+    from scanobjectnn_amd import data_utils as DU
+    rng = np.random.RandomState(2)
+    pcs = (rng.randn(6, 50, 3) * [3.0, 0.5, 7.0] + [10.0, -4.0, 2.5]).astype(np.float32)
+    want = DU.normalize_data(DU.center_data(pcs.copy()))
+    got = DU.normalize_data_device(DU.center_data_device(torch.from_numpy(pcs))).numpy()
+    assert np.allclose(got, want, atol=1e-6)
+    assert np.allclose(np.sqrt((got ** 2).sum(-1)).max(1), 1.0, atol=1e-6)
+    assert np.allclose(got.mean(1), 0.0, atol=1e-6)
+
+
+def test_epoch_indices_reproduce_get_current_data_h5():
+    from scanobjectnn_amd import data_utils as DU
+    rng = np.random.RandomState(0)
+    pcs = rng.rand(7, 30, 3).astype(np.float32)
+    labels = np.arange(7)
+    want, wl = DU.get_current_data_h5(pcs, labels, 12, rng=np.random.RandomState(5))
+    ip, ic = DU.epoch_indices(7, 30, 12, np.random.RandomState(5))
+    assert np.array_equal(pcs[:, ip][ic], want) and np.array_equal(labels[ic], wl)
+
+
+def test_raw_object_loader(tmp_path):
+    """`load_pc_file` / `load_data` (`data_utils.py:50-101`): float32 stream [count, 11 floats per point]; with_bg=False
+    keeps the most frequent label outside {0,1,2}; clouds shorter than num_points are dropped"""
+    import pickle
+    from scanobjectnn_amd import data_utils as DU
+    rng = np.random.RandomState(1)
+
+    def write(name, n, labels):
+        body = rng.rand(n, 11).astype(np.float32)
+        body[:, 10] = labels          # the LAST column is what `load_pc_file` filters on (`pc[:,-1]`, :66-72)
+        np.concatenate([[np.float32(n)], body.reshape(-1)]).astype(np.float32).tofile(tmp_path / name)
+        return body
+    a = write("a.bin", 40, np.r_[np.zeros(10), np.full(20, 5), np.full(10, 7)])
+    write("b.bin", 8, np.full(8, 4))
+    pc = DU.load_pc_file("a.bin", str(tmp_path))
+    assert pc.shape == (40, 3) and np.array_equal(pc, a[:, :3])
+    fg = DU.load_pc_file("a.bin", str(tmp_path), with_bg=False)
+    assert fg.shape == (20, 3) and np.array_equal(fg, a[10:30, :3])
+    with open(tmp_path / "split.pickle", "wb") as f:
+        pickle.dump([{"filename": "objects_bin/a.bin", "label": 3}, {"filename": "objects_bin/b.bin", "label": 9}], f)
+    pcs, labels = DU.load_data(str(tmp_path / "split.pickle"), num_points=16, data_path=str(tmp_path))
+    assert len(pcs) == 1 and labels == [3]
+    cur, lab = DU.get_current_data(pcs, labels, 16, rng=np.random.RandomState(0))
+    assert cur.shape == (1, 16, 3) and lab.tolist() == [3]
+
+
+def test_trainer_flags_are_the_references():
+    """`pointnet2/train.py:25-46`: same flag names; the boolean switches are typed (the reference's are truthy strings)"""
+    from scanobjectnn_amd.pointnet2 import train as T
+    a = T.parse_args([])
+    assert (a.with_bg, a.norm, a.center_data, a.num_class, a.optimizer, a.momentum) == (True, True, True, 15, "adam", 0.9)
+    assert (a.num_point, a.batch_size, a.max_epoch, a.decay_step, a.decay_rate) == (1024, 16, 250, 200000, 0.7)
+    b = T.parse_args(["--center_data", "false", "--norm", "0", "--optimizer", "momentum", "--momentum", "0.8",
+                      "--num_class", "11", "--gpu", "0", "--normal", "--with_bg", "no"])
+    assert (b.center_data, b.norm, b.with_bg, b.optimizer, b.momentum, b.num_class) == (False, False, False, "momentum", 0.8, 11)

@@ -123,3 +123,45 @@ def test_partseg_train_loop(tmp_path):
     assert all(np.isfinite(r["mean_loss"]) and r["mean_loss"] > 0 for r in log)
     assert log[-1]["mean_loss"] < 1.5 * log[0]["mean_loss"]          # not diverging (12 optimiser steps only)
     assert "graph.fa_layer3/conv_2/weights" in torch.load(tmp_path / "model.pt")
+
+
+def test_trainer_real_data_path_centres_and_normalises(tmp_path, monkeypatch):
+    """`pointnet2/train.py:100-106`: a loaded set is centred and scaled to the unit sphere before anything else (the
+    ball-query radii assume it).  An UN-normalised .npz goes through the trainer; the tensors entering get_model in
+    training must be normalize_data(center_data(x)) restricted to the epoch's point subset / cloud order.  Also runs
+    the momentum optimiser (`--optimizer momentum`, :165-166)."""
+    from scanobjectnn_amd import data_utils as DU
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg as m
+    from scanobjectnn_amd.pointnet2 import train as T
+    rng = np.random.RandomState(3)
+    raw = (synth_clouds(16, 600, seed=5) * rng.uniform(2.0, 9.0, (16, 1, 1)) + rng.uniform(-5, 5, (16, 1, 3))).astype(np.float32)
+    labels = synth_labels(16, seed=5)
+    np.savez(tmp_path / "train.npz", data=raw, label=labels)
+    np.savez(tmp_path / "test.npz", data=raw[:8], label=labels[:8])
+    seen = []
+    real = m.get_model
+
+    def spy(point_cloud, is_training, bn_decay=None, **kw):
+        if is_training:
+            seen.append(point_cloud.detach().cpu().numpy().copy())
+        return real(point_cloud, is_training, bn_decay=bn_decay, **kw)
+    monkeypatch.setattr(m, "get_model", spy)
+    args = T.parse_args(["--model", "pointnet2_cls_ssg", "--num_point", "512", "--batch_size", "8", "--max_epoch", "1",
+                         "--train_file", str(tmp_path / "train.npz"), "--test_file", str(tmp_path / "test.npz"),
+                         "--log_dir", str(tmp_path), "--no_augment", "--optimizer", "momentum", "--seed", "4"])
+    log = T.train(args)
+    assert len(log) == 1 and np.isfinite(log[0]["mean_loss"])
+    want = DU.normalize_data(DU.center_data(raw.copy()))
+    ip, ic = DU.epoch_indices(16, 600, 512, np.random.RandomState(4))
+    want = want[:, ip][ic]
+    assert len(seen) == 2
+    got = np.concatenate(seen)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-6
+    assert np.abs(np.sqrt((got ** 2).sum(-1)).max(1) - 1.0).max() <= 1e-5          # on the unit sphere ...
+    off = T.parse_args(["--model", "pointnet2_cls_ssg", "--num_point", "512", "--batch_size", "8", "--max_epoch", "1",
+                        "--train_file", str(tmp_path / "train.npz"), "--test_file", str(tmp_path / "test.npz"),
+                        "--log_dir", str(tmp_path), "--no_augment", "--center_data", "false", "--norm", "false",
+                        "--seed", "4"])
+    del seen[:]
+    T.train(off)
+    assert np.abs(np.concatenate(seen) - raw[:, ip][ic]).max() == 0.0               # ... unless switched off
