@@ -2,27 +2,38 @@
 //
 // Replaces grouping/tf_grouping_g.cu:3-141 of the reference (behaviour only).
 //
-// Ball query design (CDNA4-first, not the reference's one-block-per-cloud scan):
-//   * grid = (query tiles, clouds); every lane owns ONE query for the whole scan, so the
-//     reference's "first nsample hits in ascending dataset order" falls out of the scan
-//     order with no cross-lane bookkeeping;
-//   * the dataset cloud is staged ONCE per workgroup into LDS as SoA x[],y[],z[] by
-//     coalesced dword loads of the (n,3) AoS tensor; the inner loop reads it with
-//     wave-uniform ds_read_b128 (4 points per instruction, broadcast, conflict free);
-//   * `sqrtf(d2) < r` is replaced by the exactly equivalent `d2 <= T`, T = the largest
-//     fp32 with sqrtf(T) < r, computed on the host (sqrtf is monotone and correctly
-//     rounded).  The naive d2 < r*r is NOT equivalent;
-//   * the multi-radius (MSG) form tests up to 4 radii against one d2 in the same pass;
+// Ball query design (CDNA4-first, not the reference's one-block-per-cloud thread-per-query scan).
+// Measured on MI355X: this loop is bound by INSTRUCTION ISSUE -- every VALU or SALU wave-instruction costs a SIMD
+// about four cycles, whatever the lane count (rocprofv3 SQ_INSTS_VALU + SQ_INSTS_SALU of three earlier formulations:
+// 118 M instructions x 4 cycles / 1024 SIMDs = the kernel time).  So the design minimises instructions per pair test:
+//   * the DATASET lives in registers, lane l owning the PL CONSECUTIVE points PL*l .. PL*l + PL-1 (the cloud is
+//     staged once per workgroup through LDS -- coalesced global reads, conflict-free 16-byte LDS reads with a
+//     3 PL + 4 dword lane stride -- then never touched again);
+//   * the QUERY is wave-uniform (read out of a lane with v_readlane): one VALU instruction tests it against 64
+//     dataset points (compilers pair two of a lane's points into v_pk_* instructions: 128 per instruction), no
+//     divergence, no LDS, no load in the scan;
+//   * a hit is ONE BIT: lane l, bit c <=> point PL*l + c.  The reference's "first nsample hits in ascending
+//     dataset order" is lane-major, bit-minor order of that bitmap, so the slot of every hit is
+//     (exclusive wave scan of the per-lane popcounts, 6 DPP adds) + (rank of the bit inside its lane): the ordering
+//     work is ~40 instructions per QUERY instead of ~15 per 64 pair tests;
+//   * hits leave as a few scattered stores into ONE idx row (3-5 store instructions per query; the reference wrote
+//     64 different rows per store); the padding with the first hit is one coalesced store of the row's tail;
+//   * `sqrtf(d2) < r` is replaced by the exactly equivalent `d2 <= T`, T = the largest fp32 with
+//     sqrtf(T) < r, computed on the host (sqrtf is monotone and correctly rounded).  The naive
+//     d2 < r*r is NOT equivalent;
+//   * the multi-radius (MSG) form keeps one bitmap per radius against one d2 in the same pass;
 //   * distances are uncontracted fp32: ((dx*dx + dy*dy) + dz*dz), dx = query - dataset
 //     (file is compiled with -ffp-contract=off).
+// Bound: instruction issue / fp32 VALU, not HBM: the algorithmic bytes are 98 KB per cloud against 1.05 M pair
+// tests.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 namespace {
 
 constexpr int kQbpMaxScales = 4;
-constexpr int kQbpTile = 4096;  // dataset points staged per LDS pass (48 KiB)
 
 struct QbpScale {
     float thresh;  // d2 <= thresh  <=>  max(sqrtf(d2),1e-20f) < radius
@@ -47,87 +58,139 @@ float qbp_threshold(float radius) {
     return sqrtf(t) < radius ? t : -1.f;
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void qbp_kernel(int n, int m, QbpArgs<NS> a,
+__device__ __forceinline__ float rl_f(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside the 16-lane DPP rows, then the two
+// row-broadcast steps of gfx9 (the sequence LLVM's own wave scan uses); lanes a step does not reach add 0
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+// NS radii; PL dataset points per lane (a pass covers 64 PL consecutive points); 4 waves per workgroup, all on one
+// cloud, every wave owning `qpw` consecutive queries (qpw <= 64: their coordinates and running state sit one per lane)
+template <int NS, int PL>
+__global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs<NS> a,
                                                   const float *__restrict__ xyz1,
                                                   const float *__restrict__ xyz2) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int STRIDE = 3 * PL + 4;          // dwords per lane in LDS: 16-byte aligned, conflict-free b128 reads
+    constexpr int W = PL > 32 ? 2 : 1;          // 32-bit bitmap words per lane and radius
+    __shared__ __attribute__((aligned(16))) float stage[64 * STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
+    const int q0 = (blockIdx.x * 4 + wave) * qpw;
+    const int nq = q0 < m ? min(qpw, m - q0) : 0;      // a wave without queries still helps staging the cloud
     const float *p1 = xyz1 + (size_t)b * n * 3;
-    const int j = blockIdx.x * nthr + tid;
-    const bool valid = j < m;
-    const size_t q = (size_t)b * m + (valid ? j : 0);
+    const size_t qbase = (size_t)b * m + q0;
 
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (valid) {
-        qx = xyz2[q * 3 + 0];
-        qy = xyz2[q * 3 + 1];
-        qz = xyz2[q * 3 + 2];
+    float qxv = 0.f, qyv = 0.f, qzv = 0.f;     // lane j: query q0 + j
+    if (lane < nq) {
+        const float *qp = xyz2 + (qbase + lane) * 3;
+        qxv = qp[0]; qyv = qp[1]; qzv = qp[2];
     }
-    int cnt[NS], first[NS];
-    int *row[NS];
+    int cntv[NS], firstv[NS];                  // lane j: hits so far / first hit of query q0 + j
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        cnt[s] = 0;
-        first[s] = 0;
-        row[s] = a.s[s].idx + q * a.s[s].nsample;
-    }
-    bool done = !valid;
+    for (int s = 0; s < NS; ++s) cntv[s] = firstv[s] = 0;
 
-    for (int t0 = 0; t0 < n; t0 += kQbpTile) {
-        const int tn = min(kQbpTile, n - t0);
-        const int tp = (tn + 3) & ~3;  // padded to the b128 read width
-        float *xs = lds, *ys = lds + tp, *zs = lds + 2 * tp;
+    for (int t0 = 0; t0 < n; t0 += 64 * PL) {
+        // ---- stage 64 PL points: AoS run of 3 PL dwords per lane, coalesced reads
         if (t0) __syncthreads();
-        for (int e = tid; e < tn * 3; e += nthr) {  // coalesced AoS read -> SoA LDS
-            const float v = p1[(size_t)t0 * 3 + e];
-            const int k = e / 3;
-            lds[(e - k * 3) * tp + k] = v;
-        }
-        if (tid < tp - tn) {  // pad so that d2 = +inf for the tail
-            xs[tn + tid] = 3.0e38f;
-            ys[tn + tid] = 3.0e38f;
-            zs[tn + tid] = 3.0e38f;
+        const int tn = min(64 * PL, n - t0);
+        for (int e = tid; e < 64 * PL * 3; e += 256) {
+            const int ln = e / (3 * PL), r = e - ln * (3 * PL);
+            // beyond the cloud: a point whose distance to anything overflows to +inf (inf <= T is false)
+            stage[ln * STRIDE + r] = e < tn * 3 ? p1[(size_t)t0 * 3 + e] : 3.0e38f;
         }
         __syncthreads();
-        if (__all(done)) continue;  // wave-uniform; barriers above stay matched
-
-        for (int k0 = 0; k0 < tp; k0 += 4) {
-            const float4 X = *reinterpret_cast<const float4 *>(xs + k0);
-            const float4 Y = *reinterpret_cast<const float4 *>(ys + k0);
-            const float4 Z = *reinterpret_cast<const float4 *>(zs + k0);
-            const float px[4] = {X.x, X.y, X.z, X.w};
-            const float py[4] = {Y.x, Y.y, Y.z, Y.w};
-            const float pz[4] = {Z.x, Z.y, Z.z, Z.w};
+        float p[3 * PL];                        // x, y, z of this lane's PL points
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float dx = qx - px[u], dy = qy - py[u], dz = qz - pz[u];
-                const float d2 = dx * dx + dy * dy + dz * dz;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    if (!done && d2 <= a.s[s].thresh && cnt[s] < a.s[s].nsample) {
-                        const int k = t0 + k0 + u;
-                        if (cnt[s] == 0) first[s] = k;
-                        row[s][cnt[s]] = k;
-                        ++cnt[s];
-                    }
-                }
-            }
+        for (int i = 0; i < 3 * PL / 4; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(&stage[lane * STRIDE + 4 * i]);
+            p[4 * i + 0] = v.x; p[4 * i + 1] = v.y; p[4 * i + 2] = v.z; p[4 * i + 3] = v.w;
+        }
+        const bool last_pass = t0 + 64 * PL >= n;
+        const int kbase = t0 + PL * lane;       // index of this lane's first point
+        for (int j = 0; j < nq; ++j) {
+            const float qx = rl_f(qxv, j), qy = rl_f(qyv, j), qz = rl_f(qzv, j);
+            int cnt0[NS], first[NS];
             bool full = true;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) full = full && (cnt[s] >= a.s[s].nsample);
-            done = done || full;
-            if (__all(done)) break;
+            for (int s = 0; s < NS; ++s) {
+                cnt0[s] = __builtin_amdgcn_readlane(cntv[s], j);
+                first[s] = __builtin_amdgcn_readlane(firstv[s], j);
+                full = full && cnt0[s] >= a.s[s].nsample;
+            }
+            unsigned hb[NS][W];                 // hit bitmap: word c / 32, bit c % 32 <=> point kbase + c
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int w = 0; w < W; ++w) hb[s][w] = 0u;
+            if (!full) {
+#pragma unroll
+                for (int c = 0; c < PL; ++c) {
+                    const float dx = qx - p[3 * c], dy = qy - p[3 * c + 1], dz = qz - p[3 * c + 2];
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) hb[s][c / 32] |= d2 <= a.s[s].thresh ? (1u << (c % 32)) : 0u;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int ns = a.s[s].nsample;
+                int *row = a.s[s].idx + (qbase + j) * ns;
+                int cnt = cnt0[s];
+                if (cnt0[s] < ns) {                                       // wave-uniform
+                    const int mine = __popc(hb[s][0]) + (W > 1 ? __popc(hb[s][W - 1]) : 0);
+                    const int incl = wave_incl_scan(mine);
+                    const int total = __builtin_amdgcn_readlane(incl, 63);
+                    if (total > 0) {                                      // wave-uniform
+                        if (cnt0[s] == 0) {       // first hit of the query: lowest lane with a bit, its lowest bit
+                            const int fl = (int)__builtin_ctzll(__ballot(mine > 0));
+                            const int myfirst = kbase + (hb[s][0] ? __builtin_ctz(hb[s][0])
+                                                                  : 32 + __builtin_ctz(hb[s][W - 1] | 0x80000000u));
+                            first[s] = __builtin_amdgcn_readlane(myfirst, fl);
+                        }
+                        int pos = cnt0[s] + incl - mine;                  // slot of this lane's first hit
+#pragma unroll
+                        for (int w = 0; w < W; ++w) {
+                            unsigned bits = hb[s][w];
+                            while (bits != 0u && pos < ns) {              // per lane: 0-3 hits, rarely more
+                                row[pos] = kbase + 32 * w + __builtin_ctz(bits);
+                                bits &= bits - 1u;
+                                ++pos;
+                            }
+                        }
+                        cnt = cnt0[s] + total;
+                    }
+                    cntv[s] = lane == j ? cnt : cntv[s];
+                    firstv[s] = lane == j ? first[s] : firstv[s];
+                }
+                if (last_pass) {
+                    // pad the row with the first hit (rows with no hit at all: 0, the build's definition of what the
+                    // reference leaves unwritten) and publish the count
+                    const int c = cnt < ns ? cnt : ns;
+                    for (int l = c + lane; l < ns; l += 64) row[l] = first[s];
+                    if (a.s[s].cnt && lane == 0) a.s[s].cnt[qbase + j] = c;
+                }
+            }
         }
     }
-
-    if (valid) {
+    if (n <= 0) {   // empty dataset: every row is "no hit"
+        for (int j = 0; j < nq; ++j) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            for (int l = cnt[s]; l < a.s[s].nsample; ++l) row[s][l] = first[s];
-            if (a.s[s].cnt) a.s[s].cnt[q] = cnt[s];
+            for (int s = 0; s < NS; ++s) {
+                int *row = a.s[s].idx + (qbase + j) * a.s[s].nsample;
+                for (int l = lane; l < a.s[s].nsample; l += 64) row[l] = 0;
+                if (a.s[s].cnt && lane == 0) a.s[s].cnt[qbase + j] = 0;
+            }
         }
     }
 }
@@ -135,11 +198,18 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, QbpArgs<NS> a,
 template <int NS>
 int launch_qbp(int b, int n, int m, const QbpArgs<NS> &a, const float *xyz1, const float *xyz2,
                hipStream_t st) {
-    const int threads = m >= 256 ? 256 : ((m + kWave - 1) / kWave) * kWave;
-    const int tile = n < kQbpTile ? n : kQbpTile;
-    const size_t lds = (size_t)3 * ((tile + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL((qbp_kernel<NS>), dim3(cdiv(m, threads), b), dim3(threads), lds, st, n, m, a,
-                       xyz1, xyz2);
+    // queries per wave: enough waves to fill the chip several times over, but not so few queries per wave that
+    // staging the cloud and loading it into registers dominates
+    long long qpw = ((long long)b * m + 8191) / 8192;
+    qpw = qpw < 8 ? 8 : (qpw > 64 ? 64 : qpw);
+    if (qpw > m) qpw = m;
+    const dim3 grid(cdiv(m, qpw * 4), b);
+#define PCOPS_QBP_P(P_) hipLaunchKernelGGL((qbp_kernel<NS, P_>), grid, dim3(256), 0, st, n, m, (int)qpw, a, xyz1, xyz2)
+    if (n <= 512) PCOPS_QBP_P(8);              // points per lane: the smallest that covers the cloud in one pass
+    else if (n <= 1024) PCOPS_QBP_P(16);
+    else if (n <= 2048) PCOPS_QBP_P(32);
+    else PCOPS_QBP_P(64);                      // n > 4096: several passes, per-query state carried one per lane
+#undef PCOPS_QBP_P
     return pcops_launch_status();
 }
 

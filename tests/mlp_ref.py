@@ -29,8 +29,17 @@ def fused_pattern(out):
         if Y is None:
             masks.append(None)
         else:
+            # the kernels decide with ONE fused multiply-add, fmaf(y, scale, shift) > 0.  In float64 the product of
+            # two fp32 numbers is exact and the sum keeps the sign of the exact value, which is the sign the
+            # correctly rounded fp32 FMA has: bit-for-bit the kernels' decision.  (A separately rounded fp32
+            # multiply + add differs for a handful of the 5e8 elements of a bench-size layer, and a single wrong
+            # mask bit moves one row of dx by O(1).)
             n = Y.shape[1]
-            masks.append(torch.addcmul(sh[:n], Y, sc[:n]) > 0)
+            m = torch.empty(Y.shape, dtype=torch.bool, device=Y.device)
+            step = max(1, (1 << 26) // n)
+            for r0 in range(0, Y.shape[0], step):
+                m[r0:r0 + step] = (Y[r0:r0 + step].double() * sc[:n].double() + sh[:n].double()) > 0
+            masks.append(m)
     return masks, argmax
 
 
