@@ -44,9 +44,11 @@ int pcops_abi_version(void);
 /* ------------------------------------------------------------------ sampling */
 /* farthestpointsamplingLauncher(b,n,m,inp,temp,out)   sampling/tf_sampling.cpp:94,
  * kernel sampling/tf_sampling_g.cu:105-170.  inp (b,n,3) -> out (b,m) int32.
- * `temp` is the reference's (32,n) scratch; this implementation keeps the running
- * min-distances in registers, needs no scratch and ignores it (may be NULL);
- * pcops_farthest_point_sample_workspace_bytes() reports 0. */
+ * `temp` is the reference's (32,n) scratch.  Up to n = 16384 this implementation keeps the
+ * cloud AND the running min-distances in registers and ignores it (may be NULL);
+ * larger clouds take the streamed form (the reference's path beyond its LDS-resident
+ * points, tf_sampling_g.cu:133-141) and need pcops_farthest_point_sample_workspace_bytes(b, n)
+ * = 4*b*n bytes there (0 for n <= 16384). */
 int pcops_farthest_point_sample(int b, int n, int m, const float *inp, float *temp,
                                 int *out, pcops_stream_t stream);
 unsigned long long pcops_farthest_point_sample_workspace_bytes(int b, int n);

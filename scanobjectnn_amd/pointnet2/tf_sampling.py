@@ -27,7 +27,11 @@ def farthest_point_sample(npoint, inp):
     inp = _check_xyz(inp.detach(), "inp")
     b, n, _ = inp.shape
     out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
-    _lib.call("pcops_farthest_point_sample", b, n, npoint, _lib.ptr(inp), None, _lib.ptr(out))
+    # scratch the launcher asks for (0 bytes while the cloud fits the register-resident kernel, i.e. n <= 16384;
+    # the reference always allocates its (32, n) `temp`, tf_sampling.cpp:115)
+    nbytes = int(_lib.load().pcops_farthest_point_sample_workspace_bytes(b, n))
+    temp = torch.empty(nbytes // 4, dtype=torch.float32, device=inp.device) if nbytes else None
+    _lib.call("pcops_farthest_point_sample", b, n, npoint, _lib.ptr(inp), _lib.ptr(temp), _lib.ptr(out))
     return out
 
 

@@ -9,6 +9,7 @@ import torch
 
 from conftest import load_golden
 from oracle import oracle as O
+from scanobjectnn_amd import _lib
 from scanobjectnn_amd.pointnet2 import tf_grouping, tf_interpolate, tf_sampling
 from scanobjectnn_amd.synth import synth_clouds
 
@@ -122,6 +123,17 @@ def test_fps_vs_oracle(B, Nn, M, kind):
     c = synth_clouds(B, Nn, seed=Nn + M, kind=kind)
     idx = tf_sampling.farthest_point_sample(M, T(c))
     np.testing.assert_array_equal(N(idx), O.farthest_point_sample(M, c))
+
+
+def test_fps_beyond_the_register_resident_size():
+    """n > 16384: the streamed kernel (running min-distance in the caller's scratch), same indices as the oracle
+    incl. the (k mod 512, k) tie rule on duplicated points; the reference handles any n (tf_sampling_g.cu:133-141)"""
+    c = synth_clouds(2, 20000, seed=3, kind="ball")
+    c[1, 15000:15010] = c[1, 7]                                  # exact duplicates -> distance ties
+    idx = tf_sampling.farthest_point_sample(96, T(c))
+    np.testing.assert_array_equal(N(idx), O.farthest_point_sample(96, c))
+    assert _lib.load().pcops_farthest_point_sample_workspace_bytes(2, 20000) == 4 * 2 * 20000
+    assert _lib.load().pcops_farthest_point_sample_workspace_bytes(2, 16384) == 0
 
 
 def test_fps_ties_follow_reference_rule():
