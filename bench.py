@@ -110,6 +110,9 @@ def _algo(name, a):
     if name == "pcops_mlp_bn_relu_maxpool":
         G, S, C = a[:3]
         return 4 * G * S * C + 5 * G * C, 0, ""
+    if name == "pcops_mlp_bn_relu_maxpool_rows":      # (rows computed, C): the max over compacted groups re-reads Y once
+        R, C = a[:2]
+        return 4 * R * C, 0, ""
     if name == "pcops_mlp_bn_relu_apply":
         R, C = a[:2]
         return 8 * R * C, 0, ""
@@ -143,7 +146,8 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
            "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
            "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1,
-           "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2}
+           "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2,
+           "pcops_mlp_bn_relu_maxpool_rows": 2}
 
 
 class KernelTimer:
@@ -154,8 +158,26 @@ class KernelTimer:
     def __init__(self):
         self.records = []     # (name, args, start_event, end_event)
         self._open = None
+        self._rows = {}       # id -> _lib.Rows of the compacted stacks seen (kept alive until the summary)
+
+    def _rows_computed(self, rows):
+        """rows a compacted stack really computed (a 4-byte device -> host copy, after the timed region)"""
+        return rows.num_rows()
 
     def __call__(self, name, phase, args):
+        if name == "pcops_mlp_bn_relu_maxpool_rows":
+            ref, args = args[5], args[:2]
+            owner = _lib.Rows.by_struct.get(id(ref._obj))
+            self._rows[id(owner)] = owner
+            args = args + (("rows", id(owner)),)
+        elif name.endswith("_rows"):
+            # compacted-row entry points (pcops.h): same argument list + a pcops_rows_t*; NULL = the plain entry point
+            ref, args, name = args[-1], args[:-1], name[:-5]
+            if ref is not None:
+                owner = _lib.Rows.by_struct.get(id(ref._obj))
+                if owner is not None:
+                    self._rows[id(owner)] = owner           # kept alive until the summary reads its row count
+                    args = args + (("rows", id(owner)),)
         if phase == "pre":
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -168,17 +190,40 @@ class KernelTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
+        frac_cache = {}
         for name, args, s, e in self.records:
             ms = s.elapsed_time(e)
+            compacted = None
+            if args and isinstance(args[-1], tuple) and args[-1][0] == "rows":
+                rid, args = args[-1][1], args[:-1]
+                if rid not in frac_cache:
+                    frac_cache[rid] = self._rows_computed(self._rows[rid])
+                compacted = frac_cache[rid]
+            full_args = args
+            if compacted is not None and name.startswith("pcops_mlp_"):
+                args = (compacted,) + tuple(args[1:])          # the rows the kernel really walks
             by, work, unit = _algo(name, args)
-            key = (name,) + tuple(args[:_NSHAPE.get(name, 3)])
+            if compacted is not None and name.startswith("pcops_sa_"):
+                b_, n_, m_, s_ = full_args[:4]
+                scale = compacted / float(b_ * m_ * s_)
+                by = int(by * scale)                           # dominated by the (rows, c) activations
+            args = full_args
+            key = (name,) + tuple(args[:_NSHAPE.get(name, 3)]) + (("compacted",) if compacted is not None else ())
             d = agg.setdefault(key, {"kernel": name, "shape": list(key[1:]), "launches": 0, "ms": 0.0,
-                                     "bytes": by, "work": work, "work_unit": unit})
+                                     "bytes": 0, "work": 0, "work_unit": unit})
             d["launches"] += 1
             d["ms"] += ms
+            d["bytes"] += by          # per-launch averages below: compacted row counts vary from step to step
+            d["work"] += work
+            if compacted is not None:
+                d["rows_computed"] = d.get("rows_computed", 0) + compacted
         out = []
         for d in agg.values():
             avg_ms = d["ms"] / d["launches"]
+            d["bytes"] /= d["launches"]
+            d["work"] /= d["launches"]
+            if "rows_computed" in d:
+                d["rows_computed"] /= d["launches"]
             d["avg_us"] = avg_ms * 1e3
             d["gbs"] = d["bytes"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             d["gwork_s"] = d["work"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -29,6 +29,15 @@ extern "C" {
 
 typedef void *pcops_stream_t; /* hipStream_t */
 
+/* A COMPACTED row set for the grouped shared MLP (see "compacted rows" below): device pointers only, the struct
+ * itself lives on the host and is read at call time. */
+typedef struct pcops_rows {
+    const void *blocks;     /* device, 16 bytes per 16-row block: int group, int row_in_group of the block's first row,
+                               float weight of that row (1 unless it is row 0 of its group), int 0; 16-byte aligned */
+    const int *block_start; /* device [groups + 1]: first block of every group, last entry = number of blocks */
+    const int *rows;        /* device [1]: number of rows = 16 * number of blocks */
+} pcops_rows_t;
+
 typedef enum pcops_status {
     PCOPS_OK = 0,
     PCOPS_ERR_NULL_POINTER = -1,
@@ -299,6 +308,73 @@ int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const fl
                                 const float *Wxyz, const float *bias, const float *p, const float *q, const float *t,
                                 const float *sumG, const float *mean, long long rows, float *dWxyz, float *dbias,
                                 pcops_stream_t stream);
+
+/* ------------------------------------------------------------------ compacted rows
+ * query_ball_point pads a neighbourhood that holds fewer than nsample points with copies of its first member
+ * (grouping/tf_grouping_g.cu:26-32), and the reference pushes every copy through the whole shared MLP
+ * (pointnet2/utils/pointnet_util.py:117-127): at the PB_T50_RS-shaped SSG config 39 % of the rows of the second
+ * set-abstraction level are such copies.  A copy computes exactly what its original computes, so the grouped stack
+ * runs on a COMPACTED row set instead -- per group its pts_cnt real members, rounded up to whole blocks of 16 rows
+ * with copies of member 0 (16 * ceil(cnt / 16) <= nsample rows instead of nsample) -- and the first row of every
+ * group carries the weight w = nsample - rows_of_the_group + 1 of the copies that were dropped:
+ *   forward   BN batch statistics weigh that row with w (the max-pool ignores copies anyway);
+ *   backward  the row stands for the SUM of the gradients of its w twins: dY = p.G + w (q.Y + t), everything
+ *             downstream of dY (ReLU mask, dgrad, wgrad, the scatter-add) is linear in it.
+ * Same mathematics as the uncompacted stack (only the summation order of the statistics changes).
+ * The number of rows depends on the data: it lives on the device (pcops_rows_t.rows); the M / b*m*s arguments of the
+ * *_rows entry points are the UNCOMPACTED row count, i.e. the upper bound the buffers and launches are sized with,
+ * and batch-norm divisors (pcops_mlp_bn_finalize / _bn_bwd_coeffs R) stay the uncompacted count.
+ * rows == NULL: exactly the entry point without the suffix.  Compacted rows need the wave-stream shapes
+ * (>= 8192 rows, channel counts multiples of 8): PCOPS_ERR_UNSUPPORTED otherwise. */
+unsigned long long pcops_rows_max_blocks(int b, int m, int s);
+/* builds blocks / block_start / rows from pts_cnt (b,m) of pcops_query_ball_point; s % 16 == 0.
+ * blocks: 16 * pcops_rows_max_blocks(b,m,s) bytes, block_start: b*m + 1 ints, rows: 1 int. */
+int pcops_rows_plan(int b, int m, int s, const int *pts_cnt, void *blocks, int *block_start, int *rows,
+                    pcops_stream_t stream);
+int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                            const float *pro_shift, const float *W, const float *bias, float *Y,
+                            float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_gemm_fwd_xyz_rows(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
+                                const float *pro_shift, const float *W, const float *bias, float *Y,
+                                float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_gemm_dgrad_rows(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                              int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                              const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
+                              float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_gemm_dgrad_xyz_rows(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                                  const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                                  int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                                  const float *off4, const float *xyzw, const float *prev_scale,
+                                  const float *prev_shift, float *Gprev, float *stats_partial, float *xyz_stats,
+                                  const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_wgrad_rows(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
+                         const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                         const float *t, const float *gpool, const unsigned char *argmax, int S,
+                         const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                         const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_wgrad_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                             const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                             const float *t, const float *gpool, const unsigned char *argmax, int S,
+                             const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                             const pcops_rows_t *rows, pcops_stream_t stream);
+/* out[g] = max over the rows of group g of relu(scale*Y + shift); argmax = row-in-group of the first maximiser */
+int pcops_mlp_bn_relu_maxpool_rows(long long G, int C, const float *Y, const float *scale, const float *shift,
+                                   const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,
+                                   pcops_stream_t stream);
+/* pcops_sa_gather_fwd / pcops_sa_scatter_bwd over compacted rows: Y, off4, G are (rows, c) / (rows, 4) in the
+ * compacted order; idx stays the (b,m,s) tensor of the ball query */
+int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
+                             const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
+                             float *off4, float *stats_partial, float *moments, const pcops_rows_t *rows,
+                             pcops_stream_t stream);
+int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
+                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                              const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
+                              const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
+                              float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
+                              const float *fwd_bias, void *workspace, const pcops_rows_t *rows,
+                              pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

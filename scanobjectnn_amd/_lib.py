@@ -6,6 +6,7 @@ test infrastructure and is never imported from here).
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -54,6 +55,17 @@ SIGNATURES = {
     "pcops_edge_pool_bwd": ([_I, _I, _I, _I, _I] + [_P] * 15, True),
     "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
+    # ---- compacted rows (pcops.h "compacted rows"): the suffix-less signature + a pcops_rows_t* before the stream
+    "pcops_rows_plan": ([_I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_dgrad_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_dgrad_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_relu_maxpool_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_scatter_bwd_rows": ([_I, _I, _I, _I, _I] + [_P] * 23, True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
@@ -70,7 +82,42 @@ PLAIN = {
     "pcops_sa_scatter_rows": ([_I, _I], _I),
     "pcops_edge_pool_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
+    "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
 }
+
+
+class RowsT(C.Structure):
+    """pcops_rows_t: device pointers of a compacted row set (blocks, block_start, rows)"""
+    _fields_ = [("blocks", C.c_void_p), ("block_start", C.c_void_p), ("rows", C.c_void_p)]
+
+
+class Rows:
+    """A compacted row set of one grouped stack (pcops.h "compacted rows"): owns the three device buffers and the
+    host-side struct the *_rows entry points take."""
+    by_struct = weakref.WeakValueDictionary()
+
+    def __init__(self, pts_cnt, nsample):
+        b, m = pts_cnt.shape
+        lib = load()
+        nb = int(lib.pcops_rows_max_blocks(b, m, int(nsample)))
+        dev = pts_cnt.device
+        self.blocks = torch.empty((nb, 4), dtype=torch.int32, device=dev)
+        self.block_start = torch.empty(b * m + 1, dtype=torch.int32, device=dev)
+        self.rows = torch.empty(1, dtype=torch.int32, device=dev)
+        call("pcops_rows_plan", b, m, int(nsample), pts_cnt.data_ptr(), self.blocks.data_ptr(),
+             self.block_start.data_ptr(), self.rows.data_ptr())
+        self.struct = RowsT(self.blocks.data_ptr(), self.block_start.data_ptr(), self.rows.data_ptr())
+        self.full_rows = b * m * int(nsample)
+        Rows.by_struct[id(self.struct)] = self          # lets a profiling hook find the owner of a byref() argument
+
+    def num_rows(self):
+        """rows actually computed (device -> host copy: profiling / tests only)"""
+        return int(self.rows.item())
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
 
 _lib = None
 

@@ -19,6 +19,62 @@
 
 namespace {
 
+// ---- compacted rows (pcops_rows_t, see pcops.h "compacted rows") -------------------------------------------------
+constexpr int kBlk = 16;
+struct RowBlock { int g, s0; float w; int pad; };
+
+__device__ __forceinline__ int rows_blocks_of(int cnt, int S) {
+    const int c = cnt < 1 ? 1 : cnt;                       // a neighbourhood without any hit is S copies of index 0
+    const int nb = (c + kBlk - 1) / kBlk;
+    return nb < S / kBlk ? nb : S / kBlk;
+}
+
+// block_start = exclusive scan of the blocks per group, rows = 16 * total; one workgroup, contiguous runs per thread
+__global__ __launch_bounds__(1024) void rows_plan_scan_kernel(int G, int S, const int *__restrict__ cnt,
+                                                              int *__restrict__ bstart, int *__restrict__ rows) {
+    __shared__ int sc[1024];
+    const int tid = threadIdx.x;
+    const int per = (G + 1023) / 1024;
+    const int g0 = tid * per, g1 = min(G, g0 + per);
+    int local = 0;
+    for (int g = g0; g < g1; ++g) local += rows_blocks_of(cnt[g], S);
+    sc[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? sc[tid - off] : 0;
+        __syncthreads();
+        sc[tid] += v;
+        __syncthreads();
+    }
+    int run = sc[tid] - local;
+    for (int g = g0; g < g1; ++g) {
+        bstart[g] = run;
+        run += rows_blocks_of(cnt[g], S);
+    }
+    if (tid == 1023) {
+        bstart[G] = sc[1023];
+        rows[0] = sc[1023] * kBlk;
+    }
+}
+
+__global__ __launch_bounds__(256) void rows_plan_fill_kernel(long long total, int S, const int *__restrict__ cnt,
+                                                             const int *__restrict__ bstart,
+                                                             RowBlock *__restrict__ blocks) {
+    const int bpg = S / kBlk;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int g = (int)(e / bpg), k = (int)(e - (long long)g * bpg);
+        const int nb = rows_blocks_of(cnt[g], S);
+        if (k < nb) {
+            RowBlock rb;
+            rb.g = g;
+            rb.s0 = k * kBlk;
+            rb.w = k == 0 ? (float)(S - nb * kBlk + 1) : 1.f;      // row 0 also stands for the copies that were dropped
+            rb.pad = 0;
+            blocks[bstart[g] + k] = rb;
+        }
+    }
+}
+
 // one quad of Y[b,j,s,:] in the forward's own operation order -- the backward kernels REBUILD the first layer's
 // output with it instead of reading it back (bit-identical, and one (b,m,s,c) tensor less to stream from HBM):
 //   y = (bias + Ctr) + Q;  y = fma(dz, w2, fma(dy, w1, fma(dx, w0, y)))
@@ -48,7 +104,11 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ bias,
                                                             const int *__restrict__ idx, float *__restrict__ Y,
                                                             float *__restrict__ off4, float *__restrict__ stats,
-                                                            float *__restrict__ moments, int groups_per_block) {
+                                                            float *__restrict__ moments, int groups_per_block,
+                                                            const RowBlock *__restrict__ blocks,
+                                                            const int *__restrict__ bstart) {
+    // blocks != NULL: compacted rows -- group g writes its first 16 (bstart[g+1] - bstart[g]) rows to rows
+    // 16 bstart[g] ..., and its row 0 enters the statistics / moments with the weight of the copies left out
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [RL][2][C] statistics scratch | staged rows
     const int c4n = C / 4;
     const int RL = 256 / c4n;
@@ -82,11 +142,22 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                 dx = px[0] - new_xyz[g * 3 + 0]; dy = px[1] - new_xyz[g * 3 + 1]; dz = px[2] - new_xyz[g * 3 + 2];
             }
             st4[t] = make_float4(dx, dy, dz, __int_as_float(i));
-            if (off4) *reinterpret_cast<float4 *>(off4 + r * 4) = make_float4(dx, dy, dz, 0.f);
+            long long ro = r;                 // output row
+            float wt = 1.f;                   // weight of the row in the sums
+            bool keep = true;
+            if (blocks) {
+                const int sg = t % S, b0 = bstart[g];
+                keep = sg < (bstart[g + 1] - b0) * kBlk;
+                ro = (long long)b0 * kBlk + sg;
+                if (sg == 0) wt = blocks[b0].w;
+            }
+            if (!keep) continue;
+            if (off4) *reinterpret_cast<float4 *>(off4 + ro * 4) = make_float4(dx, dy, dz, 0.f);
             if (moments) {
-                mo[0] = fmaf(dx, dx, mo[0]); mo[1] = fmaf(dx, dy, mo[1]); mo[2] = fmaf(dx, dz, mo[2]);
-                mo[3] = fmaf(dy, dy, mo[3]); mo[4] = fmaf(dy, dz, mo[4]); mo[5] = fmaf(dz, dz, mo[5]);
-                mo[6] += dx; mo[7] += dy; mo[8] += dz;
+                const float wx = wt * dx, wy = wt * dy, wz = wt * dz;
+                mo[0] = fmaf(wx, dx, mo[0]); mo[1] = fmaf(wx, dy, mo[1]); mo[2] = fmaf(wx, dz, mo[2]);
+                mo[3] = fmaf(wy, dy, mo[3]); mo[4] = fmaf(wy, dz, mo[4]); mo[5] = fmaf(wz, dz, mo[5]);
+                mo[6] += wx; mo[7] += wy; mo[8] += wz;
             }
         }
         __syncthreads();
@@ -99,16 +170,27 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                     ctr.x += c4.x; ctr.y += c4.y; ctr.z += c4.z; ctr.w += c4.w;
                 }
                 const float4 *sg = st4 + (g - gb) * S;
-                for (int s = rl; s < S; s += RL) {
-                    const long long r = g * S + s;
+                int Sg = S;
+                long long rbase = g * S;
+                float w0row = 1.f;
+                if (blocks) {
+                    const int b0 = bstart[g];
+                    Sg = (bstart[g + 1] - b0) * kBlk;
+                    rbase = (long long)b0 * kBlk;
+                    w0row = blocks[b0].w;
+                }
+                for (int s = rl; s < Sg; s += RL) {
+                    const long long r = rbase + s;
                     const float4 e = sg[s];
                     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (Q) q = *reinterpret_cast<const float4 *>(Q + (b * n + __float_as_int(e.w)) * (long long)C + cq);
                     const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, e.x, e.y, e.z, w0, w1, w2);
                     if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
-                    s1[0] += y.x; s1[1] += y.y; s1[2] += y.z; s1[3] += y.w;
-                    s2[0] = fmaf(y.x, y.x, s2[0]); s2[1] = fmaf(y.y, y.y, s2[1]);
-                    s2[2] = fmaf(y.z, y.z, s2[2]); s2[3] = fmaf(y.w, y.w, s2[3]);
+                    const float wt = s == 0 ? w0row : 1.f;
+                    const float4 wy = make_float4(wt * y.x, wt * y.y, wt * y.z, wt * y.w);
+                    s1[0] += wy.x; s1[1] += wy.y; s1[2] += wy.z; s1[3] += wy.w;
+                    s2[0] = fmaf(wy.x, y.x, s2[0]); s2[1] = fmaf(wy.y, y.y, s2[1]);
+                    s2[2] = fmaf(wy.z, y.z, s2[2]); s2[3] = fmaf(wy.w, y.w, s2[3]);
                 }
             }
         }
@@ -469,15 +551,31 @@ static int scatter_lds_slice(int n, int C, bool has_dq, bool has_xyz, size_t *ld
 // wave per source point sums those rows of dY in registers and writes dQ[b, i, :] once -- no float atomics, no
 // memset, every row of G / Y read once with 16-byte loads, dWxyz / dbias partial sums in the same pass.
 //   order [b][m*S] int2 : (row-in-cloud j*S + s, idx) sorted by idx      start [b][n+1] int32 : list boundaries
+// compacted rows (blocks != NULL): the list covers the cloud's rows 16 bstart[b m] .. 16 bstart[(b+1) m] - 1 and
+// order.x is the row relative to the cloud's first row
 __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const int *__restrict__ idx,
-                                                            int2 *__restrict__ order, int *__restrict__ start) {
+                                                            int2 *__restrict__ order, int *__restrict__ start,
+                                                            int m, int S, const RowBlock *__restrict__ blocks,
+                                                            const int *__restrict__ bstart) {
     extern __shared__ int si[];                 // cnt[n] | cursor[n] | scan scratch [1024]
     int *cnt = si, *cursor = si + n, *sc = si + 2 * n;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int *ib = idx + (long long)b * mS;
+    long long r0 = (long long)b * mS;
+    int nrows = mS;
+    if (blocks) {
+        r0 = (long long)bstart[(long long)b * m] * kBlk;
+        nrows = (int)((long long)bstart[(long long)(b + 1) * m] * kBlk - r0);
+    }
+    auto index_of = [&](int e) {                // source point of the cloud's row e
+        if (!blocks) return ib[e];
+        const long long r = r0 + e;
+        const RowBlock rb = blocks[r / kBlk];
+        return idx[(long long)rb.g * S + rb.s0 + (int)(r % kBlk)];
+    };
     for (int i = tid; i < n; i += 1024) cnt[i] = 0;
     __syncthreads();
-    for (int e = tid; e < mS; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+    for (int e = tid; e < nrows; e += 1024) atomicAdd(&cnt[index_of(e)], 1);
     __syncthreads();
     // exclusive scan: each thread owns a contiguous run of bins
     const int per = (n + 1023) / 1024;
@@ -499,11 +597,11 @@ __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const
         sb[i] = run;
         run += cnt[i];
     }
-    if (tid == 0) sb[n] = mS;
+    if (tid == 0) sb[n] = nrows;
     __syncthreads();
-    int2 *ob = order + (long long)b * mS;
-    for (int e = tid; e < mS; e += 1024) {
-        const int i = ib[e];
+    int2 *ob = order + r0;
+    for (int e = tid; e < nrows; e += 1024) {
+        const int i = index_of(e);
         ob[atomicAdd(&cursor[i], 1)] = make_int2(e, i);
     }
 }
@@ -514,6 +612,8 @@ struct CsrArgs {
     const float *xyz, *new_xyz;
     const int2 *order;
     float *dQ, *wpart;
+    const RowBlock *blocks;      // compacted rows: see sa_csr_build_kernel; the first row of a block carries a weight
+    const int *bstart;
 };
 
 // YONLY: the pooled form -- dY = q.Y + t everywhere plus p.gpool at the arg-max rows, which the streaming
@@ -543,8 +643,15 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
         for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
         for (long long ch = (long long)blockIdx.x * 4 + wave; ch < nchunks; ch += wstride) {
             const int b = (int)(ch / nch);
-            const int kb = (int)(ch - (long long)b * nch) * CH, ke = min(mS, kb + CH);
-            const int2 *ob = a.order + (long long)b * mS;
+            long long rowoff = (long long)b * mS;
+            int nrows = mS;
+            if (a.blocks) {
+                rowoff = (long long)a.bstart[(long long)b * m] * kBlk;
+                nrows = (int)((long long)a.bstart[(long long)(b + 1) * m] * kBlk - rowoff);
+            }
+            const int kb = (int)(ch - (long long)b * nch) * CH, ke = min(nrows, kb + CH);
+            if (kb >= nrows) continue;                   // wave-uniform
+            const int2 *ob = a.order + rowoff;
             int cur = -1;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             auto flush = [&]() {
@@ -565,7 +672,7 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
                     const int2 oe = ob[k < kse ? k : kb];
                     ee[u] = oe.x;
                     ii[u] = oe.y;
-                    const long long r = (long long)b * mS + ee[u];
+                    const long long r = rowoff + ee[u];
                     yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
                     if (!YONLY) gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
                 }
@@ -576,10 +683,18 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
                     const float4 y = yy[u];
                     const float4 gm = YONLY ? make_float4(0.f, 0.f, 0.f, 0.f) : gg[u];
                     float d[4];
-                    d[0] = fmaf(cp.x, gm.x, fmaf(cq.x, y.x, ct.x));
-                    d[1] = fmaf(cp.y, gm.y, fmaf(cq.y, y.y, ct.y));
-                    d[2] = fmaf(cp.z, gm.z, fmaf(cq.z, y.z, ct.z));
-                    d[3] = fmaf(cp.w, gm.w, fmaf(cq.w, y.w, ct.w));
+                    float wt = 1.f;
+                    int j = (int)((unsigned)ee[u] / (unsigned)S);          // group inside the cloud
+                    if (a.blocks) {
+                        const long long r = rowoff + ee[u];
+                        const RowBlock rb = a.blocks[r / kBlk];
+                        wt = (r % kBlk) == 0 ? rb.w : 1.f;
+                        j = rb.g - b * m;
+                    }
+                    d[0] = fmaf(cp.x, gm.x, wt * fmaf(cq.x, y.x, ct.x));
+                    d[1] = fmaf(cp.y, gm.y, wt * fmaf(cq.y, y.y, ct.y));
+                    d[2] = fmaf(cp.z, gm.z, wt * fmaf(cq.z, y.z, ct.z));
+                    d[3] = fmaf(cp.w, gm.w, wt * fmaf(cq.w, y.w, ct.w));
                     const int i = ii[u];
                     if (i != cur) {
                         if (cur >= 0) flush();
@@ -590,7 +705,6 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
                     for (int e = 0; e < 4; ++e) acc[e] += d[e];
                     if (a.wpart) {
                         if (a.xyz) {
-                            const int j = (int)((unsigned)ee[u] / (unsigned)S);
                             const float *px = a.xyz + ((long long)b * n + i) * 3;
                             const float *cx = a.new_xyz + ((long long)b * m + j) * 3;
                             const float ox = px[0] - cx[0], oy = px[1] - cx[1], oz = px[2] - cx[2];
@@ -929,10 +1043,49 @@ unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) 
     return sizeof(int) * (2ull * b * m * s + (unsigned long long)b * (n + 1));
 }
 
+unsigned long long pcops_rows_max_blocks(int b, int m, int s) {
+    return (unsigned long long)b * m * (s / kBlk);
+}
+
+int pcops_rows_plan(int b, int m, int s, const int *pts_cnt, void *blocks, int *block_start, int *rows,
+                    pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && m >= 1 && s >= kBlk && s % kBlk == 0 && s <= 256);
+    PCOPS_REQUIRE_PTR(pts_cnt); PCOPS_REQUIRE_PTR(blocks); PCOPS_REQUIRE_PTR(block_start); PCOPS_REQUIRE_PTR(rows);
+    if (reinterpret_cast<uintptr_t>(blocks) & 15) return PCOPS_ERR_UNSUPPORTED;
+    const long long G = (long long)b * m;
+    PCOPS_REQUIRE_SHAPE(G * (s / kBlk) < (1ll << 27));         // 16 x blocks rows fit an int
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(rows_plan_scan_kernel, dim3(1), dim3(1024), 0, st, (int)G, s, pts_cnt, block_start, rows);
+    const long long total = G * (s / kBlk);
+    const unsigned grid = cdiv(total, 256) < 4096u ? cdiv(total, 256) : 4096u;
+    hipLaunchKernelGGL(rows_plan_fill_kernel, dim3(grid), dim3(256), 0, st, total, s, pts_cnt, block_start,
+                       static_cast<RowBlock *>(blocks));
+    return pcops_launch_status();
+}
+
+static int gather_rows_ok(const pcops_rows_t *rows, int s) {
+    if (!rows) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(rows->blocks); PCOPS_REQUIRE_PTR(rows->block_start); PCOPS_REQUIRE_PTR(rows->rows);
+    PCOPS_REQUIRE_SHAPE(s % kBlk == 0);
+    return PCOPS_OK;
+}
+
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
                         float *off4, float *stats_partial, float *moments, pcops_stream_t stream) {
+    return pcops_sa_gather_fwd_rows(b, n, m, s, c, Q, Ctr, xyz, new_xyz, Wxyz, bias, idx, Y, off4, stats_partial,
+                                    moments, nullptr, stream);
+}
+
+int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
+                             const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
+                             float *off4, float *stats_partial, float *moments, const pcops_rows_t *rows,
+                             pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
+    {
+        const int rrc = gather_rows_ok(rows, s);
+        if (rrc) return rrc;
+    }
     PCOPS_REQUIRE_SHAPE(c <= 1024 && 256 % (c / 4) == 0);
     const long long G = (long long)b * m;
     if (G == 0) return PCOPS_OK;
@@ -946,7 +1099,8 @@ int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        ((size_t)rl * 2 * c + staged) * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
-                       Wxyz, bias, idx, Y, off4, stats_partial, moments, gather_groups_per_block(G));
+                       Wxyz, bias, idx, Y, off4, stats_partial, moments, gather_groups_per_block(G),
+                       rows ? static_cast<const RowBlock *>(rows->blocks) : nullptr, rows ? rows->block_start : nullptr);
     return pcops_launch_status();
 }
 
@@ -956,7 +1110,28 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
                          const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
                          float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
                          const float *fwd_bias, void *workspace, pcops_stream_t stream) {
+    return pcops_sa_scatter_bwd_rows(b, n, m, s, c, G, Y, p, q, t, gpool, argmax, pool_scale, pool_shift, idx, xyz,
+                                     new_xyz, dQ, dCtr, wpartial, dWxyz, dbias, fwd_Q, fwd_Ctr, fwd_Wxyz, fwd_bias,
+                                     workspace, nullptr, stream);
+}
+
+int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
+                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                              const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,
+                              const float *new_xyz, float *dQ, float *dCtr, float *wpartial, float *dWxyz,
+                              float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
+                              const float *fwd_bias, void *workspace, const pcops_rows_t *rows,
+                              pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
+    {
+        const int rrc = gather_rows_ok(rows, s);
+        if (rrc) return rrc;
+    }
+    const RowBlock *rblocks = rows ? static_cast<const RowBlock *>(rows->blocks) : nullptr;
+    const int *rbstart = rows ? rows->block_start : nullptr;
+    // compacted rows: only the gather (CSR) formulation of the feature gradient walks them -- G materialised, no
+    // per-group output; anything else is the caller's uncompacted path
+    if (rows && (gpool || dCtr || !dQ || !workspace || !G)) return PCOPS_ERR_UNSUPPORTED;
     const bool rc_fwd = (fwd_Wxyz || fwd_bias) && !fwd_Q && !fwd_Ctr && !dQ;   // Y rebuilt, never read
     if (fwd_Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     PCOPS_REQUIRE_SHAPE(c <= 1024 && (c >= 256 || 256 % c == 0));
@@ -982,6 +1157,7 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
     const int lpr = c <= 256 ? c / 4 : 64;
     const bool csr_shape = (c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384 &&
                            (long long)m * s < (1ll << 30) && 2 * (size_t)n * 4 + 4096 <= 160 * 1024;
+    if (rows && !(scatter_csr_enabled() && csr_shape)) return PCOPS_ERR_UNSUPPORTED;
     if (scatter_csr_enabled() && workspace && dQ && csr_shape) {
         const bool split = dCtr || gpool;        // per-group outputs / pooled form: streaming pass first
         if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
@@ -1016,9 +1192,10 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PCOPS_ERR_LAUNCH;
-        hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
+        hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start, m, s, rblocks,
+                           rbstart);
         float *wp2 = split ? nullptr : wp;
-        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2};
+        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2, rblocks, rbstart};
         const bool small = (long long)b * ((m * s + 63) / 64) < 4 * kCsrGrid;   // fewer 64-row chunks than waves
 #define PCOPS_CSR_LAUNCH(LPR_, Y_, CH_)                                                                            \
     hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, Y_, CH_>), dim3(kCsrGrid), dim3(256), 0, st, a)
@@ -1162,7 +1339,8 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return PCOPS_ERR_LAUNCH;
-    hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start);
+    hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start, m, s,
+                       (const RowBlock *)nullptr, (const int *)nullptr);
     const long long total = G * c;
     const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
     hipLaunchKernelGGL(edge_pool_bwd_ctr_kernel, dim3(grid), dim3(256), 0, st, total, n, m, s, c, gpool, ysel, SQ, Ctr,

@@ -39,7 +39,16 @@ constexpr int kLdA = 36;   // A tile row stride in floats (16 B aligned, conflic
 enum AMode { A_PLAIN = 0, A_BNRELU = 1, A_DY = 2, A_DYPOOL = 3, A_DYPOOLU = 4 };
 // A_DYPOOLU: A_DYPOOL with S % 32 == 0 -- a 32-row tile / stripe lies inside ONE pooling group, so its gpool / arg-max
 // quad is loaded once per tile and the row-in-group is (row0 % S) + r (wave-stream kernels only)
-constexpr bool is_pool(int am) { return am == A_DYPOOL || am == A_DYPOOLU; }
+// A_DYPOOLB: the pooled form over COMPACTED rows (pcops_rows_t, see pcops.h): rows come in blocks of kBlk = 16 that lie
+// inside one pooling group each, so a 32-row tile / stripe needs two (gpool, arg-max) quads, one per block, and the
+// row-in-group is block.s0 + (r % 16); the block table replaces the division by S
+constexpr int A_DYPOOLB = 6;
+// A_DYW (weight-gradient kernel only): A_DY over compacted rows, i.e. with the block weights.  A separate mode so
+// that the uncompacted instantiations carry none of it (the 64 x 64 tile lives on a 128-register budget)
+constexpr int A_DYW = 7;
+constexpr bool is_pool(int am) { return am == A_DYPOOL || am == A_DYPOOLU || am == A_DYPOOLB; }
+constexpr int kBlk = 16;        // rows per block of a compacted row set
+struct RowBlock { int g, s0; float w; int pad; };   // group, row-in-group of the block's first row, weight of that row
 // A_XYZ: the operand is the BN+ReLU of a first layer that is ARITHMETIC in three per-row offsets,
 //   y[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))      (csrc/gather.hip first_layer_quad order)
 // rebuilt from off4[row] = (dx, dy, dz, 0) instead of being read: 16 bytes per row instead of 4 K (wave-stream only)
@@ -108,6 +117,11 @@ struct GemmArgs {
     const float *pgamma;                // [N]
     float *ysel;                        // [M / (32 pool_sub)][N]
     unsigned char *psel;                // [M / (32 pool_sub)][N]
+    // compacted rows (wave-stream kernels only): the row count lives on the device (M above is the upper bound the
+    // launch is sized with), blocks[i] describes rows 16 i .. 16 i + 15.  The first row of a group stands for w rows of
+    // the uncompacted tensor: statistics weigh it with w, and its dY is p.G + w (q.Y + t)
+    const RowBlock *blocks;
+    const int *Mdev;
 };
 
 __device__ __forceinline__ float4 ld4(const float *p, bool vec, int k, int K) {
@@ -387,10 +401,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // wave id as a SCALAR: everything derived from it (tile index, buffer descriptors) is then provably wave-uniform
     // and hipcc does not wrap each buffer access in a waterfall loop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int M = a.M, K = a.K, N = a.N;
+    const bool compact = a.blocks != nullptr;
+    const int M = a.Mdev ? __builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;
+    const int K = a.K, N = a.N;
     const int nchunk = (K + KC - 1) / KC;
     const int Kp = nchunk * KC;
     constexpr int CROWS = WST ? (NCOEF > 0 ? NCOEF : 1) : 6;
+    constexpr bool B_ = AM == A_DYPOOLB;             // two pooling blocks per tile
+    static_assert(!B_ || KC == 64, "block-wise pooled operand: row = lane / 16 + 4 j");
     float *Ws = lds;                                        // [Kp][BN], or [2][KC][BN] when streamed
     float *coef = Ws + (size_t)(WST ? 2 * KC : Kp) * BN;    // [CROWS][Kp]
     float *ecoef = coef + CROWS * Kp;                       // [6][BN]: bias | (mask scale, mask shift) | xyz-form w0 w1 w2 b
@@ -501,6 +519,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     float4 pa[NLD];                                  // A_PLAIN/A_BNRELU: X;  A_DY: G;  A_DYPOOL: gpool
     float4 pb[is_dy(AM) ? NLD : 1];                  // A_DY*: raw Y
     unsigned pm[(is_pool(AM)) ? NLD : 1];         // A_DYPOOL: 4 arg-max bytes
+    float bw[2] = {1.f, 1.f};                        // compacted rows: weight of the first row of the tile's two blocks
+    int bs0[2] = {0, 0};                             //                 row-in-group of the first row of each block
 
     // per-lane byte offsets inside a tile (the row part of element e = lane + 64 j is added as a SCALAR offset)
     const unsigned xvoff = (unsigned)((lane / C4) * a.ldx + (lane % C4) * 4) * 4u;
@@ -510,7 +530,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     constexpr bool U_ = AM == A_DYPOOLU;             // one pooling group per tile
     auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
-        if (is_pool(AM)) {
+        if (compact && (is_dy(AM) || B_)) {
+            const int nblk = (M + kBlk - 1) / kBlk;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                long long bi = tile * 2 + h;
+                bi = bi < nblk ? bi : nblk - 1;
+                const RowBlock rb = a.blocks[bi];            // wave-uniform
+                bw[h] = rb.w;
+                bs0[h] = rb.s0;
+                if (B_) {
+                    int c = (lane % C4) * 4 + kc * KC;
+                    c = c < K ? c : K - 4;
+                    pa[h] = *reinterpret_cast<const float4 *>(a.gpool + (long long)rb.g * K + c);
+                    pm[h] = *reinterpret_cast<const unsigned *>(a.argmax + (long long)rb.g * K + c);
+                }
+            }
+        }
+        if (is_pool(AM) && !B_) {
             const PoolRows pr(row0, a.S);
 #pragma unroll
             for (int j = 0; j < (U_ ? 1 : NLD); ++j) {
@@ -561,7 +598,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
             const bool in = (row0 + r < M) && (c < K);
-            float4 x = pa[U_ ? 0 : j];
+            float4 x = pa[U_ ? 0 : (B_ ? j / 4 : j)];
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
                 x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
@@ -580,17 +617,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     long long gdummy;
                     unsigned s;
                     if (U_) s = (unsigned)(prs.s0 + r);
+                    else if (B_) s = (unsigned)(bs0[j / 4] + (r & (kBlk - 1)));
                     else prs.split(r, glast, gdummy, s);
-                    const unsigned am = pm[U_ ? 0 : j];
+                    const unsigned am = pm[U_ ? 0 : (B_ ? j / 4 : j)];
                     g.x = ((am & 0xffu) == (unsigned)s && fmaf(y.x, c3.x, c4.x) > 0.f) ? x.x : 0.f;
                     g.y = (((am >> 8) & 0xffu) == (unsigned)s && fmaf(y.y, c3.y, c4.y) > 0.f) ? x.y : 0.f;
                     g.z = (((am >> 16) & 0xffu) == (unsigned)s && fmaf(y.z, c3.z, c4.z) > 0.f) ? x.z : 0.f;
                     g.w = ((am >> 24) == (unsigned)s && fmaf(y.w, c3.w, c4.w) > 0.f) ? x.w : 0.f;
                 }
-                x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
-                x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
-                x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
-                x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
+                if (compact && C4 == 16 && j % 4 == 0) {
+                    // rows 0 and 16 of the tile (lanes 0..15 at j = 0 / 4) open a block: dY = p.G + w (q.Y + t)
+                    const float w = lane < 16 ? bw[j / 4] : 1.f;
+                    x.x = fmaf(c0.x, g.x, w * fmaf(c1.x, y.x, c2.x));
+                    x.y = fmaf(c0.y, g.y, w * fmaf(c1.y, y.y, c2.y));
+                    x.z = fmaf(c0.z, g.z, w * fmaf(c1.z, y.z, c2.z));
+                    x.w = fmaf(c0.w, g.w, w * fmaf(c1.w, y.w, c2.w));
+                } else {
+                    x.x = fmaf(c0.x, g.x, fmaf(c1.x, y.x, c2.x));
+                    x.y = fmaf(c0.y, g.y, fmaf(c1.y, y.y, c2.y));
+                    x.z = fmaf(c0.z, g.z, fmaf(c1.z, y.z, c2.z));
+                    x.w = fmaf(c0.w, g.w, fmaf(c1.w, y.w, c2.w));
+                }
             }
             if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
@@ -713,6 +760,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
             const float4 eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
             const float4 em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
+            float ew[2] = {1.f, 1.f};                        // compacted rows: statistics weight of rows 0 / 16
+            if (EM == E_FWD && compact) {
+                const int nblk = (M + kBlk - 1) / kBlk;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    long long bi = tile * 2 + hb;
+                    bi = bi < nblk ? bi : nblk - 1;
+                    ew[hb] = a.blocks[bi].w;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int nt = 0; nt < NTH; ++nt)
@@ -729,9 +786,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 if (row < M && ocin) {
                     if (EM == E_FWD) {
                         o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
+                        if (compact && O4 == 16 && j % 4 == 0) {      // rows 0 / 16 of the tile stand for w rows
+                            const float w = lane < 16 ? ew[j / 4] : 1.f;
+                            const float4 wo = make_float4(w * o.x, w * o.y, w * o.z, w * o.w);
+                            s1[h][0] += wo.x; s1[h][1] += wo.y; s1[h][2] += wo.z; s1[h][3] += wo.w;
+                            s2[h][0] = fmaf(wo.x, o.x, s2[h][0]); s2[h][1] = fmaf(wo.y, o.y, s2[h][1]);
+                            s2[h][2] = fmaf(wo.z, o.z, s2[h][2]); s2[h][3] = fmaf(wo.w, o.w, s2[h][3]);
+                        } else {
                         s1[h][0] += o.x; s1[h][1] += o.y; s1[h][2] += o.z; s1[h][3] += o.w;
                         s2[h][0] = fmaf(o.x, o.x, s2[h][0]); s2[h][1] = fmaf(o.y, o.y, s2[h][1]);
                         s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
+                        }
                         if (POOL) {   // rows arrive in ascending order: a strict comparison keeps the first extremum
                             const int sr = sub * 32 + r;
                             const float ov[4] = {o.x * em.x, o.y * em.y, o.z * em.z, o.w * em.w};
@@ -960,10 +1025,12 @@ int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
     if (ws_enabled() && ws_plan(a, AM, &pl)) {
         int rc;
-        if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
+        if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
+        else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
         else rc = launch_gemm_ws<AM, EM>(a, pl, st);
         return rc;
     }
+    if (a.blocks) return PCOPS_ERR_UNSUPPORTED;      // compacted rows: wave-stream kernels only
     return launch_gemm_rt<AM, EM>(a, st);
 }
 
@@ -1084,6 +1151,47 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(long long G, int S
         float ys[4] = {0.f, 0.f, 0.f, 0.f};
         int am[4] = {0, 0, 0, 0};
         const float *base = Y + (g * S) * C + c;
+        for (int s = 0; s < S; ++s) {
+            const float4 y = *reinterpret_cast<const float4 *>(base + (long long)s * C);
+            const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
+            const float a2 = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
+            if (a0 > m[0]) { m[0] = a0; am[0] = s; ys[0] = y.x; }
+            if (a1 > m[1]) { m[1] = a1; am[1] = s; ys[1] = y.y; }
+            if (a2 > m[2]) { m[2] = a2; am[2] = s; ys[2] = y.z; }
+            if (a3 > m[3]) { m[3] = a3; am[3] = s; ys[3] = y.w; }
+        }
+        *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(m[0], m[1], m[2], m[3]);
+        if (argmax) {
+            uchar4 q;
+            q.x = (unsigned char)am[0]; q.y = (unsigned char)am[1];
+            q.z = (unsigned char)am[2]; q.w = (unsigned char)am[3];
+            *reinterpret_cast<uchar4 *>(argmax + g * C + c) = q;
+        }
+        if (ysel) *reinterpret_cast<float4 *>(ysel + g * C + c) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    }
+}
+
+// the same over COMPACTED rows: group g owns rows 16 bstart[g] .. 16 bstart[g+1] - 1 (its real members followed by
+// copies of member 0 up to the block boundary; the first maximiser wins, so a copy is never the arg-max)
+__global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(long long G, int C, const float *__restrict__ Y,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   const int *__restrict__ bstart,
+                                                                   float *__restrict__ out,
+                                                                   unsigned char *__restrict__ argmax,
+                                                                   float *__restrict__ ysel) {
+    const int c4n = C / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < G * c4n; e += (long long)gridDim.x * 256) {
+        const long long g = e / c4n;
+        const int c = (int)(e - g * c4n) * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float m[4] = {-1.f, -1.f, -1.f, -1.f};
+        float ys[4] = {0.f, 0.f, 0.f, 0.f};
+        int am[4] = {0, 0, 0, 0};
+        const long long r0 = (long long)bstart[g] * kBlk;
+        const int S = (bstart[g + 1] - bstart[g]) * kBlk;
+        const float *base = Y + r0 * C + c;
         for (int s = 0; s < S; ++s) {
             const float4 y = *reinterpret_cast<const float4 *>(base + (long long)s * C);
             const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
@@ -1248,6 +1356,8 @@ struct WgradArgs {
     const float *dsc; const float *dsh; const float *gpool; const unsigned char *argmax; int S;
     float *part;             // [gridDim.z][K][N] partial dW
     float *dbpart;           // [gridDim.z][N] partial db (written by blockIdx.x == 0)
+    const RowBlock *blocks;  // compacted rows (producer/consumer kernel only), see GemmArgs
+    const int *Mdev;
 };
 
 template <int VK, int VN>
@@ -1601,7 +1711,8 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, N = a.N;
-    const long long M = a.M;
+    constexpr bool compact = DMODE == A_DYW || DMODE == A_DYPOOLB;      // compacted rows (block table + device row count)
+    const long long M = compact ? (long long)__builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;
     const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
     const int grp = blockIdx.x, ngrp = gridDim.x;
     float *coefA = lds;                        // [6][KB]  scale, shift | xyz-form w0 w1 w2 b
@@ -1661,8 +1772,33 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
         const unsigned dstep = (unsigned)(256 / D4) * (unsigned)a.ldy * 4u;
         const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
         constexpr bool U_ = DMODE == A_DYPOOLU;                // one pooling group per stripe
+        constexpr bool B_ = DMODE == A_DYPOOLB;                // compacted rows: one pooling group per 16-row block
+        constexpr int NBLK = RS / kBlk;                        // blocks per stripe
+        constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
+        static_assert(QD <= kBlk && kBlk % QD == 0, "block of row pt / D4 + j QD is (j QD) / 16");
+        float bw[compact ? NBLK : 1];                          // weight of the first row of each block of the stripe
+        int bs0[B_ ? NBLK : 1];
+#pragma unroll
+        for (int h = 0; h < (compact ? NBLK : 1); ++h) bw[h] = 1.f;
+#pragma unroll
+        for (int h = 0; h < (B_ ? NBLK : 1); ++h) bs0[h] = 0;
         auto issue = [&](long long stripe) {
             const long long row0 = stripe * RS;
+            if (compact) {
+                const long long nblk = (M + kBlk - 1) / kBlk;
+#pragma unroll
+                for (int h = 0; h < NBLK; ++h) {
+                    long long bi = stripe * NBLK + h;
+                    bi = bi < nblk ? bi : nblk - 1;
+                    const RowBlock rb = a.blocks[bi];          // wave-uniform
+                    bw[h] = rb.w;
+                    if (B_) {
+                        bs0[h] = rb.s0;
+                        pg[h] = *reinterpret_cast<const float4 *>(a.gpool + (long long)rb.g * N + dcl);
+                        pm[h] = *reinterpret_cast<const unsigned *>(a.argmax + (long long)rb.g * N + dcl);
+                    }
+                }
+            }
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
             const __amdgpu_buffer_rsrc_t rg =
@@ -1679,7 +1815,9 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
-                if (is_pool(DMODE)) {
+                if (B_) {
+                    // loaded per block above
+                } else if (is_pool(DMODE)) {
                     if (U_) {
                         if (j == 0) {
                             const long long gi = pr.g0 < glast ? pr.g0 : glast;
@@ -1723,23 +1861,34 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
             for (int j = 0; j < ND; ++j) {
                 const int r = pt / D4 + j * (256 / D4);
                 const float4 y = py[j];
-                float4 g = pg[U_ ? 0 : j];
+                const int hb = (j * QD) / kBlk;                // block of this row inside the stripe (compile time)
+                float4 g = pg[U_ ? 0 : (B_ ? hb : j)];
                 if (is_pool(DMODE)) {
                     long long gdummy;
                     unsigned s;
                     if (U_) s = (unsigned)(prs.s0 + r);
+                    else if (B_) s = (unsigned)(bs0[B_ ? hb : 0] + (r & (kBlk - 1)));
                     else prs.split(r, glast, gdummy, s);
-                    const unsigned am = pm[U_ ? 0 : j];
+                    const unsigned am = pm[U_ ? 0 : (B_ ? hb : j)];
                     g.x = ((am & 0xffu) == s && fmaf(y.x, cds.x, cdh.x) > 0.f) ? g.x : 0.f;
                     g.y = (((am >> 8) & 0xffu) == s && fmaf(y.y, cds.y, cdh.y) > 0.f) ? g.y : 0.f;
                     g.z = (((am >> 16) & 0xffu) == s && fmaf(y.z, cds.z, cdh.z) > 0.f) ? g.z : 0.f;
                     g.w = ((am >> 24) == s && fmaf(y.w, cds.w, cdh.w) > 0.f) ? g.w : 0.f;
                 }
                 float4 d;
-                d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
-                d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
-                d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
-                d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+                if (compact && (j * QD) % kBlk == 0) {
+                    // a row that opens a block (r % 16 == 0): dY = p.G + w (q.Y + t)
+                    const float w = (r & (kBlk - 1)) == 0 ? bw[compact ? hb : 0] : 1.f;
+                    d.x = fmaf(cp.x, g.x, w * fmaf(cq.x, y.x, ct.x));
+                    d.y = fmaf(cp.y, g.y, w * fmaf(cq.y, y.y, ct.y));
+                    d.z = fmaf(cp.z, g.z, w * fmaf(cq.z, y.z, ct.z));
+                    d.w = fmaf(cp.w, g.w, w * fmaf(cq.w, y.w, ct.w));
+                } else {
+                    d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
+                    d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
+                    d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
+                    d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+                }
                 if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
                 dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
                 *reinterpret_cast<float4 *>(&dst[r * LD + KB + dcq]) = d;
@@ -2048,7 +2197,8 @@ static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
     if (!(ws_enabled() && ws_plan(a, AM, &pl))) return PCOPS_ERR_UNSUPPORTED;
     int rc;
-    if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
+    if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
+    else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
     else rc = launch_gemm_ws<AM, EM>(a, pl, st);
     return rc;
 }
@@ -2068,9 +2218,25 @@ unsigned long long pcops_mlp_reduce_workspace_bytes(int N) {
     return (unsigned long long)kRedSlices * 2 * (unsigned long long)N * sizeof(double);
 }
 
-int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
-                       const float *pro_shift, const float *W, const float *bias, float *Y,
-                       float *stats_partial, pcops_stream_t stream) {
+static int rows_ok(const pcops_rows_t *rows) {
+    if (!rows) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(rows->blocks); PCOPS_REQUIRE_PTR(rows->block_start); PCOPS_REQUIRE_PTR(rows->rows);
+    if (reinterpret_cast<uintptr_t>(rows->blocks) & 15) return PCOPS_ERR_UNSUPPORTED;
+    return PCOPS_OK;
+}
+#define PCOPS_ROWS(args_, rows_)                                                      \
+    do {                                                                              \
+        const int rrc_ = rows_ok(rows_);                                              \
+        if (rrc_) return rrc_;                                                        \
+        if (rows_) {                                                                  \
+            (args_).blocks = static_cast<const RowBlock *>((rows_)->blocks);          \
+            (args_).Mdev = (rows_)->rows;                                             \
+        }                                                                             \
+    } while (0)
+
+int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                            const float *pro_shift, const float *W, const float *bias, float *Y,
+                            float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 0 && K >= 1 && N >= 1 && ldx >= K);
     if (M == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
@@ -2079,8 +2245,15 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    PCOPS_ROWS(a, rows);
     if (pro_scale) return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
     return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));
+}
+
+int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                       const float *pro_shift, const float *W, const float *bias, float *Y,
+                       float *stats_partial, pcops_stream_t stream) {
+    return pcops_mlp_gemm_fwd_rows(M, K, N, X, ldx, pro_scale, pro_shift, W, bias, Y, stats_partial, nullptr, stream);
 }
 
 static bool fwd_pool_shape_ok(int M, int K, int N, int S) {
@@ -2172,6 +2345,22 @@ int pcops_mlp_bn_relu_maxpool(long long G, int S, int C, const float *Y, const f
     return pcops_launch_status();
 }
 
+int pcops_mlp_bn_relu_maxpool_rows(long long G, int C, const float *Y, const float *scale, const float *shift,
+                                   const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,
+                                   pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && C >= 4 && C % 4 == 0);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
+    PCOPS_REQUIRE_PTR(rows);
+    const int rrc = rows_ok(rows);
+    if (rrc) return rrc;
+    const long long total = G * (C / 4);
+    const unsigned grid = cdiv(total, 256) < 32768u ? cdiv(total, 256) : 32768u;
+    hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), G, C, Y, scale,
+                       shift, rows->block_start, out, argmax, ysel);
+    return pcops_launch_status();
+}
+
 int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *scale, const float *shift,
                             float *out, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(R >= 0 && C >= 4 && C % 4 == 0);
@@ -2247,6 +2436,15 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
                          int S, const float *pool_scale, const float *pool_shift, const float *Wt,
                          const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
                          float *stats_partial, pcops_stream_t stream) {
+    return pcops_mlp_gemm_dgrad_rows(M, K, Nout, G, Y, p, q, t, gpool, argmax, S, pool_scale, pool_shift, Wt, Yprev,
+                                     prev_scale, prev_shift, Gprev, stats_partial, nullptr, stream);
+}
+
+int pcops_mlp_gemm_dgrad_rows(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                              int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                              const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
+                              float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 0 && K >= 1 && Nout >= 1);
     if (M == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
@@ -2257,6 +2455,7 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
     a.v3 = pool_scale; a.v4 = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     a.W = Wt; a.Y = Gprev; a.ldy = Nout; a.Yprev = Yprev; a.msc = prev_scale; a.msh = prev_shift;
     a.stats = stats_partial;
+    PCOPS_ROWS(a, rows);
     hipStream_t st = as_stream(stream);
     if (gpool) {
         PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
@@ -2287,6 +2486,13 @@ int pcops_mlp_xyz_supported(int M, int C1, int N2) {
 int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                            const float *pro_shift, const float *W, const float *bias, float *Y,
                            float *stats_partial, pcops_stream_t stream) {
+    return pcops_mlp_gemm_fwd_xyz_rows(M, K, N, off4, xyzw, pro_scale, pro_shift, W, bias, Y, stats_partial, nullptr,
+                                       stream);
+}
+
+int pcops_mlp_gemm_fwd_xyz_rows(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
+                                const float *pro_shift, const float *W, const float *bias, float *Y,
+                                float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && N >= 1);
     PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(pro_scale); PCOPS_REQUIRE_PTR(pro_shift);
     PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
@@ -2295,6 +2501,7 @@ int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *
     a.M = M; a.K = K; a.N = N; a.X = nullptr; a.ldx = K; a.v0 = pro_scale; a.v1 = pro_shift;
     a.off4 = off4; a.xw = xyzw; a.xw_ld = K;
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    PCOPS_ROWS(a, rows);
     return launch_gemm_ws_only<A_XYZ, E_FWD>(a, as_stream(stream));
 }
 
@@ -2306,6 +2513,16 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
                              const float *off4, const float *xyzw, const float *prev_scale,
                              const float *prev_shift, float *Gprev, float *stats_partial, float *xyz_stats,
                              pcops_stream_t stream) {
+    return pcops_mlp_gemm_dgrad_xyz_rows(M, K, Nout, G, Y, p, q, t, gpool, argmax, S, pool_scale, pool_shift, Wt, off4,
+                                         xyzw, prev_scale, prev_shift, Gprev, stats_partial, xyz_stats, nullptr, stream);
+}
+
+int pcops_mlp_gemm_dgrad_xyz_rows(int M, int K, int Nout, const float *G, const float *Y, const float *p,
+                                  const float *q, const float *t, const float *gpool, const unsigned char *argmax,
+                                  int S, const float *pool_scale, const float *pool_shift, const float *Wt,
+                                  const float *off4, const float *xyzw, const float *prev_scale,
+                                  const float *prev_shift, float *Gprev, float *stats_partial, float *xyz_stats,
+                                  const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && Nout >= 1);
     PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw);
@@ -2319,6 +2536,7 @@ int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float
     a.W = Wt; a.Y = Gprev; a.ldy = Nout; a.msc = prev_scale; a.msh = prev_shift;
     a.off4 = off4; a.xw = xyzw; a.xw_ld = Nout;
     a.stats = stats_partial; a.xstats = xyz_stats;
+    PCOPS_ROWS(a, rows);
     hipStream_t st = as_stream(stream);
     if (gpool) {
         PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale); PCOPS_REQUIRE_PTR(pool_shift);
@@ -2379,8 +2597,11 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     PcWgradPlan pc;
     // producer/consumer kernel for the pooled forms and the widest tile; the single-role kernel (256 accumulator
     // registers per wave) is ahead on the narrow materialised-G shapes
+    if (a.blocks && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc)))
+        return PCOPS_ERR_UNSUPPORTED;            // compacted rows: producer/consumer kernel only
     if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc) &&
-        (gpool || pc.tn == 4 || a.amode == A_XYZ || !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
+        (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks ||
+         !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
         splits = pc.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
         const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
@@ -2394,7 +2615,13 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     } while (0)
 #define PCOPS_PC_MODES(TK_, TN_)                                                                           \
     do {                                                                                                   \
-        if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);                   \
+        if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW);      \
+        else if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYW); \
+        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYW);   \
+        else if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);              \
+        else if (a.amode == A_XYZ && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLB);                \
+        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLB); \
+        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLB);   \
         else if (a.amode == A_XYZ && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLU);           \
         else if (a.amode == A_XYZ) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOL);                             \
         else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);        \
@@ -2458,6 +2685,15 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
                     const float *t, const float *gpool, const unsigned char *argmax, int S,
                     const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                     pcops_stream_t stream) {
+    return pcops_mlp_wgrad_rows(M, K, N, X, ldx, a_scale, a_shift, G, Y, p, q, t, gpool, argmax, S, pool_scale,
+                                pool_shift, partial, dW, db, nullptr, stream);
+}
+
+int pcops_mlp_wgrad_rows(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
+                         const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                         const float *t, const float *gpool, const unsigned char *argmax, int S,
+                         const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                         const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW);
@@ -2467,6 +2703,7 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
     a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = X; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
     a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
     a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    PCOPS_ROWS(a, rows);
     return wgrad_impl(a, partial, dW, db, as_stream(stream));
 }
 
@@ -2477,6 +2714,15 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
                         const float *t, const float *gpool, const unsigned char *argmax, int S,
                         const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                         pcops_stream_t stream) {
+    return pcops_mlp_wgrad_xyz_rows(M, K, N, off4, xyzw, a_scale, a_shift, G, Y, p, q, t, gpool, argmax, S, pool_scale,
+                                    pool_shift, partial, dW, db, nullptr, stream);
+}
+
+int pcops_mlp_wgrad_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                             const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                             const float *t, const float *gpool, const unsigned char *argmax, int S,
+                             const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
+                             const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1);
     PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift);
     PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
@@ -2489,6 +2735,7 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
     a.off4 = off4; a.xw = xyzw; a.xw_ld = K;
     a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
     a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    PCOPS_ROWS(a, rows);
     return wgrad_impl(a, partial, dW, db, as_stream(stream));
 }
 

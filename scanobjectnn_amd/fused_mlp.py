@@ -15,6 +15,8 @@ Two kinds of first layer:
           of a GROUPED stack applied before the grouping (it is linear; see csrc/gather.hip), so neither the
           grouped input nor a (3+C)-wide concat is ever built and its backward is one scatter-add.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -50,8 +52,10 @@ def _p(t):
 
 
 class FusedMLPStack(torch.autograd.Function):
-    """apply(a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased_moving_var, L, *per_layer)
+    """apply(a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased_moving_var, rows, L, *per_layer)
 
+    rows: None, or a `_lib.Rows` compacted row set of the grouped stack (ball-query padding left out, pcops.h
+          "compacted rows"): gather first layer, max-pooled, no Ctr term
     dense first layer : a0 = x2d (R, K0); ctr .. bias = None
     gather first layer: idx (B, M, S) int32 and any of a0 = Q (B, N, C1), ctr (B, M, C1),
                         xyz (B, N, 3) + new_xyz (B, M, 3) + wxyz (3, C1), bias (C1);  R = B*M*S
@@ -59,8 +63,9 @@ class FusedMLPStack(torch.autograd.Function):
     for a gather first layer.  Returns (R//S, C_L) if pool else (R, C_L)."""
 
     @staticmethod
-    def forward(ctx, a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased, L, *tensors):
+    def forward(ctx, a0, ctr, idx, xyz, new_xyz, wxyz, bias, S, pool, training, decay, eps, unbiased, rows, L, *tensors):
         lib = _lib.load()
+        rref = rows.ref if rows is not None else None
         identity = bool(int(pool) & 2)      # gather stack whose idx is 0..n-1 per cloud (group_all): scatter = reshape
         pool = bool(int(pool) & 1)
         gather = idx is not None
@@ -87,6 +92,8 @@ class FusedMLPStack(torch.autograd.Function):
         virt = (gather and a0 is None and ctr is None and wxyz is not None and (L >= 3 or (L == 2 and not pool))
                 and not sync and (training or not need_grad)
                 and bool(lib.pcops_mlp_xyz_supported(R, C1, layers[1][0].shape[-1])))
+        if rows is not None and gather and a0 is None and not virt:
+            rows = rref = None          # a stored coordinate-only first layer has no compacted backward: plain rows
         off4 = xyzw = mom = None
         if virt:
             off4 = _f32((R, 4), dev)
@@ -99,8 +106,8 @@ class FusedMLPStack(torch.autograd.Function):
                 Y = None if virt else _f32((R, N), dev)
                 P = lib.pcops_sa_gather_stats_rows(B * M)
                 part = _f32((P, 2, N), dev) if training else None
-                _lib.call("pcops_sa_gather_fwd", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
-                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), _p(mom))
+                _lib.call("pcops_sa_gather_fwd_rows", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
+                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), _p(mom), rref)
                 W2 = None
             else:
                 N = w.shape[-1]
@@ -110,8 +117,12 @@ class FusedMLPStack(torch.autograd.Function):
                 P = lib.pcops_mlp_stats_rows(R)
                 part = _f32((P, 2, N), dev) if training else None
                 if li == 1 and virt:
-                    _lib.call("pcops_mlp_gemm_fwd_xyz", R, K, N, off4.data_ptr(), xyzw.data_ptr(), sc_prev.data_ptr(),
-                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
+                    _lib.call("pcops_mlp_gemm_fwd_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(), sc_prev.data_ptr(),
+                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
+                elif rows is not None:
+                    # compacted rows: the max over the (variable-length) groups is its own pass below
+                    _lib.call("pcops_mlp_gemm_fwd_rows", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
+                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
                 elif (pool and li == L - 1 and sc_prev is not None and ld == K
                         and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)):
                     # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics)
@@ -159,8 +170,12 @@ class FusedMLPStack(torch.autograd.Function):
             else:
                 argmax = torch.empty((G, C), dtype=torch.uint8, device=dev) if (training or need_grad) else None
                 ysel = _f32((G, C), dev) if (training or need_grad) else None
-                _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
-                          shifts[-1].data_ptr(), out.data_ptr(), _p(argmax), _p(ysel))
+                if rows is not None:
+                    _lib.call("pcops_mlp_bn_relu_maxpool_rows", G, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                              shifts[-1].data_ptr(), rref, out.data_ptr(), _p(argmax), _p(ysel))
+                else:
+                    _lib.call("pcops_mlp_bn_relu_maxpool", G, S, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                              shifts[-1].data_ptr(), out.data_ptr(), _p(argmax), _p(ysel))
         else:
             out = _f32((R, C), dev)
             _lib.call("pcops_mlp_bn_relu_apply", R, C, Ys[-1].data_ptr(), scales[-1].data_ptr(),
@@ -169,6 +184,7 @@ class FusedMLPStack(torch.autograd.Function):
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
                          [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
+            ctx.rows = rows
         return out
 
     @staticmethod
@@ -180,6 +196,8 @@ class FusedMLPStack(torch.autograd.Function):
         virt = off4 is not None
         widths = [g.shape[0] for g in gammas]
         S, pool, L, R, K0, gather, identity, training, sync = ctx.meta
+        rows = ctx.rows
+        rref = rows.ref if rows is not None else None
         dev = grad_out.device
         grad_out = grad_out.contiguous()
         grads = [None] * (6 * L)
@@ -255,11 +273,11 @@ class FusedMLPStack(torch.autograd.Function):
                 if d0 is not None:   # gather formulation over an inverse index
                     wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,
                                       dtype=torch.int32, device=dev)
-                _lib.call("pcops_sa_scatter_bwd", B, Nsrc, M, S, N, Gptr, _p(Ys[0]), p.data_ptr(),
+                _lib.call("pcops_sa_scatter_bwd_rows", B, Nsrc, M, S, N, Gptr, _p(Ys[0]), p.data_ptr(),
                           q.data_ptr(), t.data_ptr(), gp, am, psc, psh, idx.data_ptr(),
                           _p(xyz) if wxyz is not None else None, _p(new_xyz) if wxyz is not None else None,
                           _p(d0), _p(d1), _p(wpart), _p(dwxyz), _p(dbias), _p(a0), _p(ctr), _p(wxyz), _p(bias),
-                          _p(wsp))
+                          _p(wsp), rref)
                 d0 = d0_out
                 break
 
@@ -273,13 +291,13 @@ class FusedMLPStack(torch.autograd.Function):
             scratch = _f32(splits * (K * N + N), dev)
             dW, db = _f32((K, N), dev), _f32(N, dev)
             if xyz_prev:
-                _lib.call("pcops_mlp_wgrad_xyz", R, K, N, off4.data_ptr(), xyzw.data_ptr(), scales[0].data_ptr(),
+                _lib.call("pcops_mlp_wgrad_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(), scales[0].data_ptr(),
                           shifts[0].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am,
-                          S, psc, psh, scratch.data_ptr(), dW.data_ptr(), db.data_ptr())
+                          S, psc, psh, scratch.data_ptr(), dW.data_ptr(), db.data_ptr(), rref)
             else:
-                _lib.call("pcops_mlp_wgrad", R, K, N, src.data_ptr(), ld, asc, ash, Gptr, Ys[l].data_ptr(),
+                _lib.call("pcops_mlp_wgrad_rows", R, K, N, src.data_ptr(), ld, asc, ash, Gptr, Ys[l].data_ptr(),
                           p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S, psc, psh, scratch.data_ptr(),
-                          dW.data_ptr(), db.data_ptr())
+                          dW.data_ptr(), db.data_ptr(), rref)
             grads[6 * l + 0] = dW
             grads[6 * l + 1] = db
             if l > 0 or ctx.needs_input_grad[0]:
@@ -290,16 +308,17 @@ class FusedMLPStack(torch.autograd.Function):
                     P = lib.pcops_mlp_stats_rows(R)
                     part = _f32((P, 2, K), dev)
                     xstats = _f32((P, 3, K), dev)
-                    _lib.call("pcops_mlp_gemm_dgrad_xyz", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
+                    _lib.call("pcops_mlp_gemm_dgrad_xyz_rows", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
                               t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), off4.data_ptr(), xyzw.data_ptr(),
-                              scales[0].data_ptr(), shifts[0].data_ptr(), None, part.data_ptr(), xstats.data_ptr())
+                              scales[0].data_ptr(), shifts[0].data_ptr(), None, part.data_ptr(), xstats.data_ptr(),
+                              rref)
                 elif l > 0:
                     P = lib.pcops_mlp_stats_rows(R)
                     part = _f32((P, 2, K), dev)
-                    _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
+                    _lib.call("pcops_mlp_gemm_dgrad_rows", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
                               t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), Ys[l - 1].data_ptr(),
                               scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Gprev.data_ptr(),
-                              part.data_ptr())
+                              part.data_ptr(), rref)
                 else:
                     _lib.call("pcops_mlp_gemm_dgrad", R, N, K, Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(),
                               t.data_ptr(), gp, am, S, psc, psh, Wt.data_ptr(), None, None, None,
@@ -308,7 +327,7 @@ class FusedMLPStack(torch.autograd.Function):
                 Gm = Gprev
 
         out = [d0 if ctx.needs_input_grad[0] else None, d1, None, None, None, dwxyz, dbias,
-               None, None, None, None, None, None, None]
+               None, None, None, None, None, None, None, None]
         for i in range(L):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
@@ -475,12 +494,31 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
     """x: (..., K0) channel-last; rows are flattened; S rows per pooling group (contiguous)."""
     x2d = x.reshape(-1, x.shape[-1]).contiguous()
     return FusedMLPStack.apply(x2d, None, None, None, None, None, None, int(S), bool(pool), bool(training),
-                               float(decay), float(eps), bool(unbiased), len(layer_tensors),
+                               float(decay), float(eps), bool(unbiased), None, len(layer_tensors),
                                *_flat(layer_tensors, False))
 
 
+COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
+
+
+def _compactable(idx, pool, L, widths, Q, Ctr, xyz, wxyz, identity_idx):
+    """ball-query padding can be left out of this stack (pcops.h "compacted rows"): max-pooled gather stack of at
+    least two layers without a per-group term, wave-stream sized, group size a multiple of the 16-row block"""
+    B, M, S = idx.shape
+    if not (COMPACT_MIN_S and pool and not identity_idx and Ctr is None and L >= 2):
+        return False
+    if S < COMPACT_MIN_S or S % 16 or S > 256 or B * M * S < 32768 or any(w % 32 for w in widths):
+        return False
+    if _dist.sync_bn_active():
+        return False
+    if Q is not None:       # the feature gradient walks the compacted rows through the inverse index
+        c1, n = Q.shape[2], Q.shape[1]
+        return (c1 in (32, 64, 128) or c1 % 256 == 0) and n <= 16384
+    return wxyz is not None and L >= 3      # coordinate-only first layer: only as the arithmetic (never stored) form
+
+
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
-                     new_xyz=None, wxyz=None, bias=None, identity_idx=False):
+                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None):
     """Grouped stack whose first conv was applied before the grouping:
          Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
     idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
@@ -500,7 +538,11 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
         _w, _b, gamma, beta, mm, mv = layer_tensors[0]
         return EdgeConvPool.apply(c(Q), c(Ctr), idx.contiguous(), gamma, beta, mm, mv, bool(training), float(decay),
                                   float(eps), bool(unbiased))
+    rows = None
+    if pts_cnt is not None and _compactable(idx, pool, len(layer_tensors), [l[2].shape[0] for l in layer_tensors],
+                                            Q, Ctr, xyz, wxyz, identity_idx):
+        rows = _lib.Rows(pts_cnt.contiguous(), S)
     return FusedMLPStack.apply(c(Q), c(Ctr), idx.contiguous(), c(xyz.detach()) if xyz is not None else None,
                                c(new_xyz.detach()) if new_xyz is not None else None, c(wxyz), c(bias), int(S),
                                int(bool(pool)) | (2 if identity_idx else 0), bool(training), float(decay), float(eps),
-                               bool(unbiased), len(layer_tensors), *_flat(layer_tensors, True))
+                               bool(unbiased), rows, len(layer_tensors), *_flat(layer_tensors, True))

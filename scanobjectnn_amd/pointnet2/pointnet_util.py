@@ -66,7 +66,7 @@ def _mlp_stack_unfused(x, widths, scope_fmt, bn, is_training, bn_decay, data_for
 
 
 def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training, bn_decay, use_xyz,
-                       xyz_first, pool_max, identity_idx=False):
+                       xyz_first, pool_max, identity_idx=False, pts_cnt=None):
     """Grouped shared MLP without ever building the grouped input.  The first 1x1 conv is linear, so
          concat(xyz[idx] - new_xyz, points[idx]) W + b  =  (points W_f + b)[idx] + (xyz[idx] - new_xyz) W_xyz :
     the feature part runs once per SOURCE point (B*N rows through a library GEMM instead of B*M*S) and the
@@ -92,8 +92,10 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
         else:
             kw = dict(Q=lin(pts2d, w1, b1).view(b, n, c1))
     decay = bn_decay if bn_decay is not None else 0.9
+    # pts_cnt (the ball query's hit counts): rows beyond it are copies of the group's first member -- the stack may
+    # leave them out and weigh that member instead (fused_mlp "compacted rows"); None: every row is computed
     out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers,
-                                     identity_idx=identity_idx, **kw)
+                                     identity_idx=identity_idx, pts_cnt=pts_cnt, **kw)
     return out.view(b, m, 1 if pool_max else s, widths[-1])
 
 
@@ -130,12 +132,14 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).expand(b, 1, n).contiguous()
             else:
                 new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+                _pts_cnt = None
                 if knn:
                     _, idx = knn_point(nsample, xyz, new_xyz)
                 else:
                     idx, _pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
             new_points = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp, 'conv%d', is_training, bn_decay,
-                                            use_xyz, True, pool_max, identity_idx=group_all)
+                                            use_xyz, True, pool_max, identity_idx=group_all,
+                                            pts_cnt=None if group_all else _pts_cnt)
             grouped_xyz = None
         else:
             if group_all:
@@ -178,7 +182,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             fmt = 'conv%d_' % i + '%d'
             if xyz.is_cuda and _gather_fusable(points, mlp_list[i], bn, idx.shape[2], True, xyz):
                 grouped = _grouped_mlp_fused(xyz, points, new_xyz, idx, mlp_list[i], fmt, is_training, bn_decay,
-                                             use_xyz, False, True)          # [feats | xyz] order (:184)
+                                             use_xyz, False, True, pts_cnt=_cnt)   # [feats | xyz] order (:184)
             else:
                 grouped_xyz = group_point(xyz, idx) - new_xyz.unsqueeze(2)
                 if points is None:

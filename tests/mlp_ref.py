@@ -24,6 +24,19 @@ def fused_pattern(out):
     if len(node.saved) == 11:           # EdgeConvPool: ONE pooled layer, only the arg-max row is a discrete decision
         return [None], node.saved[5]
     Ys, scales, shifts, argmax = node.saved[7], node.saved[10], node.saved[11], node.saved[14]
+    expand = None
+    rows = getattr(node, "rows", None)
+    if rows is not None:
+        # compacted rows: the stack ran on 16 * ceil(cnt / 16) rows per group.  Map every row (g, s) of the full
+        # (b, m, S) layout to the compacted row that computed it: s itself while it exists, row 0 of the group (whose
+        # copy it is) beyond -- then the masks below line up with the uncompacted float64 reference
+        idx = node.saved[2]
+        S = idx.shape[2]
+        bs = rows.block_start.long()
+        first = bs[:-1] * 16
+        nrow = (bs[1:] - bs[:-1]) * 16
+        s_ar = torch.arange(S, device=idx.device).view(1, S)
+        expand = (first.view(-1, 1) + torch.where(s_ar < nrow.view(-1, 1), s_ar, torch.zeros_like(s_ar))).reshape(-1)
     masks = []
     for Y, sc, sh in zip(Ys, scales, shifts):
         if Y is None:
@@ -39,7 +52,7 @@ def fused_pattern(out):
             step = max(1, (1 << 26) // n)
             for r0 in range(0, Y.shape[0], step):
                 m[r0:r0 + step] = (Y[r0:r0 + step].double() * sc[:n].double() + sh[:n].double()) > 0
-            masks.append(m)
+            masks.append(m if expand is None else m[expand])
     return masks, argmax
 
 
