@@ -1192,14 +1192,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(long long G, 
         const long long r0 = (long long)bstart[g] * kBlk;
         const int S = (bstart[g + 1] - bstart[g]) * kBlk;
         const float *base = Y + r0 * C + c;
-        for (int s = 0; s < S; ++s) {
-            const float4 y = *reinterpret_cast<const float4 *>(base + (long long)s * C);
-            const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
-            const float a2 = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
-            if (a0 > m[0]) { m[0] = a0; am[0] = s; ys[0] = y.x; }
-            if (a1 > m[1]) { m[1] = a1; am[1] = s; ys[1] = y.y; }
-            if (a2 > m[2]) { m[2] = a2; am[2] = s; ys[2] = y.z; }
-            if (a3 > m[3]) { m[3] = a3; am[3] = s; ys[3] = y.w; }
+        // S is a multiple of 16: eight rows are requested before the first is looked at (a row-at-a-time loop has ONE
+        // 16-byte load in flight per lane and spends 93 % of its wave cycles in s_waitcnt)
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float4 yv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) yv[u] = *reinterpret_cast<const float4 *>(base + (long long)(s0 + u) * C);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 y = yv[u];
+                const int s = s0 + u;
+                const float a0 = fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(y.y, sc.y, sh.y), 0.f);
+                const float a2 = fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(y.w, sc.w, sh.w), 0.f);
+                if (a0 > m[0]) { m[0] = a0; am[0] = s; ys[0] = y.x; }
+                if (a1 > m[1]) { m[1] = a1; am[1] = s; ys[1] = y.y; }
+                if (a2 > m[2]) { m[2] = a2; am[2] = s; ys[2] = y.z; }
+                if (a3 > m[3]) { m[3] = a3; am[3] = s; ys[3] = y.w; }
+            }
         }
         *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(m[0], m[1], m[2], m[3]);
         if (argmax) {
