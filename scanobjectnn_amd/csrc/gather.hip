@@ -768,9 +768,19 @@ __global__ __launch_bounds__(1024) void xyz_first_layer_grads_kernel(int P1, con
     // wave reads consecutive floats
     if (tid < 9 * 112) {
         const int l = tid / 9, k = tid % 9;
-        double a = 0.0;
-        for (int r = l; r < P2; r += 112) a += (double)moments[(long long)r * 9 + k];
-        smM[k][l] = a;
+        // eight independent loads in flight per thread (a one-at-a-time loop over the 16 384 partial rows of the SSG
+        // config made this tiny kernel take 130 us, all of it load latency); the summation order stays fixed
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int r = l;
+        for (; r + 7 * 112 < P2; r += 8 * 112) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = moments[(long long)(r + u * 112) * 9 + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += (double)v[u];
+        }
+        for (; r < P2; r += 112) a[0] += (double)moments[(long long)r * 9 + k];
+        smM[k][l] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (c < C)
