@@ -32,14 +32,20 @@ def get_bn_decay(global_step, batch_size, bn_decay_decay_step=float(DECAY_STEP))
 class FlatParams:
     """Re-homes every parameter of `module` (and its gradient) as a view into ONE flat fp32 buffer."""
 
+    ALIGN = 4   # floats: every parameter starts on a 16-byte boundary (the kernels read weights 16 bytes at a time;
+    #             a weight matrix at an odd offset silently takes the slow generic GEMM -- measured on DGCNN's
+    #             320 -> 1024 layer: 3.4 ms instead of 2.3 ms).  The gaps stay zero in both buffers.
+
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        pad = lambda k: (k + self.ALIGN - 1) // self.ALIGN * self.ALIGN   # noqa: E731
+        n = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self._zeros = torch.zeros(max(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self._zeros = torch.zeros(max(pad(p.numel()) for p in self.params), dtype=torch.float32, device=dev)
         self._gviews = []
+        self._pads = []
         off = 0
         for p in self.params:
             k = p.numel()
@@ -47,7 +53,8 @@ class FlatParams:
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
             self._gviews.append(p.grad)
-            off += k
+            self._pads.append(pad(k) - k)
+            off += pad(k)
         self.numel = n
 
     def zero_grad(self):
@@ -64,7 +71,11 @@ class FlatParams:
     def collect(self):
         """after backward(): pack the per-parameter gradients into the flat bucket with ONE concatenation and make
         p.grad a view of it again (parameters the loss did not reach contribute zeros)"""
-        pieces = [(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()]) for p in self.params]
+        pieces = []
+        for p, gap in zip(self.params, self._pads):
+            pieces.append(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()])
+            if gap:
+                pieces.append(self._zeros[:gap])
         torch.cat(pieces, out=self.grad)
         for p, v in zip(self.params, self._gviews):
             p.grad = v

@@ -38,17 +38,34 @@ def test_tf_adam_one_and_two_steps_by_hand():
         lin.bias.fill_(-1.0)
     fp = TU.FlatParams(lin)
     opt = TU.TFAdam(fp)
-    assert fp.flat.numel() == 2 and lin.weight.data_ptr() == fp.flat.data_ptr()
+    # every parameter starts on a 16-byte boundary of the flat buffers (the gaps stay zero)
+    A = TU.FlatParams.ALIGN
+    assert fp.flat.numel() == 2 * A and lin.weight.data_ptr() == fp.flat.data_ptr()
+    assert lin.bias.data_ptr() == fp.flat.data_ptr() + 4 * A
+
+    class _View:            # the two scalars, wherever the flat layout puts them
+        def __init__(self, t):
+            self.t = t
+
+        def copy_(self, v):
+            self.t.zero_()
+            self.t[0], self.t[A] = v[0], v[1]
+
+    real_flat, real_grad = fp.flat, fp.grad
     g1 = torch.tensor([0.5, -0.25])
-    fp.grad.copy_(g1)
+    _View(fp.grad).copy_(g1)
     opt.step(0.1)
+    fp.flat = real_flat[[0, A]]          # compare the two live entries; the gaps must not have moved
+    assert real_flat[1:A].abs().max() == 0 and real_flat[A + 1:].abs().max() == 0
     m, v = 0.1 * g1, 0.001 * g1 * g1
     lr_t = 0.1 * math.sqrt(1 - 0.999) / (1 - 0.9)
     want = torch.tensor([2.0, -1.0]) - lr_t * m / (v.sqrt() + 1e-8)
     assert torch.allclose(fp.flat, want, atol=1e-7)
+    fp.flat = real_flat
     g2 = torch.tensor([-1.0, 0.125])
-    fp.grad.copy_(g2)
+    _View(fp.grad).copy_(g2)
     opt.step(0.1)
+    fp.flat = real_flat[[0, A]]
     m, v = 0.9 * m + 0.1 * g2, 0.999 * v + 0.001 * g2 * g2
     lr_t = 0.1 * math.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
     want = want - lr_t * m / (v.sqrt() + 1e-8)
@@ -62,7 +79,9 @@ def test_flat_params_gradients_accumulate_in_place():
     x = torch.randn(5, 3)
     net(x).sum().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
-    assert torch.equal(ref, fp.grad) and fp.grad.abs().sum() > 0
+    # the bucket holds every gradient at its 16-byte aligned offset and zeros in the gaps
+    assert all(p.grad.data_ptr() % 16 == fp.grad.data_ptr() % 16 for p in net.parameters())
+    assert torch.isclose(ref.abs().sum(), fp.grad.abs().sum()) and fp.grad.abs().sum() > 0
     fp.zero_grad()
     assert all(p.grad.abs().sum() == 0 for p in net.parameters())
 
@@ -134,11 +153,11 @@ def test_momentum_optimizer_matches_hand_computation():
     opt = TU.make_optimizer("momentum", fp, 0.9)
     p, acc = np.array([1.0, -2.0]), np.zeros(2)
     for g in ([0.5, 0.25], [-1.0, 2.0], [0.125, 0.0]):
-        fp.grad.copy_(torch.tensor(g))
+        lin.weight.grad.copy_(torch.tensor([g]))            # p.grad is a view of the flat gradient bucket
         opt.step(0.1)
         acc = 0.9 * acc + np.array(g)
         p = p - 0.1 * acc
-    assert np.allclose(fp.flat.numpy(), p, atol=1e-6)
+    assert np.allclose(lin.weight.detach().numpy().ravel(), p, atol=1e-6)
     assert isinstance(TU.make_optimizer("adam", fp), TU.TFAdam)
     with pytest.raises(ValueError):
         TU.make_optimizer("sgd", fp)
