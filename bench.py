@@ -248,10 +248,10 @@ def _measured_traffic(dom):
 
 
 def _ball_query_fractions(x, kernels):
-    """SA1 ball query of the SSG config on the bench's own clouds: pair tests actually executed, fp32-VALU fraction
-    and HBM fraction.  The kernel scans a query's dataset in slabs of 64 points and stops at the slab holding the
-    nsample-th hit, so executed pairs = 64 * slabs scanned (computed here from idx / pts_cnt, outside the timed
-    region); `pairs_nominal` = b*m*n is what a full scan would test."""
+    """SA1 ball query of the SSG config on the bench's own clouds: pair tests executed, fp32-VALU fraction and HBM
+    fraction.  The kernel keeps a cloud in registers and tests every query against all of it (one bit per hit, no
+    early exit -- csrc/grouping.hip), so executed pairs = b*m*n; it is bound by instruction issue (9 VALU lane-ops per
+    pair test at best), not by HBM: both fractions are reported, as SURVEY.md section 8d asks."""
     from scanobjectnn_amd.pointnet2 import tf_grouping, tf_sampling
     out = {}
     for d in kernels:
@@ -263,9 +263,7 @@ def _ball_query_fractions(x, kernels):
         with torch.no_grad():
             q = tf_sampling.gather_point(x, tf_sampling.farthest_point_sample(m, x))
             idx, cnt = tf_grouping.query_ball_point(float(r), int(s), x, q)
-            last = idx[:, :, s - 1].long()
-            slabs = torch.where(cnt >= s, last // 64 + 1, torch.full_like(last, (n + 63) // 64))
-            executed = int(slabs.sum().item()) * 64
+            executed = b * m * n
         t = d["avg_us"] * 1e-6
         out = {"shape": d["shape"], "avg_us": d["avg_us"], "pairs_nominal": b * m * n, "pairs_executed": executed,
                "pair_tests_per_s": executed / t,

@@ -22,15 +22,23 @@ OUT = os.path.join(ROOT, "gpurun_out")
 # (kernel-name fragment, total grid threads or None) -> bench.py key.  Template arguments:
 # gemm_ws_kernel<NT, AM, EM, KC, WAVES, EH, VAR>, wgrad_pc_kernel<TK, TN, AMODE, DMODE>
 KEYS = [
-    ("gemm_ws_kernel<4, 4, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128)"),
-    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 1024 * 512, "pcops_mlp_gemm_fwd_pool(2097152, 128, 256, 64)"),
+    # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
+    ("gemm_ws_kernel<4, 6, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
+    ("wgrad_pc_kernel<2, 4, 1, 6>", None, "pcops_mlp_wgrad(2097152, 128, 256, 'compacted')"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", 512 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 128, 'compacted')"),
+    ("gemm_ws_kernel<4, 2, 1, 64, 8, 2, 0>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128, 'compacted')"),
+    ("wgrad_pc_kernel<2, 2, 1, 7>", None, "pcops_mlp_wgrad(2097152, 128, 128, 'compacted')"),
+    ("bn_relu_maxpool_rows_kernel", None, "pcops_mlp_bn_relu_maxpool_rows(32768, 256, 'compacted')"),
+    ("sa_scatter_csr_kernel<32, false, 64>", None, "pcops_sa_scatter_bwd(256, 512, 128, 64, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
-    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", None, "pcops_mlp_gemm_fwd(2097152, 128, 128)"),
-    ("gemm_ws_kernel<4, 2, 1, 64, 8, 2, 0>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128)"),
-    ("wgrad_pc_kernel<2, 4, 1, 4>", 256 * 512, "pcops_mlp_wgrad(2097152, 128, 256)"),
     ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),
     ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
     ("gemm_ws_kernel<2, 2, 3, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad_xyz(4194304, 64, 64)"),
+    ("gemm_ws_kernel<2, 5, 0, 64, 8, 1, 0>", None, "pcops_mlp_gemm_fwd_xyz(4194304, 64, 64)"),
+    ("wgrad_pc_kernel<1, 1, 5, 2>", None, "pcops_mlp_wgrad_xyz(4194304, 64, 64)"),
+    ("qbp_kernel<1, 32>", 512 * 1024, "pcops_query_ball_point(256, 2048, 512, 0.2, 32)"),
+    ("fps_kernel<256, 8, true>", 256 * 256, "pcops_farthest_point_sample(256, 2048, 512)"),
 ]
 
 
@@ -38,7 +46,7 @@ def one_pass(counter):
     d = os.path.join(OUT, "pmc_%s" % counter)
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp",
                    env=dict(os.environ, TMPDIR="/tmp"))
     agg = collections.defaultdict(list)
@@ -55,7 +63,7 @@ def mfma_pass():
     d = os.path.join(OUT, "pmc_MFMA")
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "-d", d, "-o", "p", "--output-format", "csv",
-           "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+           "--", sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp",
                    env=dict(os.environ, TMPDIR="/tmp"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
