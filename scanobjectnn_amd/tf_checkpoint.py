@@ -16,8 +16,10 @@ tensorflow/core/lib/io/{table_builder,format,block_builder}.cc -- the LevelDB ta
       key ""  -> BundleHeaderProto {1: num_shards, 2: endianness, 3: VersionDef}
       key v   -> BundleEntryProto  {1: dtype, 2: TensorShapeProto, 3: shard_id, 4: offset, 5: size, 6: fixed32 masked crc32c}
   <prefix>.data-SSSSS-of-NNNNN   raw little-endian tensor bytes at [offset, offset+size)
-PARITY NOTE: no TensorFlow and no TensorFlow-written checkpoint exist in this environment; reader and writer are
-tested against each other and against the format rules above (tests/test_tf_checkpoint_cpu.py), not against a real file.
+PARITY NOTE: no TensorFlow and no TensorFlow-written checkpoint exist in this environment.  The writer is pinned by a
+hand-assembled byte image; the reader additionally by a bundle assembled in the test from the format description by an
+independent code path (bit-serial CRC, own varint / protobuf / block code, two data shards, multi-block index with
+prefix compression, reversed and unknown proto fields) -- tests/test_tf_checkpoint_cpu.py.  Not against a real file.
 """
 import re
 import struct
