@@ -158,15 +158,25 @@ struct TopK {
     }
 };
 
+// Candidates that beat a lane's current k-th distance are QUEUED in LDS (slot-major, conflict free) instead of being
+// inserted at once: the per-candidate work is then one compare (+ two LDS writes for the ~5 % that pass), and the
+// sorted insertion -- 4 VALU per list slot, the expensive part -- runs for whole batches when some lane's queue
+// is nearly full.  The queue keeps arrival (= ascending index) order and the insertion re-checks against the
+// up-to-date k-th value, so the result is that of inserting every candidate in order.
+constexpr int kKnnQD = 12;             // queue slots per lane; a flush is due when any lane holds more than QD - 4
+
 template <int CP, int KL>
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, const float *__restrict__ x,
                                                           int *__restrict__ nn_idx) {
     constexpr int CH = 128;            // candidate rows per LDS chunk
     constexpr int LD = CP + 1;         // odd row stride: lanes 0..31 read 32 rows at one column without conflicts
     constexpr int NKK = CP / 2;        // MFMAs per tile
+    constexpr int QD = kKnnQD;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cs = lds;                   // [CH][LD]
-    float *sc = cs + CH * LD;          // [CH]
+    float *sc = cs + CH * LD;          // [CH]   (16-byte aligned: CH * LD is a multiple of 4)
+    float *qd = sc + CH;               // [QD][256] queued distances
+    int *qj = reinterpret_cast<int *>(qd + QD * 256);   // [QD][256] and their indices
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
@@ -187,22 +197,63 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
 
     TopK<KL> top;
     top.init();
-    float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};   // parked candidates (arrival order) and their count
-    int bj[4] = {0, 0, 0, 0};
-    int nb = 0;
+    int nq = 0;                        // entries in this lane's queue
+    auto flush = [&]() {
+        const int mx = (int)wave_max_u32((unsigned)nq);
+        for (int u = 0; u < mx; ++u) {
+            const float d = u < nq ? qd[u * 256 + tid] : INFINITY;
+            const int j = qj[u * 256 + tid];
+            top.insert_ascending(d, j);
+        }
+        nq = 0;
+    };
 
+    // the candidate chunks are software pipelined: chunk i+1 travels global -> registers (16-byte loads when the rows
+    // are 16-byte multiples) while the MFMAs and the top-k bookkeeping of chunk i run; the registers go to LDS at the
+    // top of the next iteration.  (Loading a chunk right before it is needed left the matrix pipe idle 73 % of the time.)
+    constexpr int NQ4 = CH * (CP / 4);                    // float4 per chunk
+    constexpr int NV = (NQ4 + 255) / 256;                 // float4 per thread per chunk
+    const bool vec = (c == CP) && (CP % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
+    float4 pre[NV];
+    auto fetch = [&](int j0n) {
+        const int tnn = min(CH, n - j0n);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e4 = tid + 256 * u;                  // float4 index inside the chunk: row e4 / (CP/4)
+            const int r = e4 / (CP / 4), l = (e4 - r * (CP / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e4 < NQ4 && r < tnn) {
+                const float *src = xb + (size_t)(j0n + r) * c;
+                if (vec) {
+                    v = *reinterpret_cast<const float4 *>(src + l);
+                } else {
+                    v.x = l + 0 < c ? src[l + 0] : 0.f; v.y = l + 1 < c ? src[l + 1] : 0.f;
+                    v.z = l + 2 < c ? src[l + 2] : 0.f; v.w = l + 3 < c ? src[l + 3] : 0.f;
+                }
+            }
+            pre[u] = v;
+        }
+    };
+    if (n > 0) fetch(0);
     for (int j0 = 0; j0 < n; j0 += CH) {
         const int tn = min(CH, n - j0);
         __syncthreads();
-        for (int e = tid; e < CH * CP; e += 256) {
-            const int r = e / CP, l = e - r * CP;
-            cs[r * LD + l] = (r < tn && l < c) ? xb[(size_t)(j0 + r) * c + l] : 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e4 = tid + 256 * u;
+            const int r = e4 / (CP / 4), l = (e4 - r * (CP / 4)) * 4;
+            if (e4 < NQ4) {
+                float *dst = cs + r * LD + l;              // odd row stride: scalar stores
+                dst[0] = pre[u].x; dst[1] = pre[u].y; dst[2] = pre[u].z; dst[3] = pre[u].w;
+            }
         }
         __syncthreads();
+        if (j0 + CH < n) fetch(j0 + CH);                   // in flight during this chunk's tiles
         if (tid < CH) {
             float s = 0.f;
+#pragma unroll 16
             for (int l = 0; l < CP; ++l) s = fmaf(cs[tid * LD + l], cs[tid * LD + l], s);
-            sc[tid] = s;
+            sc[tid] = tid < tn ? s : INFINITY;             // rows beyond the cloud: distance +inf, never a neighbour
         }
         __syncthreads();
         for (int t = 0; t < (tn + 31) / 32; ++t) {
@@ -214,37 +265,26 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
             for (int kk = 0; kk < NKK; ++kk)
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * kk], bq[kk], acc, 0, 0, 0);
             // acc[v]: candidate row 32 t + (v&3) + 8 (v>>2) + 4 half, query li
-            // candidates that beat the lane's current k-th distance are parked in a 4-slot register buffer; the
-            // (expensive, wave-wide) sorted insertion runs only when SOME lane's buffer is full -- about 5x fewer
-            // insertion passes than inserting whenever any lane has a hit.  Arrival order is kept, and the
-            // insertion re-checks against the up-to-date k-th value, so the result is unchanged.
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = 32 * t + (v & 3) + 8 * (v >> 2) + 4 * half;
-                const int j = j0 + row;
-                float d = (sq + (-2.f * acc[v])) + sc[row];
-                if (!(j < n)) d = INFINITY;
-                const bool hit = d < top.v[KL - 1];
-                bd[3] = (hit && nb == 3) ? d : bd[3]; bj[3] = (hit && nb == 3) ? j : bj[3];
-                bd[2] = (hit && nb == 2) ? d : bd[2]; bj[2] = (hit && nb == 2) ? j : bj[2];
-                bd[1] = (hit && nb == 1) ? d : bd[1]; bj[1] = (hit && nb == 1) ? j : bj[1];
-                bd[0] = (hit && nb == 0) ? d : bd[0]; bj[0] = (hit && nb == 0) ? j : bj[0];
-                nb += hit ? 1 : 0;
-                if (__any(nb == 4)) {
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int row0 = 32 * t + 8 * g4 + 4 * half;
+                const float4 s4 = *reinterpret_cast<const float4 *>(sc + row0);
+                const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                const float kth = top.v[KL - 1];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        top.insert_ascending(u < nb ? bd[u] : INFINITY, bj[u]);
-                        bd[u] = INFINITY;
+                for (int e = 0; e < 4; ++e) {
+                    const float d = (sq + (-2.f * acc[4 * g4 + e])) + sv[e];
+                    if (d < kth) {
+                        qd[nq * 256 + tid] = d;
+                        qj[nq * 256 + tid] = j0 + row0 + e;
+                        ++nq;
                     }
-                    nb = 0;
                 }
+                if (__any(nq > QD - 4)) flush();
             }
         }
     }
-    if (__any(nb > 0)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) top.insert_ascending(u < nb ? bd[u] : INFINITY, bj[u]);
-    }
+    if (__any(nq > 0)) flush();
 
     // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
 #pragma unroll
@@ -263,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
 
 template <int CP, int KL>
 int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, hipStream_t st) {
-    const size_t lds = (size_t)(128 * (CP + 1) + 128) * sizeof(float);
+    const size_t lds = (size_t)(128 * (CP + 1) + 128 + 2 * kKnnQD * 256) * sizeof(float);
     auto kern = knn_mfma_kernel<CP, KL>;
     if (lds > 48 * 1024) {
         static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
