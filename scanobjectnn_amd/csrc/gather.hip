@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_q_kernel(int B, int n, int 
                                                               const float *__restrict__ tv,
                                                               const int2 *__restrict__ order,
                                                               float *__restrict__ dQ) {
-    constexpr int RW = 64 / LPR, U = 4, CH = 64;
+    constexpr int RW = 64 / LPR, U = 8, CH = 64;       // U rows in flight per lane set (latency bound: L2 gathers)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rsub = lane / LPR, quad = lane % LPR;
     const int mS = m * S;
@@ -1357,10 +1357,10 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
                        arg, idx, scale, shift, p, q, t, dCtr, dQ);
     const int lpr = c <= 256 ? c / 4 : 64;
     switch (lpr) {
-        case 8: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<8>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
-        case 16: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<16>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
-        case 32: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<32>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
-        default: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<64>, dim3(kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        case 8: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<8>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        case 16: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<16>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        case 32: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<32>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
+        default: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<64>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
     }
     return pcops_launch_status();
 }
