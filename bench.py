@@ -113,6 +113,9 @@ def _algo(name, a):
     if name == "pcops_mlp_bn_relu_maxpool_rows":      # (rows computed, C): the max over compacted groups re-reads Y once
         R, C = a[:2]
         return 4 * R * C, 0, ""
+    if name == "pcops_mlp_pool_combine_rows":         # (rows computed, C): one partial per 16-row block, 5 bytes each
+        R, C = a[:2]
+        return 5 * (R // 16) * C, 0, ""
     if name == "pcops_mlp_bn_relu_apply":
         R, C = a[:2]
         return 8 * R * C, 0, ""
@@ -147,7 +150,7 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
            "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1,
            "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2,
-           "pcops_mlp_bn_relu_maxpool_rows": 2}
+           "pcops_mlp_bn_relu_maxpool_rows": 2, "pcops_mlp_pool_combine_rows": 2}
 
 
 class KernelTimer:
@@ -165,11 +168,21 @@ class KernelTimer:
         return rows.num_rows()
 
     def __call__(self, name, phase, args):
-        if name == "pcops_mlp_bn_relu_maxpool_rows":
-            ref, args = args[5], args[:2]
+        if name in ("pcops_mlp_bn_relu_maxpool_rows", "pcops_mlp_pool_combine_rows"):
+            # (G, C, ...) with the pcops_rows_t* in the middle: keep the name, shape = (G, C)
+            ref = args[5] if name == "pcops_mlp_bn_relu_maxpool_rows" else args[7]
+            args = args[:2]
             owner = _lib.Rows.by_struct.get(id(ref._obj))
-            self._rows[id(owner)] = owner
-            args = args + (("rows", id(owner)),)
+            if owner is not None:
+                self._rows[id(owner)] = owner
+                args = args + (("rows", id(owner)),)
+        elif name == "pcops_mlp_gemm_fwd_pool_rows":
+            # per-block pooled epilogue on compacted rows: accounted like the plain forward GEMM (+ the block partials)
+            ref, args, name = args[-1], args[:3], "pcops_mlp_gemm_fwd"
+            owner = _lib.Rows.by_struct.get(id(ref._obj))
+            if owner is not None:
+                self._rows[id(owner)] = owner
+                args = args + ("pool", ("rows", id(owner)))
         elif name.endswith("_rows"):
             # compacted-row entry points (pcops.h): same argument list + a pcops_rows_t*; NULL = the plain entry point
             ref, args, name = args[-1], args[:-1], name[:-5]

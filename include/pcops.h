@@ -358,6 +358,18 @@ int pcops_mlp_wgrad_xyz_rows(long long M, int K, int N, const float *off4, const
                              const float *t, const float *gpool, const unsigned char *argmax, int S,
                              const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                              const pcops_rows_t *rows, pcops_stream_t stream);
+/* last layer of a max-pooled stack over compacted rows, pooling fused into the epilogue: ypart / ppart
+ * [pcops_rows_max_blocks][N] receive, per 16-row block, the selected raw value (max for gamma >= 0, min otherwise)
+ * and its row-in-group; pcops_mlp_pool_combine_rows picks per group -> out = relu(scale*ysel + shift), argmax, ysel */
+int pcops_mlp_gemm_fwd_pool_rows_supported(int M, int K, int N);
+int pcops_mlp_gemm_fwd_pool_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                                 const float *pro_shift, const float *W, const float *bias, const float *gamma,
+                                 float *Y, float *stats_partial, float *ypart, unsigned char *ppart,
+                                 const pcops_rows_t *rows, pcops_stream_t stream);
+int pcops_mlp_pool_combine_rows(long long G, int C, const float *ypart, const unsigned char *ppart,
+                                const float *gamma, const float *scale, const float *shift,
+                                const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,
+                                pcops_stream_t stream);
 /* out[g] = max over the rows of group g of relu(scale*Y + shift); argmax = row-in-group of the first maximiser */
 int pcops_mlp_bn_relu_maxpool_rows(long long G, int C, const float *Y, const float *scale, const float *shift,
                                    const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_relu_maxpool_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_pool_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_combine_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd_rows": ([_I, _I, _I, _I, _I] + [_P] * 23, True),
 }
@@ -83,6 +85,7 @@ PLAIN = {
     "pcops_edge_pool_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
+    "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),
 }
 
 

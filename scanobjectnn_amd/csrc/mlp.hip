@@ -652,6 +652,30 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     for (int h = 0; h < EH; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
+    // combine the 64/O4 lanes that own a column quad (larger key, then lower row) and write the selected raw value
+    // and its row-in-group for output slot `slot`; resets the running extremum
+    auto pool_flush = [&](int h, long long slot, bool wr, float4 em, int ocq) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int off = 32; off >= O4; off >>= 1) {
+                const float ov = __shfl_xor(pmx[h][e], off, 64);
+                const int oa = __shfl_xor(pax[h][e], off, 64);
+                if (ov > pmx[h][e] || (ov == pmx[h][e] && oa < pax[h][e])) { pmx[h][e] = ov; pax[h][e] = oa; }
+            }
+        }
+        if (lane < O4 && wr) {
+            const long long o4 = slot * N + n0 + ocq;
+            *reinterpret_cast<float4 *>(a.ysel + o4) =
+                make_float4(pmx[h][0] * em.x, pmx[h][1] * em.y, pmx[h][2] * em.z, pmx[h][3] * em.w);
+            uchar4 qa;
+            qa.x = (unsigned char)pax[h][0]; qa.y = (unsigned char)pax[h][1];
+            qa.z = (unsigned char)pax[h][2]; qa.w = (unsigned char)pax[h][3];
+            *reinterpret_cast<uchar4 *>(a.psel + o4) = qa;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
+    };
     long long st = (long long)rowgrp * WAVES + wave;
     int sub = 0;
     if (st < nsuper) issue(st * SUB, 0);
@@ -761,13 +785,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             const float4 eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
             const float4 em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
             float ew[2] = {1.f, 1.f};                        // compacted rows: statistics weight of rows 0 / 16
+            int es0[2] = {0, 0};                             //                 row-in-group of rows 0 / 16
             if (EM == E_FWD && compact) {
                 const int nblk = (M + kBlk - 1) / kBlk;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {
                     long long bi = tile * 2 + hb;
                     bi = bi < nblk ? bi : nblk - 1;
-                    ew[hb] = a.blocks[bi].w;
+                    const RowBlock rb = a.blocks[bi];
+                    ew[hb] = rb.w;
+                    es0[hb] = rb.s0;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -798,7 +825,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
                         }
                         if (POOL) {   // rows arrive in ascending order: a strict comparison keeps the first extremum
-                            const int sr = sub * 32 + r;
+                            const int sr = compact ? es0[(O4 == 16) ? j / 4 : 0] + (r & (kBlk - 1)) : sub * 32 + r;
                             const float ov[4] = {o.x * em.x, o.y * em.y, o.z * em.z, o.w * em.w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
@@ -827,31 +854,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 }
                 if (EM != E_MASKX || a.Y)
                     buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
+                if (POOL && compact && O4 == 16 && (j & 3) == 3) {
+                    // compacted rows: a 16-row block (rows 4 (j-3) .. 4 j + 3 of the tile) lies inside ONE group -- its
+                    // extremum goes out as a partial (block index), pcops_mlp_pool_combine_rows picks per group
+                    const long long blk = tile * 2 + j / 4;
+                    pool_flush(h, blk, blk * kBlk < M && ocin, em, ocq);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (POOL && sub == SUB - 1) {
-                // group complete: combine the 64/O4 lanes that own this column quad (larger key, then lower row)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int off = 32; off >= O4; off >>= 1) {
-                        const float ov = __shfl_xor(pmx[h][e], off, 64);
-                        const int oa = __shfl_xor(pax[h][e], off, 64);
-                        if (ov > pmx[h][e] || (ov == pmx[h][e] && oa < pax[h][e])) { pmx[h][e] = ov; pax[h][e] = oa; }
-                    }
-                }
-                if (lane < O4 && ocin) {
-                    const long long o4 = st * N + n0 + ocq;
-                    *reinterpret_cast<float4 *>(a.ysel + o4) =
-                        make_float4(pmx[h][0] * em.x, pmx[h][1] * em.y, pmx[h][2] * em.z, pmx[h][3] * em.w);
-                    uchar4 qa;
-                    qa.x = (unsigned char)pax[h][0]; qa.y = (unsigned char)pax[h][1];
-                    qa.z = (unsigned char)pax[h][2]; qa.w = (unsigned char)pax[h][3];
-                    *reinterpret_cast<uchar4 *>(a.psel + o4) = qa;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
-            }
+            if (POOL && !compact && sub == SUB - 1) pool_flush(h, st, ocin, em, ocq);   // group complete
         }
         }
         st = nst;
@@ -1218,6 +1229,34 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(long long G, 
             *reinterpret_cast<uchar4 *>(argmax + g * C + c) = q;
         }
         if (ysel) *reinterpret_cast<float4 *>(ysel + g * C + c) = make_float4(ys[0], ys[1], ys[2], ys[3]);
+    }
+}
+
+// compacted rows: per group the best of its blocks' partial extrema (written by the fused epilogue per 16-row block:
+// the selected raw value and its row-in-group); sign(gamma) decides between max and min, the first block wins ties
+// (blocks are in row order) -> ysel, arg-max, out = relu(scale * ysel + shift)
+__global__ __launch_bounds__(256) void pool_combine_rows_kernel(long long total, int C, const float *__restrict__ ypart,
+                                                                const unsigned char *__restrict__ ppart,
+                                                                const float *__restrict__ gamma,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift,
+                                                                const int *__restrict__ bstart, float *__restrict__ out,
+                                                                unsigned char *__restrict__ argmax,
+                                                                float *__restrict__ ysel) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long g = e / C;
+        const int c = (int)(e - g * C);
+        const float sg = gamma[c] < 0.f ? -1.f : 1.f;
+        const int b0 = bstart[g], b1 = bstart[g + 1];
+        float best = ypart[(long long)b0 * C + c];
+        int arg = ppart[(long long)b0 * C + c];
+        for (int bk = b0 + 1; bk < b1; ++bk) {
+            const float y = ypart[(long long)bk * C + c];
+            if (y * sg > best * sg) { best = y; arg = ppart[(long long)bk * C + c]; }
+        }
+        out[e] = fmaxf(fmaf(best, scale[c], shift[c]), 0.f);
+        if (argmax) argmax[e] = (unsigned char)arg;
+        if (ysel) ysel[e] = best;
     }
 }
 
@@ -2292,6 +2331,50 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
     WsPlan pl;
     if (!ws_plan(a, A_BNRELU, &pl)) return PCOPS_ERR_UNSUPPORTED;   // pointer alignment
     return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
+}
+
+int pcops_mlp_gemm_fwd_pool_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
+                                 const float *pro_shift, const float *W, const float *bias, const float *gamma,
+                                 float *Y, float *stats_partial, float *ypart, unsigned char *ppart,
+                                 const pcops_rows_t *rows, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(pro_scale);
+    PCOPS_REQUIRE_PTR(pro_shift); PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(ypart); PCOPS_REQUIRE_PTR(ppart);
+    PCOPS_REQUIRE_PTR(rows);
+    if (ldx != K || (reinterpret_cast<uintptr_t>(ypart) & 15) || (reinterpret_cast<uintptr_t>(ppart) & 3))
+        return PCOPS_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.pool_sub = 1; a.pgamma = gamma; a.ysel = ypart; a.psel = ppart;       // one partial per 16-row block
+    PCOPS_ROWS(a, rows);
+    WsPlan pl;
+    if (!(ws_enabled() && ws_plan(a, A_BNRELU, &pl))) return PCOPS_ERR_UNSUPPORTED;
+    return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
+}
+
+int pcops_mlp_gemm_fwd_pool_rows_supported(int M, int K, int N) {
+    GemmArgs a = {};
+    a.M = M; a.K = K; a.N = N; a.ldx = K; a.ldy = N; a.pool_sub = 1;
+    WsPlan pl;
+    return ws_enabled() && ws_plan(a, A_BNRELU, &pl) ? 1 : 0;
+}
+
+int pcops_mlp_pool_combine_rows(long long G, int C, const float *ypart, const unsigned char *ppart,
+                                const float *gamma, const float *scale, const float *shift,
+                                const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,
+                                pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && C >= 1);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(ypart); PCOPS_REQUIRE_PTR(ppart); PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(scale);
+    PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out); PCOPS_REQUIRE_PTR(rows);
+    const int rrc = rows_ok(rows);
+    if (rrc) return rrc;
+    const long long total = G * C;
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(pool_combine_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, C, ypart, ppart,
+                       gamma, scale, shift, rows->block_start, out, argmax, ysel);
+    return pcops_launch_status();
 }
 
 int pcops_mlp_pool_select(long long G, int C, const float *ysel, const float *scale, const float *shift,

@@ -84,7 +84,7 @@ class FusedMLPStack(torch.autograd.Function):
         src, ld, sc_prev, sh_prev, K = a0, K0, None, None, K0
         vecs = _VecArena([l[2].shape[0] for l in layers], 4, dev)
         ws = _workspace(max(l[2].shape[0] for l in layers), dev) if training else None
-        pooled_raw = None
+        pooled_raw = pooled_parts = None
         # a first layer with only the coordinate term is ARITHMETIC in three offsets per row: it is never stored, the
         # next layer and the whole backward rebuild it from off4 (16 bytes per row instead of 4 C1)
         # (with SyncBN, or a backward through eval-mode BN, the layer is materialised: its gradient shortcut assumes
@@ -119,8 +119,17 @@ class FusedMLPStack(torch.autograd.Function):
                 if li == 1 and virt:
                     _lib.call("pcops_mlp_gemm_fwd_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(), sc_prev.data_ptr(),
                               sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
+                elif (rows is not None and pool and li == L - 1 and sc_prev is not None and ld == K and FUSE_POOL_ROWS
+                        and lib.pcops_mlp_gemm_fwd_pool_rows_supported(R, K, N)):
+                    # compacted rows: the epilogue emits the extremum of every 16-row block (a block lies inside one
+                    # group), a small pass picks per group afterwards
+                    nbk = rows.blocks.shape[0]
+                    pooled_parts = (_f32((nbk, N), dev), torch.empty((nbk, N), dtype=torch.uint8, device=dev))
+                    _lib.call("pcops_mlp_gemm_fwd_pool_rows", R, K, N, src.data_ptr(), ld, sc_prev.data_ptr(),
+                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), Y.data_ptr(),
+                              _p(part), pooled_parts[0].data_ptr(), pooled_parts[1].data_ptr(), rref)
                 elif rows is not None:
-                    # compacted rows: the max over the (variable-length) groups is its own pass below
+                    # compacted rows without the fused epilogue: the max over the groups is its own pass below
                     _lib.call("pcops_mlp_gemm_fwd_rows", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
                               W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
                 elif (pool and li == L - 1 and sc_prev is not None and ld == K
@@ -163,7 +172,13 @@ class FusedMLPStack(torch.autograd.Function):
         if pool:
             G = R // S
             out = _f32((G, C), dev)
-            if pooled_raw is not None:
+            if pooled_parts is not None:
+                argmax = torch.empty((G, C), dtype=torch.uint8, device=dev)
+                ysel = _f32((G, C), dev)
+                _lib.call("pcops_mlp_pool_combine_rows", G, C, pooled_parts[0].data_ptr(), pooled_parts[1].data_ptr(),
+                          layers[-1][2].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(), rref,
+                          out.data_ptr(), argmax.data_ptr(), ysel.data_ptr())
+            elif pooled_raw is not None:
                 ysel, argmax = pooled_raw
                 _lib.call("pcops_mlp_pool_select", G, C, ysel.data_ptr(), scales[-1].data_ptr(),
                           shifts[-1].data_ptr(), out.data_ptr())
@@ -498,6 +513,7 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
                                *_flat(layer_tensors, False))
 
 
+FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 
 
