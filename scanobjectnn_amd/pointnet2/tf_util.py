@@ -86,7 +86,8 @@ def _dense(x2d, kernel2d, biases):
     with the output padded to 4 columns."""
     rows, k = x2d.shape
     n = kernel2d.shape[1]
-    if x2d.is_cuda and rows >= 32768 and k % 8 == 0 and n <= 64:
+    small_batch_wide = FC_PCOPS and rows <= 4096 and k >= 256 and k % 8 == 0      # the classifier head (B x 1024 -> 512 ...)
+    if x2d.is_cuda and k % 8 == 0 and ((rows >= 32768 and n <= 64) or small_batch_wide):
         pad = (-n) % 4
         w = F.pad(kernel2d, (0, pad)) if pad else kernel2d
         b = F.pad(biases, (0, pad)) if pad else biases
@@ -152,6 +153,10 @@ def _stack_variables(cin, widths, scope_fmt, stddev, weight_decay, use_xavier, m
 
 
 FUSED_MLP = os.environ.get("PCOPS_FUSED_MLP", "1") != "0"
+# fully connected head through the libpcops GEMMs as well (a few hundred rows into 512 / 256 / 15 columns).  OFF by
+# default: measured on the SSG step (B = 256) the library GEMMs win -- 13.5 ms/step against 14.0 with this on (the
+# libpcops kernels are built for millions of rows; a 256-row problem leaves most of the chip idle in either case)
+FC_PCOPS = os.environ.get("PCOPS_FC", "0") != "0"
 
 
 def conv2d_stack(inputs, widths, scope_fmt, is_training, bn_decay, pool_max=False, use_xavier=True,
