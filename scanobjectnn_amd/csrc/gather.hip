@@ -15,6 +15,8 @@
 //   sa_gather_fwd : Y = Q[idx] + Ctr, plus the per-channel (sum, sum of squares) partials batch-norm needs
 //   sa_scatter_bwd: dY = p.G + q.Y + t rebuilt on the fly (same contract as mlp.hip), dQ += scatter(dY)
 //                   (fp32 atomics, L2 resident), dCtr[b, j, :] = sum_s dY (in-block, no atomics)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -1001,6 +1003,129 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_q_kernel(int B, int n, int 
     }
 }
 
+// ---- EdgeConv backward, second formulation (no global atomics) -----------------------------------------------------
+// dQ[b,i,:] = sum over the rows (j,s) with idx[j,s] = i of dY[j,s,:],  dY = q (Q[i] + Ctr[j]) + t  everywhere, plus
+// a[j,c] = p[c] relu'(.) gpool[j,c] at the ONE row s = arg[j,c] of every (group, channel).
+//   edge_pool_bwd_sparse_kernel: the a-term.  One workgroup = (cloud, slice of 16 channels); the slice of dQ
+//     (n x 16 floats, 128 KB at n = 2048) lives in LDS, the (group, channel) values are added there with LDS atomics
+//     -- G x C of them, 20x fewer than the dense term, so their modest rate does not matter -- and the slice leaves
+//     with plain coalesced stores: dQ needs no memset and no global atomic.  dCtr is written on the way.
+//   edge_pool_bwd_dense_kernel: the dense term.  OWNER computes: a lane set per source point walks the point's list of
+//     the inverse index (start[i] .. start[i+1]) and adds  q (cnt Q[i] + sum Ctr[j]) + cnt t  to dQ[b,i,:] with a
+//     plain read-modify-write (it is the only writer of that row after the sparse kernel finished).
+constexpr int kEdgeSlice = 16;
+
+__global__ __launch_bounds__(1024) void edge_pool_bwd_sparse_kernel(int n, int m, int S, int C,
+                                                                    const float *__restrict__ gpool,
+                                                                    const float *__restrict__ ysel,
+                                                                    const float *__restrict__ SQ,
+                                                                    const float *__restrict__ Ctr,
+                                                                    const unsigned char *__restrict__ arg,
+                                                                    const int *__restrict__ idx,
+                                                                    const float *__restrict__ scale,
+                                                                    const float *__restrict__ shift,
+                                                                    const float *__restrict__ p,
+                                                                    const float *__restrict__ q,
+                                                                    const float *__restrict__ t,
+                                                                    float *__restrict__ dCtr, float *__restrict__ dQ) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];          // [n][kEdgeSlice]
+    constexpr int NT = 1024, GL = NT / kEdgeSlice, U = 4;                // 64 groups per pass, 4 passes in flight
+    const int nsl = C / kEdgeSlice;
+    const int b = blockIdx.x / nsl, c0 = (blockIdx.x % nsl) * kEdgeSlice;
+    const int tid = threadIdx.x, cl = tid % kEdgeSlice, gl = tid / kEdgeSlice;
+    for (int e = tid; e < n * kEdgeSlice; e += NT) acc[e] = 0.f;
+    __syncthreads();
+    const int c = c0 + cl;
+    const float sc = scale[c], sh = shift[c], pc = p[c], qc = q[c], tc = t[c];
+    const float kf = (float)S;
+    for (int j0 = gl; j0 < m; j0 += GL * U) {
+        // all loads of U groups are requested before the first is used (this loop is nothing but load latency)
+        float ys[U], gp[U], ce[U], sq[U];
+        int ar[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL < m ? j0 + u * GL : j0;
+            const long long e = ((long long)b * m + j) * C + c;
+            ys[u] = ysel[e]; gp[u] = gpool[e]; ce[u] = Ctr[e]; sq[u] = SQ[e]; ar[u] = arg[e];
+        }
+        int di[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL < m ? j0 + u * GL : j0;
+            di[u] = idx[((long long)b * m + j) * S + ar[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL;
+            if (j >= m) continue;
+            const long long e = ((long long)b * m + j) * C + c;
+            const float a = fmaf(ys[u], sc, sh) > 0.f ? pc * gp[u] : 0.f;
+            dCtr[e] = fmaf(qc, fmaf(kf, ce[u], sq[u]), fmaf(kf, tc, a));
+            if (a != 0.f) atomicAdd(&acc[di[u] * kEdgeSlice + cl], a);
+        }
+    }
+    __syncthreads();
+    float *dst = dQ + (long long)b * n * C + c0;
+    for (int e = tid; e < n * (kEdgeSlice / 4); e += NT) {
+        const int i = e / (kEdgeSlice / 4), quad = (e % (kEdgeSlice / 4)) * 4;
+        *reinterpret_cast<float4 *>(dst + (long long)i * C + quad) = *reinterpret_cast<const float4 *>(&acc[i * kEdgeSlice + quad]);
+    }
+}
+
+template <int LPR>     // lanes per point: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
+__global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, int m, int S, int C,
+                                                                  const float *__restrict__ Q,
+                                                                  const float *__restrict__ Ctr,
+                                                                  const float *__restrict__ qv,
+                                                                  const float *__restrict__ tv,
+                                                                  const int2 *__restrict__ order,
+                                                                  const int *__restrict__ start,
+                                                                  float *__restrict__ dQ) {
+    constexpr int PW = 64 / LPR, U = 4;          // points per wave, list entries in flight per point
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int psub = lane / LPR, quad = lane % LPR;
+    const long long npts = (long long)B * n;
+    const long long pstride = (long long)gridDim.x * 4 * PW;
+    const int mS = m * S;
+    for (int cb = 0; cb < C; cb += 4 * LPR) {
+        const int c0 = cb + quad * 4;
+        const float4 cq = *reinterpret_cast<const float4 *>(qv + c0);
+        const float4 ct = *reinterpret_cast<const float4 *>(tv + c0);
+        for (long long pt0 = ((long long)blockIdx.x * 4 + wave) * PW; pt0 < npts; pt0 += pstride) {
+            const long long pt = pt0 + psub;
+            const bool pin = pt < npts;
+            const int b = (int)((pin ? pt : 0) / n), i = (int)((pin ? pt : 0) - (long long)b * n);
+            const int *sb = start + (long long)b * (n + 1);
+            const int k0 = pin ? sb[i] : 0, k1 = pin ? sb[i + 1] : 0;
+            const int2 *ob = order + (long long)b * mS;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = k0; k < k1; k += U) {
+                float4 cc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u < k1 ? k + u : k0;
+                    const int j = (int)((unsigned)ob[kk].x / (unsigned)S);
+                    cc[u] = *reinterpret_cast<const float4 *>(Ctr + ((long long)b * m + j) * C + c0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (k + u < k1) { acc[0] += cc[u].x; acc[1] += cc[u].y; acc[2] += cc[u].z; acc[3] += cc[u].w; }
+            }
+            if (pin && k1 > k0) {
+                const float kf = (float)(k1 - k0);
+                const float4 qi = *reinterpret_cast<const float4 *>(Q + pt * C + c0);
+                float4 *dst = reinterpret_cast<float4 *>(dQ + pt * C + c0);
+                float4 d = *dst;
+                d.x += fmaf(cq.x, fmaf(kf, qi.x, acc[0]), kf * ct.x);
+                d.y += fmaf(cq.y, fmaf(kf, qi.y, acc[1]), kf * ct.y);
+                d.z += fmaf(cq.z, fmaf(kf, qi.z, acc[2]), kf * ct.z);
+                d.w += fmaf(cq.w, fmaf(kf, qi.w, acc[3]), kf * ct.w);
+                *dst = d;
+            }
+        }
+    }
+}
+
 // out[L] = sum_p part[p][L] in double (deterministic)
 __global__ __launch_bounds__(256) void sum_rows_kernel(int P, int L, const float *__restrict__ part,
                                                        float *__restrict__ out) {
@@ -1337,8 +1462,11 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     PCOPS_REQUIRE_SHAPE((c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384);
     PCOPS_REQUIRE_PTR(dQ);
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
     const long long G = (long long)b * m;
+    static const bool owner = [] { const char *e = getenv("PCOPS_EDGE_BWD_OWNER"); return !(e && e[0] == '0'); }();
+    const size_t slice_lds = (size_t)n * kEdgeSlice * sizeof(float);
+    const bool use_owner = owner && G > 0 && c % kEdgeSlice == 0 && slice_lds <= 160 * 1024;
+    if (!use_owner && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
     if (G == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
@@ -1351,11 +1479,28 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
         return PCOPS_ERR_LAUNCH;
     hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start, m, s,
                        (const RowBlock *)nullptr, (const int *)nullptr);
+    const int lpr = c <= 256 ? c / 4 : 64;
+    if (use_owner) {
+        // no global atomics: the sparse arg-row term through an LDS-resident slice (this also initialises dQ, no
+        // memset), then the dense term by the owner of every source point
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(edge_pool_bwd_sparse_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(edge_pool_bwd_sparse_kernel, dim3(b * (c / kEdgeSlice)), dim3(1024), slice_lds, st, n, m, s, c,
+                           gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ);
+        const unsigned dgrid = 2048;
+        switch (lpr) {
+            case 8: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<8>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
+            case 16: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<16>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
+            case 32: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<32>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
+            default: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<64>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
+        }
+        return pcops_launch_status();
+    }
     const long long total = G * c;
     const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
     hipLaunchKernelGGL(edge_pool_bwd_ctr_kernel, dim3(grid), dim3(256), 0, st, total, n, m, s, c, gpool, ysel, SQ, Ctr,
                        arg, idx, scale, shift, p, q, t, dCtr, dQ);
-    const int lpr = c <= 256 ? c / 4 : 64;
     switch (lpr) {
         case 8: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<8>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
         case 16: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<16>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
