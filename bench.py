@@ -420,6 +420,8 @@ def main():
     ap.add_argument("--augment", action="store_true",
                     help="put the device-side rotate + jitter of the input pipeline (provider.py) inside the timed step")
     ap.add_argument("--sync_bn", action="store_true", help="all-reduce the BN batch statistics over the ranks")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-reproducible backward passes (pcops_set_deterministic); reported in config, not the metric run")
     args = ap.parse_args()
 
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
@@ -441,6 +443,9 @@ def main():
     B = args.batch or cfg_batch
     N = args.num_point or cfg_n
     D.SYNC_BN = bool(args.sync_bn) and world > 1
+    if args.deterministic:
+        from scanobjectnn_amd import _lib as _pl
+        _pl.set_deterministic(True)
 
     def make_inputs(kind):
         xx = torch.from_numpy(synth_clouds(B, N, seed=1234 + rank, kind=kind)).to(dev)
@@ -591,7 +596,7 @@ def main():
                                "train step = %sfwd+bwd+allreduce+Adam"
                                % (args.model, args.kind, N, B, "rotate+jitter+" if args.augment else ""),
                    "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world,
-                   "sync_bn": bool(D.SYNC_BN)},
+                   "sync_bn": bool(D.SYNC_BN), "deterministic": bool(args.deterministic)},
         "rccl_ranks": rccl_ranks,
         "per_rank_clouds_per_s": per_rank,
         "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,

@@ -114,6 +114,29 @@ int pcops_three_interpolate_grad(int b, int n, int c, int m, const float *grad_o
                                  const int *idx, const float *weight,
                                  float *grad_points, pcops_stream_t stream);
 
+/* ------------------------------------------------------ deterministic backward passes
+ * SURVEY section 5 / reference hazard: groupPointGrad, scatteraddpoint and threeinterpolate_grad add with float
+ * atomics (tf_grouping_g.cu:61-78, tf_sampling_g.cu:183-192), so two runs of the reference differ in the last bits.
+ * pcops_set_deterministic(1) (or PCOPS_DETERMINISTIC=1 in the environment) makes every backward pass of this library
+ * bit-reproducible: scatter-adds are taken by ONE owner per destination point that walks the point's list of source
+ * rows in ascending row order.  Entry points that only exist in an atomic form (the four *_grad launchers above and
+ * below, the pooled / dCtr forms of pcops_sa_scatter_bwd) then return PCOPS_ERR_UNSUPPORTED instead of silently adding
+ * in arrival order; pcops_scatter_rows_sorted is their ordered replacement. */
+void pcops_set_deterministic(int on);
+int pcops_get_deterministic(void);
+
+/* out[b][d][0..c) (+)= sum over the rows e of cloud b with idx[b][e] == d, in ASCENDING e, of
+ *                        w[b][e] * src[b][e / div][0..c)         (w == NULL: weight 1; accumulate != 0: "+=")
+ * idx (b, rows) values in [0, ndst), src (b, rows / div, ld_src), out (b, ndst, c).  One call covers
+ *   groupPointGrad      rows = m*nsample, ndst = n, div = 1          (tf_grouping.cpp:173)
+ *   scatteraddpoint     rows = m, ndst = n, c = 3, div = 1           (tf_sampling.cpp:150)
+ *   threeinterpolate_grad  rows = 3 n, ndst = m, div = 3, w = weight (tf_interpolate.cpp:131-153)
+ *   the neighbour term of pcops_edge_feature_grad  rows = n*k, ndst = n, src = grad_out + c, ld_src = 2 c
+ * workspace: pcops_scatter_rows_workspace_bytes(b, rows, ndst) bytes, 8-byte aligned.  ndst <= 19 000. */
+unsigned long long pcops_scatter_rows_workspace_bytes(int b, int rows, int ndst);
+int pcops_scatter_rows_sorted(int b, int rows, int ndst, int c, int div, int ld_src, const int *idx, const float *w,
+                              const float *src, float *out, int accumulate, void *workspace, pcops_stream_t stream);
+
 /* ------------------------------------------------------------- DGCNN kNN graph */
 /* The reference has no native code here (dgcnn/utils/tf_util.py:638-706 is
  * matmul + top_k + gather in TF-Python); these are the native units a TF-style
@@ -134,6 +157,10 @@ int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn
 /* gradient of the above w.r.t. x: grad_out (b,n,k,2c) -> grad_x (b,n,c) */
 int pcops_edge_feature_grad(int b, int n, int c, int k, const float *grad_out,
                             const int *nn_idx, float *grad_x, pcops_stream_t stream);
+/* the x_i half of the above only: grad_x[b,i,:] = sum_s (ga - gb)[b,i,s,:] with plain stores (deterministic mode: the
+ * neighbour half is pcops_scatter_rows_sorted with accumulate = 1) */
+int pcops_edge_feature_grad_central(int b, int n, int c, int k, const float *grad_out, float *grad_x,
+                                    pcops_stream_t stream);
 
 /* ------------------------------------------------- shared per-point MLP (1x1 conv + BN + ReLU [+ max-pool])
  * The reference has no native code for this stage: it is a chain of TensorFlow ops per layer

@@ -68,6 +68,8 @@ SIGNATURES = {
     "pcops_mlp_pool_combine_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd_rows": ([_I, _I, _I, _I, _I] + [_P] * 23, True),
+    "pcops_scatter_rows_sorted": ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], True),
+    "pcops_edge_feature_grad_central": ([_I, _I, _I, _I, _P, _P], True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
@@ -86,6 +88,9 @@ PLAIN = {
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
     "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),
+    "pcops_scatter_rows_workspace_bytes": ([_I, _I, _I], _U64),
+    "pcops_set_deterministic": ([_I], None),
+    "pcops_get_deterministic": ([], _I),
 }
 
 
@@ -171,6 +176,32 @@ def check(t, dtype, name, ndim=None):
     if ndim is not None and t.dim() != ndim:
         raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
     return t.contiguous()
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible backward passes (pcops.h "deterministic backward passes"): every scatter-add is taken by one
+    owner in ascending row order.  Process-wide; PCOPS_DETERMINISTIC=1 in the environment sets it at load time."""
+    load().pcops_set_deterministic(1 if on else 0)
+
+
+def deterministic():
+    return bool(load().pcops_get_deterministic())
+
+
+def scatter_rows_sorted(idx, src, ndst, div=1, w=None, out=None, c=None, ld=None, src_ptr=None):
+    """out (B, ndst, C) = ordered scatter-add of the rows of src (pcops_scatter_rows_sorted).  idx (B, rows) int32;
+    src (B, rows / div, C) unless c / ld / src_ptr describe a strided view; out given -> accumulate."""
+    b, rows = idx.shape[0], idx[0].numel()
+    if c is None:
+        c, ld = src.shape[-1], src.shape[-1]
+    acc = out is not None
+    if out is None:
+        out = torch.empty((b, ndst, c), dtype=torch.float32, device=idx.device)
+    ws = torch.empty(int(load().pcops_scatter_rows_workspace_bytes(b, rows, ndst)) // 8 + 1, dtype=torch.int64,
+                     device=idx.device)
+    call("pcops_scatter_rows_sorted", b, rows, ndst, c, div, ld, idx.data_ptr(), ptr(w),
+         src_ptr if src_ptr is not None else src.data_ptr(), out.data_ptr(), 1 if acc else 0, ws.data_ptr())
+    return out
 
 
 _hooks = []  # profiling hooks: callables (name, phase, args) with phase in {"pre", "post"}

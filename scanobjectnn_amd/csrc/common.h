@@ -22,6 +22,8 @@ static inline hipStream_t as_stream(pcops_stream_t s) { return reinterpret_cast<
 
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
+extern "C" int pcops_get_deterministic(void);     // abi.hip: bit-reproducible backward passes requested
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 // unsigned max across the 64 lanes of a wave, wave-uniform result.  DPP row shifts + the two gfx9 row broadcasts

@@ -558,7 +558,8 @@ static int scatter_lds_slice(int n, int C, bool has_dq, bool has_xyz, size_t *ld
 __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const int *__restrict__ idx,
                                                             int2 *__restrict__ order, int *__restrict__ start,
                                                             int m, int S, const RowBlock *__restrict__ blocks,
-                                                            const int *__restrict__ bstart) {
+                                                            const int *__restrict__ bstart,
+                                                            int2 *__restrict__ sorted = nullptr) {
     extern __shared__ int si[];                 // cnt[n] | cursor[n] | scan scratch [1024]
     int *cnt = si, *cursor = si + n, *sc = si + 2 * n;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -606,6 +607,26 @@ __global__ __launch_bounds__(1024) void sa_csr_build_kernel(int n, int mS, const
         const int i = index_of(e);
         ob[atomicAdd(&cursor[i], 1)] = make_int2(e, i);
     }
+    if (!sorted) return;
+    // deterministic mode: the slots above were handed out by atomics, i.e. in no particular order.  A rank sort per
+    // point (a wave each; the rows of a list are distinct) rewrites every list in ascending row order, so the owner
+    // that walks it adds in the same order every run.  O(L^2 / 64) per list -- the price of the switch.
+    __syncthreads();
+    int2 *ob2 = sorted + r0;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < n; i += 16) {
+        const int L = cnt[i], s0 = cursor[i] - L;
+        for (int a0 = 0; a0 < L; a0 += 64) {
+            const int ka = a0 + lane < L ? ob[s0 + a0 + lane].x : 0x7fffffff;
+            int rank = 0;
+            for (int b0 = 0; b0 < L; b0 += 64) {
+                const int kb = b0 + lane < L ? ob[s0 + b0 + lane].x : 0x7fffffff;
+                const int nb = min(64, L - b0);
+                for (int t = 0; t < nb; ++t) rank += __builtin_amdgcn_readlane(kb, t) < ka ? 1 : 0;
+            }
+            if (a0 + lane < L) ob2[s0 + rank] = make_int2(ka, i);
+        }
+    }
 }
 
 struct CsrArgs {
@@ -616,6 +637,7 @@ struct CsrArgs {
     float *dQ, *wpart;
     const RowBlock *blocks;      // compacted rows: see sa_csr_build_kernel; the first row of a block carries a weight
     const int *bstart;
+    const int *start;            // [b][n+1] list boundaries (owner kernel)
 };
 
 // YONLY: the pooled form -- dY = q.Y + t everywhere plus p.gpool at the arg-max rows, which the streaming
@@ -733,6 +755,111 @@ __global__ __launch_bounds__(256) void sa_scatter_csr_kernel(CsrArgs a) {
 #pragma unroll
                     for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off, 64);
                     if (rsub == 0) red[wave][i][quad * 4 + e] = v;
+                }
+            __syncthreads();
+            for (int e = tid; e < 4 * 4 * LPR; e += 256) {
+                const int i = e / (4 * LPR), c = e % (4 * LPR);
+                a.wpart[((long long)blockIdx.x * 4 + i) * C + cb + c] =
+                    red[0][i][c] + red[1][i][c] + red[2][i][c] + red[3][i][c];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// OWNER form of the same pass: a lane set per SOURCE POINT walks the point's list start[i] .. start[i+1] and writes
+// dQ[b, i, :] once with a plain store -- no atomic, no memset, and with the lists in ascending row order (sorted build)
+// the sum is taken in the same order every run.  Long lists (ball query favours low indices) unbalance the waves a
+// little; the atomics of the chunked form cost more than that.
+template <int LPR>
+__global__ __launch_bounds__(256) void sa_scatter_owner_kernel(CsrArgs a) {
+    constexpr int PW = 64 / LPR, U = 4;          // points per wave, list entries in flight per point
+    __shared__ float red[4][4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int psub = lane / LPR, quad = lane % LPR;
+    const int n = a.n, m = a.m, S = a.S, C = a.C, mS = m * S;
+    const long long npts = (long long)a.b * n;
+    const long long pstride = (long long)gridDim.x * 4 * PW;
+    for (int cb = 0; cb < C; cb += 4 * LPR) {
+        const int c0 = cb + quad * 4;
+        const float4 cp = *reinterpret_cast<const float4 *>(a.p + c0);
+        const float4 cq = *reinterpret_cast<const float4 *>(a.q + c0);
+        const float4 ct = *reinterpret_cast<const float4 *>(a.t + c0);
+        float aw[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
+        for (long long pt0 = ((long long)blockIdx.x * 4 + wave) * PW; pt0 < npts; pt0 += pstride) {
+            const long long pt = pt0 + psub;
+            const bool pin = pt < npts;
+            const int b = (int)((pin ? pt : 0) / n), i = (int)((pin ? pt : 0) - (long long)b * n);
+            long long rowoff = (long long)b * mS;
+            if (a.blocks) rowoff = (long long)a.bstart[(long long)b * m] * kBlk;
+            const int *sb = a.start + (long long)b * (n + 1);
+            const int k0 = pin ? sb[i] : 0, k1 = pin ? sb[i + 1] : 0;
+            const int2 *ob = a.order + rowoff;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (a.wpart && a.xyz) {
+                const float *pp = a.xyz + ((long long)b * n + i) * 3;
+                px = pp[0]; py = pp[1]; pz = pp[2];
+            }
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = k0; k < k1; k += U) {
+                float4 yy[U], gg[U];
+                float wt[U];
+                int jj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = k + u < k1 ? k + u : k0;
+                    const int e = ob[kk].x;
+                    const long long r = rowoff + e;
+                    yy[u] = *reinterpret_cast<const float4 *>(a.Y + r * C + c0);
+                    gg[u] = *reinterpret_cast<const float4 *>(a.Gm + r * C + c0);
+                    wt[u] = 1.f;
+                    jj[u] = (int)((unsigned)e / (unsigned)S);
+                    if (a.blocks) {
+                        const RowBlock rb = a.blocks[r / kBlk];
+                        wt[u] = (r % kBlk) == 0 ? rb.w : 1.f;
+                        jj[u] = rb.g - b * m;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (k + u >= k1) continue;
+                    const float4 y = yy[u], gm = gg[u];
+                    float d[4];
+                    d[0] = fmaf(cp.x, gm.x, wt[u] * fmaf(cq.x, y.x, ct.x));
+                    d[1] = fmaf(cp.y, gm.y, wt[u] * fmaf(cq.y, y.y, ct.y));
+                    d[2] = fmaf(cp.z, gm.z, wt[u] * fmaf(cq.z, y.z, ct.z));
+                    d[3] = fmaf(cp.w, gm.w, wt[u] * fmaf(cq.w, y.w, ct.w));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += d[e];
+                    if (a.wpart) {
+                        if (a.xyz) {
+                            const float *cx = a.new_xyz + ((long long)b * m + jj[u]) * 3;
+                            const float ox = px - cx[0], oy = py - cx[1], oz = pz - cx[2];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                aw[0][e] = fmaf(ox, d[e], aw[0][e]);
+                                aw[1][e] = fmaf(oy, d[e], aw[1][e]);
+                                aw[2][e] = fmaf(oz, d[e], aw[2][e]);
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) aw[3][e] += d[e];
+                    }
+                }
+            }
+            if (pin) *reinterpret_cast<float4 *>(a.dQ + pt * C + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        if (a.wpart) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = aw[i][e];
+#pragma unroll
+                    for (int off = 32; off >= LPR; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (psub == 0) red[wave][i][quad * 4 + e] = v;
                 }
             __syncthreads();
             for (int e = tid; e < 4 * 4 * LPR; e += 256) {
@@ -1015,6 +1142,7 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_q_kernel(int B, int n, int 
 //     plain read-modify-write (it is the only writer of that row after the sparse kernel finished).
 constexpr int kEdgeSlice = 16;
 
+template <bool DET>     // DET: dCtr only -- the arg-row term is added by the owner walk (edge_pool_bwd_dense_kernel<., true>)
 __global__ __launch_bounds__(1024) void edge_pool_bwd_sparse_kernel(int n, int m, int S, int C,
                                                                     const float *__restrict__ gpool,
                                                                     const float *__restrict__ ysel,
@@ -1033,8 +1161,10 @@ __global__ __launch_bounds__(1024) void edge_pool_bwd_sparse_kernel(int n, int m
     const int nsl = C / kEdgeSlice;
     const int b = blockIdx.x / nsl, c0 = (blockIdx.x % nsl) * kEdgeSlice;
     const int tid = threadIdx.x, cl = tid % kEdgeSlice, gl = tid / kEdgeSlice;
-    for (int e = tid; e < n * kEdgeSlice; e += NT) acc[e] = 0.f;
-    __syncthreads();
+    if (!DET) {
+        for (int e = tid; e < n * kEdgeSlice; e += NT) acc[e] = 0.f;
+        __syncthreads();
+    }
     const int c = c0 + cl;
     const float sc = scale[c], sh = shift[c], pc = p[c], qc = q[c], tc = t[c];
     const float kf = (float)S;
@@ -1061,9 +1191,10 @@ __global__ __launch_bounds__(1024) void edge_pool_bwd_sparse_kernel(int n, int m
             const long long e = ((long long)b * m + j) * C + c;
             const float a = fmaf(ys[u], sc, sh) > 0.f ? pc * gp[u] : 0.f;
             dCtr[e] = fmaf(qc, fmaf(kf, ce[u], sq[u]), fmaf(kf, tc, a));
-            if (a != 0.f) atomicAdd(&acc[di[u] * kEdgeSlice + cl], a);
+            if (!DET && a != 0.f) atomicAdd(&acc[di[u] * kEdgeSlice + cl], a);
         }
     }
+    if (DET) return;
     __syncthreads();
     float *dst = dQ + (long long)b * n * C + c0;
     for (int e = tid; e < n * (kEdgeSlice / 4); e += NT) {
@@ -1072,7 +1203,15 @@ __global__ __launch_bounds__(1024) void edge_pool_bwd_sparse_kernel(int n, int m
     }
 }
 
-template <int LPR>     // lanes per point: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
+struct EdgeSparse {     // what the arg-row term needs (deterministic mode only)
+    const float *gpool, *ysel, *scale, *shift, *p;
+    const unsigned char *arg;
+};
+
+// DET: the lists are in ascending row order and the owner also adds the arg-row term p.g of every (group, channel)
+// whose arg-max is this list entry -- more bytes per entry (gpool, ysel, arg next to Ctr), but every sum has one owner
+// and a fixed order; dQ is written, not updated.
+template <int LPR, bool DET>     // lanes per point: C = 4 LPR for LPR < 64; LPR == 64 walks C in blocks of 256
 __global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, int m, int S, int C,
                                                                   const float *__restrict__ Q,
                                                                   const float *__restrict__ Ctr,
@@ -1080,7 +1219,7 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, 
                                                                   const float *__restrict__ tv,
                                                                   const int2 *__restrict__ order,
                                                                   const int *__restrict__ start,
-                                                                  float *__restrict__ dQ) {
+                                                                  float *__restrict__ dQ, EdgeSparse sp) {
     constexpr int PW = 64 / LPR, U = 4;          // points per wave, list entries in flight per point
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int psub = lane / LPR, quad = lane % LPR;
@@ -1091,6 +1230,12 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, 
         const int c0 = cb + quad * 4;
         const float4 cq = *reinterpret_cast<const float4 *>(qv + c0);
         const float4 ct = *reinterpret_cast<const float4 *>(tv + c0);
+        float4 psc, psh, pp;
+        if (DET) {
+            psc = *reinterpret_cast<const float4 *>(sp.scale + c0);
+            psh = *reinterpret_cast<const float4 *>(sp.shift + c0);
+            pp = *reinterpret_cast<const float4 *>(sp.p + c0);
+        }
         for (long long pt0 = ((long long)blockIdx.x * 4 + wave) * PW; pt0 < npts; pt0 += pstride) {
             const long long pt = pt0 + psub;
             const bool pin = pt < npts;
@@ -1099,23 +1244,42 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, 
             const int k0 = pin ? sb[i] : 0, k1 = pin ? sb[i + 1] : 0;
             const int2 *ob = order + (long long)b * mS;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float asp[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = k0; k < k1; k += U) {
-                float4 cc[U];
+                float4 cc[U], gg[DET ? U : 1], ys[DET ? U : 1];
+                unsigned am[DET ? U : 1], sr[DET ? U : 1];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int kk = k + u < k1 ? k + u : k0;
-                    const int j = (int)((unsigned)ob[kk].x / (unsigned)S);
-                    cc[u] = *reinterpret_cast<const float4 *>(Ctr + ((long long)b * m + j) * C + c0);
+                    const unsigned e = (unsigned)ob[kk].x;
+                    const int j = (int)(e / (unsigned)S);
+                    const long long ge = ((long long)b * m + j) * C + c0;
+                    cc[u] = *reinterpret_cast<const float4 *>(Ctr + ge);
+                    if (DET) {
+                        gg[u] = *reinterpret_cast<const float4 *>(sp.gpool + ge);
+                        ys[u] = *reinterpret_cast<const float4 *>(sp.ysel + ge);
+                        am[u] = *reinterpret_cast<const unsigned *>(sp.arg + ge);
+                        sr[u] = e - (unsigned)j * (unsigned)S;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (k + u < k1) { acc[0] += cc[u].x; acc[1] += cc[u].y; acc[2] += cc[u].z; acc[3] += cc[u].w; }
+                    if (k + u < k1) {
+                        acc[0] += cc[u].x; acc[1] += cc[u].y; acc[2] += cc[u].z; acc[3] += cc[u].w;
+                        if (DET) {
+                            const unsigned a4 = am[u], s = sr[u];
+                            if ((a4 & 0xffu) == s && fmaf(ys[u].x, psc.x, psh.x) > 0.f) asp[0] += pp.x * gg[u].x;
+                            if (((a4 >> 8) & 0xffu) == s && fmaf(ys[u].y, psc.y, psh.y) > 0.f) asp[1] += pp.y * gg[u].y;
+                            if (((a4 >> 16) & 0xffu) == s && fmaf(ys[u].z, psc.z, psh.z) > 0.f) asp[2] += pp.z * gg[u].z;
+                            if ((a4 >> 24) == s && fmaf(ys[u].w, psc.w, psh.w) > 0.f) asp[3] += pp.w * gg[u].w;
+                        }
+                    }
             }
-            if (pin && k1 > k0) {
+            if (pin && (DET || k1 > k0)) {
                 const float kf = (float)(k1 - k0);
                 const float4 qi = *reinterpret_cast<const float4 *>(Q + pt * C + c0);
                 float4 *dst = reinterpret_cast<float4 *>(dQ + pt * C + c0);
-                float4 d = *dst;
+                float4 d = DET ? make_float4(asp[0], asp[1], asp[2], asp[3]) : *dst;
                 d.x += fmaf(cq.x, fmaf(kf, qi.x, acc[0]), kf * ct.x);
                 d.y += fmaf(cq.y, fmaf(kf, qi.y, acc[1]), kf * ct.y);
                 d.z += fmaf(cq.z, fmaf(kf, qi.z, acc[2]), kf * ct.z);
@@ -1123,6 +1287,34 @@ __global__ __launch_bounds__(256) void edge_pool_bwd_dense_kernel(int B, int n, 
                 *dst = d;
             }
         }
+    }
+}
+
+// generic owner-walk scatter-add over sorted lists (deterministic mode of the unfused gradient ops):
+//   out[b][d][ch] (+)= sum over the rows e of cloud b with idx[b][e] == d, ascending e, of  w[b][e] * src[b][e / div][ch]
+// one thread per (destination point, channel); adjacent threads read adjacent channels of the same rows
+__global__ __launch_bounds__(256) void scatter_rows_sorted_kernel(long long total, int rows, int ndst, int c, int div,
+                                                                  int ld, const float *__restrict__ w,
+                                                                  const float *__restrict__ src,
+                                                                  const int2 *__restrict__ order,
+                                                                  const int *__restrict__ start,
+                                                                  float *__restrict__ out, int accumulate) {
+    const int rows_src = rows / div;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long pt = e / c;
+        const int ch = (int)(e - pt * c);
+        const int b = (int)(pt / ndst), d = (int)(pt - (long long)b * ndst);
+        const int *sb = start + (long long)b * (ndst + 1);
+        const int2 *ob = order + (long long)b * rows;
+        const float *sp = src + (long long)b * rows_src * ld + ch;
+        const float *wb = w ? w + (long long)b * rows : nullptr;
+        float acc = 0.f;
+        for (int k = sb[d]; k < sb[d + 1]; ++k) {
+            const int r = ob[k].x;
+            const float v = sp[(long long)(r / div) * ld];
+            acc += wb ? wb[r] * v : v;
+        }
+        out[e] = accumulate ? out[e] + acc : acc;
     }
 }
 
@@ -1152,6 +1344,16 @@ static bool scatter_csr_enabled() {
     return on;
 }
 
+// owner walk outside deterministic mode: measured 2569 us against 592 us of the chunked form on the SA2 scatter of the
+// headline step (a few low-index points own lists hundreds of rows long and serialise their waves) -- off by default
+static bool scatter_owner_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_SCATTER_OWNER");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 static bool scatter_lds_enabled() {
     static const bool on = [] {
         const char *e = getenv("PCOPS_SCATTER_LDS");
@@ -1175,7 +1377,37 @@ int pcops_sa_scatter_rows(int b, int m) {
 }
 
 unsigned long long pcops_sa_scatter_workspace_bytes(int b, int n, int m, int s) {
-    return sizeof(int) * (2ull * b * m * s + (unsigned long long)b * (n + 1));
+    // order | start | order rewritten in ascending row order (deterministic mode)
+    return sizeof(int) * (4ull * b * m * s + (unsigned long long)b * (n + 1) + 2);
+}
+
+unsigned long long pcops_scatter_rows_workspace_bytes(int b, int rows, int ndst) {
+    return sizeof(int) * (4ull * b * rows + (unsigned long long)b * (ndst + 1) + 2);
+}
+
+int pcops_scatter_rows_sorted(int b, int rows, int ndst, int c, int div, int ld_src, const int *idx, const float *w,
+                              const float *src, float *out, int accumulate, void *workspace, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && rows >= 0 && ndst >= 1 && c >= 1 && div >= 1 && rows % div == 0 && ld_src >= c);
+    if (b == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(out); PCOPS_REQUIRE_PTR(workspace);
+    if (rows > 0) { PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(src); }
+    if (reinterpret_cast<uintptr_t>(workspace) & 7) return PCOPS_ERR_UNSUPPORTED;
+    const size_t blds = (2 * (size_t)ndst + 1024) * sizeof(int);
+    if (blds > 160 * 1024 || (long long)rows >= (1ll << 30)) return PCOPS_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    int2 *order = static_cast<int2 *>(workspace);
+    int *start = reinterpret_cast<int *>(order + (size_t)b * rows);
+    int2 *sorted = reinterpret_cast<int2 *>(start + (((size_t)b * (ndst + 1) + 1) & ~(size_t)1));
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, ndst, rows, idx, order, start, 1, rows > 0 ? rows : 1,
+                       (const RowBlock *)nullptr, (const int *)nullptr, sorted);
+    const long long total = (long long)b * ndst * c;
+    const unsigned grid = cdiv(total, 256) < 32768u ? cdiv(total, 256) : 32768u;
+    hipLaunchKernelGGL(scatter_rows_sorted_kernel, dim3(grid), dim3(256), 0, st, total, rows, ndst, c, div, ld_src, w, src,
+                       sorted, start, out, accumulate);
+    return pcops_launch_status();
 }
 
 unsigned long long pcops_rows_max_blocks(int b, int m, int s) {
@@ -1293,9 +1525,14 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
     const bool csr_shape = (c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384 &&
                            (long long)m * s < (1ll << 30) && 2 * (size_t)n * 4 + 4096 <= 160 * 1024;
     if (rows && !(scatter_csr_enabled() && csr_shape)) return PCOPS_ERR_UNSUPPORTED;
+    const bool det = pcops_get_deterministic() != 0;
+    // deterministic mode: only the owner walk below adds a feature gradient in a fixed order
+    // (the pooled single-layer form adds its arg-row term with atomics: no ordered variant)
+    if (det && dQ && !(scatter_csr_enabled() && workspace && csr_shape && !gpool)) return PCOPS_ERR_UNSUPPORTED;
     if (scatter_csr_enabled() && workspace && dQ && csr_shape) {
         const bool split = dCtr || gpool;        // per-group outputs / pooled form: streaming pass first
-        if (hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
+        const bool owner = !gpool && (det || scatter_owner_enabled());
+        if (!owner && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
         if (split) {
             size_t lb = 0;
             const int cs0 = scatter_lds_slice(n, c, false, xyz != nullptr, &lb);
@@ -1327,10 +1564,28 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PCOPS_ERR_LAUNCH;
+        int2 *sorted = det ? reinterpret_cast<int2 *>(start + (((size_t)b * (n + 1) + 1) & ~(size_t)1)) : nullptr;
         hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start, m, s, rblocks,
-                           rbstart);
+                           rbstart, sorted);
         float *wp2 = split ? nullptr : wp;
-        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, order, dQ, wp2, rblocks, rbstart};
+        CsrArgs a = {b, n, m, s, c, G, Y, p, q, t, xyz, new_xyz, sorted ? sorted : order, dQ, wp2, rblocks, rbstart, start};
+        if (owner) {
+            switch (lpr) {
+                case 8: hipLaunchKernelGGL(sa_scatter_owner_kernel<8>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+                case 16: hipLaunchKernelGGL(sa_scatter_owner_kernel<16>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+                case 32: hipLaunchKernelGGL(sa_scatter_owner_kernel<32>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+                case 64: hipLaunchKernelGGL(sa_scatter_owner_kernel<64>, dim3(kCsrGrid), dim3(256), 0, st, a); break;
+                default: return PCOPS_ERR_UNSUPPORTED;
+            }
+            int rc = pcops_launch_status();
+            if (rc) return rc;
+            if (wp2) {
+                if (dWxyz) hipLaunchKernelGGL(sum_rows_kernel, dim3(3 * c), dim3(256), 0, st, kCsrGrid, 4 * c, wp2, dWxyz);
+                if (dbias) hipLaunchKernelGGL(sum_rows_kernel, dim3(c), dim3(256), 0, st, kCsrGrid, 4 * c, wp2 + 3 * c, dbias);
+                rc = pcops_launch_status();
+            }
+            return rc;
+        }
         const bool small = (long long)b * ((m * s + 63) / 64) < 4 * kCsrGrid;   // fewer 64-row chunks than waves
 #define PCOPS_CSR_LAUNCH(LPR_, Y_, CH_)                                                                            \
     hipLaunchKernelGGL((sa_scatter_csr_kernel<LPR_, Y_, CH_>), dim3(kCsrGrid), dim3(256), 0, st, a)
@@ -1464,8 +1719,10 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     hipStream_t st = as_stream(stream);
     const long long G = (long long)b * m;
     static const bool owner = [] { const char *e = getenv("PCOPS_EDGE_BWD_OWNER"); return !(e && e[0] == '0'); }();
+    const bool det = pcops_get_deterministic() != 0;
     const size_t slice_lds = (size_t)n * kEdgeSlice * sizeof(float);
-    const bool use_owner = owner && G > 0 && c % kEdgeSlice == 0 && slice_lds <= 160 * 1024;
+    const bool use_owner = G > 0 && c % kEdgeSlice == 0 && (det || (owner && slice_lds <= 160 * 1024));
+    if (det && G > 0 && !use_owner) return PCOPS_ERR_UNSUPPORTED;
     if (!use_owner && hipMemsetAsync(dQ, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess) return PCOPS_ERR_LAUNCH;
     if (G == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
@@ -1477,24 +1734,42 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(sa_csr_build_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return PCOPS_ERR_LAUNCH;
+    int2 *sorted = det ? reinterpret_cast<int2 *>(start + (((size_t)b * (n + 1) + 1) & ~(size_t)1)) : nullptr;
     hipLaunchKernelGGL(sa_csr_build_kernel, dim3(b), dim3(1024), blds, st, n, m * s, idx, order, start, m, s,
-                       (const RowBlock *)nullptr, (const int *)nullptr);
+                       (const RowBlock *)nullptr, (const int *)nullptr, sorted);
     const int lpr = c <= 256 ? c / 4 : 64;
     if (use_owner) {
         // no global atomics: the sparse arg-row term through an LDS-resident slice (this also initialises dQ, no
-        // memset), then the dense term by the owner of every source point
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(edge_pool_bwd_sparse_kernel),
+        // memset), then the dense term by the owner of every source point.  Deterministic mode: the first kernel only
+        // writes dCtr, the owner adds both terms in ascending row order.
+        const EdgeSparse sp = {gpool, ysel, scale, shift, p, arg};
+        const unsigned dgrid = 2048;
+#define PCOPS_EDGE_DENSE(LPR_, DET_)                                                                                  \
+    hipLaunchKernelGGL((edge_pool_bwd_dense_kernel<LPR_, DET_>), dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, \
+                       DET_ ? sorted : order, start, dQ, sp)
+        if (det) {
+            hipLaunchKernelGGL(edge_pool_bwd_sparse_kernel<true>, dim3(b * (c / kEdgeSlice)), dim3(1024), 0, st, n, m, s, c,
+                               gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ);
+            switch (lpr) {
+                case 8: PCOPS_EDGE_DENSE(8, true); break;
+                case 16: PCOPS_EDGE_DENSE(16, true); break;
+                case 32: PCOPS_EDGE_DENSE(32, true); break;
+                default: PCOPS_EDGE_DENSE(64, true); break;
+            }
+            return pcops_launch_status();
+        }
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(edge_pool_bwd_sparse_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return PCOPS_ERR_LAUNCH;
-        hipLaunchKernelGGL(edge_pool_bwd_sparse_kernel, dim3(b * (c / kEdgeSlice)), dim3(1024), slice_lds, st, n, m, s, c,
+        hipLaunchKernelGGL(edge_pool_bwd_sparse_kernel<false>, dim3(b * (c / kEdgeSlice)), dim3(1024), slice_lds, st, n, m, s, c,
                            gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ);
-        const unsigned dgrid = 2048;
         switch (lpr) {
-            case 8: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<8>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
-            case 16: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<16>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
-            case 32: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<32>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
-            default: hipLaunchKernelGGL(edge_pool_bwd_dense_kernel<64>, dim3(dgrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, start, dQ); break;
+            case 8: PCOPS_EDGE_DENSE(8, false); break;
+            case 16: PCOPS_EDGE_DENSE(16, false); break;
+            case 32: PCOPS_EDGE_DENSE(32, false); break;
+            default: PCOPS_EDGE_DENSE(64, false); break;
         }
+#undef PCOPS_EDGE_DENSE
         return pcops_launch_status();
     }
     const long long total = G * c;

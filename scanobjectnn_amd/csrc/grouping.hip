@@ -359,6 +359,7 @@ extern "C" int pcops_group_point_grad(int b, int n, int c, int m, int nsample, c
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 0 && m >= 0 && nsample >= 0);
     if ((long long)b * n * c == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(grad_points);
+    if (pcops_get_deterministic()) return PCOPS_ERR_UNSUPPORTED;   // float atomics: pcops_scatter_rows_sorted instead
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * n * c, st) != hipSuccess)
         return PCOPS_ERR_LAUNCH;

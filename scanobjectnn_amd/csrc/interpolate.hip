@@ -164,6 +164,7 @@ extern "C" int pcops_three_interpolate_grad(int b, int n, int c, int m, const fl
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0 && c >= 0);
     if ((long long)b * m * c == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(grad_points);
+    if (pcops_get_deterministic()) return PCOPS_ERR_UNSUPPORTED;   // float atomics: pcops_scatter_rows_sorted instead
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * m * c, st) != hipSuccess)
         return PCOPS_ERR_LAUNCH;

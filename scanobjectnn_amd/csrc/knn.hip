@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void edge_feature_kernel(long long total, int 
 }
 
 // grad_x[b,i,:] += sum_s (ga - gb)[b,i,s,:] ; grad_x[b,nn[b,i,s],:] += gb[b,i,s,:]
+template <bool CENTRAL>
 __global__ __launch_bounds__(256) void edge_feature_grad_kernel(long long total, int n, int c, int k,
                                                                 const float *__restrict__ grad_out,
                                                                 const int *__restrict__ nn_idx,
@@ -463,9 +464,10 @@ __global__ __launch_bounds__(256) void edge_feature_grad_kernel(long long total,
             const float ga = grad_out[edge * 2 * c + col];
             const float gb = grad_out[edge * 2 * c + c + col];
             central += ga - gb;
-            atomicAdd(&grad_x[(bi * n + nn_idx[edge]) * (long long)c + col], gb);
+            if (!CENTRAL) atomicAdd(&grad_x[(bi * n + nn_idx[edge]) * (long long)c + col], gb);
         }
-        atomicAdd(&grad_x[e], central);
+        if (CENTRAL) grad_x[e] = central;       // the neighbour term is the caller's sorted scatter (deterministic mode)
+        else atomicAdd(&grad_x[e], central);
     }
 }
 
@@ -554,6 +556,7 @@ extern "C" int pcops_edge_feature_grad(int b, int n, int c, int k, const float *
     const long long total = (long long)b * n * c;
     if (total == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(grad_x);
+    if (pcops_get_deterministic()) return PCOPS_ERR_UNSUPPORTED;   // atomics: use _central + pcops_scatter_rows_sorted
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)total, st) != hipSuccess)
         return PCOPS_ERR_LAUNCH;
@@ -561,7 +564,20 @@ extern "C" int pcops_edge_feature_grad(int b, int n, int c, int k, const float *
     PCOPS_REQUIRE_PTR(grad_out);
     PCOPS_REQUIRE_PTR(nn_idx);
     const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
-    hipLaunchKernelGGL(edge_feature_grad_kernel, dim3(grid), dim3(256), 0, st, total, n, c, k,
+    hipLaunchKernelGGL(edge_feature_grad_kernel<false>, dim3(grid), dim3(256), 0, st, total, n, c, k,
                        grad_out, nn_idx, grad_x);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_edge_feature_grad_central(int b, int n, int c, int k, const float *grad_out, float *grad_x,
+                                               pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 0 && k >= 0);
+    const long long total = (long long)b * n * c;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(grad_x);
+    if (k > 0) PCOPS_REQUIRE_PTR(grad_out);
+    const unsigned grid = cdiv(total, 256) < 16384u ? cdiv(total, 256) : 16384u;
+    hipLaunchKernelGGL(edge_feature_grad_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), total, n, c, k,
+                       grad_out, (const int *)nullptr, grad_x);
     return pcops_launch_status();
 }

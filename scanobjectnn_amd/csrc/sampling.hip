@@ -236,6 +236,7 @@ extern "C" int pcops_gather_point_grad(int b, int n, int m, const float *out_g, 
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0);
     if ((long long)b * n == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(inp_g);
+    if (pcops_get_deterministic()) return PCOPS_ERR_UNSUPPORTED;   // float atomics: pcops_scatter_rows_sorted instead
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(inp_g, 0, sizeof(float) * (size_t)b * n * 3, st) != hipSuccess)
         return PCOPS_ERR_LAUNCH;

@@ -167,6 +167,11 @@ class _EdgeFeature(torch.autograd.Function):
         k = nn_idx.shape[2]
         grad_out = grad_out.contiguous()
         grad_x = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
+        if _lib.deterministic():     # x_i half with plain stores, neighbour half by the ordered owner walk
+            _lib.call("pcops_edge_feature_grad_central", b, n, c, k, _lib.ptr(grad_out), _lib.ptr(grad_x))
+            _lib.scatter_rows_sorted(nn_idx.view(b, n * k), None, n, out=grad_x, c=c, ld=2 * c,
+                                     src_ptr=grad_out.data_ptr() + 4 * c)
+            return grad_x, None
         _lib.call("pcops_edge_feature_grad", b, n, c, k, _lib.ptr(grad_out), _lib.ptr(nn_idx),
                   _lib.ptr(grad_x))
         return grad_x, None

@@ -93,6 +93,8 @@ class _GroupPoint(torch.autograd.Function):
         b, n, c = ctx.shape
         _, m, s = idx.shape
         grad_out = grad_out.contiguous()
+        if _lib.deterministic():     # ordered owner walk instead of float atomics
+            return _lib.scatter_rows_sorted(idx.view(b, m * s), grad_out.view(b, m * s, c), n), None
         grad_points = torch.empty((b, n, c), dtype=torch.float32, device=grad_out.device)
         _lib.call("pcops_group_point_grad", b, n, c, m, s, _lib.ptr(grad_out), _lib.ptr(idx),
                   _lib.ptr(grad_points))

@@ -44,6 +44,8 @@ class _ThreeInterpolate(torch.autograd.Function):
         b, m, c = ctx.shape
         n = idx.shape[1]
         grad_out = grad_out.contiguous()
+        if _lib.deterministic():     # ordered owner walk instead of float atomics
+            return _lib.scatter_rows_sorted(idx.view(b, 3 * n), grad_out, m, div=3, w=weight), None, None
         grad_points = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
         _lib.call("pcops_three_interpolate_grad", b, n, c, m, _lib.ptr(grad_out), _lib.ptr(idx),
                   _lib.ptr(weight), _lib.ptr(grad_points))

@@ -51,6 +51,8 @@ class _GatherPoint(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         out_g = out_g.contiguous()
         b, m, _ = out_g.shape
+        if _lib.deterministic():     # ordered owner walk instead of float atomics
+            return _lib.scatter_rows_sorted(idx, out_g, ctx.n), None
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
         _lib.call("pcops_gather_point_grad", b, ctx.n, m, _lib.ptr(out_g), _lib.ptr(idx), _lib.ptr(inp_g))
         return inp_g, None

@@ -75,6 +75,8 @@ def parse_args(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--sync_bn", action="store_true", help="BN statistics of the global batch (all-reduced)")
     p.add_argument("--no_augment", action="store_true", help="skip rotate + jitter (tests / debugging)")
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible backward passes: ordered owner sums instead of float atomics (slower)")
     return p.parse_args(argv)
 
 
@@ -144,6 +146,9 @@ def train(args):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     D.SYNC_BN = bool(args.sync_bn)
+    if args.deterministic:
+        from scanobjectnn_amd import _lib
+        _lib.set_deterministic(True)
     mod = importlib.import_module(MODELS[args.model])
     partseg = args.model.endswith("_partseg")
     with_mask = "parts" if partseg else args.model.endswith("_bga")
