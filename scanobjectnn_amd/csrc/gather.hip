@@ -788,7 +788,13 @@ __global__ __launch_bounds__(256) void sa_scatter_owner_kernel(CsrArgs a) {
         float aw[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) aw[i][0] = aw[i][1] = aw[i][2] = aw[i][3] = 0.f;
-        for (long long pt0 = ((long long)blockIdx.x * 4 + wave) * PW; pt0 < npts; pt0 += pstride) {
+        // the longest lists belong to the lowest indices of every cloud (ball query pads with a group's first index):
+        // with a plain stride those points, n apart, would all land on the same few waves -- each pass rotates the
+        // wave -> point map by an odd step instead
+        const long long nwv = (long long)gridDim.x * 4;
+        const long long wv = (long long)blockIdx.x * 4 + wave;
+        for (long long pass = 0; pass * pstride < npts; ++pass) {
+            const long long pt0 = pass * pstride + ((wv + pass * 1031) % nwv) * PW;
             const long long pt = pt0 + psub;
             const bool pin = pt < npts;
             const int b = (int)((pin ? pt : 0) / n), i = (int)((pin ? pt : 0) - (long long)b * n);
