@@ -241,6 +241,45 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
                     const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                     pcops_stream_t stream);
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
+/* C [M][N] = A [M][K] B [K][N], row-major with leading dimensions: the small weight x weight products and row vectors
+ * around the big kernels (32 x 32 output tile per workgroup, fp32 MFMA, fixed summation order) */
+int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                     pcops_stream_t stream);
+
+/* ---- algebraic backward of a POOLED top layer (the last conv of a set-abstraction stack / of a stack pooled over a
+ * whole cloud: pointnet_util.py:139-147, dgcnn.py "agg", transform_nets.py "tconv3").
+ *   Y = X W + b,  X = relu(bn_prev(Yprev)) [M][Kp],  out[g] = max over the S rows of group g of relu(bn(Y))
+ * dY = p.G + q.Y + t has ONE non-zero row of G per (group, channel).  Substituting Y = X W + b:
+ *   dX = X (W diag(q) W^T) + 1 (W (q.b + t))^T + (p.G) W^T            Kp x Kp product instead of N x Kp
+ *   dW = (X^T X) (W diag(q)) + (X^T 1)(q.b + t)^T + X^T (p.G)         Kp x Kp Gram matrix instead of Kp x N
+ *   db = 1^T (p.G) + q.((X^T 1) W + M b) + M t
+ * Neither needs Y; the (p.G) terms touch M/S * N rows.  N = 2 Kp .. 8 Kp in the reference's stacks, so the two large
+ * products lose 1/2 .. 7/8 of their flops.  Same numbers as pcops_mlp_gemm_dgrad / pcops_mlp_wgrad up to fp32
+ * rounding (different summation order).
+ *   pcops_mlp_pool_top_supported  1 when the four entry points below take (M, Kp, N, S)
+ *   pcops_mlp_pool_top_addend       addend [(M/S) min(S,N)][Kp] = the rows of (p.G) W^T that are not zero, compacted;
+ *                                 rowmap [M] = slot of a row or -1.  gout / ysel / argmax [M/S][N] as in
+ *                                 pcops_mlp_gemm_dgrad (gpool form), Wt [N][Kp] from pcops_mlp_transpose
+ *   pcops_mlp_gemm_dgrad_top      Gprev [M][Kp] = mask_prev . (X Mq + addend[rowmap] + vconst), stats_partial as
+ *                                 pcops_mlp_gemm_dgrad;  Mq [Kp][Kp] = W diag(q) W^T, vconst [Kp] = W (q.b + t)
+ *   pcops_mlp_gram                gram [Kp][Kp] = X^T X, xsum [Kp] = X^T 1; partial: pcops_mlp_wgrad_splits(M,Kp,Kp)
+ *                                 copies of (Kp Kp + Kp) floats
+ *   pcops_mlp_pool_top_wsparse    Ssp [Kp][N] = X^T (p.G), cfsum [N] = 1^T (p.G)
+ * prev_scale == prev_shift == NULL: X is the stack's raw input (a one-layer stack) -- no mask, no statistics.
+ * All sums in a fixed order (deterministic). */
+int pcops_mlp_pool_top_supported(int M, int Kp, int N, int S);
+int pcops_mlp_pool_top_addend(int M, int Kp, int N, int S, const float *gout, const float *ysel,
+                            const unsigned char *argmax, const float *pool_scale, const float *pool_shift,
+                            const float *p, const float *Wt, float *addend, int *rowmap, pcops_stream_t stream);
+int pcops_mlp_gemm_dgrad_top(int M, int Kp, const float *Yprev, const float *prev_scale, const float *prev_shift,
+                             const float *Mq, const float *vconst, const float *addend, long long addend_rows,
+                             const int *rowmap, float *Gprev, float *stats_partial, pcops_stream_t stream);
+int pcops_mlp_gram(long long M, int Kp, const float *Yprev, int ldx, const float *a_scale, const float *a_shift,
+                   float *partial, float *gram, float *xsum, pcops_stream_t stream);
+int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, const float *ysel,
+                               const unsigned char *argmax, const float *pool_scale, const float *pool_shift,
+                               const float *p, const float *Yprev, const float *prev_scale, const float *prev_shift,
+                               float *Ssp, float *cfsum, pcops_stream_t stream);
 /* The layer that FOLLOWS an arithmetic first layer  y1[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))
  * (grouped xyz offsets only: the first set-abstraction level, pointnet_util.py:44-54 with points == None).  y1 is
  * rebuilt from off4 [M][4] = (dx, dy, dz, 0) and xyzw [4][C1] (rows w0, w1, w2, b) wherever the plain entry points

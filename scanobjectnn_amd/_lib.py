@@ -46,6 +46,11 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
+    "pcops_small_gemm": ([_I, _I, _I, _P, _I, _P, _I, _P, _I], True),
+    "pcops_mlp_pool_top_addend": ([_I, _I, _I, _I] + [_P] * 9, True),
+    "pcops_mlp_gemm_dgrad_top": ([_I, _I] + [_P] * 6 + [_LL] + [_P] * 3, True),
+    "pcops_mlp_gram": ([_LL, _I, _P, _I, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_top_wsparse": ([_I, _I, _I, _I] + [_P] * 11, True),
     "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
@@ -89,6 +94,7 @@ PLAIN = {
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
     "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),
     "pcops_scatter_rows_workspace_bytes": ([_I, _I, _I], _U64),
+    "pcops_mlp_pool_top_supported": ([_I, _I, _I, _I], _I),
     "pcops_set_deterministic": ([_I], None),
     "pcops_get_deterministic": ([], _I),
 }
@@ -204,6 +210,7 @@ def scatter_rows_sorted(idx, src, ndst, div=1, w=None, out=None, c=None, ld=None
     return out
 
 
+_SYNC_EVERY_CALL = os.environ.get("PCOPS_SYNC", "0") == "1"
 _hooks = []  # profiling hooks: callables (name, phase, args) with phase in {"pre", "post"}
 
 
@@ -216,5 +223,10 @@ def call(name, *args):
     status = getattr(lib, name)(*args, stream)
     for h in _hooks:
         h(name, "post", args)
+    if _SYNC_EVERY_CALL and status == 0:      # debugging aid (PCOPS_SYNC=1): a device fault is reported at its launch
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            raise PcopsError("%s: device fault (%s)" % (name, e))
     if status != 0:
         raise PcopsError("%s failed: %s (status %d)" % (name, strerror(status), status))

@@ -53,6 +53,9 @@ struct RowBlock { int g, s0; float w; int pad; };   // group, row-in-group of th
 //   y[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))      (csrc/gather.hip first_layer_quad order)
 // rebuilt from off4[row] = (dx, dy, dz, 0) instead of being read: 16 bytes per row instead of 4 K (wave-stream only)
 constexpr int A_XYZ = 5;
+// weight-gradient kernels only: the "dY" side is the A operand itself, relu(bn(X)) -- the Gram matrix X^T X of a layer's
+// input (pcops_mlp_gram), which is what the algebraic form of a pooled top layer's weight gradient is built from
+constexpr int A_SELFD = 8;
 constexpr bool is_dy(int am) { return am == A_DY || is_pool(am); }
 __device__ __forceinline__ float xyz_y(float4 o, float w0, float w1, float w2, float b) {
     return fmaf(o.z, w2, fmaf(o.y, w1, fmaf(o.x, w0, b)));
@@ -75,8 +78,14 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // a voffset no tensor reaches: forces the bounds check to fail
-enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2, E_MASKX = 3 };   // E_MASKX: E_MASK with the previous layer in xyz form
-constexpr bool is_mask(int em) { return em == E_MASK || em == E_MASKX; }
+enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2, E_MASKX = 3, E_MASKA = 4 };
+// E_MASKX: E_MASK with the previous layer in xyz form
+// E_MASKA: E_MASK of  acc + addend[rowmap[row]] + vconst  -- the data gradient of a POOLED top layer in its algebraic
+//          form (pcops_mlp_gemm_dgrad_top): acc = relu(bn(Yprev)) . (W diag(q) W^T), the few arg-max rows come in
+//          through the compact addend, the constant row W (q.b + t) through vconst
+constexpr int E_PLAINA = 5;      // E_PLAIN of acc + addend[rowmap[row]] + vconst (the same gradient w.r.t. a stack's raw input)
+constexpr bool is_mask(int em) { return em == E_MASK || em == E_MASKX || em == E_MASKA; }
+constexpr bool has_add(int em) { return em == E_MASKA || em == E_PLAINA; }
 
 struct GemmArgs {
     int M, K, N;
@@ -122,6 +131,12 @@ struct GemmArgs {
     // the uncompacted tensor: statistics weigh it with w, and its dY is p.G + w (q.Y + t)
     const RowBlock *blocks;
     const int *Mdev;
+    // E_MASKA
+    const float *addend;     // [slots][add_ld] compact rows added before the mask
+    const int *rowmap;       // [M] slot of a row, or -1
+    int add_ld;
+    long long add_bytes;     // size of addend (< kOOB: a slot of -1 becomes an offset the bounds check rejects)
+    const float *vconst;     // [N] added to every row
 };
 
 __device__ __forceinline__ float4 ld4(const float *p, bool vec, int k, int K) {
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     if (rowgrp >= nrowgrp) {
         // padding workgroup: the statistics buffer has a fixed number of partial rows (pcops_mlp_stats_rows), the rows
         // no tile owner writes are zeroed here instead of by a separate memset launch
-        if (EM != E_PLAIN && a.stats)
+        if (EM != E_PLAIN && EM != E_PLAINA && a.stats)
             for (int i = tid; i < 2 * BN; i += NTHR)
                 if (n0 + i % BN < N) a.stats[((long long)rowgrp * 2 + i / BN) * N + n0 + i % BN] = 0.f;
         if (EM == E_MASKX && a.xstats)
@@ -496,6 +511,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ecoef[(2 + i) * BN + e] = n < N ? a.xw[i * a.xw_ld + n] : 0.f;
             }
+            if (has_add(EM)) ecoef[2 * BN + e] = n < N ? a.vconst[n] : 0.f;
         }
     }
     __syncthreads();
@@ -754,7 +770,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const long long row0 = tile * 32;
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
         const __amdgpu_buffer_rsrc_t rprev =
-            make_rsrc((EM == E_MASK ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
+            make_rsrc(((EM == E_MASK || EM == E_MASKA) ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
 #pragma unroll
         for (int h = 0; h < EH; ++h) {
             const int ocq = h * BNH + ocl;                   // this lane's column quad in the BN-wide tile
@@ -776,11 +792,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                                         xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
                 }
             }
-            if (EM == E_MASK) {
+            if (EM == E_MASK || EM == E_MASKA) {
                 // the mask tensor is requested HERE (not a tile ahead): it would cost NST more live float4 across the
                 // whole MFMA phase, and with two waves per SIMD the partner wave covers this latency
 #pragma unroll
                 for (int j = 0; j < NST; ++j) py[j] = buf_load4(rprev, yvoff, (unsigned)j * yrowstep);
+            }
+            float4 pad[has_add(EM) ? NST : 1];
+            if (has_add(EM)) {
+                // compact addend rows: most rows have none (slot -1 -> an offset the bounds check rejects -> zeros)
+                const __amdgpu_buffer_rsrc_t radd = make_rsrc(a.addend, a.add_bytes);
+#pragma unroll
+                for (int j = 0; j < NST; ++j) {
+                    const long long row = row0 + (lane + 64 * j) / O4;
+                    const int slot = row < M ? a.rowmap[row] : -1;
+                    const unsigned off = (slot >= 0 && ocin) ? ((unsigned)slot * (unsigned)a.add_ld + (unsigned)(n0 + ocq)) * 4u : kOOB;
+                    pad[j] = buf_load4(radd, off, 0u);
+                }
             }
             const float4 eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
             const float4 em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
@@ -831,8 +859,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                             for (int e = 0; e < 4; ++e)
                                 if (ov[e] > pmx[h][e]) { pmx[h][e] = ov[e]; pax[h][e] = sr; }
                         }
+                    } else if (EM == E_PLAINA) {
+                        const float4 vc = *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq]);
+                        o.x += pad[j].x + vc.x; o.y += pad[j].y + vc.y; o.z += pad[j].z + vc.z; o.w += pad[j].w + vc.w;
                     } else if (is_mask(EM)) {
                         const float4 yp = py[j];
+                        if (EM == E_MASKA) {
+                            const float4 vc = *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq]);
+                            o.x += pad[j].x + vc.x; o.y += pad[j].y + vc.y; o.z += pad[j].z + vc.z; o.w += pad[j].w + vc.w;
+                        }
                         o.x = fmaf(yp.x, eb.x, em.x) > 0.f ? o.x : 0.f;
                         o.y = fmaf(yp.y, eb.y, em.y) > 0.f ? o.y : 0.f;
                         o.z = fmaf(yp.z, eb.z, em.z) > 0.f ? o.z : 0.f;
@@ -870,7 +905,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         ++round;
     }
 
-    if (EM != E_PLAIN && a.stats) {
+    if (EM != E_PLAIN && EM != E_PLAINA && a.stats) {
         // lanes l, l + O4, l + 2 O4 ... own the same 4 columns
 #pragma unroll
         for (int h = 0; h < EH; ++h) {
@@ -1010,7 +1045,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
             return PCOPS_ERR_LAUNCH;                                                                  \
         a.nrowgrp = pl.gy;                                                                            \
-        const int P_ = (a.stats && EM != E_PLAIN) ? pcops_mlp_stats_rows(a.M) : 0;                    \
+        const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
@@ -1563,9 +1598,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
     for (int e = tid; e < NB; e += 256) {
         const int n = n0 + e;
         const bool in = n < N;
-        coefD[e] = in ? a.p[n] : 0.f;
-        coefD[NB + e] = in ? a.q[n] : 0.f;
-        coefD[2 * NB + e] = in ? a.t[n] : 0.f;
+        coefD[e] = (in && a.p) ? a.p[n] : 0.f;
+        coefD[NB + e] = (in && a.q) ? a.q[n] : 0.f;
+        coefD[2 * NB + e] = (in && a.t) ? a.t[n] : 0.f;
         coefD[3 * NB + e] = (DMODE == A_DYPOOL && in) ? a.dsc[n] : 0.f;
         coefD[4 * NB + e] = (DMODE == A_DYPOOL && in) ? a.dsh[n] : 0.f;
     }
@@ -1780,9 +1815,9 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
     for (int e = tid; e < NB; e += 512) {
         const int n = n0 + e;
         const bool in = n < N;
-        coefD[e] = in ? a.p[n] : 0.f;
-        coefD[NB + e] = in ? a.q[n] : 0.f;
-        coefD[2 * NB + e] = in ? a.t[n] : 0.f;
+        coefD[e] = (in && a.p) ? a.p[n] : 0.f;
+        coefD[NB + e] = (in && a.q) ? a.q[n] : 0.f;
+        coefD[2 * NB + e] = (in && a.t) ? a.t[n] : 0.f;
         coefD[3 * NB + e] = (is_pool(DMODE) && in) ? a.dsc[n] : 0.f;
         coefD[4 * NB + e] = (is_pool(DMODE) && in) ? a.dsh[n] : 0.f;
     }
@@ -1879,7 +1914,7 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                         pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
                         pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
                     }
-                } else {
+                } else if (DMODE != A_SELFD) {
                     pg[j] = buf_load4(rg, dvoff, (unsigned)j * dstep);
                 }
             }
@@ -1910,7 +1945,7 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                 const int r = pt / D4 + j * (256 / D4);
                 const float4 y = py[j];
                 const int hb = (j * QD) / kBlk;                // block of this row inside the stripe (compile time)
-                float4 g = pg[U_ ? 0 : (B_ ? hb : j)];
+                float4 g = DMODE == A_SELFD ? make_float4(0.f, 0.f, 0.f, 0.f) : pg[U_ ? 0 : (B_ ? hb : j)];
                 if (is_pool(DMODE)) {
                     long long gdummy;
                     unsigned s;
@@ -1924,7 +1959,14 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                     g.w = ((am >> 24) == s && fmaf(y.w, cds.w, cdh.w) > 0.f) ? g.w : 0.f;
                 }
                 float4 d;
-                if (compact && (j * QD) % kBlk == 0) {
+                if (DMODE == A_SELFD && AMODE == A_PLAIN) {
+                    d = y;
+                } else if (DMODE == A_SELFD) {
+                    d.x = fmaxf(fmaf(y.x, cq.x, ct.x), 0.f);
+                    d.y = fmaxf(fmaf(y.y, cq.y, ct.y), 0.f);
+                    d.z = fmaxf(fmaf(y.z, cq.z, ct.z), 0.f);
+                    d.w = fmaxf(fmaf(y.w, cq.w, ct.w), 0.f);
+                } else if (compact && (j * QD) % kBlk == 0) {
                     // a row that opens a block (r % 16 == 0): dY = p.G + w (q.Y + t)
                     const float w = (r & (kBlk - 1)) == 0 ? bw[compact ? hb : 0] : 1.f;
                     d.x = fmaf(cp.x, g.x, w * fmaf(cq.x, y.x, ct.x));
@@ -2039,7 +2081,7 @@ struct PcWgradPlan {
 };
 
 static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
-                          const void *gpool, const void *argmax, PcWgradPlan *pl) {
+                          const void *gpool, const void *argmax, PcWgradPlan *pl, bool narrow = false) {
     if (M < 8 * 1024) return false;
     if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
@@ -2048,6 +2090,7 @@ static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, con
         return false;
     pl->tk = K <= 64 ? 1 : 2;
     pl->tn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+    if (narrow && pl->tn == 4 && (N + 127) / 128 * 128 < (N + 255) / 256 * 256) pl->tn = 2;   // less padding (N = 320)
     const int KB = 64 * pl->tk, NB = 64 * pl->tn;
     pl->kblocks = (K + KB - 1) / KB;
     pl->nblocks = (N + NB - 1) / NB;
@@ -2237,6 +2280,276 @@ int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Algebraic backward of a POOLED top layer  Y = X W + b,  X = relu(bn(Yprev)),  out = max_group relu(bn(Y)).
+// Its dY = p.G + q.Y + t has a DENSE part that is affine in X and a SPARSE part (one row per group and channel):
+//   dX = (p.G) W^T + X (W diag(q) W^T) + 1 (W (q.b + t))^T
+//   dW = X^T (p.G) + (X^T X) (W diag(q)) + (X^T 1) (q.b + t)^T
+// so neither gradient needs Y, and the two big products shrink from K x N to K x K (N = 2K in every SA module, N = 3.2K
+// .. 8K for the layers pooled over whole clouds).  The sparse parts are G x N row operations:
+//   pool_top_addend_kernel   per group: arg-max rows -> compact addend rows  sum_c cf[c] Wt[c][:]  + the row -> slot map
+//   pool_top_wsparse_kernel per channel: sum over the groups of cf X[arg row][:]
+// cf[g][c] = p[c] gout[g][c] [relu(bn(ysel[g][c])) > 0].  Sums run in ascending channel / group order (deterministic).
+template <int NT>      // threads: 1024 for few large groups (a wave set per segment needs the waves), 256 otherwise
+__global__ __launch_bounds__(NT) void pool_top_addend_kernel(int S, int C, int Kp, int slots_per_group,
+                                                              const float *__restrict__ gout,
+                                                              const float *__restrict__ ysel,
+                                                              const unsigned char *__restrict__ arg,
+                                                              const float *__restrict__ sc, const float *__restrict__ sh,
+                                                              const float *__restrict__ p, const float *__restrict__ Wt,
+                                                              float *__restrict__ addend, int *__restrict__ rowmap) {
+    // hit-driven: the (row, channel) pairs with a non-zero coefficient are compacted, sorted by (row, channel) with a
+    // bitonic network in LDS (<= 1024 keys), cut into one segment per row, and a 16-lane set per segment adds the
+    // segment's Wt rows in ascending channel order.  Work is O(hits log hits), not O(S C).
+    __shared__ float cf[1024];
+    __shared__ unsigned key[1024];                 // row << 10 | channel, 0xFFFFFFFF padding
+    __shared__ int segstart[1025];                 // first sorted position of segment i
+    __shared__ int wcount[16];
+    constexpr int CPT = 1024 / NT, NW = NT / 64;     // channels per thread, waves
+    const long long g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int s = tid; s < S; s += NT) rowmap[g * S + s] = -1;
+    // ---- coefficients and compaction of the hits (C <= 1024: four channels per thread)
+    float v[CPT];
+    unsigned row[CPT];
+    unsigned long long hm[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = i * NT + tid;
+        v[i] = 0.f;
+        row[i] = 0;
+        if (c < C) {
+            const long long e = g * C + c;
+            v[i] = fmaf(ysel[e], sc[c], sh[c]) > 0.f ? p[c] * gout[e] : 0.f;
+            row[i] = arg[e];
+            cf[c] = v[i];
+        }
+        hm[i] = __ballot(v[i] != 0.f);
+        if (lane == 0) wcount[i * NW + wave] = __popcll(hm[i]);
+        key[c] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    int nh = 0, base[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        for (int w = 0; w < NW; ++w) {
+            if (w == wave) base[i] = nh;
+            nh += wcount[i * NW + w];
+        }
+    if (nh == 0) return;                           // a chunk that won no channel (layers pooled over whole clouds)
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (v[i] != 0.f)
+            key[base[i] + __popcll(hm[i] & ((1ull << lane) - 1ull))] = (row[i] << 10) | (unsigned)(i * NT + tid);
+    int n2 = 64;
+    while (n2 < nh) n2 <<= 1;
+    // ---- bitonic sort of key[0 .. n2): n2 / 2 compare-exchanges per stage
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < n2 / 2; t += NT) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned a = key[lo], b = key[hi];
+                if ((a > b) == ((lo & k) == 0)) { key[lo] = b; key[hi] = a; }
+            }
+        }
+    __syncthreads();
+    // ---- segments: a new one wherever the row changes (positions i * 256 + tid, i.e. ascending over (i, wave, lane))
+    bool first[CPT];
+    unsigned long long fm[CPT];
+    unsigned mykey[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int pos = i * NT + tid;
+        mykey[i] = pos < nh ? key[pos] : 0u;
+        first[i] = pos < nh && (pos == 0 || (key[pos - 1] >> 10) != (mykey[i] >> 10));
+        fm[i] = __ballot(first[i]);
+    }
+    __syncthreads();                               // wcount is reused
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) wcount[i * NW + wave] = __popcll(fm[i]);
+    __syncthreads();
+    int nseg = 0, sbase[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        for (int w = 0; w < NW; ++w) {
+            if (w == wave) sbase[i] = nseg;
+            nseg += wcount[i * NW + w];
+        }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (first[i]) {
+            const int si = sbase[i] + __popcll(fm[i] & ((1ull << lane) - 1ull));
+            segstart[si] = i * NT + tid;
+            rowmap[g * S + (mykey[i] >> 10)] = (int)(g * slots_per_group) + si;
+        }
+    if (tid == 0) segstart[nseg] = nh;
+    __syncthreads();
+    // ---- a 16-lane set per segment; lane q of the set owns the float4 columns q, q + 16, ... of the Kp-wide row
+    constexpr int KQ = 8;                          // Kp <= 512
+    const int sub = lane >> 4, q = lane & 15;
+    const int kq = (Kp + 63) / 64;
+    for (int si = wave * 4 + sub; si < nseg; si += NW * 4) {
+        const int e0 = segstart[si], e1 = segstart[si + 1];
+        float4 acc[KQ];
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = e0; e < e1; ++e) {
+            const int c = key[e] & 1023u;
+            const float w = cf[c];
+            const float *src = Wt + (long long)c * Kp;
+#pragma unroll
+            for (int i = 0; i < KQ; ++i) {
+                const int k = (i * 16 + q) * 4;
+                if (i < kq && k < Kp) {
+                    const float4 wt = *reinterpret_cast<const float4 *>(src + k);
+                    acc[i].x = fmaf(w, wt.x, acc[i].x); acc[i].y = fmaf(w, wt.y, acc[i].y);
+                    acc[i].z = fmaf(w, wt.z, acc[i].z); acc[i].w = fmaf(w, wt.w, acc[i].w);
+                }
+            }
+        }
+        float *dst = addend + (g * slots_per_group + si) * (long long)Kp;
+#pragma unroll
+        for (int i = 0; i < KQ; ++i) {
+            const int k = (i * 16 + q) * 4;
+            if (i < kq && k < Kp) *reinterpret_cast<float4 *>(dst + k) = acc[i];
+        }
+    }
+}
+
+// one workgroup per channel c, its 4 waves take a quarter of the groups each:
+//   Ssp[k][c] = sum_g cf[g][c] X[g S + arg[g][c]][k],  cfsum[c] = sum_g cf[g][c]      (wave partials added in order)
+__global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int S, int C, int Kp,
+                                                               const float *__restrict__ gout,
+                                                               const float *__restrict__ ysel,
+                                                               const unsigned char *__restrict__ arg,
+                                                               const float *__restrict__ sc, const float *__restrict__ sh,
+                                                               const float *__restrict__ p,
+                                                               const float *__restrict__ Yprev,
+                                                               const float *__restrict__ psc, const float *__restrict__ psh,
+                                                               float *__restrict__ Ssp, float *__restrict__ cfsum) {
+    constexpr int KR = 8, U = 8;                                    // Kp <= 64 KR; hit rows in flight
+    __shared__ float red[4][64 * KR + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const float scc = sc[c], shc = sh[c], pc = p[c];
+    const int kr = (Kp + 63) / 64;                                  // registers in use (wave-uniform)
+    float asc[KR], ash[KR], acc[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        const int k = lane + 64 * i;
+        asc[i] = (k < Kp && psc) ? psc[k] : 1.f;
+        ash[i] = (k < Kp && psc) ? psh[k] : 0.f;
+        acc[i] = 0.f;
+    }
+    float csum = 0.f;
+    const long long gq = (G + 3) / 4;
+    const long long gend = (wave + 1) * gq < G ? (wave + 1) * gq : G;
+    for (long long g0 = wave * gq; g0 < gend; g0 += 64) {
+        const long long g = g0 + lane;
+        float cf = 0.f;
+        int row = 0;
+        if (g < gend) {
+            const long long e = g * C + c;
+            cf = fmaf(ysel[e], scc, shc) > 0.f ? pc * gout[e] : 0.f;
+            row = arg[e];
+        }
+        unsigned long long hits = __ballot(cf != 0.f);
+        while (hits) {                                              // wave-uniform: U hit groups at a time
+            float w[U];
+            long long r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                w[u] = 0.f;
+                r[u] = 0;
+                if (hits) {
+                    const int l = __builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cf), l));
+                    r[u] = (g0 + l) * S + __builtin_amdgcn_readlane(row, l);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KR; ++i) {
+                if (i >= kr) break;
+                const int k = lane + 64 * i;
+                float x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = (k < Kp) ? Yprev[r[u] * Kp + k] : 0.f;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float xv = psc ? fmaxf(fmaf(x[u], asc[i], ash[i]), 0.f) : x[u];
+                    acc[i] = fmaf(w[u], xv, acc[i]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) csum += w[u];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KR; ++i) red[wave][lane + 64 * i] = acc[i];
+    if (lane == 0) red[wave][64 * KR] = csum;
+    __syncthreads();
+    for (int k = threadIdx.x; k < Kp; k += 256)
+        Ssp[(long long)k * C + c] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    if (threadIdx.x == 0)
+        cfsum[c] = (red[0][64 * KR] + red[1][64 * KR]) + (red[2][64 * KR] + red[3][64 * KR]);
+}
+
+// C [M][N] = A [M][K] B [K][N] for the SMALL products around the big kernels (weights x weights: K x K Gram algebra,
+// matrix-vector rows).  One 32 x 32 tile per workgroup so that even a 512 x 512 result fills the chip; the 4 waves split
+// K and add their accumulators through LDS in a fixed order.
+__global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
+                                                         const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                                         int ldc) {
+    __shared__ float As[4][32][17], Bs[4][16][33], red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int kchunks = (K + 15) / 16;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    float ra[8], rb[8];
+    auto fetch = [&](int ch) {
+        const int k0 = ch * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            const int r = e >> 4, kk = e & 15;
+            ra[i] = (ch < kchunks && m0 + r < M && k0 + kk < K) ? A[(long long)(m0 + r) * lda + k0 + kk] : 0.f;
+            const int kb = e >> 5, c = e & 31;
+            rb[i] = (ch < kchunks && k0 + kb < K && n0 + c < N) ? B[(long long)(k0 + kb) * ldb + n0 + c] : 0.f;
+        }
+    };
+    fetch(wave);
+    for (int ch = wave; ch < kchunks; ch += 4) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = lane + 64 * i;
+            As[wave][e >> 4][e & 15] = ra[i];
+            Bs[wave][e >> 5][e & 31] = rb[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fetch(ch + 4);                              // the next chunk's loads fly under this chunk's MFMAs
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[wave][lane & 31][2 * st + (lane >> 5)],
+                                                       Bs[wave][2 * st + (lane >> 5)][lane & 31], acc, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) red[wave][(v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)][lane & 31] = acc[v];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        if (m0 + r < M && n0 + c < N)
+            C[(long long)(m0 + r) * ldc + n0 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+    }
+}
 
 // ============================================================================ C ABI
 // wave-stream kernel or nothing (the xyz-form modes have no tiled fallback)
@@ -2691,8 +3004,11 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     // registers per wave) is ahead on the narrow materialised-G shapes
     if (a.blocks && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc)))
         return PCOPS_ERR_UNSUPPORTED;            // compacted rows: producer/consumer kernel only
-    if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc) &&
-        (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks ||
+    const bool self = a.dmode == A_SELFD;
+    if (self && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, true)))
+        return PCOPS_ERR_UNSUPPORTED;            // Gram matrix: producer/consumer kernel only
+    if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, self) &&
+        (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks || self ||
          !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
         splits = pc.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
@@ -2707,7 +3023,9 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     } while (0)
 #define PCOPS_PC_MODES(TK_, TN_)                                                                           \
     do {                                                                                                   \
-        if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW);      \
+        if (a.dmode == A_SELFD && a.amode == A_PLAIN) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_SELFD);         \
+        else if (a.dmode == A_SELFD) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_SELFD);                         \
+        else if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW); \
         else if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYW); \
         else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYW);   \
         else if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);              \
@@ -2829,6 +3147,103 @@ int pcops_mlp_wgrad_xyz_rows(long long M, int K, int N, const float *off4, const
     a.dsc = pool_scale; a.dsh = pool_shift; a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     PCOPS_ROWS(a, rows);
     return wgrad_impl(a, partial, dW, db, as_stream(stream));
+}
+
+/* ---- algebraic backward of a pooled top layer (see pool_top_addend_kernel) */
+static bool dgrad_top_plan(int M, int Kp, WsPlan *pl) {
+    GemmArgs a = {};
+    a.M = M; a.K = Kp; a.N = Kp; a.ldx = Kp; a.ldy = Kp;
+    return ws_enabled() && Kp % 64 == 0 && Kp <= 512 && ws_plan(a, A_BNRELU, pl);
+}
+
+int pcops_mlp_pool_top_supported(int M, int Kp, int N, int S) {
+    WsPlan pl;
+    PcWgradPlan pc;
+    if (S < 1 || S > 256 || M % S != 0 || N % 4 != 0 || N > 1024) return 0;
+    if (!dgrad_top_plan(M, Kp, &pl)) return 0;
+    if (!(wgrad_pc_enabled() && wgrad_pc_plan(M, Kp, Kp, Kp, nullptr, nullptr, nullptr, nullptr, nullptr, &pc, true))) return 0;
+    const long long slots = (long long)(M / S) * (S < N ? S : N);
+    return slots * Kp * 4 < (long long)kOOB ? 1 : 0;
+}
+
+/* compact arg-max rows of the data gradient: addend [(M/S) min(S,N)][Kp], rowmap [M] (slot or -1) */
+int pcops_mlp_pool_top_addend(int M, int Kp, int N, int S, const float *gout, const float *ysel,
+                            const unsigned char *argmax, const float *pool_scale, const float *pool_shift,
+                            const float *p, const float *Wt, float *addend, int *rowmap, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && S >= 1 && S <= 256 && M % S == 0 && Kp % 4 == 0 && N >= 1 && N <= 65535);
+    PCOPS_REQUIRE_PTR(gout); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale);
+    PCOPS_REQUIRE_PTR(pool_shift); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(addend);
+    PCOPS_REQUIRE_PTR(rowmap);
+    if (reinterpret_cast<uintptr_t>(Wt) & 15 || reinterpret_cast<uintptr_t>(addend) & 15) return PCOPS_ERR_UNSUPPORTED;
+    if (N > 1024 || Kp > 512) return PCOPS_ERR_UNSUPPORTED;
+    if (M / S <= 512)
+        hipLaunchKernelGGL(pool_top_addend_kernel<1024>, dim3(M / S), dim3(1024), 0, as_stream(stream), S, N, Kp,
+                           S < N ? S : N, gout, ysel, argmax, pool_scale, pool_shift, p, Wt, addend, rowmap);
+    else
+        hipLaunchKernelGGL(pool_top_addend_kernel<256>, dim3(M / S), dim3(256), 0, as_stream(stream), S, N, Kp,
+                           S < N ? S : N, gout, ysel, argmax, pool_scale, pool_shift, p, Wt, addend, rowmap);
+    return pcops_launch_status();
+}
+
+/* Gprev = mask . (relu(bn(Yprev)) Mq + addend[rowmap] + vconst), statistics as pcops_mlp_gemm_dgrad */
+int pcops_mlp_gemm_dgrad_top(int M, int Kp, const float *Yprev, const float *prev_scale, const float *prev_shift,
+                             const float *Mq, const float *vconst, const float *addend, long long addend_rows,
+                             const int *rowmap, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && Kp >= 1);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(Mq);
+    PCOPS_REQUIRE_PTR(vconst); PCOPS_REQUIRE_PTR(addend); PCOPS_REQUIRE_PTR(rowmap); PCOPS_REQUIRE_PTR(Gprev);
+    PCOPS_REQUIRE_ARG((prev_scale == nullptr) == (prev_shift == nullptr));
+    WsPlan pl;
+    if (!dgrad_top_plan(M, Kp, &pl)) return PCOPS_ERR_UNSUPPORTED;
+    GemmArgs a = {};
+    a.M = M; a.K = Kp; a.N = Kp; a.X = Yprev; a.ldx = Kp; a.v0 = prev_scale; a.v1 = prev_shift;
+    a.W = Mq; a.Y = Gprev; a.ldy = Kp; a.Yprev = Yprev; a.msc = prev_scale; a.msh = prev_shift;
+    a.stats = stats_partial; a.addend = addend; a.rowmap = rowmap; a.add_ld = Kp; a.vconst = vconst;
+    a.add_bytes = addend_rows * Kp * 4;
+    if (addend_rows < 1 || a.add_bytes >= (long long)kOOB) return PCOPS_ERR_UNSUPPORTED;
+    if (!prev_scale) {      // X is the stack's raw input: plain dX, no mask, no statistics
+        a.stats = nullptr;
+        return launch_gemm_ws_only<A_PLAIN, E_PLAINA>(a, as_stream(stream));
+    }
+    return launch_gemm_ws_only<A_BNRELU, E_MASKA>(a, as_stream(stream));
+}
+
+/* gram [Kp][Kp] = X^T X, xsum [Kp] = X^T 1 with X = relu(Yprev * a_scale + a_shift);  partial as pcops_mlp_wgrad
+ * (pcops_mlp_wgrad_splits(M, Kp, Kp) copies) */
+int pcops_mlp_gram(long long M, int Kp, const float *Yprev, int ldx, const float *a_scale, const float *a_shift,
+                   float *partial, float *gram, float *xsum, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && Kp >= 1 && ldx >= Kp);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(gram);
+    PCOPS_REQUIRE_ARG((a_scale == nullptr) == (a_shift == nullptr));
+    WgradArgs a = {};
+    a.M = M; a.K = Kp; a.N = Kp;
+    a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = Yprev; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = A_SELFD; a.G = Yprev; a.Y = Yprev; a.ldy = ldx; a.p = a_scale; a.q = a_scale; a.t = a_shift; a.S = 1;
+    return wgrad_impl(a, partial, gram, xsum, as_stream(stream));
+}
+
+/* Ssp [Kp][N] = X^T (p.G) (the arg-max rows only), cfsum [N] = column sums of p.G */
+int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, const float *ysel,
+                               const unsigned char *argmax, const float *pool_scale, const float *pool_shift,
+                               const float *p, const float *Yprev, const float *prev_scale, const float *prev_shift,
+                               float *Ssp, float *cfsum, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && S >= 1 && S <= 256 && M % S == 0 && Kp >= 1 && Kp <= 512 && N >= 1);
+    PCOPS_REQUIRE_PTR(gout); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(pool_scale);
+    PCOPS_REQUIRE_PTR(pool_shift); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(Yprev);
+    PCOPS_REQUIRE_ARG((prev_scale == nullptr) == (prev_shift == nullptr));
+    PCOPS_REQUIRE_PTR(Ssp); PCOPS_REQUIRE_PTR(cfsum);
+    hipLaunchKernelGGL(pool_top_wsparse_kernel, dim3(N), dim3(256), 0, as_stream(stream), (long long)(M / S), S, N,
+                       Kp, gout, ysel, argmax, pool_scale, pool_shift, p, Yprev, prev_scale, prev_shift, Ssp, cfsum);
+    return pcops_launch_status();
+}
+
+int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                     pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && lda >= K && ldb >= N && ldc >= N);
+    PCOPS_REQUIRE_PTR(A); PCOPS_REQUIRE_PTR(B); PCOPS_REQUIRE_PTR(C);
+    hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), M, K, N, A,
+                       lda, B, ldb, C, ldc);
+    return pcops_launch_status();
 }
 
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream) {

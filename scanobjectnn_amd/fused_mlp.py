@@ -198,6 +198,7 @@ class FusedMLPStack(torch.autograd.Function):
         if training or need_grad:
             ctx.saved = (a0, ctr, idx, xyz, new_xyz, wxyz, bias, Ys, means, rstds, scales, shifts, Ws,
                          [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
+            ctx.biases = [l[1] for l in layers]
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
             ctx.rows = rows
         return out
@@ -298,6 +299,18 @@ class FusedMLPStack(torch.autograd.Function):
 
             K = Ws[l].shape[0]
             xyz_prev = virt and l == 1          # the layer below is the arithmetic first layer (never stored)
+            if (pooled and POOL_TOP and rows is None and not xyz_prev and S >= 64 and N >= 2 * K
+                    and (l > 0 or (not gather and K0 == K)) and ctx.biases[l] is not None
+                    and lib.pcops_mlp_pool_top_supported(R, K, N, S)):
+                # algebraic form (pcops.h "algebraic backward of a pooled top layer"): K x K products instead of K x N
+                prev = (Ys[l - 1], scales[l - 1], shifts[l - 1]) if l > 0 else (a0, None, None)
+                Gm, part = _pool_top_backward(R, K, N, S, Ws[l], ctx.biases[l].detach(), p, q, t, grad_out, ysel,
+                                              argmax, scales[l], shifts[l], prev[0], prev[1], prev[2], grads, l, dev,
+                                              l > 0 or ctx.needs_input_grad[0])
+                P = lib.pcops_mlp_stats_rows(R)
+                if l == 0:
+                    d0 = Gm
+                continue
             if l == 0:
                 src, ld, asc, ash = a0, K0, None, None
             elif not xyz_prev:
@@ -347,6 +360,47 @@ class FusedMLPStack(torch.autograd.Function):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
         return tuple(out)
+
+
+def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh, Yprev, psc, psh, grads, l, dev,
+                       need_dx=True):
+    """dW, db (into grads) and the masked data gradient + its statistics of a pooled top layer, from the Kp x Kp
+    products of pcops.h's algebraic form.  Returns (Gprev, stats_partial)."""
+    lib = _lib.load()
+    Wt = _f32((N, K), dev)
+    _lib.call("pcops_mlp_transpose", K, N, W.data_ptr(), Wt.data_ptr())
+    Wq = W * q[:N]                                  # W diag(q)
+    u = torch.addcmul(t[:N], q[:N], b)              # q.b + t
+    Gprev = part = None
+    if need_dx:
+        Mq, v = _f32((K, K), dev), _f32(K, dev)
+        _lib.call("pcops_small_gemm", K, N, K, Wq.data_ptr(), N, Wt.data_ptr(), K, Mq.data_ptr(), K)
+        _lib.call("pcops_small_gemm", 1, N, K, u.data_ptr(), N, Wt.data_ptr(), K, v.data_ptr(), K)
+        G = R // S
+        addend = _f32((G * min(S, N), K), dev)
+        rowmap = torch.empty(R, dtype=torch.int32, device=dev)
+        _lib.call("pcops_mlp_pool_top_addend", R, K, N, S, grad_out.data_ptr(), ysel.data_ptr(), argmax.data_ptr(),
+                  sc.data_ptr(), sh.data_ptr(), p.data_ptr(), Wt.data_ptr(), addend.data_ptr(), rowmap.data_ptr())
+        Gprev = _f32((R, K), dev)
+        part = _f32((lib.pcops_mlp_stats_rows(R), 2, K), dev) if psc is not None else None
+        _lib.call("pcops_mlp_gemm_dgrad_top", R, K, Yprev.data_ptr(), _p(psc), _p(psh), Mq.data_ptr(),
+                  v.data_ptr(), addend.data_ptr(), addend.shape[0], rowmap.data_ptr(), Gprev.data_ptr(), _p(part))
+    # weight gradient
+    splits = lib.pcops_mlp_wgrad_splits(R, K, K)
+    scratch = _f32(splits * (K * K + K), dev)
+    gram, xsum = _f32((K, K), dev), _f32(K, dev)
+    _lib.call("pcops_mlp_gram", R, K, Yprev.data_ptr(), K, _p(psc), _p(psh), scratch.data_ptr(),
+              gram.data_ptr(), xsum.data_ptr())
+    Ssp, cfsum = _f32((K, N), dev), _f32(N, dev)
+    _lib.call("pcops_mlp_pool_top_wsparse", R, K, N, S, grad_out.data_ptr(), ysel.data_ptr(), argmax.data_ptr(),
+              sc.data_ptr(), sh.data_ptr(), p.data_ptr(), Yprev.data_ptr(), _p(psc), _p(psh),
+              Ssp.data_ptr(), cfsum.data_ptr())
+    dW, xw = _f32((K, N), dev), _f32(N, dev)
+    _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW.data_ptr(), N)
+    _lib.call("pcops_small_gemm", 1, K, N, xsum.data_ptr(), K, W.data_ptr(), N, xw.data_ptr(), N)
+    grads[6 * l + 0] = torch.addr(dW.add_(Ssp), xsum, u)
+    grads[6 * l + 1] = cfsum + q[:N] * (xw + float(R) * b) + float(R) * t[:N]
+    return Gprev, part
 
 
 class _RowsLinear(torch.autograd.Function):
@@ -514,6 +568,7 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
 
 
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
+POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 
 
