@@ -158,10 +158,15 @@ class KernelTimer:
     stream: `_lib.call` passes torch.cuda.current_stream() to the C ABI, and torch.cuda.Event.record()
     records on that same stream)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []     # (name, args, start_event, end_event)
         self._open = None
         self._rows = {}       # id -> _lib.Rows of the compacted stacks seen (kept alive until the summary)
+        # only = (kernel, shape) of ONE table row: nothing else is bracketed (two event records per launch of ~160
+        # launches cost ~0.4 ms of a 13 ms step; the timed region only carries the dominant kernel's events)
+        self.only = None
+        if only is not None:
+            self.only = (only[0], tuple(x for x in only[1] if x != "compacted"))
 
     def _rows_computed(self, rows):
         """rows a compacted stack really computed (a 4-byte device -> host copy, after the timed region)"""
@@ -191,6 +196,10 @@ class KernelTimer:
                 if owner is not None:
                     self._rows[id(owner)] = owner           # kept alive until the summary reads its row count
                     args = args + (("rows", id(owner)),)
+        if self.only is not None:
+            n = _NSHAPE.get(name, 3)
+            if name != self.only[0] or tuple(args[:n]) != self.only[1][:n]:
+                return
         if phase == "pre":
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -495,7 +504,7 @@ def main():
         with torch.no_grad():
             return net(inputs["x"], is_training=False)
 
-    def measure(step, steps, warmup, with_kernels):
+    def measure(step, steps, warmup, with_kernels, only=None):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
         for _ in range(warmup):
             step()
@@ -503,7 +512,7 @@ def main():
         # region (tens of ms with the autograd graphs of a step alive) would let the device queue run dry
         gc.collect()
         gc.disable()
-        timer = KernelTimer() if with_kernels else None
+        timer = KernelTimer(only) if with_kernels else None
         if timer:
             _lib._hooks.append(timer)
         del ar_events[:]
@@ -523,7 +532,13 @@ def main():
         return D.max_over_ranks(elapsed, dev), local_elapsed, host_elapsed, (timer.summary() if timer else [])
 
     step = fwd_step if args.forward_only else train_step
-    elapsed, local_elapsed, host_elapsed, kernels = measure(step, args.steps, args.warmup, True)
+    # pass 1 (not the metric): every libpcops launch bracketed by HIP events -> the per-kernel table, and which kernel
+    # dominates.  pass 2 (the metric): W warm-up + exactly K timed steps in which only the DOMINANT kernel's launches
+    # carry events -- its duration is measured live inside the timed region, the other ~160 launches run unbracketed.
+    profile_steps = max(3, min(10, args.steps))
+    _, _, _, kernels = measure(step, profile_steps, args.warmup, True)
+    dom_key = (kernels[0]["kernel"], kernels[0]["shape"]) if kernels else None
+    elapsed, local_elapsed, host_elapsed, dom_live = measure(step, args.steps, args.warmup, dom_key is not None, dom_key)
     ar_ms = [a.elapsed_time(b) for a, b in ar_events]
     per_rank = D.gather_floats(B * args.steps / local_elapsed, dev)      # every rank's own clouds/s
     ar_all = D.gather_floats(sum(ar_ms) / max(len(ar_ms), 1), dev)
@@ -563,7 +578,10 @@ def main():
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
         d["mfma_frac"] = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
         d["bound_frac"] = max(d["hbm_frac"], d["mfma_frac"])
-    dom = kernels[0] if kernels else None
+    for d in dom_live:
+        d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
+        d["mfma_frac"] = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
+    dom = dom_live[0] if dom_live else (kernels[0] if kernels else None)      # measured inside the timed region
     roofline = None
     if dom is not None:
         # the binding roofline of the dominant kernel = the one it sits closer to: HBM for the streaming
@@ -602,6 +620,9 @@ def main():
         "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,
         "allreduce_share_of_step": (max(ar_all) / (elapsed / args.steps * 1e3)) if world > 1 else 0.0,
         "roofline": roofline,
+        "kernels_steps": profile_steps,
+        "kernels_pass": "separate untimed pass of %d steps with every launch bracketed by HIP events; the timed region "
+                        "brackets the dominant kernel only (roofline)" % profile_steps,
         "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit",
                                         "hbm_frac", "mfma_frac", "bound_frac")} for d in kernels[:24]],
     }

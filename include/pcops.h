@@ -184,7 +184,10 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
  *   ysel[g,c] = max_s y (gamma[c] >= 0) | min_s y (gamma[c] < 0),  argsel[g,c] = first row attaining it (8 bit)
  * and, once scale/shift are known, pcops_mlp_pool_select gives out = relu(scale*ysel + shift) without re-reading
  * Y.  S % 32 == 0, S <= 256, M % S == 0, ldx == K; PCOPS_ERR_UNSUPPORTED when the shape is outside what
- * pcops_mlp_gemm_fwd_pool_supported(M,K,N,S) accepts. */
+ * pcops_mlp_gemm_fwd_pool_supported(M,K,N,S) accepts.
+ * pro_scale == pro_shift == NULL: X is the stack's raw input.  Y == NULL: the activation is not stored at all (it then
+ * only exists as statistics and group extrema) -- enough for a forward without backward and for the algebraic backward
+ * of a pooled top layer below. */
 int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S);
 int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx, const float *pro_scale,
                             const float *pro_shift, const float *W, const float *bias, const float *gamma,

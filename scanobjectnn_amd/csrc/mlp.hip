@@ -887,7 +887,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         }
                     }
                 }
-                if (EM != E_MASKX || a.Y)
+                // (a pooled forward whose backward is algebraic, or that has no backward, passes Y == NULL: the
+                // activation only exists as statistics and group extrema)
+                if ((EM != E_MASKX && !(EM == E_FWD && POOL)) || a.Y)
                     buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
                 if (POOL && compact && O4 == 16 && (j & 3) == 3) {
                     // compacted rows: a 16-row block (rows 4 (j-3) .. 4 j + 3 of the tile) lies inside ONE group -- its
@@ -2632,8 +2634,9 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
                             float *Y, float *stats_partial, float *ysel, unsigned char *argsel,
                             pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K && S >= 1);
-    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(pro_scale);
-    PCOPS_REQUIRE_PTR(pro_shift); PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(argsel);
+    PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W);
+    PCOPS_REQUIRE_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
+    PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(argsel);
     if (!fwd_pool_shape_ok(M, K, N, S) || ldx != K) return PCOPS_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(ysel) & 15) || (reinterpret_cast<uintptr_t>(argsel) & 3))
         return PCOPS_ERR_UNSUPPORTED;
@@ -2643,6 +2646,7 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
     a.pool_sub = S / 32; a.pgamma = gamma; a.ysel = ysel; a.psel = argsel;
     WsPlan pl;
     if (!ws_plan(a, A_BNRELU, &pl)) return PCOPS_ERR_UNSUPPORTED;   // pointer alignment
+    if (!pro_scale) return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));      // the stack's raw input
     return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
 }
 

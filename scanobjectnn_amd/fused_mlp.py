@@ -132,13 +132,18 @@ class FusedMLPStack(torch.autograd.Function):
                     # compacted rows without the fused epilogue: the max over the groups is its own pass below
                     _lib.call("pcops_mlp_gemm_fwd_rows", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
                               W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
-                elif (pool and li == L - 1 and sc_prev is not None and ld == K
-                        and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)):
-                    # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics)
+                elif (pool and li == L - 1 and ld == K and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)
+                        and (sc_prev is not None or li == 0)):
+                    # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics).
+                    # The activation itself is only stored when a backward will read it: not for a forward without
+                    # gradient, not when the layer takes the algebraic backward
                     G = R // S
                     pooled_raw = (_f32((G, N), dev), torch.empty((G, N), dtype=torch.uint8, device=dev))
-                    _lib.call("pcops_mlp_gemm_fwd_pool", R, K, N, S, src.data_ptr(), ld, sc_prev.data_ptr(),
-                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), Y.data_ptr(),
+                    if not need_grad or _pool_top_ok(lib, R, K, N, S, li, gather, K0, rows, virt and li == 1,
+                                                     b is not None):
+                        Y = None
+                    _lib.call("pcops_mlp_gemm_fwd_pool", R, K, N, S, src.data_ptr(), ld, _p(sc_prev),
+                              _p(sh_prev), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), _p(Y),
                               _p(part), pooled_raw[0].data_ptr(), pooled_raw[1].data_ptr())
                 else:
                     _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
@@ -220,7 +225,7 @@ class FusedMLPStack(torch.autograd.Function):
         d0 = d1 = dwxyz = dbias = None
 
         # ---- top of the stack: statistics of the masked upstream gradient
-        C = Ys[-1].shape[1]
+        C = widths[-1]
         ws = _workspace(max(widths), dev)
         vecs = _VecArena(widths, 3, dev)
         if pool:
@@ -299,9 +304,7 @@ class FusedMLPStack(torch.autograd.Function):
 
             K = Ws[l].shape[0]
             xyz_prev = virt and l == 1          # the layer below is the arithmetic first layer (never stored)
-            if (pooled and POOL_TOP and rows is None and not xyz_prev and S >= 64 and N >= 2 * K
-                    and (l > 0 or (not gather and K0 == K)) and ctx.biases[l] is not None
-                    and lib.pcops_mlp_pool_top_supported(R, K, N, S)):
+            if pooled and _pool_top_ok(lib, R, K, N, S, l, gather, K0, rows, xyz_prev, ctx.biases[l] is not None):
                 # algebraic form (pcops.h "algebraic backward of a pooled top layer"): K x K products instead of K x N
                 prev = (Ys[l - 1], scales[l - 1], shifts[l - 1]) if l > 0 else (a0, None, None)
                 Gm, part = _pool_top_backward(R, K, N, S, Ws[l], ctx.biases[l].detach(), p, q, t, grad_out, ysel,
@@ -360,6 +363,13 @@ class FusedMLPStack(torch.autograd.Function):
             out.extend(grads[6 * i:6 * i + 4])
             out.extend([None, None])
         return tuple(out)
+
+
+def _pool_top_ok(lib, R, K, N, S, l, gather, K0, rows, xyz_prev, has_bias):
+    """the pooled top layer l takes the algebraic backward (pcops.h): K x K products instead of K x N, no use of Y"""
+    return bool(POOL_TOP and rows is None and not xyz_prev and S >= 64 and N >= 2 * K
+                and (l > 0 or (not gather and K0 == K)) and has_bias
+                and lib.pcops_mlp_pool_top_supported(R, K, N, S))
 
 
 def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh, Yprev, psc, psh, grads, l, dev,
