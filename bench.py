@@ -107,6 +107,22 @@ def _algo(name, a):
     if name == "pcops_mlp_wgrad":             # dW[K,N] = A[M,K]^T dY[M,N]; reads X, G?, Y
         M, K, N = a[:3]
         return 4 * (M * K + (1 if a[7] is None else 2) * M * N), 2 * M * K * N, "flop"
+    # ---- algebraic backward of a pooled top layer (pcops.h): K x K products + the arg-max rows
+    if name == "pcops_mlp_gemm_dgrad_top":    # Gprev[M,Kp] = mask . (X Mq + addend rows + v): reads X, writes Gprev
+        M, Kp = a[:2]
+        return 4 * (2 * M * Kp), 2 * M * Kp * Kp, "flop"
+    if name == "pcops_mlp_gram":              # X^T X: one pass over X
+        M, Kp = a[:2]
+        return 4 * M * Kp, 2 * M * Kp * Kp, "flop"
+    if name == "pcops_mlp_pool_top_addend":   # per (group, channel) 9 bytes in, a Kp-wide weight row through L2, compact rows out
+        M, Kp, N, S = a[:4]
+        return (M // S) * N * 9 + 4 * (M // S) * min(S, N) * Kp + 4 * M, 2 * (M // S) * N * Kp, "flop(VALU)"
+    if name == "pcops_mlp_pool_top_wsparse":  # per (group, channel) 9 bytes in + a Kp-wide activation row
+        M, Kp, N, S = a[:4]
+        return (M // S) * N * (9 + 4 * Kp), 2 * (M // S) * N * Kp, "flop(VALU)"
+    if name == "pcops_small_gemm":
+        M, K, N = a[:3]
+        return 4 * (M * K + K * N + M * N), 2 * M * K * N, "flop"
     if name == "pcops_mlp_bn_relu_maxpool":
         G, S, C = a[:3]
         return 4 * G * S * C + 5 * G * C, 0, ""
@@ -150,7 +166,9 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_mlp_transpose": 2, "pcops_mlp_bn_eval_coeffs": 1, "pcops_mlp_gemm_fwd_pool": 4,
            "pcops_mlp_pool_select": 2, "pcops_mlp_pool_bwd_stats": 2, "pcops_xyz_first_layer_grads": 1,
            "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2,
-           "pcops_mlp_bn_relu_maxpool_rows": 2, "pcops_mlp_pool_combine_rows": 2}
+           "pcops_mlp_bn_relu_maxpool_rows": 2, "pcops_mlp_pool_combine_rows": 2,
+           "pcops_mlp_gemm_dgrad_top": 2, "pcops_mlp_gram": 2, "pcops_mlp_pool_top_addend": 4,
+           "pcops_mlp_pool_top_wsparse": 4, "pcops_scatter_rows_sorted": 5, "pcops_edge_feature_grad_central": 4}
 
 
 class KernelTimer:

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- bash tools/collect_round.sh): everything DESIGN.md section 5 cites for a round --
+# bench lines of the five models, rocprofv3 kernel-trace stats of the SSG and DGCNN steps, PMC traffic / MFMA passes.
+# Results under gpurun_out/round/ ; copy the summaries into profiles/ (rNN_*) afterwards.
+set -u
+cd "$(dirname "$0")/.."
+R=gpurun_out/round; rm -rf $R; mkdir -p $R
+export TMPDIR=/tmp
+python bench.py > $R/bench_ssg.json 2> $R/bench_ssg.err
+for m in pointnet2_cls_bga pointnet2_cls_msg dgcnn dgcnn_bga; do
+  python bench.py --model $m --no-cpu-baseline --steps 20 --warmup 5 > $R/bench_$m.json 2> $R/bench_$m.err
+done
+python bench.py --deterministic --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $R/bench_ssg_det.json 2>/dev/null
+python bench.py --model dgcnn --deterministic --no-cpu-baseline --no-extras --steps 10 --warmup 3 > $R/bench_dgcnn_det.json 2>/dev/null
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/$R/kt_ssg -o p --output-format csv -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OLDPWD/$R/kt_ssg.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/$R/kt_dgcnn -o p --output-format csv -- python $OLDPWD/bench.py --model dgcnn --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OLDPWD/$R/kt_dgcnn.json 2>/dev/null )
+# per (kernel, grid) averages from the raw trace: one template instantiation serves several shapes, the stats CSV lumps them
+python - "$R" <<'PY'
+import collections, csv, glob, sys
+for d in ("kt_ssg", "kt_dgcnn"):
+    agg = collections.defaultdict(list)
+    for f in glob.glob("%s/%s/**/*kernel_trace.csv" % (sys.argv[1], d), recursive=True):
+        for r in csv.DictReader(open(f)):
+            grid = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+            agg[(r["Kernel_Name"], grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open("%s/%s_by_grid.csv" % (sys.argv[1], d), "w") as out:
+        w = csv.writer(out)
+        w.writerow(["Name", "GridSize", "Calls", "TotalDurationNs", "AverageNs"])
+        for (n, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([n, g, len(v), sum(v), sum(v) / len(v)])
+PY
+find $R -name "*kernel_trace.csv" -delete; find $R -name "*agent_info.csv" -delete
+python tools/collect_traffic.py > $R/traffic.log 2>&1
+python tools/collect_traffic.py --mfma > $R/mfma.log 2>&1
+cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_detail.json gpurun_out/pmc_mfma.json $R/ 2>/dev/null
+ls -la $R

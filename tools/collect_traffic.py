@@ -25,11 +25,12 @@ KEYS = [
     # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
     ("gemm_ws_kernel<4, 6, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
     ("wgrad_pc_kernel<2, 4, 1, 6>", None, "pcops_mlp_wgrad(2097152, 128, 256, 'compacted')"),
-    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),   # + per-block pooling
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", 512 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 2, 1, 64, 8, 2, 0>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128, 'compacted')"),
     ("wgrad_pc_kernel<2, 2, 1, 7>", None, "pcops_mlp_wgrad(2097152, 128, 128, 'compacted')"),
-    ("bn_relu_maxpool_rows_kernel", None, "pcops_mlp_bn_relu_maxpool_rows(32768, 256, 'compacted')"),
+    ("gemm_ws_kernel<4, 1, 4, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad_top(32768, 512)"),
+    ("wgrad_pc_kernel<2, 4, 1, 8>", None, "pcops_mlp_gram(32768, 512)"),
     ("sa_scatter_csr_kernel<32, false, 64>", None, "pcops_sa_scatter_bwd(256, 512, 128, 64, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
     ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),
@@ -91,6 +92,16 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--mfma" in sys.argv:
         return mfma_pass()
+    if "--from-detail" in sys.argv:         # re-key an existing per-(kernel, grid) table with the current KEYS (no GPU)
+        detail = json.load(open(sys.argv[sys.argv.index("--from-detail") + 1]))
+        table = {}
+        for k, v in sorted(detail.items(), key=lambda kv: -kv[1]["bytes_per_launch"]):
+            name, grid = k.rsplit("|grid=", 1)
+            for frag, g, key in KEYS:
+                if frag in name and (g is None or g == int(grid)) and key not in table:
+                    table[key] = v["bytes_per_launch"]
+        json.dump(table, sys.stdout, indent=1)
+        return
     fetch, nf = one_pass("FETCH_SIZE")
     write, _ = one_pass("WRITE_SIZE")
     table, detail = {}, {}
