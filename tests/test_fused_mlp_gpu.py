@@ -61,6 +61,10 @@ CASES = [  # (R, S, K0, widths, pool)
     # K > 256: weights streamed through LDS in 64-row chunks (one workgroup barrier per chunk)
     (256 * 128, 128, 260, [256, 512, 1024], True),  # SA3 of the SSG config at B=256 (pooled 1024-wide last layer)
     (33000, 1, 320, [1024, 64], False),            # DGCNN aggregation shapes, ragged tail, N=64 behind K=1024
+    # one-layer stacks pooled over 256-row chunks (DGCNN agg / T-Net tconv3): pooled forward on the raw input without
+    # storing Y, algebraic backward with the plain-input variants (A_PLAIN operand, E_PLAINA epilogue, plain Gram)
+    (64 * 256, 256, 320, [1024], True),
+    (48 * 256, 256, 128, [1024], True),
 ]
 
 
@@ -166,6 +170,56 @@ def test_fused_model_as_accurate_as_layerwise(monkeypatch):
 
 
 # ---------------------------------------------------------------------------- gather-first stacks
+@pytest.mark.parametrize("R,S,K0,widths", [(64 * 256, 256, 320, [1024]), (256 * 128, 128, 260, [256, 512, 1024]),
+                                           (128 * 64 * 4, 64, 132, [128, 128, 256])])
+def test_pool_top_backward_is_taken_and_equals_the_plain_form(R, S, K0, widths, monkeypatch):
+    """the algebraic backward of a pooled top layer (pcops.h; fused_mlp._pool_top_backward) runs for these shapes --
+    its entry points are seen on the call hook, the pooled forward stores no Y -- and gives the gradients of the plain
+    dgrad / wgrad kernels to fp32 rounding (the two forms differ in summation order only)"""
+    from scanobjectnn_amd import _lib
+    g = torch.Generator().manual_seed(R)
+    x0 = torch.randn(R, K0, generator=g).to(DEV)
+    go = None
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(fused_mlp, "POOL_TOP", mode)
+        x = x0.clone().requires_grad_(True)
+        layers = make_layers(K0, widths, seed=5)
+        for l in layers:
+            for t in l[:4]:
+                t.requires_grad_(True)
+        names = []
+
+        def hook(name, phase, args):
+            if phase == "pre":
+                names.append((name, args))
+        _lib._hooks.append(hook)
+        try:
+            out = fused_mlp.mlp_stack(x, S, True, True, 0.9, EPS, True, [tuple(l) for l in layers])
+            if go is None:
+                go = torch.randn(out.shape, generator=g).to(DEV)
+            out.backward(go)
+        finally:
+            _lib._hooks.remove(hook)
+        called = [n for n, _ in names]
+        if mode:
+            for want in ("pcops_mlp_gemm_dgrad_top", "pcops_mlp_gram", "pcops_mlp_pool_top_addend",
+                         "pcops_mlp_pool_top_wsparse"):
+                assert want in called, called
+            pooled = [a for n, a in names if n == "pcops_mlp_gemm_fwd_pool"]
+            assert pooled and pooled[-1][11] is None          # Y: not stored
+        else:
+            assert "pcops_mlp_gemm_dgrad_top" not in called
+        res[mode] = [out.detach().clone(), x.grad.clone()] + [t.grad.clone() for l in layers for t in l[:4]]
+    assert torch.equal(res[True][0], res[False][0])           # same forward kernel, with and without the Y store
+    names = ["dx"] + ["L%d.%s" % (i, n) for i in range(len(widths)) for n in ("dW", "db", "dgamma", "dbeta")]
+    for name, a, b in zip(names, res[True][1:], res[False][1:]):
+        # the gradient of a bias in front of a batch norm is zero in exact arithmetic: both forms return rounding
+        # noise there, judged on the scale of the upstream gradient instead of its own
+        scale = go.abs().max().item() if name.endswith(".db") else b.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (a - b).abs().max().item(), scale)
+
+
 GATHER_CASES = [  # (B, N, M, S, widths, pool)
     (4, 256, 64, 32, [64, 64, 128], True),      # SA1-like
     (3, 100, 37, 16, [128, 128, 256], True),    # SA2-like, ragged group count
