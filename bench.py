@@ -414,12 +414,18 @@ def cpu_ops_baseline(seconds_budget=6.0):
             "note": "sharded = one thread per cloud shard (the C functions run outside the GIL); reference bench sizes"}
 
 
+def _shared_gpu_debug():
+    """PCOPS_BENCH_SHARED_GPU=1: every rank on cuda:0 over gloo -- exercises the N > 1 control flow (barriers, gathers,
+    the two measurement passes) on a one-GPU box.  The line is tagged `shared_gpu_debug`; its value means nothing."""
+    return os.environ.get("PCOPS_BENCH_SHARED_GPU", "0") == "1"
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` with no rank environment: start the N ranks through torch.distributed.run."""
     import socket
     import subprocess
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
+    if ndev < args.gpus and not _shared_gpu_debug():
         raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) are visible" % (args.gpus, ndev))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -454,7 +460,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env("gloo" if _shared_gpu_debug() else None)
+    if _shared_gpu_debug():
+        local = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE=%s); refusing to "
                          "report a number for a different world size" % (args.gpus, world, os.environ.get("WORLD_SIZE")))
@@ -632,7 +640,8 @@ def main():
                                "train step = %sfwd+bwd+allreduce+Adam"
                                % (args.model, args.kind, N, B, "rotate+jitter+" if args.augment else ""),
                    "global_batch": global_batch, "num_point": N, "parallelism": "dp%d" % world,
-                   "sync_bn": bool(D.SYNC_BN), "deterministic": bool(args.deterministic)},
+                   "sync_bn": bool(D.SYNC_BN), "deterministic": bool(args.deterministic),
+                   **({"shared_gpu_debug": True} if _shared_gpu_debug() else {})},
         "rccl_ranks": rccl_ranks,
         "per_rank_clouds_per_s": per_rank,
         "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,
