@@ -1,0 +1,126 @@
+"""Data parallelism THROUGH THE HIP KERNELS: two ranks share the one GPU of the test box (gloo; RCCL refuses two ranks
+on one device), each takes half of the clouds, and with SyncBN the all-reduced gradient of the fused stacks must be the
+single-process gradient of the whole batch -- this is the only place where `dist.allreduce_stat_partials` inside
+`FusedMLPStack` / `EdgeConvPool` (forward statistics, backward p/q/t from global sums, rank-local dgamma/dbeta) meets
+the real kernels.  Without SyncBN: per-rank BN statistics, gradient = mean of the two per-shard gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, N = 8, 512
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _build(name):
+    from scanobjectnn_amd.dgcnn import dgcnn
+    from scanobjectnn_amd.graph import Model
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg
+    from scanobjectnn_amd.synth import synth_clouds, synth_labels
+    mod = {"ssg": pointnet2_cls_ssg, "dgcnn": dgcnn}[name]
+    x = torch.from_numpy(synth_clouds(B, N, seed=3)).to(DEV)
+    y = torch.from_numpy(synth_labels(B, seed=3)).to(DEV)
+    net = Model(mod.get_model, device=DEV, seed=0).build(x[:2].contiguous())
+    return mod, net, x, y
+
+
+def _grads(mod, net, x, y):
+    net.zero_grad(set_to_none=True)
+    torch.manual_seed(5)
+    out = net(x, is_training=True, bn_decay=0.9)
+    mod.get_loss(out[0], y).backward()
+    return torch.cat([p.grad.reshape(-1) for _, p in sorted(net.named_parameters()) if p.grad is not None])
+
+
+def _worker(rank, world, port, name, sync, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from scanobjectnn_amd import dist as D
+    D.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    D.SYNC_BN = sync
+    mod, net, x, y = _build(name)
+    import torch.nn.functional as F
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x      # per-rank masks would not add up to one process's
+    lo, hi = D.shard_range(B, rank, world)
+    g = _grads(mod, net, x[lo:hi].contiguous(), y[lo:hi].contiguous())
+    dist.all_reduce(g)
+    g /= world
+    bufs = torch.cat([v.reshape(-1).float() for k, v in sorted(net.state_dict().items()) if "moving" in k or "pop_" in k])
+    q.put((rank, g.cpu().tolist(), bufs.cpu().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ranks(name, sync):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, sync, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return [(torch.tensor(g), torch.tensor(b)) for _, g, b in res]
+
+
+def _no_dropout(monkeypatch):
+    import torch.nn.functional as F
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+
+
+@pytest.mark.parametrize("name", ["ssg", "dgcnn"])
+def test_sync_bn_two_ranks_equal_one_process_on_the_whole_batch(name, monkeypatch):
+    res = _run_ranks(name, True)
+    _no_dropout(monkeypatch)
+    mod, net, x, y = _build(name)
+    want = _grads(mod, net, x, y).cpu()
+    wbufs = torch.cat([v.reshape(-1).float() for k, v in sorted(net.state_dict().items())
+                       if "moving" in k or "pop_" in k]).cpu()
+    assert torch.equal(res[0][0], res[1][0])
+    err = (res[0][0] - want).norm().item() / want.norm().item()
+    # ssg: ReLU flips between two fp32 evaluations.  dgcnn: its later EdgeConv layers build their
+    # kNN graph on learned features, a neighbour that changes on a near-tie moves those layers' gradients by ~2 %
+    # (measured: dgcnn1 and the T-Net, whose graphs are on xyz, agree to 1e-3; dgcnn2-4 differ by 2e-2)
+    gtol, btol = {"ssg": (2e-3, 1e-4), "dgcnn": (5e-2, 5e-3)}[name]
+    assert err <= gtol, err
+    assert torch.allclose(res[0][1], wbufs, rtol=btol, atol=1e-5)      # moving statistics of the GLOBAL batch
+    assert torch.allclose(res[1][1], wbufs, rtol=btol, atol=1e-5)
+
+
+def test_without_sync_bn_the_ranks_keep_their_own_statistics():
+    """default mode: per-rank BN statistics (the reference has no multi-GPU code) -- the all-reduced
+    gradient is the mean of the two per-shard gradients, each computed with its shard's statistics"""
+    res = _run_ranks("ssg", False)
+    import torch.nn.functional as F
+    F_dropout = F.dropout
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    try:
+        mod, net, x, y = _build("ssg")
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        halves = []
+        for lo, hi in ((0, B // 2), (B // 2, B)):
+            net.load_state_dict(sd)
+            halves.append(_grads(mod, net, x[lo:hi].contiguous(), y[lo:hi].contiguous()).cpu())
+    finally:
+        F.dropout = F_dropout
+    want = 0.5 * (halves[0] + halves[1])
+    assert torch.equal(res[0][0], res[1][0])
+    assert (res[0][0] - want).norm().item() / want.norm().item() <= 2e-3
+    assert not torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-6)     # different shards, different statistics
