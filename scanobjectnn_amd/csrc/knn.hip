@@ -161,7 +161,8 @@ struct TopK {
 // (Round 2 also tried pipelining the tiles INSIDE a wave -- the MFMA chain of tile t+1 issued two at a time between
 // the selection instructions of tile t, fragments preloaded a group ahead, branch-free pushes: 2482 vs 2505 us on 64
 // channels, 1090 vs 937 us on 3.  Per SIMD the time is close to (VALU + SALU + LDS instructions) x ~4.5 cycles PLUS the
-// MFMA time -- 765 instructions per 32 x 32 tile -- so fewer instructions per distance is the lever, not more overlap.)
+// MFMA time -- 765 instructions per 32 x 32 tile -- so fewer instructions per distance is the lever, not more overlap.
+// Two tiles per iteration with interleaved, independent MFMA chains: 2478 vs 2505 us (64 channels), 1107 vs 937 us (3).)
 // Candidates that beat a lane's current k-th distance are QUEUED in LDS (slot-major, conflict free) instead of being
 // inserted at once: the per-candidate work is then one compare (+ two LDS writes for the ~5 % that pass), and the
 // sorted insertion -- 4 VALU per list slot, the expensive part -- runs for whole batches when some lane's queue
