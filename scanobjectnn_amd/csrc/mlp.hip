@@ -377,8 +377,11 @@ struct PoolRows {
     int s0, S;
     float invS;
     __device__ PoolRows(long long row0, int S_) : S(S_) {
-        g0 = (long long)((unsigned long long)row0 / (unsigned)S_);
-        s0 = (int)(row0 - g0 * S_);
+        // row indices fit 32 bits (M is an int at the ABI): a 32-bit division is ~25 scalar instructions, the 64-bit one
+        // this replaced ~100 -- twice per stripe and wave it was most of the 80 M SALU instructions of the SA1 wgrad
+        const unsigned q = (unsigned)row0 / (unsigned)S_;
+        g0 = (long long)q;
+        s0 = (int)((unsigned)row0 - q * (unsigned)S_);
         invS = 1.0f / (float)S_;
     }
     __device__ void split(int r, long long glast, long long &g, unsigned &s) const {
