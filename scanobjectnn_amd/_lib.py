@@ -11,7 +11,7 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcops.so")
+LIB_PATH = os.environ.get("PCOPS_LIB") or os.path.join(_HERE, "libpcops.so")      # PCOPS_LIB: A/B runs of two builds
 
 _I, _F, _P, _U64, _LL = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong, C.c_longlong
 

@@ -613,10 +613,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             c3 = *reinterpret_cast<const float4 *>(&coef[3 * Kp + c]);
             c4 = *reinterpret_cast<const float4 *>(&coef[4 * Kp + c]);
         }
+        const int rem = (int)((long long)M - row0 < 32 ? (long long)M - row0 : 32);   // rows of this tile (scalar, 32 bit)
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
-            const bool in = (row0 + r < M) && (c < K);
+            const bool in = (r < rem) && (c < K);
             float4 x = pa[U_ ? 0 : (B_ ? j / 4 : j)];
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
@@ -771,6 +772,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         if (active) {
         // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
+        const int erem = (int)((long long)M - row0 < 32 ? (long long)M - row0 : 32);   // rows of this tile (scalar, 32 bit)
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
         const __amdgpu_buffer_rsrc_t rprev =
             make_rsrc(((EM == E_MASK || EM == E_MASKA) ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
@@ -807,8 +809,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 const __amdgpu_buffer_rsrc_t radd = make_rsrc(a.addend, a.add_bytes);
 #pragma unroll
                 for (int j = 0; j < NST; ++j) {
-                    const long long row = row0 + (lane + 64 * j) / O4;
-                    const int slot = row < M ? a.rowmap[row] : -1;
+                    const int rr = (lane + 64 * j) / O4;
+                    const int slot = rr < erem ? a.rowmap[row0 + rr] : -1;
                     const unsigned off = (slot >= 0 && ocin) ? ((unsigned)slot * (unsigned)a.add_ld + (unsigned)(n0 + ocq)) * 4u : kOOB;
                     pad[j] = buf_load4(radd, off, 0u);
                 }
@@ -839,9 +841,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
                 const int r = (lane + 64 * j) / O4;
-                const long long row = row0 + r;
                 float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocl]);
-                if (row < M && ocin) {
+                if (r < erem && ocin) {
                     if (EM == E_FWD) {
                         o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
                         if (compact && O4 == 16 && j % 4 == 0) {      // rows 0 / 16 of the tile stand for w rows
