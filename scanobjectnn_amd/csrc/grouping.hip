@@ -285,6 +285,62 @@ __global__ __launch_bounds__(64) void selection_sort_kernel(long long rows, int 
     }
 }
 
+// The same sort with one WAVE per row and the row in LDS (n <= 8192): every step's minimum search is n / 64 LDS reads per
+// lane + a 6-step butterfly on (value, index) instead of n global loads by one lane.  The reference's scan keeps the
+// FIRST minimum that is strictly smaller than v[s] (`x < mv`, selection_sort.cpp:29-36): lanes keep their first minimum
+// (ascending t, strict <), the butterfly prefers the smaller index on equal values, and the winner only replaces
+// position s if it is strictly smaller than v[s] -- NaNs never win and a NaN at s never moves, as in the scalar loop.
+__global__ __launch_bounds__(256) void selection_sort_wave_kernel(long long rows, int n, int k, int waves,
+                                                                  const float *__restrict__ dist,
+                                                                  int *__restrict__ outi, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * waves + wave;
+    if (wave >= waves || r >= rows) return;
+    float *v = sm + (size_t)wave * 2 * n;
+    int *ix = reinterpret_cast<int *>(v + n);
+    const float *src = dist + r * n;
+    for (int t = lane; t < n; t += 64) {
+        v[t] = src[t];
+        ix[t] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int kk = k < n ? k : n;
+    for (int s = 0; s < kk; ++s) {
+        float mv = INFINITY;
+        int mn = 0x7fffffff;
+        for (int t = s + 1 + lane; t < n; t += 64) {
+            const float x = v[t];
+            if (x < mv) { mv = x; mn = t; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(mv, off, 64);
+            const int on = __shfl_xor(mn, off, 64);
+            if (ov < mv || (ov == mv && on < mn)) { mv = ov; mn = on; }
+        }
+        const float vs = v[s];
+        if (mn != 0x7fffffff && mv < vs) {          // wave-uniform
+            if (lane == 0) {
+                v[mn] = vs;
+                v[s] = mv;
+                const int ti = ix[mn];
+                ix[mn] = ix[s];
+                ix[s] = ti;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float *vo = out + r * n;
+    int *io = outi + r * n;
+    for (int t = lane; t < n; t += 64) {
+        vo[t] = v[t];
+        io[t] = ix[t];
+    }
+}
+
 }  // namespace
 
 extern "C" int pcops_query_ball_point_multi(int b, int n, int m, int nscale, const float *radius,
@@ -382,6 +438,17 @@ extern "C" int pcops_selection_sort(int b, int n, int m, int k, const float *dis
     PCOPS_REQUIRE_PTR(dist);
     PCOPS_REQUIRE_PTR(outi);
     PCOPS_REQUIRE_PTR(out);
+    if (n <= 8192) {        // a wave per row, the row in LDS
+        int waves = (int)(65536 / ((size_t)8 * n));
+        waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+        const size_t lds = (size_t)waves * 8 * n;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_wave_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(selection_sort_wave_kernel, dim3(cdiv(rows, waves)), dim3(256), lds, as_stream(stream), rows, n,
+                           k, waves, dist, outi, out);
+        return pcops_launch_status();
+    }
     hipLaunchKernelGGL(selection_sort_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, as_stream(stream),
                        rows, n, k, dist, outi, out);
     return pcops_launch_status();

@@ -209,6 +209,22 @@ def test_selection_sort_golden(case):
     np.testing.assert_array_equal(N(out), g["out"])
 
 
+@pytest.mark.parametrize("n,k", [(70, 5), (1000, 32), (3000, 20), (8192, 8), (9000, 4), (33, 64)])
+def test_selection_sort_rows_of_every_size_vs_oracle(n, k):
+    """the wave-per-row kernel (row in LDS, n <= 8192) and the lane-per-row fallback against the literal restatement of
+    the reference's scalar loop, on rows with many exact ties (quantised values), a NaN inside a row and a NaN heading
+    one: the unstable swap order, `x < mv` picking the FIRST minimum, NaNs never winning -- all bit for bit"""
+    rng = np.random.default_rng(n)
+    d = (rng.integers(0, 50, size=(2, 5, n)) * 0.25).astype(np.float32)
+    d[0, 1, n // 2] = np.nan
+    d[1, 2, 0] = np.nan
+    d[1, 3, :] = 1.0                                   # a constant row: nothing may move
+    outi, out = tf_grouping.select_top_k(k, T(d))
+    oi, ov = O.select_top_k(k, d)
+    np.testing.assert_array_equal(N(outi), oi)
+    np.testing.assert_array_equal(N(out), ov)
+
+
 def test_knn_point_vs_oracle():
     rng = np.random.default_rng(8)
     x1 = rng.standard_normal((2, 150, 3)).astype(np.float32)
