@@ -106,11 +106,15 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs
         const int tn = min(64 * PL, n - t0);
         for (int e = tid; e < 64 * PL * 3; e += 256) {
             const int ln = e / (3 * PL), r = e - ln * (3 * PL);
+            // a lane's run is stored PAIR-WISE, (x0 x1 y0 y1 z0 z1)(x2 x3 ...): two consecutive points then sit in
+            // adjacent registers per coordinate, which is what the packed fp32 instructions (v_pk_add / v_pk_mul: two
+            // points per instruction) take as their 64-bit operands
+            const int c = r / 3, d = r - 3 * c;
             // beyond the cloud: a point whose distance to anything overflows to +inf (inf <= T is false)
-            stage[ln * STRIDE + r] = e < tn * 3 ? p1[(size_t)t0 * 3 + e] : 3.0e38f;
+            stage[ln * STRIDE + 6 * (c >> 1) + 2 * d + (c & 1)] = e < tn * 3 ? p1[(size_t)t0 * 3 + e] : 3.0e38f;
         }
         __syncthreads();
-        float p[3 * PL];                        // x, y, z of this lane's PL points
+        float p[3 * PL];                        // pairs of this lane's PL points: x0 x1 y0 y1 z0 z1 | x2 x3 ...
 #pragma unroll
         for (int i = 0; i < 3 * PL / 4; ++i) {
             const float4 v = *reinterpret_cast<const float4 *>(&stage[lane * STRIDE + 4 * i]);
@@ -128,18 +132,34 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs
                 first[s] = __builtin_amdgcn_readlane(firstv[s], j);
                 full = full && cnt0[s] >= a.s[s].nsample;
             }
-            unsigned hb[NS][W];                 // hit bitmap: word c / 32, bit c % 32 <=> point kbase + c
+            // hit bitmap, filled by SHIFTING the compare result in (v_cmp writes VCC, v_addc_co computes hb + hb + VCC:
+            // two instructions per point and radius instead of compare + select + or): after the 32 points of a word,
+            // point kbase + 32 w + c sits at bit 31 - c of word w -- ascending index = descending bit, read with clz
+            unsigned hb[NS][W];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int w = 0; w < W; ++w) hb[s][w] = 0u;
             if (!full) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
-                for (int c = 0; c < PL; ++c) {
-                    const float dx = qx - p[3 * c], dy = qy - p[3 * c + 1], dz = qz - p[3 * c + 2];
-                    const float d2 = dx * dx + dy * dy + dz * dz;
+                for (int i = 0; i < PL / 2; ++i) {
+                    const f32x2 px = {p[6 * i], p[6 * i + 1]}, py = {p[6 * i + 2], p[6 * i + 3]},
+                                pz = {p[6 * i + 4], p[6 * i + 5]};
+                    const f32x2 dx = qx2 - px, dy = qy2 - py, dz = qz2 - pz;
+                    const f32x2 d2 = dx * dx + dy * dy + dz * dz;       // per component ((dx dx + dy dy) + dz dz), uncontracted
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) hb[s][c / 32] |= d2 <= a.s[s].thresh ? (1u << (c % 32)) : 0u;
+                    for (int s = 0; s < NS; ++s) {
+                        asm("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                            : "+v"(hb[s][(2 * i) / 32]) : "v"(d2.x), "s"(a.s[s].thresh) : "vcc");
+                        asm("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                            : "+v"(hb[s][(2 * i) / 32]) : "v"(d2.y), "s"(a.s[s].thresh) : "vcc");
+                    }
+                }
+                if (PL < 32) {                  // a partly filled word: move point 0 to bit 31
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) hb[s][0] <<= (32 - (PL < 32 ? PL : 0)) & 31;
                 }
             }
 #pragma unroll
@@ -154,8 +174,8 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs
                     if (total > 0) {                                      // wave-uniform
                         if (cnt0[s] == 0) {       // first hit of the query: lowest lane with a bit, its lowest bit
                             const int fl = (int)__builtin_ctzll(__ballot(mine > 0));
-                            const int myfirst = kbase + (hb[s][0] ? __builtin_ctz(hb[s][0])
-                                                                  : 32 + __builtin_ctz(hb[s][W - 1] | 0x80000000u));
+                            const int myfirst = kbase + (hb[s][0] ? __builtin_clz(hb[s][0])
+                                                                  : 32 + __builtin_clz(hb[s][W - 1] | 1u));
                             first[s] = __builtin_amdgcn_readlane(myfirst, fl);
                         }
                         int pos = cnt0[s] + incl - mine;                  // slot of this lane's first hit
@@ -163,8 +183,9 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs
                         for (int w = 0; w < W; ++w) {
                             unsigned bits = hb[s][w];
                             while (bits != 0u && pos < ns) {              // per lane: 0-3 hits, rarely more
-                                row[pos] = kbase + 32 * w + __builtin_ctz(bits);
-                                bits &= bits - 1u;
+                                const int c = __builtin_clz(bits);
+                                row[pos] = kbase + 32 * w + c;
+                                bits &= ~(0x80000000u >> c);
                                 ++pos;
                             }
                         }
