@@ -248,6 +248,11 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
  * around the big kernels (32 x 32 output tile per workgroup, fp32 MFMA, fixed summation order) */
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                      pcops_stream_t stream);
+/* C = op(A) op(B) + bias: transA != 0 -> A is stored [K][M], transB != 0 -> B is stored [N][K]; bias [N] or NULL.
+ * The three products of a fully connected layer on a few hundred rows (tf_util.py:187-213 fully_connected: Y = X W + b,
+ * dX = dY W^T, dW = X^T dY) without a transposed copy of anything. */
+int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                        const float *bias, float *C, int ldc, pcops_stream_t stream);
 
 /* ---- algebraic backward of a POOLED top layer (the last conv of a set-abstraction stack / of a stack pooled over a
  * whole cloud: pointnet_util.py:139-147, dgcnn.py "agg", transform_nets.py "tconv3").

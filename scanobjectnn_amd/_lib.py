@@ -47,6 +47,7 @@ SIGNATURES = {
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
     "pcops_small_gemm": ([_I, _I, _I, _P, _I, _P, _I, _P, _I], True),
+    "pcops_small_gemm_ex": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I], True),
     "pcops_mlp_pool_top_addend": ([_I, _I, _I, _I] + [_P] * 9, True),
     "pcops_mlp_gemm_dgrad_top": ([_I, _I] + [_P] * 6 + [_LL] + [_P] * 3, True),
     "pcops_mlp_gram": ([_LL, _I, _P, _I, _P, _P, _P, _P, _P], True),

@@ -2509,7 +2509,7 @@ __global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int 
 // K and add their accumulators through LDS in a fixed order.
 __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
-                                                         int ldc) {
+                                                         int ldc, int transA, int transB, const float *__restrict__ bias) {
     __shared__ float As[4][32][17], Bs[4][16][33], red[4][32][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -2524,9 +2524,12 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
         for (int i = 0; i < 8; ++i) {
             const int e = lane + 64 * i;
             const int r = e >> 4, kk = e & 15;
-            ra[i] = (ch < kchunks && m0 + r < M && k0 + kk < K) ? A[(long long)(m0 + r) * lda + k0 + kk] : 0.f;
+            // transA: A is stored [K][M] (the product is A^T ...), transB: B is stored [N][K]
+            const long long ia = transA ? (long long)(k0 + kk) * lda + m0 + r : (long long)(m0 + r) * lda + k0 + kk;
+            ra[i] = (ch < kchunks && m0 + r < M && k0 + kk < K) ? A[ia] : 0.f;
             const int kb = e >> 5, c = e & 31;
-            rb[i] = (ch < kchunks && k0 + kb < K && n0 + c < N) ? B[(long long)(k0 + kb) * ldb + n0 + c] : 0.f;
+            const long long ib = transB ? (long long)(n0 + c) * ldb + k0 + kb : (long long)(k0 + kb) * ldb + n0 + c;
+            rb[i] = (ch < kchunks && k0 + kb < K && n0 + c < N) ? B[ib] : 0.f;
         }
     };
     fetch(wave);
@@ -2553,7 +2556,8 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
     for (int e = tid; e < 32 * 32; e += 256) {
         const int r = e >> 5, c = e & 31;
         if (m0 + r < M && n0 + c < N)
-            C[(long long)(m0 + r) * ldc + n0 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+            C[(long long)(m0 + r) * ldc + n0 + c] =
+                ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) + (bias ? bias[n0 + c] : 0.f);
     }
 }
 
@@ -2571,6 +2575,9 @@ static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
 }
 
 extern "C" {
+
+int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                        const float *bias, float *C, int ldc, pcops_stream_t stream);
 
 int pcops_mlp_stats_rows(int M) {
     // upper bound of the partial-statistics rows any gemm kernel emits for M rows (buffers are sized with
@@ -3247,10 +3254,15 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
 
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                      pcops_stream_t stream) {
-    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && lda >= K && ldb >= N && ldc >= N);
+    return pcops_small_gemm_ex(M, K, N, A, lda, 0, B, ldb, 0, nullptr, C, ldc, stream);
+}
+
+int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                        const float *bias, float *C, int ldc, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     PCOPS_REQUIRE_PTR(A); PCOPS_REQUIRE_PTR(B); PCOPS_REQUIRE_PTR(C);
     hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), M, K, N, A,
-                       lda, B, ldb, C, ldc);
+                       lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias);
     return pcops_launch_status();
 }
 

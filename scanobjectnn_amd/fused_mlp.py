@@ -413,6 +413,44 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
     return Gprev, part
 
 
+class _SmallLinear(torch.autograd.Function):
+    """Y = X W + b for a few hundred rows (the classifier head: B x 1024 -> 512 -> 256 -> classes) on
+    pcops_small_gemm_ex -- 32 x 32 output tiles with a 4-way K split fill the chip where a library GEMM picks a
+    256 x 256 tile and runs on one or two CUs; dX = dY W^T and dW = X^T dY read the operands transposed in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        R, K = x.shape
+        N = w.shape[1]
+        y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        _lib.call("pcops_small_gemm_ex", R, K, N, x.data_ptr(), K, 0, w.data_ptr(), N, 0, _p(b), y.data_ptr(), N)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        R, K = x.shape
+        N = w.shape[1]
+        gy = gy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, K), dtype=torch.float32, device=x.device)
+            _lib.call("pcops_small_gemm_ex", R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx.data_ptr(), K)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((K, N), dtype=torch.float32, device=x.device)
+            _lib.call("pcops_small_gemm_ex", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum(dim=0)
+        return dx, dw, db
+
+
+def small_linear(x, w, b):
+    """(rows, K) @ (K, N) + b on the small-GEMM kernel, differentiable (rows up to a few thousand)"""
+    return _SmallLinear.apply(x.contiguous(), w.contiguous(), b)
+
+
 class _RowsLinear(torch.autograd.Function):
     """Y = X W + b on (rows, K) through the libpcops GEMMs, backward included.  Exists for the per-source-point
     contraction of a grouped first layer (Q = points W_f + b): rows = B*N is large and the weight gradient is a

@@ -86,8 +86,9 @@ def _dense(x2d, kernel2d, biases):
     with the output padded to 4 columns."""
     rows, k = x2d.shape
     n = kernel2d.shape[1]
-    small_batch_wide = FC_PCOPS and rows <= 4096 and k >= 256 and k % 8 == 0      # the classifier head (B x 1024 -> 512 ...)
-    if x2d.is_cuda and k % 8 == 0 and ((rows >= 32768 and n <= 64) or small_batch_wide):
+    if x2d.is_cuda and FC_PCOPS and rows <= 4096 and x2d.dtype == torch.float32:
+        return fused_mlp.small_linear(x2d, kernel2d, biases)        # the classifier head (B x 1024 -> 512 -> 256 -> classes)
+    if x2d.is_cuda and k % 8 == 0 and rows >= 32768 and n <= 64:
         pad = (-n) % 4
         w = F.pad(kernel2d, (0, pad)) if pad else kernel2d
         b = F.pad(biases, (0, pad)) if pad else biases
@@ -153,10 +154,10 @@ def _stack_variables(cin, widths, scope_fmt, stddev, weight_decay, use_xavier, m
 
 
 FUSED_MLP = os.environ.get("PCOPS_FUSED_MLP", "1") != "0"
-# fully connected head through the libpcops GEMMs as well (a few hundred rows into 512 / 256 / 15 columns).  OFF by
-# default: measured on the SSG step (B = 256) the library GEMMs win -- 13.5 ms/step against 14.0 with this on (the
-# libpcops kernels are built for millions of rows; a 256-row problem leaves most of the chip idle in either case)
-FC_PCOPS = os.environ.get("PCOPS_FC", "0") != "0"
+# fully connected head (a few hundred rows into 512 / 256 / class columns) on pcops_small_gemm_ex instead of the
+# library GEMM.  (Round 2 first tried the big-row GEMM kernels for this: 14.0 ms/step against 13.5 -- they are built
+# for millions of rows.  The 32 x 32-tile kernel with a K split is the right shape: see the A/B in DESIGN section 9.)
+FC_PCOPS = os.environ.get("PCOPS_FC", "1") != "0"
 
 
 def conv2d_stack(inputs, widths, scope_fmt, is_training, bn_decay, pool_max=False, use_xavier=True,

@@ -220,6 +220,26 @@ def test_pool_top_backward_is_taken_and_equals_the_plain_form(R, S, K0, widths, 
         assert (a - b).abs().max().item() <= 2e-4 * scale + 1e-6, (name, (a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("R,K,N", [(256, 1024, 512), (256, 512, 256), (256, 256, 15), (7, 33, 5), (1, 64, 40),
+                                   (300, 100, 130)])
+def test_small_linear_forward_and_backward(R, K, N):
+    """the classifier head's dense layers on pcops_small_gemm_ex (plain, transposed-B and transposed-A products) against
+    float64"""
+    g = torch.Generator().manual_seed(R * K + N)
+    x = torch.randn(R, K, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+    go = torch.randn(R, N, generator=g).to(DEV)
+    y = fused_mlp.small_linear(x, w, b)
+    y.backward(go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yd = xd @ wd + bd
+    yd.backward(go.double())
+    for got, want in ((y, yd), (x.grad, xd.grad), (w.grad, wd.grad), (b.grad, bd.grad)):
+        scale = want.abs().max().item()
+        assert (got.double() - want.detach()).abs().max().item() <= 3e-6 * scale * max(1.0, (max(R, K) / 64) ** 0.5)
+
+
 GATHER_CASES = [  # (B, N, M, S, widths, pool)
     (4, 256, 64, 32, [64, 64, 128], True),      # SA1-like
     (3, 100, 37, 16, [128, 128, 256], True),    # SA2-like, ragged group count
