@@ -35,5 +35,9 @@ def input_transform_net(edge_feature, is_training, bn_decay=None, K=3, is_dist=F
         weights = get_variable('weights', [256, K * K], constant_initializer(0.0))
         biases = get_variable('biases', [K * K], constant_initializer(0.0))
         eye = torch.eye(K, dtype=torch.float32, device=net.device).flatten()
-        transform = torch.addmm(biases + eye, net, weights)
+        if net.is_cuda:
+            from .. import fused_mlp
+            transform = fused_mlp.small_linear(net, weights, biases + eye)     # (B, 256) -> K*K on the small-GEMM kernel
+        else:
+            transform = torch.addmm(biases + eye, net, weights)
     return transform.view(batch_size, K, K)
