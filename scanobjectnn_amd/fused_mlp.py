@@ -32,7 +32,11 @@ class _VecArena:
     time), carved from ONE zeroed allocation per pass instead of one fill launch per vector"""
 
     def __init__(self, widths, per_width, dev):
-        self.buf = torch.zeros(sum(((n + 3) // 4 * 4) * per_width for n in widths), dtype=torch.float32, device=dev)
+        total = sum(((n + 3) // 4 * 4) * per_width for n in widths)
+        # the zero fill only matters for the padding lanes of a width that is not a multiple of 4 (every vector is
+        # written in full by the kernel that owns it): the usual case needs no fill launch at all
+        alloc = torch.empty if all(n % 4 == 0 for n in widths) else torch.zeros
+        self.buf = alloc(total, dtype=torch.float32, device=dev)
         self.off = 0
 
     def take(self, n):
