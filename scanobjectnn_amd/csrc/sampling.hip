@@ -40,7 +40,13 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
     const float *p = inp + (size_t)b * n * 3;
     int *o = out + (size_t)b * m;
 
+    // Instruction count is what a round costs (one wave per SIMD, ~150 instructions per round at 4.5 cycles each next to
+    // the barrier): the coordinates sit pair-wise in adjacent registers so that the distance arithmetic is packed fp32
+    // (two points per instruction), min(d, md) is one v_med3, and the lane's best key is found as max of the distance
+    // words followed by max of the tie-break words of the points that attain it (u32 maxima instead of 64-bit compares
+    // with selects).  A slot beyond the cloud keeps md = 0 and tie-break 0: it loses against every real point.
     float px[P], py[P], pz[P], md[P];
+    unsigned tb[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int k = t + i * T;
@@ -49,10 +55,13 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
             py[i] = p[k * 3 + 1];
             pz[i] = p[k * 3 + 2];
             if (LDSPTS) pts[k] = make_float4(px[i], py[i], pz[i], 0.f);
+            md[i] = 1e38f;
+            tb[i] = fps_tiebreak((unsigned)k);
         } else {
             px[i] = py[i] = pz[i] = 0.f;
+            md[i] = 0.f;
+            tb[i] = 0u;
         }
-        md[i] = 1e38f;
     }
     if (t == 0) o[0] = 0;
     if (LDSPTS) __syncthreads();
@@ -66,18 +75,28 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, const float *__res
         } else {
             x1 = p[old * 3 + 0]; y1 = p[old * 3 + 1]; z1 = p[old * 3 + 2];
         }
-        unsigned long long best = 0ull;  // below every valid key
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        unsigned hi = 0u;
+        if (P >= 2) {
+            const f32x2 qx = {x1, x1}, qy = {y1, y1}, qz = {z1, z1};
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int k = t + i * T;
-            const float dx = px[i] - x1, dy = py[i] - y1, dz = pz[i] - z1;
-            const float d = dx * dx + dy * dy + dz * dz;
-            const float d2 = fminf(d, md[i]);
-            md[i] = d2;
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(d2) << 32) | fps_tiebreak((unsigned)k);
-            best = (k < n && key > best) ? key : best;
+            for (int i = 0; i + 1 < P; i += 2) {
+                const f32x2 vx = {px[i], px[i + 1]}, vy = {py[i], py[i + 1]}, vz = {pz[i], pz[i + 1]};
+                const f32x2 dx = vx - qx, dy = vy - qy, dz = vz - qz;
+                const f32x2 d = dx * dx + dy * dy + dz * dz;         // per component ((dx dx + dy dy) + dz dz), uncontracted
+                md[i] = __builtin_amdgcn_fmed3f(d.x, md[i], -INFINITY);          // = min(d, md): one instruction
+                md[i + 1] = __builtin_amdgcn_fmed3f(d.y, md[i + 1], -INFINITY);
+            }
+        } else {
+            const float dx = px[0] - x1, dy = py[0] - y1, dz = pz[0] - z1;
+            md[0] = __builtin_amdgcn_fmed3f(dx * dx + dy * dy + dz * dz, md[0], -INFINITY);
         }
+#pragma unroll
+        for (int i = 0; i < P; ++i) hi = max(hi, __float_as_uint(md[i]));     // distances are >= 0: bit order = value order
+        unsigned lo = 0u;
+#pragma unroll
+        for (int i = 0; i < P; ++i) lo = max(lo, __float_as_uint(md[i]) == hi ? tb[i] : 0u);
+        unsigned long long best = ((unsigned long long)hi << 32) | lo;
         best = wave_max_u64(best);
         if (NW > 1) {
             unsigned long long *s = slots + (j & 1) * NW;
