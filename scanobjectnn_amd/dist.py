@@ -50,12 +50,13 @@ def shard_range(total, rank, world):
     return rank * per, (rank + 1) * per
 
 
-def allreduce_mean_(flat_grad, world=None):
-    """In-place mean over ranks of the flat gradient bucket (sum all-reduce, then 1/R)."""
+def allreduce_mean_(flat_grad, world=None, force=False):
+    """In-place mean over ranks of the flat gradient bucket (sum all-reduce, then 1/R).  force: issue the collective
+    even for a single rank (the RCCL smoke test)."""
     if not dist.is_initialized():
         return flat_grad
     world = world or dist.get_world_size()
-    if world == 1:
+    if world == 1 and not force:
         return flat_grad
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     flat_grad.mul_(1.0 / world)

@@ -1,16 +1,32 @@
-"""Evaluation loop -- restates the metric loop of `pointnet2/evaluate_scenennobjects.py:152-231`:
-`num_votes` rotations about the up axis (angle vote/num_votes * 2π, provider.rotate_point_cloud_by_angle),
-logits SUMMED over the votes, argmax, overall accuracy and mean per-class accuracy.  Visual dumps are out of
-scope.  `eval_seg_one_epoch` adds the mask accuracy of `evaluate_seg_scenennobjects.py:336`
-(correct points / (seen clouds * points))."""
+"""Evaluation -- the caller `pointnet2/evaluate_scenennobjects.py` restated: its command line (`:27-44`), the restore
+of a trained model (`saver.restore`, `:141`), the metric loop (`:152-231`: `num_votes` rotations about the up axis at
+angle vote/num_votes * 2π, logits SUMMED over the votes, argmax, overall and mean per-class accuracy, mean loss), and
+its outputs: `dump_dir/pred_label.txt` (one "predicted, true" line per cloud, `:209`), `dump_dir/log_evaluate.txt` and
+the per-class table (`:224-231`).  Visual dumps (`--visu`: jpg / ply of the error cases) are out of scope.
+`eval_seg_one_epoch` adds the mask accuracy of `evaluate_seg_scenennobjects.py:336` (correct points / (seen clouds *
+points)).
+
+  python -m scanobjectnn_amd.pointnet2.evaluate_scenennobjects --model pointnet2_cls_ssg --num_point 1024 \
+         --batch_size 32 --model_path log/model.pt | log/model.ckpt --test_file test.npz --num_votes 12
+
+`--model_path` is either this package's `model.pt` (state dict under the reference's TF scope names, written by
+`train.py`) or the PREFIX of a TensorFlow tensor bundle (`model.ckpt` -> `model.ckpt.index` + `.data-*`), i.e. a
+checkpoint the reference's `tf.train.Saver` wrote (read without TensorFlow by `tf_checkpoint.py`).
+"""
+import argparse
+import importlib
 import math
+import os
 
 import numpy as np
 import torch
 
-from .. import provider
+from .. import data_utils, provider
 
 NUM_CLASSES = 15
+# training_data/shape_names_ext.txt (the 15 ScanObjectNN categories, label order)
+SHAPE_NAMES = ["bag", "bin", "box", "cabinet", "chair", "desk", "display", "door", "shelf", "table", "bed", "pillow",
+               "sink", "sofa", "toilet"]
 
 
 def _host(a):
@@ -40,19 +56,34 @@ def accuracy_summary(pred, labels, num_classes=NUM_CLASSES):
 
 
 @torch.no_grad()
-def eval_one_epoch(net, data, labels, batch_size, num_votes=1, device="cuda:0"):
+def eval_one_epoch(net, data, labels, batch_size, num_votes=1, device="cuda:0", num_classes=NUM_CLASSES, loss_fn=None):
     """net: graph.Model of a classifier get_model; data (K,N,3), labels (K,).  Whole batches only (like the
-    reference: num_batches = K // BATCH_SIZE)."""
+    reference: num_batches = K // BATCH_SIZE).  loss_fn(logits, labels, end_points) -> scalar: the reference's
+    per-vote loss, averaged over the votes and weighted by the batch size (`:187,198`) -> "mean_loss"."""
     preds, seen = [], []
     labels = _host(labels)
+    loss_sum = 0.0
     for b in range(data.shape[0] // batch_size):
         pts = torch.as_tensor(data[b * batch_size:(b + 1) * batch_size], dtype=torch.float32, device=device)
-        logits = vote_logits(lambda p: net(p.contiguous(), is_training=False)[0], pts, num_votes)
+        lab_b = np.asarray(labels[b * batch_size:(b + 1) * batch_size])
+        if loss_fn is None:
+            logits = vote_logits(lambda p: net(p.contiguous(), is_training=False)[0], pts, num_votes)
+        else:
+            y = torch.as_tensor(lab_b.astype(np.int64), device=device)
+            losses = []
+
+            def predict(p):
+                out, end_points = net(p.contiguous(), is_training=False)
+                losses.append(loss_fn(out, y, end_points))
+                return out
+            logits = vote_logits(predict, pts, num_votes)
+            loss_sum += float(torch.stack(losses).sum()) * batch_size / float(num_votes)
         preds.append(logits.argmax(dim=1).cpu().numpy())
-        seen.append(np.asarray(labels[b * batch_size:(b + 1) * batch_size]))
+        seen.append(lab_b)
     pred, lab = np.concatenate(preds), np.concatenate(seen)
-    acc, mean_class_acc, per_class = accuracy_summary(pred, lab)
-    return {"accuracy": acc, "avg_class_acc": mean_class_acc, "per_class": per_class, "pred": pred, "label": lab}
+    acc, mean_class_acc, per_class = accuracy_summary(pred, lab, num_classes)
+    return {"accuracy": acc, "avg_class_acc": mean_class_acc, "per_class": per_class, "pred": pred, "label": lab,
+            "mean_loss": loss_sum / max(len(lab), 1)}
 
 
 @torch.no_grad()
@@ -94,3 +125,118 @@ def eval_partseg_one_epoch(net, data, parts, batch_size, num_classes=6, device="
     return {"accuracy": float(corr_c.sum()) / max(int(seen_c.sum()), 1),
             "avg_class_acc": float(per_class[occurs].mean()) if occurs.any() else 0.0,
             "per_class": per_class.tolist()}
+
+
+# ---- the command line of `pointnet2/evaluate_scenennobjects.py` ----------------------------------------------------
+def parse_args(argv=None):
+    from .train import MODELS, _flag
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--gpu", type=int, default=0, help="GPU to use (:27)")
+    p.add_argument("--model", default="pointnet2_cls_ssg", choices=sorted(MODELS))            # :28
+    p.add_argument("--batch_size", type=int, default=1)                                       # :29
+    p.add_argument("--num_point", type=int, default=1024)                                     # :30
+    p.add_argument("--model_path", default="log/model.ckpt",
+                   help="model.pt of this package, or the prefix of a TensorFlow tensor bundle (:32)")
+    p.add_argument("--dump_dir", default="dump/")                                             # :34
+    p.add_argument("--with_bg", type=_flag, default=True)                                     # :35
+    p.add_argument("--norm", type=_flag, default=True)                                        # :36
+    p.add_argument("--center_data", type=_flag, default=True)                                 # :37
+    p.add_argument("--num_class", type=int, default=15)                                       # :38
+    p.add_argument("--test_file", default="", help=".npz / .h5 / pickled split list (:40); synthetic clouds if empty")
+    p.add_argument("--data_path", default="", help="root of the raw objects_bin/ files for pickled split lists")
+    p.add_argument("--normal", action="store_true", help="accepted for CLI compatibility (:42); never read")
+    p.add_argument("--num_votes", type=int, default=1)                                        # :43
+    p.add_argument("--visu", type=_flag, default=False, help="accepted (:44); image / ply dumps are out of scope")
+    p.add_argument("--shape_names", default="", help="text file with one class name per line (default: the 15 "
+                   "ScanObjectNN names; the reference reads ../training_data/shape_names_*.txt, :57-62)")
+    p.add_argument("--synthetic_clouds", type=int, default=256)
+    return p.parse_args(argv)
+
+
+def restore(net, model_path, strict=True):
+    """`saver.restore(sess, MODEL_PATH)` (:141): a `.pt` state dict, or a TensorFlow tensor bundle by prefix"""
+    from .. import tf_checkpoint
+    if os.path.exists(model_path + ".index"):
+        loaded, missing, unexpected = tf_checkpoint.load_tf_checkpoint(net, model_path, strict=strict, verify=True)
+        return {"format": "tf-bundle", "loaded": len(loaded), "missing": missing, "unexpected": unexpected}
+    if not os.path.exists(model_path):
+        raise FileNotFoundError("--model_path %r: neither a state dict nor a tensor-bundle prefix (no %s.index)"
+                                % (model_path, model_path))
+    sd = torch.load(model_path, map_location="cpu")
+    res = net.load_state_dict(sd, strict=strict)
+    return {"format": "state-dict", "loaded": len(sd), "missing": list(res.missing_keys),
+            "unexpected": list(res.unexpected_keys)}
+
+
+def load_test_set(args):
+    """(:81-90): load, centre, normalise on the host exactly like the reference"""
+    if not args.test_file:
+        from ..synth import synth_clouds, synth_labels
+        data = synth_clouds(args.synthetic_clouds, max(args.num_point, 2048), seed=2)
+        labels = synth_labels(args.synthetic_clouds, 2) % args.num_class
+    elif args.test_file.endswith(".npz"):
+        data, labels = data_utils.load_npz(args.test_file)
+    elif ".h5" in args.test_file:
+        data, labels = data_utils.load_h5(args.test_file)
+    else:
+        data, labels = data_utils.load_data(args.test_file, args.num_point, with_bg_pl=args.with_bg,
+                                            data_path=args.data_path)
+    ragged = isinstance(data, list)
+    if args.center_data:
+        data = [pc - pc.mean(axis=0, dtype=np.float32) for pc in data] if ragged else data_utils.center_data(data)
+    if args.norm:
+        data = [pc / np.sqrt((pc * pc).sum(axis=-1, dtype=np.float32)).max() for pc in data] if ragged \
+            else data_utils.normalize_data(data)
+    return data, np.asarray(labels).reshape(-1)
+
+
+def evaluate(args):
+    from ..graph import Model
+    from .train import MODELS
+    if not torch.cuda.is_available() or not 0 <= args.gpu < torch.cuda.device_count():
+        raise RuntimeError("--gpu %d: no such device (%d visible)" % (args.gpu, torch.cuda.device_count()))
+    dev = torch.device("cuda", args.gpu)
+    torch.cuda.set_device(dev)
+    if args.model.endswith("_bga") or args.model.endswith("_partseg"):
+        raise SystemExit("evaluate_scenennobjects.py evaluates classifiers; mask / part models have their own metrics "
+                         "(eval_seg_one_epoch / eval_partseg_one_epoch)")
+    mod = importlib.import_module(MODELS[args.model])
+    names = [l.rstrip() for l in open(args.shape_names)] if args.shape_names else \
+        (SHAPE_NAMES if args.num_class == 15 else ["class%d" % i for i in range(args.num_class)])
+    os.makedirs(args.dump_dir, exist_ok=True)
+    log_f = open(os.path.join(args.dump_dir, "log_evaluate.txt"), "w")
+    log_f.write(str(args) + "\n")
+
+    def log_string(s):
+        log_f.write(s + "\n")
+        log_f.flush()
+        print(s)
+
+    rng = np.random.RandomState(0)                 # `np.random.seed(0)` (:66): the same two shuffles as the reference
+    data, labels = load_test_set(args)
+    kw = {"num_class": args.num_class} if args.num_class != 15 else {}
+    net = Model(mod.get_model, device=dev, seed=0, **kw).build(torch.zeros((2, args.num_point, 3), device=dev))
+    info = restore(net, args.model_path)
+    log_string("Model restored. (%s, %d variables)" % (info["format"], info["loaded"]))
+    if isinstance(data, list):
+        cur, lab = data_utils.get_current_data(data, labels, args.num_point, rng=rng)     # :161
+    else:
+        cur, lab = data_utils.get_current_data_h5(data, labels, args.num_point, rng=rng)  # :159
+    lab = np.squeeze(lab)
+    ev = eval_one_epoch(net, cur, lab, args.batch_size, num_votes=args.num_votes, device=dev,
+                        num_classes=args.num_class, loss_fn=lambda out, y, ep: mod.get_loss(out, y, ep))
+    with open(os.path.join(args.dump_dir, "pred_label.txt"), "w") as fout:                 # :209
+        for p, l in zip(ev["pred"], ev["label"]):
+            fout.write("%s, %s\n" % (names[p], names[l]))
+    log_string("total seen: %d" % len(ev["label"]))
+    log_string("eval mean loss: %f" % ev["mean_loss"])
+    log_string("eval accuracy: %f" % ev["accuracy"])
+    log_string("eval avg class acc: %f" % ev["avg_class_acc"])
+    for i, name in enumerate(names[:args.num_class]):
+        log_string("%10s:\t%0.3f" % (name, ev["per_class"][i]))
+    log_f.close()
+    return ev
+
+
+if __name__ == "__main__":
+    evaluate(parse_args())

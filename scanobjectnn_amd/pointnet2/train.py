@@ -94,6 +94,9 @@ def _load(path, with_mask, num, n_pts, seed, args):
         elif ".h5" in path:                                     # train.py:91-99
             arrs = data_utils.load_withmask_h5(path) if with_mask else data_utils.load_h5(path)
         else:                                                   # pickled split list + raw .bin objects
+            if with_mask:
+                raise ValueError("%s: pickled split lists of raw .bin objects carry no per-point masks; the mask / part "
+                                 "models need an .h5 / .npz file with a 'mask' / 'parts' array" % path)
             arrs = data_utils.load_data(path, n_pts, with_bg_pl=args.with_bg, data_path=args.data_path)
         if with_mask:
             return arrs[0], arrs[1], data_utils.convert_to_binary_mask(arrs[2])
@@ -142,7 +145,9 @@ def epoch_view(data, labels, mask, num_point, rng, dev):
 def train(args):
     rank, world, local = D.init_from_env()
     if world == 1:
-        local = args.gpu if args.gpu < torch.cuda.device_count() else 0
+        if not 0 <= args.gpu < torch.cuda.device_count():
+            raise RuntimeError("--gpu %d: no such device (%d visible)" % (args.gpu, torch.cuda.device_count()))
+        local = args.gpu
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     D.SYNC_BN = bool(args.sync_bn)
@@ -213,15 +218,15 @@ def train(args):
             tot[0] /= world
         loss_sum, correct, seen = (float(v) for v in tot.tolist())            # the epoch's only host sync
         D.broadcast_buffers_(net)                # per-rank BN moving statistics -> rank 0's, before eval / checkpoint
-        td = test_data if not isinstance(test_data, list) else \
-            torch.as_tensor(np.array([pc[:args.num_point] for pc in test_data]), dtype=torch.float32, device=dev)
-        td = td[:, :args.num_point]
+        # the reference draws a FRESH point subset and cloud order for every evaluation from the same global stream
+        # as the training epochs (`train.py:275`: get_current_data_h5 on TEST_DATA) -- same here, same `rng`
+        td, tl, tm = epoch_view(test_data, test_lab, test_mask, args.num_point, rng, dev)
         if partseg:
-            ev = EV.eval_partseg_one_epoch(net, td, test_mask[:, :args.num_point], per_rank, device=dev)
+            ev = EV.eval_partseg_one_epoch(net, td, tm, per_rank, device=dev)
         elif with_mask:
-            ev = EV.eval_seg_one_epoch(net, td, test_lab, test_mask[:, :args.num_point], per_rank, device=dev)
+            ev = EV.eval_seg_one_epoch(net, td, tl, tm, per_rank, device=dev)
         else:
-            ev = EV.eval_one_epoch(net, td, test_lab, per_rank, device=dev)
+            ev = EV.eval_one_epoch(net, td, tl, per_rank, device=dev, num_classes=args.num_class)
         rec = {"epoch": epoch, "mean_loss": loss_sum / max(nb, 1), "train_acc": correct / max(seen, 1),
                "eval_acc": ev["accuracy"], "eval_avg_class_acc": ev["avg_class_acc"],
                "clouds_per_s": nb * args.batch_size / (time.time() - t0)}

@@ -124,3 +124,52 @@ def test_without_sync_bn_the_ranks_keep_their_own_statistics():
     assert torch.equal(res[0][0], res[1][0])
     assert (res[0][0] - want).norm().item() / want.norm().item() <= 2e-3
     assert not torch.allclose(res[0][1], res[1][1], rtol=1e-3, atol=1e-6)     # different shards, different statistics
+
+
+def _rccl_worker(port, q):
+    """ONE rank on the `nccl` backend (= RCCL): the process group, the communicator and the collectives the
+    data-parallel step issues are really created and run on the device -- an RCCL load / initialisation failure shows
+    up here and not first in an 8-GPU run"""
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from scanobjectnn_amd import dist as D
+    from scanobjectnn_amd import train_util as TU
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        mod, net, x, y = _build("ssg")
+        fp = TU.FlatParams(net)
+        fp.begin_step()
+        mod.get_loss(net(x, is_training=True, bn_decay=0.9)[0], y).backward()
+        g = fp.collect()
+        before = g.clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)             # the step's one collective, on the real bucket
+        dist.broadcast(fp.flat, src=0)                       # parameter broadcast at start-up
+        t = torch.tensor([3.25], dtype=torch.float64, device=DEV)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # bench.py's max-over-ranks timing
+        out = [torch.zeros_like(t)]
+        dist.all_gather(out, t)
+        dist.barrier()
+        torch.cuda.synchronize()
+        # the wrappers take the same path at world size 1 when asked to (force=True), and are no-ops otherwise
+        g2 = D.allreduce_mean_(before.clone(), force=True)
+        q.put({"backend": dist.get_backend(), "world": dist.get_world_size(), "bytes": g.numel() * 4,
+               "same": bool(torch.equal(g, before)), "same2": bool(torch.equal(g2, before)),
+               "max": float(t.item()), "gathered": float(out[0].item())})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_initialises_and_reduces_the_flat_bucket_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["backend"] == "nccl" and res["world"] == 1
+    assert res["bytes"] > 5_000_000                         # SSG's bucket: 1.47 M parameters, 5.9 MB
+    assert res["same"] and res["same2"] and res["max"] == 3.25 and res["gathered"] == 3.25
