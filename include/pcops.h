@@ -132,8 +132,13 @@ int pcops_get_deterministic(void);
  *   scatteraddpoint     rows = m, ndst = n, c = 3, div = 1           (tf_sampling.cpp:150)
  *   threeinterpolate_grad  rows = 3 n, ndst = m, div = 3, w = weight (tf_interpolate.cpp:131-153)
  *   the neighbour term of pcops_edge_feature_grad  rows = n*k, ndst = n, src = grad_out + c, ld_src = 2 c
- * workspace: pcops_scatter_rows_workspace_bytes(b, rows, ndst) bytes, 8-byte aligned.  ndst <= 19 000. */
+ * workspace: pcops_scatter_rows_workspace_bytes(b, rows, ndst) bytes, 8-byte aligned.
+ * Limits: ndst <= pcops_scatter_rows_sorted_max_ndst() (19 968: the per-cloud counting sort lives in LDS) and
+ * rows < 2^30; pcops_scatter_rows_sorted_supported(rows, ndst) is the launcher's own predicate (PCOPS_ERR_UNSUPPORTED
+ * otherwise) -- callers that may fall back to the atomic form ask it first. */
 unsigned long long pcops_scatter_rows_workspace_bytes(int b, int rows, int ndst);
+int pcops_scatter_rows_sorted_max_ndst(void);
+int pcops_scatter_rows_sorted_supported(int rows, int ndst);
 int pcops_scatter_rows_sorted(int b, int rows, int ndst, int c, int div, int ld_src, const int *idx, const float *w,
                               const float *src, float *out, int accumulate, void *workspace, pcops_stream_t stream);
 

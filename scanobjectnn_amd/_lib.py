@@ -95,6 +95,8 @@ PLAIN = {
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
     "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),
     "pcops_scatter_rows_workspace_bytes": ([_I, _I, _I], _U64),
+    "pcops_scatter_rows_sorted_max_ndst": ([], _I),
+    "pcops_scatter_rows_sorted_supported": ([_I, _I], _I),
     "pcops_mlp_pool_top_supported": ([_I, _I, _I, _I], _I),
     "pcops_set_deterministic": ([_I], None),
     "pcops_get_deterministic": ([], _I),
@@ -195,10 +197,20 @@ def deterministic():
     return bool(load().pcops_get_deterministic())
 
 
+def scatter_rows_sorted_supported(rows, ndst):
+    """the launcher's own predicate (LDS-resident counting sort: ndst <= 19 968, rows < 2^30): callers that may use
+    the atomic form instead ask before choosing the ordered one"""
+    return bool(load().pcops_scatter_rows_sorted_supported(int(rows), int(ndst)))
+
+
 def scatter_rows_sorted(idx, src, ndst, div=1, w=None, out=None, c=None, ld=None, src_ptr=None):
     """out (B, ndst, C) = ordered scatter-add of the rows of src (pcops_scatter_rows_sorted).  idx (B, rows) int32;
     src (B, rows / div, C) unless c / ld / src_ptr describe a strided view; out given -> accumulate."""
     b, rows = idx.shape[0], idx[0].numel()
+    if not scatter_rows_sorted_supported(rows, ndst):
+        raise PcopsError("ordered scatter-add (deterministic backward): %d destination points per cloud, the limit is "
+                         "%d (the per-cloud counting sort lives in LDS); rows %d must stay below 2^30.  Switch "
+                         "deterministic mode off for clouds this large." % (ndst, load().pcops_scatter_rows_sorted_max_ndst(), rows))
     if c is None:
         c, ld = src.shape[-1], src.shape[-1]
     acc = out is not None

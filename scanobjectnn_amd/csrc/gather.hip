@@ -1391,6 +1391,13 @@ unsigned long long pcops_scatter_rows_workspace_bytes(int b, int rows, int ndst)
     return sizeof(int) * (4ull * b * rows + (unsigned long long)b * (ndst + 1) + 2);
 }
 
+// the per-cloud counting sort keeps two ndst-sized tables (+ 1024 ints of scan scratch) in the 160 KB of LDS
+int pcops_scatter_rows_sorted_max_ndst(void) { return (160 * 1024 / (int)sizeof(int) - 1024) / 2; }
+
+int pcops_scatter_rows_sorted_supported(int rows, int ndst) {
+    return (ndst >= 1 && ndst <= pcops_scatter_rows_sorted_max_ndst() && rows >= 0 && (long long)rows < (1ll << 30)) ? 1 : 0;
+}
+
 int pcops_scatter_rows_sorted(int b, int rows, int ndst, int c, int div, int ld_src, const int *idx, const float *w,
                               const float *src, float *out, int accumulate, void *workspace, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && rows >= 0 && ndst >= 1 && c >= 1 && div >= 1 && rows % div == 0 && ld_src >= c);
@@ -1399,7 +1406,7 @@ int pcops_scatter_rows_sorted(int b, int rows, int ndst, int c, int div, int ld_
     if (rows > 0) { PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(src); }
     if (reinterpret_cast<uintptr_t>(workspace) & 7) return PCOPS_ERR_UNSUPPORTED;
     const size_t blds = (2 * (size_t)ndst + 1024) * sizeof(int);
-    if (blds > 160 * 1024 || (long long)rows >= (1ll << 30)) return PCOPS_ERR_UNSUPPORTED;
+    if (!pcops_scatter_rows_sorted_supported(rows, ndst)) return PCOPS_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     int2 *order = static_cast<int2 *>(workspace);
     int *start = reinterpret_cast<int *>(order + (size_t)b * rows);

@@ -51,7 +51,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         # ordered owner walk instead of float atomics: always in deterministic mode, and by default where it is also the
         # faster form -- enough destination points to spread the lists (measured at the BGA config: 2048 -> 512 points,
         # 128 channels: 244 us against 321 us with atomics; a single destination point would serialise one list)
-        if _lib.deterministic() or (SORTED_GRAD and m >= 64):
+        if _lib.deterministic() or (SORTED_GRAD and m >= 64 and _lib.scatter_rows_sorted_supported(3 * n, m)):
             return _lib.scatter_rows_sorted(idx.view(b, 3 * n), grad_out, m, div=3, w=weight), None, None
         grad_points = torch.empty((b, m, c), dtype=torch.float32, device=grad_out.device)
         _lib.call("pcops_three_interpolate_grad", b, n, c, m, _lib.ptr(grad_out), _lib.ptr(idx),

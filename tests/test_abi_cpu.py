@@ -48,6 +48,12 @@ def test_argument_validation_without_gpu():
     assert lib.pcops_knn_graph(1, 8, 3, 9, None, None, None) == -3          # k > n
     assert lib.pcops_farthest_point_sample_workspace_bytes(32, 2048) == 0
     assert lib.pcops_mlp_stats_rows(4194304) == 512 and lib.pcops_mlp_stats_rows(100) == 1
+    # the ordered scatter-add says what it supports (LDS-resident counting sort), callers ask before choosing it
+    lim = lib.pcops_scatter_rows_sorted_max_ndst()
+    assert lim == 19968
+    assert lib.pcops_scatter_rows_sorted_supported(3 * 4096, lim) == 1
+    assert lib.pcops_scatter_rows_sorted_supported(3 * 4096, lim + 1) == 0
+    assert lib.pcops_scatter_rows_sorted_supported(1 << 30, 64) == 0
 
 
 def test_no_cpu_fallback():

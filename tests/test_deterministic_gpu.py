@@ -171,3 +171,27 @@ def test_training_step_is_bit_reproducible(name, deterministic):
     num = sum(float(((g1[k] - g3[k]).double() ** 2).sum()) for k in g1)
     den = sum(float((g3[k].double() ** 2).sum()) for k in g1)
     assert (num / den) ** 0.5 <= 1e-3
+
+
+def test_large_destination_sets_fall_back_to_atomics_or_say_why():
+    """the ordered scatter keeps its counting sort in LDS (<= 19 968 destination points per cloud).  Beyond
+    that the DEFAULT three_interpolate backward must still work (atomic form), and deterministic mode must refuse with
+    a message that names the limit instead of a bare status code."""
+    from scanobjectnn_amd.pointnet2 import tf_interpolate
+    b, n, m, c = 1, 4096, 20480, 8
+    assert not _lib.scatter_rows_sorted_supported(3 * n, m) and _lib.scatter_rows_sorted_supported(3 * n, 19968)
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn((b, m, c), generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand((b, n, 3), generator=g).to(DEV)
+    up = torch.randn((b, n, c), generator=g).to(DEV)
+    tf_interpolate.three_interpolate(pts, idx, w).backward(up)
+    want = _scatter_truth(idx.view(b, 3 * n), up, m, div=3, w=w.view(b, 3 * n))
+    assert (pts.grad.double() - want).abs().max().item() <= 1e-5
+    _lib.set_deterministic(True)
+    try:
+        pts.grad = None
+        with pytest.raises(_lib.PcopsError, match="19968"):
+            tf_interpolate.three_interpolate(pts, idx, w).backward(up)
+    finally:
+        _lib.set_deterministic(False)
