@@ -177,12 +177,18 @@ int pcops_edge_feature_grad_central(int b, int n, int c, int k, const float *gra
  *
  * forward:   Y[M,N] = f(X)[M,K] W[K,N] + bias,  f = identity (pro_scale == NULL) or relu(x*pro_scale[k] +
  *            pro_shift[k]) (= BN+ReLU of the previous layer applied on the fly).  stats_partial (may be NULL):
- *            float [pcops_mlp_stats_rows(M)][2][N] per-row-group column sums of Y and Y*Y. */
+ *            float [pcops_mlp_stats_rows(M)][2][N] per-row-group column sums of (Y - pivot) and (Y - pivot)^2,
+ *            pivot = stat_pivot [N] (NULL: 0).  SHIFTED MOMENTS: the variance of a batch-norm layer
+ *            (pointnet2/utils/tf_util.py:512-531; TensorFlow computes it in two passes) is finalised from one-pass
+ *            sums, and  E[y^2] - mean^2  on fp32 partial sums loses |mean|^2 / var digits.  Any per-channel estimate of
+ *            the mean within a few standard deviations -- the layer's moving mean is the natural one -- removes that:
+ *            the shift is algebraically neutral (pcops_mlp_bn_finalize adds it back to the mean), every producer of
+ *            forward statistics (this family, pcops_sa_gather_fwd, pcops_edge_pool_fwd) takes the same argument. */
 int pcops_mlp_stats_rows(int M);
 unsigned long long pcops_mlp_reduce_workspace_bytes(int N);
 int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                        const float *pro_shift, const float *W, const float *bias, float *Y,
-                       float *stats_partial, pcops_stream_t stream);
+                       float *stats_partial, const float *stat_pivot, pcops_stream_t stream);
 /* forward of a max-pooled LAST layer with the neighbourhood reduction (the reference's reduce_max over nsample,
  * pointnet_util.py:127) fused into the GEMM epilogue.  BN+ReLU is monotone per channel -- increasing for
  * gamma >= 0, decreasing for gamma < 0 (scale = gamma * rstd) -- so per group of S consecutive rows
@@ -196,15 +202,17 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
 int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S);
 int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx, const float *pro_scale,
                             const float *pro_shift, const float *W, const float *bias, const float *gamma,
-                            float *Y, float *stats_partial, float *ysel, unsigned char *argsel,
-                            pcops_stream_t stream);
+                            float *Y, float *stats_partial, const float *stat_pivot, float *ysel,
+                            unsigned char *argsel, pcops_stream_t stream);
 int pcops_mlp_pool_select(long long G, int C, const float *ysel, const float *scale, const float *shift,
                           float *out, pcops_stream_t stream);
 /* batch statistics -> mean, rstd = 1/sqrt(var+eps) (biased var), scale = gamma*rstd, shift = beta - mean*scale;
  * moving_* (may be NULL) <- decay*moving + (1-decay)*batch (unbiased batch variance if unbiased_moving_var).
- * P = rows of stats_partial, R = rows the statistics run over, workspace >= pcops_mlp_reduce_workspace_bytes(N). */
-int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
-                          const float *gamma, const float *beta, float eps, float decay,
+ * P = rows of stats_partial, R = rows the statistics run over, workspace >= pcops_mlp_reduce_workspace_bytes(N).
+ * stat_pivot: the pivot the producer of stats_partial was given (NULL: 0):  mean = pivot + s1/R,  var = s2/R - (s1/R)^2,
+ * reduced and finalised in fp64.  stat_pivot may alias moving_mean (each channel reads it before its update). */
+int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, const float *stat_pivot,
+                          void *workspace, const float *gamma, const float *beta, float eps, float decay,
                           int unbiased_moving_var, float *moving_mean, float *moving_var, float *mean,
                           float *rstd, float *scale, float *shift, pcops_stream_t stream);
 /* eval mode: scale/shift from the moving statistics */
@@ -308,7 +316,7 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
 int pcops_mlp_xyz_supported(int M, int C1, int N2);
 int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                            const float *pro_shift, const float *W, const float *bias, float *Y,
-                           float *stats_partial, pcops_stream_t stream);
+                           float *stats_partial, const float *stat_pivot, pcops_stream_t stream);
 int pcops_mlp_gemm_dgrad_xyz(int M, int K, int Nout, const float *G, const float *Y, const float *p,
                              const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                              int S, const float *pool_scale, const float *pool_shift, const float *Wt,
@@ -328,7 +336,8 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
  *     Y[b,j,s,:] = Q[b, idx[b,j,s], :] + Ctr[b,j,:] + (xyz[b,idx,:] - new_xyz[b,j,:]) Wxyz + bias
  * Q (b,n,c), Ctr (b,m,c), xyz (b,n,3), new_xyz (b,m,3), Wxyz (3,c), bias (c), idx (b,m,s); Q, Ctr, the coordinate
  * term and bias are each optional (NULL); the coordinate term is evaluated on the centred offsets (no cancellation).
- * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial (sum Y, sum Y*Y).
+ * stats_partial (may be NULL): float [pcops_sa_gather_stats_rows(b*m)][2][c] partial sums of (Y - pivot) and
+ * (Y - pivot)^2, pivot = stat_pivot [c] or 0 (shifted moments, see pcops_mlp_gemm_fwd).
  * Y may be NULL (statistics only) and off4 (may be NULL; needs the coordinate term) receives the centred offsets
  * (dx, dy, dz, 0) per grouped row, float [b*m*s][4]: when the layer has NO Q / Ctr term it is arithmetic in those
  * three numbers, and the pcops_mlp_*_xyz entry points rebuild it on the fly instead of reading a (b,m,s,c) tensor.
@@ -337,7 +346,8 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
 int pcops_sa_gather_stats_rows(long long groups);
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *off4, float *stats_partial, float *moments, pcops_stream_t stream);
+                        float *off4, float *stats_partial, const float *stat_pivot, float *moments,
+                        pcops_stream_t stream);
 /* backward through the BN+ReLU that follows: dY = p.G + q.Y + t (pooled form when gpool != NULL, as in
  * pcops_mlp_gemm_dgrad).  Outputs, each optional: dQ (b,n,c) = scatter-add of dY over idx (zeroed here),
  * dCtr (b,m,c) = sum over s, dWxyz (3,c) = sum (xyz[idx]-new_xyz)^T dY (needs xyz/new_xyz), dbias (c) = sum dY.
@@ -364,7 +374,10 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
  * inside a group and BN+ReLU is monotone per channel, so
  *   forward : qsel[g,c] = max_s (gamma[c] >= 0) | min_s (gamma[c] < 0) of Q[idx[g,s],c], arg = first s attaining it,
  *             SQ[g,c] = sum_s Q[idx[g,s],c];  stats_partial [pcops_edge_pool_stats_rows(b*m)][2][c] = partial
- *             (sum y, sum y^2) = (SQ + k Ctr, SQ2 + 2 Ctr SQ + k Ctr^2)  -> pcops_mlp_bn_finalize
+ *             (sum y', sum y'^2), y' = y - stat_pivot (shifted moments, see pcops_mlp_gemm_fwd), evaluated as
+ *             (SQ' + k c', SQ2' + 2 c' SQ' + k c'^2) with Q taken relative to its own first row, q' = q - Q[0,0,:], and
+ *             c' = Ctr + Q[0,0,:] - pivot, so that neither a common offset of Q nor one of Ctr cancels in fp32
+ *             -> pcops_mlp_bn_finalize with the same pivot
  *   out     : out = relu(scale (qsel + Ctr) + shift), ysel = qsel + Ctr
  *   backward: with (p, q, t) from pcops_mlp_pool_bwd_stats(gpool, ysel) + pcops_mlp_bn_bwd_coeffs,
  *             dCtr[g] = q (SQ + k Ctr) + k t + a[g],  a = p gpool [relu(bn(ysel)) > 0],
@@ -373,7 +386,7 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
 int pcops_edge_pool_stats_rows(long long groups);
 int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
                         const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,
-                        pcops_stream_t stream);
+                        const float *stat_pivot, pcops_stream_t stream);
 int pcops_edge_pool_out(long long groups, int c, const float *qsel, const float *Ctr, const float *scale,
                         const float *shift, float *out, float *ysel, pcops_stream_t stream);
 int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
@@ -412,10 +425,12 @@ int pcops_rows_plan(int b, int m, int s, const int *pts_cnt, void *blocks, int *
                     pcops_stream_t stream);
 int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                             const float *pro_shift, const float *W, const float *bias, float *Y,
-                            float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream);
+                            float *stats_partial, const float *stat_pivot, const pcops_rows_t *rows,
+                            pcops_stream_t stream);
 int pcops_mlp_gemm_fwd_xyz_rows(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                                 const float *pro_shift, const float *W, const float *bias, float *Y,
-                                float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream);
+                                float *stats_partial, const float *stat_pivot, const pcops_rows_t *rows,
+                                pcops_stream_t stream);
 int pcops_mlp_gemm_dgrad_rows(int M, int K, int Nout, const float *G, const float *Y, const float *p,
                               const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                               int S, const float *pool_scale, const float *pool_shift, const float *Wt,
@@ -443,8 +458,8 @@ int pcops_mlp_wgrad_xyz_rows(long long M, int K, int N, const float *off4, const
 int pcops_mlp_gemm_fwd_pool_rows_supported(int M, int K, int N);
 int pcops_mlp_gemm_fwd_pool_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                                  const float *pro_shift, const float *W, const float *bias, const float *gamma,
-                                 float *Y, float *stats_partial, float *ypart, unsigned char *ppart,
-                                 const pcops_rows_t *rows, pcops_stream_t stream);
+                                 float *Y, float *stats_partial, const float *stat_pivot, float *ypart,
+                                 unsigned char *ppart, const pcops_rows_t *rows, pcops_stream_t stream);
 int pcops_mlp_pool_combine_rows(long long G, int C, const float *ypart, const unsigned char *ppart,
                                 const float *gamma, const float *scale, const float *shift,
                                 const pcops_rows_t *rows, float *out, unsigned char *argmax, float *ysel,
@@ -457,8 +472,8 @@ int pcops_mlp_bn_relu_maxpool_rows(long long G, int C, const float *Y, const flo
  * compacted order; idx stays the (b,m,s) tensor of the ball query */
 int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                              const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                             float *off4, float *stats_partial, float *moments, const pcops_rows_t *rows,
-                             pcops_stream_t stream);
+                             float *off4, float *stats_partial, const float *stat_pivot, float *moments,
+                             const pcops_rows_t *rows, pcops_stream_t stream);
 int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G, const float *Y, const float *p,
                               const float *q, const float *t, const float *gpool, const unsigned char *argmax,
                               const float *pool_scale, const float *pool_shift, const int *idx, const float *xyz,

@@ -33,11 +33,11 @@ SIGNATURES = {
     "pcops_knn_graph": ([_I, _I, _I, _I, _P, _P], True),
     "pcops_edge_feature": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_edge_feature_grad": ([_I, _I, _I, _I, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_bn_finalize": ([_I, _I, _LL, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bn_finalize": ([_I, _I, _LL, _P, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_eval_coeffs": ([_I, _P, _P, _P, _P, _F, _P, _P], True),
     "pcops_mlp_bn_relu_maxpool": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd_pool": ([_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_pool": ([_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_pool_select": ([_LL, _I, _P, _P, _P, _P], True),
     "pcops_mlp_bn_relu_apply": ([_LL, _I, _P, _P, _P, _P], True),
     "pcops_mlp_relu_mask_stats": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
@@ -52,27 +52,27 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad_top": ([_I, _I] + [_P] * 6 + [_LL] + [_P] * 3, True),
     "pcops_mlp_gram": ([_LL, _I, _P, _I, _P, _P, _P, _P, _P], True),
     "pcops_mlp_pool_top_wsparse": ([_I, _I, _I, _I] + [_P] * 11, True),
-    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_xyz": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),
-    "pcops_edge_pool_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_edge_pool_fwd": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_pool_out": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_pool_bwd": ([_I, _I, _I, _I, _I] + [_P] * 15, True),
     "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),
     # ---- compacted rows (pcops.h "compacted rows"): the suffix-less signature + a pcops_rows_t* before the stream
     "pcops_rows_plan": ([_I, _I, _I, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_relu_maxpool_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_mlp_gemm_fwd_pool_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_gemm_fwd_pool_rows": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_pool_combine_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
-    "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd_rows": ([_I, _I, _I, _I, _I] + [_P] * 23, True),
     "pcops_scatter_rows_sorted": ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], True),
     "pcops_edge_feature_grad_central": ([_I, _I, _I, _I, _P, _P], True),

@@ -16,7 +16,7 @@ extern "C" const char *pcops_strerror(int status) {
     }
 }
 
-extern "C" int pcops_abi_version(void) { return 1; }
+extern "C" int pcops_abi_version(void) { return 2; }   // 2: stat_pivot (shifted BN moments) on the forward-statistics producers
 
 // bit-reproducible backward passes (reference hazard tf_grouping_g.cu:61-78, tf_sampling_g.cu:183-192:
 // float atomics).  Off: scatter-adds may use atomics / unordered lists.  On: every sum is taken by one owner in

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ bias,
                                                             const int *__restrict__ idx, float *__restrict__ Y,
                                                             float *__restrict__ off4, float *__restrict__ stats,
+                                                            const float *__restrict__ pivot,
                                                             float *__restrict__ moments, int groups_per_block,
                                                             const RowBlock *__restrict__ blocks,
                                                             const int *__restrict__ bstart) {
@@ -125,6 +126,8 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
         w2 = *reinterpret_cast<const float4 *>(Wxyz + 2 * C + cq);
     }
     if (bias) bb = *reinterpret_cast<const float4 *>(bias + cq);
+    // statistics relative to a per-channel pivot (shifted moments, pcops.h pcops_mlp_gemm_fwd): sums of y - pv
+    const float4 pv = (stats && pivot) ? *reinterpret_cast<const float4 *>(pivot + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     // rows are staged first, ONE thread per grouped row: index + centred offsets go to LDS (and to off4), so the
     // C/4 lanes that then share a row read them as an LDS broadcast instead of each issuing its own global loads
     float4 *st4 = reinterpret_cast<float4 *>(sm + RL * 2 * C);        // (dx, dy, dz, index bits) per staged row
@@ -189,10 +192,11 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                     const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, e.x, e.y, e.z, w0, w1, w2);
                     if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
                     const float wt = s == 0 ? w0row : 1.f;
-                    const float4 wy = make_float4(wt * y.x, wt * y.y, wt * y.z, wt * y.w);
+                    const float4 d = make_float4(y.x - pv.x, y.y - pv.y, y.z - pv.z, y.w - pv.w);
+                    const float4 wy = make_float4(wt * d.x, wt * d.y, wt * d.z, wt * d.w);
                     s1[0] += wy.x; s1[1] += wy.y; s1[2] += wy.z; s1[3] += wy.w;
-                    s2[0] = fmaf(wy.x, y.x, s2[0]); s2[1] = fmaf(wy.y, y.y, s2[1]);
-                    s2[2] = fmaf(wy.z, y.z, s2[2]); s2[3] = fmaf(wy.w, y.w, s2[3]);
+                    s2[0] = fmaf(wy.x, d.x, s2[0]); s2[1] = fmaf(wy.y, d.y, s2[1]);
+                    s2[2] = fmaf(wy.z, d.z, s2[2]); s2[3] = fmaf(wy.w, d.w, s2[3]);
                 }
             }
         }
@@ -966,7 +970,8 @@ __global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ gamma,
                                                             float *__restrict__ SQ, float *__restrict__ qsel,
                                                             unsigned char *__restrict__ arg,
-                                                            float *__restrict__ stats, int groups_per_block) {
+                                                            float *__restrict__ stats,
+                                                            const float *__restrict__ pivot, int groups_per_block) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [GL][2][C] statistics scratch
     const int c4n = C / 4;
     const int GL = 256 / c4n;                                    // groups in flight per block
@@ -976,6 +981,13 @@ __global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, 
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const float4 ga = *reinterpret_cast<const float4 *>(gamma + cq);
     const bool up[4] = {!(ga.x < 0.f), !(ga.y < 0.f), !(ga.z < 0.f), !(ga.w < 0.f)};
+    // shifted moments (pcops.h): the statistics are those of y - pivot, and the neighbour rows enter relative to ONE
+    // sample row of Q (row 0 of cloud 0 -- any row is within a few standard deviations of the channel's mean), so the
+    // three terms of  sum (q' + c')^2 = SQ2' + 2 c' SQ' + k c'^2  are all O(variance) and nothing cancels
+    const float4 q0 = stats ? *reinterpret_cast<const float4 *>(Q + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 pv4 = (stats && pivot) ? *reinterpret_cast<const float4 *>(pivot + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float qz[4] = {q0.x, q0.y, q0.z, q0.w};
+    const float cz[4] = {q0.x - pv4.x, q0.y - pv4.y, q0.z - pv4.z, q0.w - pv4.w};     // c' = Ctr + cz
     if (gl < GL) {
         for (long long g = g0 + gl; g < g1; g += GL) {
             const long long b = g / m;
@@ -991,20 +1003,22 @@ __global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, 
                 const float qv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    sq[e] += qv[e];
-                    sq2[e] = fmaf(qv[e], qv[e], sq2[e]);
+                    const float qd = qv[e] - qz[e];
+                    sq[e] += qd;
+                    sq2[e] = fmaf(qd, qd, sq2[e]);
                     const bool better = up[e] ? qv[e] > ex[e] : qv[e] < ex[e];    // strict: first extremum wins
                     ex[e] = better ? qv[e] : ex[e];
                     ea[e] = better ? s : ea[e];
                 }
             }
-            *reinterpret_cast<float4 *>(SQ + g * C + cq) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+            const float kf = (float)S;
+            *reinterpret_cast<float4 *>(SQ + g * C + cq) =                       // the backward reads SQ = sum_s q
+                make_float4(fmaf(kf, qz[0], sq[0]), fmaf(kf, qz[1], sq[1]), fmaf(kf, qz[2], sq[2]), fmaf(kf, qz[3], sq[3]));
             *reinterpret_cast<float4 *>(qsel + g * C + cq) = make_float4(ex[0], ex[1], ex[2], ex[3]);
             uchar4 a4;
             a4.x = (unsigned char)ea[0]; a4.y = (unsigned char)ea[1]; a4.z = (unsigned char)ea[2]; a4.w = (unsigned char)ea[3];
             *reinterpret_cast<uchar4 *>(arg + g * C + cq) = a4;
-            const float cv[4] = {ct.x, ct.y, ct.z, ct.w};
-            const float kf = (float)S;
+            const float cv[4] = {ct.x + cz[0], ct.y + cz[1], ct.z + cz[2], ct.w + cz[3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 s1[e] += fmaf(kf, cv[e], sq[e]);
@@ -1452,15 +1466,16 @@ static int gather_rows_ok(const pcops_rows_t *rows, int s) {
 
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                        float *off4, float *stats_partial, float *moments, pcops_stream_t stream) {
+                        float *off4, float *stats_partial, const float *stat_pivot, float *moments,
+                        pcops_stream_t stream) {
     return pcops_sa_gather_fwd_rows(b, n, m, s, c, Q, Ctr, xyz, new_xyz, Wxyz, bias, idx, Y, off4, stats_partial,
-                                    moments, nullptr, stream);
+                                    stat_pivot, moments, nullptr, stream);
 }
 
 int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                              const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
-                             float *off4, float *stats_partial, float *moments, const pcops_rows_t *rows,
-                             pcops_stream_t stream) {
+                             float *off4, float *stats_partial, const float *stat_pivot, float *moments,
+                             const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && c >= 4 && c % 4 == 0);
     {
         const int rrc = gather_rows_ok(rows, s);
@@ -1479,7 +1494,7 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        ((size_t)rl * 2 * c + staged) * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
-                       Wxyz, bias, idx, Y, off4, stats_partial, moments, gather_groups_per_block(G),
+                       Wxyz, bias, idx, Y, off4, stats_partial, stat_pivot, moments, gather_groups_per_block(G),
                        rows ? static_cast<const RowBlock *>(rows->blocks) : nullptr, rows ? rows->block_start : nullptr);
     return pcops_launch_status();
 }
@@ -1695,7 +1710,7 @@ int pcops_edge_pool_stats_rows(long long G) { return (int)((G + 63) / 64); }
 
 int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
                         const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,
-                        pcops_stream_t stream) {
+                        const float *stat_pivot, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1 && m >= 0 && s >= 1 && s <= 256 && c >= 4 && c % 4 == 0);
     PCOPS_REQUIRE_SHAPE(c <= 1024 && 256 % (c / 4) == 0);
     const long long G = (long long)b * m;
@@ -1705,7 +1720,7 @@ int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const
     const int gl = 256 / (c / 4);
     hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3(pcops_edge_pool_stats_rows(G)), dim3(256),
                        (size_t)gl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel,
-                       arg, stats_partial, 64);
+                       arg, stats_partial, stat_pivot, 64);
     return pcops_launch_status();
 }
 

@@ -115,6 +115,10 @@ struct GemmArgs {
     const float *msc;    // E_MASK: bn scale / shift of the previous layer
     const float *msh;
     float *stats;        // [gridDim.y][2][N] partial column sums (null: none)
+    const float *pivot;  // E_FWD: [N] per-channel pivot the forward statistics are taken relative to -- sums of
+                         // (y - pivot) and (y - pivot)^2 (null: 0).  Any estimate of the channel mean within a few
+                         // standard deviations (the BN layer's moving mean) removes the cancellation of the one-pass
+                         // variance  E[y^2] - mean^2  in fp32; pcops_mlp_bn_finalize undoes the shift exactly
     int nrowgrp;         // wave-stream kernel: row groups that own tiles; workgroups beyond only zero their statistics row
     float *xstats;       // E_MASKX: [rows of stats][3][N] partial sums of off (x) Gprev -- with them the arithmetic first
                          // layer's weight gradient needs neither Gprev nor a pass over it (Y may then be NULL)
@@ -293,8 +297,9 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
             const int n = n0 + 32 * nt + (lane & 31);
             const bool ncol = n < N;
-            float bias = 0.f, msc = 0.f, msh = 0.f;
+            float bias = 0.f, msc = 0.f, msh = 0.f, pv = 0.f;
             if (EM == E_FWD && a.bias && ncol) bias = a.bias[n];
+            if (EM == E_FWD && a.pivot && ncol) pv = a.pivot[n];
             if (EM == E_MASK && ncol) { msc = a.msc[n]; msh = a.msh[n]; }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -303,8 +308,9 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
                     float o = acc[nt][v];
                     if (EM == E_FWD) {
                         o += bias;
-                        s1[nt] += o;
-                        s2[nt] = fmaf(o, o, s2[nt]);
+                        const float d = o - pv;              // statistics relative to the pivot (GemmArgs::pivot)
+                        s1[nt] += d;
+                        s2[nt] = fmaf(d, d, s2[nt]);
                     } else if (EM == E_MASK) {
                         const float yp = a.Yprev[r * a.ldy + n];
                         o = fmaf(yp, msc, msh) > 0.f ? o : 0.f;
@@ -503,13 +509,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int e = tid; e < BN; e += NTHR) {
             const int n = n0 + e;
             float e0 = 0.f, e1 = 0.f;
+            float pv = 0.f;
             if (n < N) {
                 if (EM == E_FWD && a.bias) e0 = a.bias[n];
+                if (EM == E_FWD && a.pivot) pv = a.pivot[n];
                 if (is_mask(EM)) { e0 = a.msc[n]; e1 = a.msh[n]; }
                 if (POOL) e1 = a.pgamma[n] < 0.f ? -1.f : 1.f;
             }
-            ecoef[e] = e0;
+            // forward: the accumulators START at bias - pivot, so the tile comes out of the matrix pipe as y - pivot --
+            // what the statistics sum -- and the pivot is added back on the way to the store (the add the bias used to
+            // be): shifted moments at no extra instruction
+            ecoef[e] = EM == E_FWD ? e0 - pv : e0;
             ecoef[BN + e] = e1;
+            if (EM == E_FWD) ecoef[2 * BN + e] = pv;
             if (EM == E_MASKX) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ecoef[(2 + i) * BN + e] = n < N ? a.xw[i * a.xw_ld + n] : 0.f;
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+            for (int v = 0; v < 16; ++v) acc[i][v] = EM == E_FWD ? ecoef[32 * i + (lane & 31)] : 0.f;   // bias - pivot
 
         for (int kc = 0; kc < nchunk; ++kc) {
             if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
@@ -817,6 +829,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
             const float4 eb = *reinterpret_cast<const float4 *>(&ecoef[ocq]);
             const float4 em = *reinterpret_cast<const float4 *>(&ecoef[BN + ocq]);
+            const float4 epv = EM == E_FWD ? *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq])
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);             // forward: the pivot
             float ew[2] = {1.f, 1.f};                        // compacted rows: statistics weight of rows 0 / 16
             int es0[2] = {0, 0};                             //                 row-in-group of rows 0 / 16
             if (EM == E_FWD && compact) {
@@ -844,7 +858,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocl]);
                 if (r < erem && ocin) {
                     if (EM == E_FWD) {
-                        o.x += eb.x; o.y += eb.y; o.z += eb.z; o.w += eb.w;
+                        // o = y - pivot here (accumulator start value): the statistics take it as it is
                         if (compact && O4 == 16 && j % 4 == 0) {      // rows 0 / 16 of the tile stand for w rows
                             const float w = lane < 16 ? ew[j / 4] : 1.f;
                             const float4 wo = make_float4(w * o.x, w * o.y, w * o.z, w * o.w);
@@ -856,6 +870,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         s2[h][0] = fmaf(o.x, o.x, s2[h][0]); s2[h][1] = fmaf(o.y, o.y, s2[h][1]);
                         s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
                         }
+                        o.x += epv.x; o.y += epv.y; o.z += epv.z; o.w += epv.w;          // back to y
                         if (POOL) {   // rows arrive in ascending order: a strict comparison keeps the first extremum
                             const int sr = compact ? es0[(O4 == 16) ? j / 4 : 0] + (r & (kBlk - 1)) : sub * 32 + r;
                             const float ov[4] = {o.x * em.x, o.y * em.y, o.z * em.z, o.w * em.w};
@@ -1113,6 +1128,7 @@ __global__ __launch_bounds__(256) void colreduce_stage1(int P, int N, const floa
 
 // forward BN: statistics -> (mean, rstd, scale, shift) and the moving-average update
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int N, double R, const double *__restrict__ ws,
+                                                          const float *__restrict__ pivot,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
                                                           float decay, int unbiased,
@@ -1127,8 +1143,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int N, double R, const
         s1 += ws[((long long)s * 2 + 0) * N + c];
         s2 += ws[((long long)s * 2 + 1) * N + c];
     }
-    const double mean = s1 / R;
-    double var = s2 / R - mean * mean;
+    // the sums are those of (y - pivot) and (y - pivot)^2: the shift leaves the variance untouched and is added back
+    // to the mean; with the pivot near the mean the subtraction below no longer cancels leading digits
+    const double dm = s1 / R;
+    const double mean = dm + (pivot ? (double)pivot[c] : 0.0);
+    double var = s2 / R - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * rstd;
@@ -2229,6 +2248,7 @@ __device__ __forceinline__ bool fused_col_sums(int P, int N, const float *__rest
 }
 
 __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(int P, int N, double R, const float *__restrict__ part,
+                                                                const float *__restrict__ pivot,
                                                                 const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, float eps,
                                                                 float decay, int unbiased,
@@ -2241,8 +2261,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_fused_kernel(int P, int N, d
     double s1, s2;
     int c;
     if (!fused_col_sums(P, N, part, s1, s2, c)) return;
-    const double mean = s1 / R;
-    double var = s2 / R - mean * mean;
+    const double dm = s1 / R;                                    // sums of (y - pivot), (y - pivot)^2: see bn_finalize_kernel
+    const double mean = dm + (pivot ? (double)pivot[c] : 0.0);
+    double var = s2 / R - dm * dm;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * rstd;
@@ -2610,7 +2631,8 @@ static int rows_ok(const pcops_rows_t *rows) {
 
 int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                             const float *pro_shift, const float *W, const float *bias, float *Y,
-                            float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream) {
+                            float *stats_partial, const float *stat_pivot, const pcops_rows_t *rows,
+                            pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 0 && K >= 1 && N >= 1 && ldx >= K);
     if (M == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
@@ -2618,7 +2640,7 @@ int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const 
     if (pro_scale) PCOPS_REQUIRE_SHAPE(K % 4 == 0);  // coefficient vectors are read 4 at a time
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
-    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial; a.pivot = stats_partial ? stat_pivot : nullptr;
     PCOPS_ROWS(a, rows);
     if (pro_scale) return launch_gemm<A_BNRELU, E_FWD>(a, as_stream(stream));
     return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));
@@ -2626,8 +2648,9 @@ int pcops_mlp_gemm_fwd_rows(int M, int K, int N, const float *X, int ldx, const 
 
 int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                        const float *pro_shift, const float *W, const float *bias, float *Y,
-                       float *stats_partial, pcops_stream_t stream) {
-    return pcops_mlp_gemm_fwd_rows(M, K, N, X, ldx, pro_scale, pro_shift, W, bias, Y, stats_partial, nullptr, stream);
+                       float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
+    return pcops_mlp_gemm_fwd_rows(M, K, N, X, ldx, pro_scale, pro_shift, W, bias, Y, stats_partial, stat_pivot, nullptr,
+                                   stream);
 }
 
 static bool fwd_pool_shape_ok(int M, int K, int N, int S) {
@@ -2642,8 +2665,8 @@ int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S) { return fwd_p
 
 int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx, const float *pro_scale,
                             const float *pro_shift, const float *W, const float *bias, const float *gamma,
-                            float *Y, float *stats_partial, float *ysel, unsigned char *argsel,
-                            pcops_stream_t stream) {
+                            float *Y, float *stats_partial, const float *stat_pivot, float *ysel,
+                            unsigned char *argsel, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K && S >= 1);
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W);
     PCOPS_REQUIRE_ARG((pro_scale == nullptr) == (pro_shift == nullptr));
@@ -2653,7 +2676,7 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
         return PCOPS_ERR_UNSUPPORTED;
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
-    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial; a.pivot = stats_partial ? stat_pivot : nullptr;
     a.pool_sub = S / 32; a.pgamma = gamma; a.ysel = ysel; a.psel = argsel;
     WsPlan pl;
     if (!ws_plan(a, A_BNRELU, &pl)) return PCOPS_ERR_UNSUPPORTED;   // pointer alignment
@@ -2663,8 +2686,8 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
 
 int pcops_mlp_gemm_fwd_pool_rows(int M, int K, int N, const float *X, int ldx, const float *pro_scale,
                                  const float *pro_shift, const float *W, const float *bias, const float *gamma,
-                                 float *Y, float *stats_partial, float *ypart, unsigned char *ppart,
-                                 const pcops_rows_t *rows, pcops_stream_t stream) {
+                                 float *Y, float *stats_partial, const float *stat_pivot, float *ypart,
+                                 unsigned char *ppart, const pcops_rows_t *rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && ldx >= K);
     PCOPS_REQUIRE_PTR(X); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(pro_scale);
     PCOPS_REQUIRE_PTR(pro_shift); PCOPS_REQUIRE_PTR(gamma); PCOPS_REQUIRE_PTR(ypart); PCOPS_REQUIRE_PTR(ppart);
@@ -2673,7 +2696,7 @@ int pcops_mlp_gemm_fwd_pool_rows(int M, int K, int N, const float *X, int ldx, c
         return PCOPS_ERR_UNSUPPORTED;
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
-    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial; a.pivot = stats_partial ? stat_pivot : nullptr;
     a.pool_sub = 1; a.pgamma = gamma; a.ysel = ypart; a.psel = ppart;       // one partial per 16-row block
     PCOPS_ROWS(a, rows);
     WsPlan pl;
@@ -2717,8 +2740,8 @@ int pcops_mlp_pool_select(long long G, int C, const float *ysel, const float *sc
     return pcops_launch_status();
 }
 
-int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, void *workspace,
-                          const float *gamma, const float *beta, float eps, float decay,
+int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial, const float *stat_pivot,
+                          void *workspace, const float *gamma, const float *beta, float eps, float decay,
                           int unbiased_moving_var, float *moving_mean, float *moving_var, float *mean,
                           float *rstd, float *scale, float *shift, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(P >= 1 && N >= 1 && R >= 1);
@@ -2729,15 +2752,15 @@ int pcops_mlp_bn_finalize(int P, int N, long long R, const float *stats_partial,
     hipStream_t st = as_stream(stream);
     if (P <= kFusedRows) {
         hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3((N + 31) / 32), dim3(1024), 0, st, P, N, (double)R,
-                           stats_partial, gamma, beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean,
+                           stats_partial, stat_pivot, gamma, beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean,
                            rstd, scale, shift);
         return pcops_launch_status();
     }
     double *ws = static_cast<double *>(workspace);
     int rc = reduce_stats(P, N, stats_partial, ws, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (double)R, ws, gamma,
-                       beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean, rstd, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (double)R, ws, stat_pivot,
+                       gamma, beta, eps, decay, unbiased_moving_var, moving_mean, moving_var, mean, rstd, scale, shift);
     return pcops_launch_status();
 }
 
@@ -2905,14 +2928,15 @@ int pcops_mlp_xyz_supported(int M, int C1, int N2) {
  * off4 [M][4] and xyzw [4][K]; otherwise pcops_mlp_gemm_fwd */
 int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                            const float *pro_shift, const float *W, const float *bias, float *Y,
-                           float *stats_partial, pcops_stream_t stream) {
-    return pcops_mlp_gemm_fwd_xyz_rows(M, K, N, off4, xyzw, pro_scale, pro_shift, W, bias, Y, stats_partial, nullptr,
-                                       stream);
+                           float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
+    return pcops_mlp_gemm_fwd_xyz_rows(M, K, N, off4, xyzw, pro_scale, pro_shift, W, bias, Y, stats_partial, stat_pivot,
+                                       nullptr, stream);
 }
 
 int pcops_mlp_gemm_fwd_xyz_rows(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                                 const float *pro_shift, const float *W, const float *bias, float *Y,
-                                float *stats_partial, const pcops_rows_t *rows, pcops_stream_t stream) {
+                                float *stats_partial, const float *stat_pivot, const pcops_rows_t *rows,
+                                pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && N >= 1);
     PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(pro_scale); PCOPS_REQUIRE_PTR(pro_shift);
     PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(Y);
@@ -2920,7 +2944,7 @@ int pcops_mlp_gemm_fwd_xyz_rows(int M, int K, int N, const float *off4, const fl
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = nullptr; a.ldx = K; a.v0 = pro_scale; a.v1 = pro_shift;
     a.off4 = off4; a.xw = xyzw; a.xw_ld = K;
-    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial;
+    a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial; a.pivot = stats_partial ? stat_pivot : nullptr;
     PCOPS_ROWS(a, rows);
     return launch_gemm_ws_only<A_XYZ, E_FWD>(a, as_stream(stream));
 }

@@ -105,13 +105,16 @@ class FusedMLPStack(torch.autograd.Function):
             xyzw = torch.cat([wxyz.detach(), (bias.detach() if bias is not None
                                               else torch.zeros(C1, dtype=torch.float32, device=dev)).view(1, C1)]).contiguous()
         for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
+            # forward statistics are shifted moments around the layer's moving mean (pcops.h pcops_mlp_gemm_fwd): the
+            # producer and pcops_mlp_bn_finalize get the same pivot; finalize reads it before it updates the buffer
+            piv = mm.data_ptr() if training else None
             if li == 0 and gather:
                 N = C1
                 Y = None if virt else _f32((R, N), dev)
                 P = lib.pcops_sa_gather_stats_rows(B * M)
                 part = _f32((P, 2, N), dev) if training else None
                 _lib.call("pcops_sa_gather_fwd_rows", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
-                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), _p(mom), rref)
+                          _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), piv, _p(mom), rref)
                 W2 = None
             else:
                 N = w.shape[-1]
@@ -122,7 +125,7 @@ class FusedMLPStack(torch.autograd.Function):
                 part = _f32((P, 2, N), dev) if training else None
                 if li == 1 and virt:
                     _lib.call("pcops_mlp_gemm_fwd_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(), sc_prev.data_ptr(),
-                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
+                              sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), piv, rref)
                 elif (rows is not None and pool and li == L - 1 and sc_prev is not None and ld == K and FUSE_POOL_ROWS
                         and lib.pcops_mlp_gemm_fwd_pool_rows_supported(R, K, N)):
                     # compacted rows: the epilogue emits the extremum of every 16-row block (a block lies inside one
@@ -131,11 +134,11 @@ class FusedMLPStack(torch.autograd.Function):
                     pooled_parts = (_f32((nbk, N), dev), torch.empty((nbk, N), dtype=torch.uint8, device=dev))
                     _lib.call("pcops_mlp_gemm_fwd_pool_rows", R, K, N, src.data_ptr(), ld, sc_prev.data_ptr(),
                               sh_prev.data_ptr(), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), Y.data_ptr(),
-                              _p(part), pooled_parts[0].data_ptr(), pooled_parts[1].data_ptr(), rref)
+                              _p(part), piv, pooled_parts[0].data_ptr(), pooled_parts[1].data_ptr(), rref)
                 elif rows is not None:
                     # compacted rows without the fused epilogue: the max over the groups is its own pass below
                     _lib.call("pcops_mlp_gemm_fwd_rows", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
-                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), rref)
+                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), piv, rref)
                 elif (pool and li == L - 1 and ld == K and lib.pcops_mlp_gemm_fwd_pool_supported(R, K, N, S)
                         and (sc_prev is not None or li == 0)):
                     # neighbourhood max fused into the GEMM epilogue (raw extrema; resolved after the statistics).
@@ -148,10 +151,10 @@ class FusedMLPStack(torch.autograd.Function):
                         Y = None
                     _lib.call("pcops_mlp_gemm_fwd_pool", R, K, N, S, src.data_ptr(), ld, _p(sc_prev),
                               _p(sh_prev), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), _p(Y),
-                              _p(part), pooled_raw[0].data_ptr(), pooled_raw[1].data_ptr())
+                              _p(part), piv, pooled_raw[0].data_ptr(), pooled_raw[1].data_ptr())
                 else:
                     _lib.call("pcops_mlp_gemm_fwd", R, K, N, src.data_ptr(), ld, _p(sc_prev), _p(sh_prev),
-                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part))
+                              W2.data_ptr(), b.data_ptr(), Y.data_ptr(), _p(part), piv)
             scale, shift = vecs.take(N), vecs.take(N)
             if training:
                 mean, rstd = vecs.take(N), vecs.take(N)
@@ -159,7 +162,7 @@ class FusedMLPStack(torch.autograd.Function):
                 if sync:        # SyncBN: the statistics of the global batch
                     part, Rf = _dist.allreduce_stat_partials(part, R)
                     Pf = 1
-                _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+                _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), piv, ws.data_ptr(), gamma.data_ptr(),
                           beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
                 means.append(mean)
@@ -465,7 +468,7 @@ class _RowsLinear(torch.autograd.Function):
         R, K = x.shape
         N = w.shape[1]
         y = _f32((R, N), x.device)
-        _lib.call("pcops_mlp_gemm_fwd", R, K, N, x.data_ptr(), K, None, None, w.data_ptr(), _p(b), y.data_ptr(), None)
+        _lib.call("pcops_mlp_gemm_fwd", R, K, N, x.data_ptr(), K, None, None, w.data_ptr(), _p(b), y.data_ptr(), None, None)
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         return y
@@ -483,7 +486,7 @@ class _RowsLinear(torch.autograd.Function):
             wt = _f32((N, K), dev)
             _lib.call("pcops_mlp_transpose", K, N, w.data_ptr(), wt.data_ptr())
             dx = _f32((R, K), dev)
-            _lib.call("pcops_mlp_gemm_fwd", R, N, K, g.data_ptr(), N, None, None, wt.data_ptr(), None, dx.data_ptr(), None)
+            _lib.call("pcops_mlp_gemm_fwd", R, N, K, g.data_ptr(), N, None, None, wt.data_ptr(), None, dx.data_ptr(), None, None)
         if ctx.needs_input_grad[1] or ctx.has_bias:
             n4 = (N + 3) // 4 * 4
             coef = torch.zeros(3 * n4, dtype=torch.float32, device=dev)     # p = 1, q = 0, t = 0: dY = G
@@ -523,7 +526,8 @@ class EdgeConvPool(torch.autograd.Function):
         P = lib.pcops_edge_pool_stats_rows(G)
         part = _f32((P, 2, C), dev) if training else None
         _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
-                  gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part))
+                  gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part),
+                  mm.data_ptr() if training else None)       # shifted moments around the moving mean (pcops.h)
         vecs = _VecArena([C], 4, dev)
         scale, shift = vecs.take(C), vecs.take(C)
         mean = rstd = None
@@ -534,7 +538,7 @@ class EdgeConvPool(torch.autograd.Function):
             if sync:
                 part, Rf = _dist.allreduce_stat_partials(part, G * S)
                 Pf = 1
-            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), mm.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                       beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                       mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         else:

@@ -29,7 +29,7 @@ for (M, K, N) in SHAPES:
     Y = torch.empty(M, N, device=dev)
     P = lib.pcops_mlp_stats_rows(M); part = torch.empty(P, 2, N, device=dev)
     if which in ("fwd", "all"):
-        ms = timeit(lambda: _lib.call("pcops_mlp_gemm_fwd", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), part.data_ptr()))
+        ms = timeit(lambda: _lib.call("pcops_mlp_gemm_fwd", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), part.data_ptr(), None))
         gb = (M * K + M * N) * 4 / 1e9; gf = 2.0 * M * K * N / 1e9
         print("fwd   M=%8d K=%4d N=%4d  %8.3f ms  %7.1f GB/s  %6.1f TF/s" % (M, K, N, ms, gb / ms * 1e3, gf / ms))
     if which in ("dgrad", "all"):

@@ -1,0 +1,101 @@
+"""Per-tensor gradient error of the fused path and of the layer-by-layer fp32 path against the float64 restatement
+(the numbers behind tests/test_models_parity_gpu.py::test_model_training_gradients), for several seeds: which tensors
+carry the error, and how the two fp32 paths compare seed by seed.   python tools/diag_grad_parity.py [model ...]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_models as R  # noqa: E402
+from scanobjectnn_amd.graph import Model  # noqa: E402
+from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks  # noqa: E402
+import test_models_parity_gpu as T  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def run(name, seed, verbose):
+    from scanobjectnn_amd.dgcnn import dgcnn, dgcnn_bga
+    from scanobjectnn_amd.dgcnn import tf_util as td
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga, pointnet2_cls_msg, pointnet2_cls_ssg
+    from scanobjectnn_amd.pointnet2 import tf_util as t2
+    ident = lambda inputs, is_training, scope, keep_prob=0.5, noise_shape=None: inputs  # noqa: E731
+    t2.dropout = ident
+    td.dropout = ident
+    mod, ref, n_pts, has_mask = {
+        "ssg": (pointnet2_cls_ssg, R.pointnet2_cls_ssg, 1024, False),
+        "bga": (pointnet2_cls_bga, R.pointnet2_cls_bga, 1024, True),
+        "msg": (pointnet2_cls_msg, R.pointnet2_cls_msg, 1024, False),
+        "dgcnn": (dgcnn, R.dgcnn, 256, False),
+        "dgcnn_bga": (dgcnn_bga, R.dgcnn_bga, 256, True)}[name]
+    B = 16
+    c = synth_clouds(B, n_pts, seed=21 + seed)
+    y = torch.from_numpy(synth_labels(B, seed=21 + seed))
+    mask = torch.from_numpy(synth_masks(B, n_pts, seed=21 + seed)) if has_mask else None
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(mod.get_model, device=DEV, seed=6 + seed).build(x)
+    T._randomise(net, 12 + seed)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    graphs = []
+    real = td.knn_graph
+    if name.startswith("dgcnn"):
+        def recording(point_cloud, k=20):
+            nn = real(point_cloud, k=k)
+            graphs.append(nn.cpu().numpy())
+            return nn
+        td.knn_graph = recording
+
+    def product_grads():
+        net.load_state_dict(sd)
+        net.zero_grad(set_to_none=True)
+        del graphs[:]
+        out = net(x, is_training=True, bn_decay=0.9)
+        loss = (mod.get_loss(out[0], out[1], y.to(DEV), mask.to(DEV))[0] if has_mask else mod.get_loss(out[0], y.to(DEV)))
+        loss.backward()
+        return {k: (p.grad.detach().cpu().double() if p.grad is not None else torch.zeros_like(p).cpu().double())
+                for k, p in net.named_parameters()}
+
+    gf = product_grads()
+    P = {k: v.requires_grad_(v.is_floating_point()) for k, v in R.params_from_state_dict(sd, dtype=torch.float64).items()}
+    kw = {"nn_list": list(graphs)} if name.startswith("dgcnn") else {}
+    want = ref(torch.from_numpy(c).double(), P, True, **kw)
+    (mod.get_loss(want[0], want[1], y, mask)[0] if has_mask else mod.get_loss(want, y)).backward()
+    t2.FUSED_MLP = False
+    gl = product_grads()
+    t2.FUSED_MLP = True
+    td.knn_graph = real
+    names = dict(net.named_parameters())
+    rows, nf, nl, den = [], 0.0, 0.0, 0.0
+    for k in gf:
+        if k.endswith("biases") and k[:-len("biases")] + "bn/gamma" in names:
+            continue
+        r = P[k[len("graph."):]].grad
+        r = r if r is not None else torch.zeros_like(P[k[len("graph."):]])
+        rn = r.norm().item()
+        ef, el = (gf[k] - r).norm().item(), (gl[k] - r).norm().item()
+        nf += ef * ef
+        nl += el * el
+        den += rn * rn
+        rows.append((k, rn, ef / max(rn, 1e-30), el / max(rn, 1e-30)))
+    if verbose:
+        for k, rn, a, b in sorted(rows, key=lambda t: -t[2] * t[1])[:12]:
+            print("   %-48s |ref| %.3e  fused %.2e  plain %.2e" % (k, rn, a, b))
+    return (nf / den) ** 0.5, (nl / den) ** 0.5
+
+
+if __name__ == "__main__":
+    models = sys.argv[1:] or ["msg", "dgcnn_bga", "bga", "dgcnn"]
+    out = {}
+    for m in models:
+        res = [run(m, s, s == 0) for s in range(4)]
+        out[m] = {"fused": [r[0] for r in res], "plain": [r[1] for r in res]}
+        print(m, "fused", ["%.2e" % r[0] for r in res], "plain", ["%.2e" % r[1] for r in res],
+              "geo-mean ratio %.2f" % float(np.exp(np.mean([np.log(r[0] / r[1]) for r in res]))), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "diag_grad_parity.json"), "w"), indent=1)
