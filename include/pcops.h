@@ -99,6 +99,16 @@ int pcops_group_point_grad(int b, int n, int c, int m, int nsample,
  * Full (b,m,n) outputs like the op; first k columns sorted, literal unstable order. */
 int pcops_selection_sort(int b, int n, int m, int k, const float *dist, int *outi,
                          float *out, pcops_stream_t stream);
+/* knn_point(k, xyz1, xyz2) of the Python wrapper (grouping/tf_grouping.py:49-74: tile + subtract + square + reduce_sum,
+ * SelectionSort, slice): xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> val (b,m,k) squared distances, idx (b,m,k).
+ * dist[t] = sum_l (xyz1[t,l] - xyz2[j,l])^2 with l ascending and no contraction, then the literal selection sort above;
+ * fused: a wave per query with its distance row in LDS, so neither the (b,m,n,c) difference tensor nor the (b,m,n)
+ * matrix exists.  n <= 8192 (pcops_knn_point_supported); larger clouds: pcops_knn_point_dist + pcops_selection_sort. */
+int pcops_knn_point_supported(int n);
+int pcops_knn_point(int b, int n, int c, int m, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                    pcops_stream_t stream);
+int pcops_knn_point_dist(int b, int n, int c, int m, const float *xyz1, const float *xyz2, float *dist,
+                         pcops_stream_t stream);
 
 /* ------------------------------------------------------------ 3d_interpolation */
 /* threenn_cpu(b,n,m,xyz1,xyz2,dist,idx)   3d_interpolation/tf_interpolate.cpp:60-103

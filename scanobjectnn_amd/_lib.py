@@ -74,6 +74,8 @@ SIGNATURES = {
     "pcops_mlp_pool_combine_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_gather_fwd_rows": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd_rows": ([_I, _I, _I, _I, _I] + [_P] * 23, True),
+    "pcops_knn_point": ([_I, _I, _I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_knn_point_dist": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_scatter_rows_sorted": ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], True),
     "pcops_edge_feature_grad_central": ([_I, _I, _I, _I, _P, _P], True),
 }
@@ -95,6 +97,7 @@ PLAIN = {
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
     "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),
     "pcops_scatter_rows_workspace_bytes": ([_I, _I, _I], _U64),
+    "pcops_knn_point_supported": ([_I], _I),
     "pcops_scatter_rows_sorted_max_ndst": ([], _I),
     "pcops_scatter_rows_sorted_supported": ([_I, _I], _I),
     "pcops_mlp_pool_top_supported": ([_I, _I, _I, _I], _I),

@@ -311,19 +311,41 @@ __global__ __launch_bounds__(64) void selection_sort_kernel(long long rows, int 
 // FIRST minimum that is strictly smaller than v[s] (`x < mv`, selection_sort.cpp:29-36): lanes keep their first minimum
 // (ascending t, strict <), the butterfly prefers the smaller index on equal values, and the winner only replaces
 // position s if it is strictly smaller than v[s] -- NaNs never win and a NaN at s never moves, as in the scalar loop.
+//
+// FUSED (knn_point, tf_grouping.py:49-74): the row is not read but COMPUTED -- dist[t] = sum_l (xyz1[b,t,l] - xyz2[b,j,l])^2,
+// l ascending, uncontracted (this file is built with -ffp-contract=off; the order TF's reduce_sum leaves open is fixed as in
+// oracle_knn_point) -- and only the first k columns leave, as (val, idx) of shape (b, m, k): neither the tiled
+// (b, m, n, c) difference tensor nor the (b, m, n) distance matrix of the reference graph ever exists.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void selection_sort_wave_kernel(long long rows, int n, int k, int waves,
                                                                   const float *__restrict__ dist,
-                                                                  int *__restrict__ outi, float *__restrict__ out) {
+                                                                  int *__restrict__ outi, float *__restrict__ out,
+                                                                  int c, int m, const float *__restrict__ xyz1,
+                                                                  const float *__restrict__ xyz2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r = (long long)blockIdx.x * waves + wave;
     if (wave >= waves || r >= rows) return;
     float *v = sm + (size_t)wave * 2 * n;
     int *ix = reinterpret_cast<int *>(v + n);
-    const float *src = dist + r * n;
-    for (int t = lane; t < n; t += 64) {
-        v[t] = src[t];
-        ix[t] = t;
+    if (FUSED) {
+        const float *q = xyz2 + r * c;                               // query row (b, j) = r
+        const float *p = xyz1 + (r / m) * (long long)n * c;          // its cloud
+        for (int t = lane; t < n; t += 64) {
+            float acc = 0.f;
+            for (int l = 0; l < c; ++l) {
+                const float d = p[(long long)t * c + l] - q[l];
+                acc = acc + d * d;
+            }
+            v[t] = acc;
+            ix[t] = t;
+        }
+    } else {
+        const float *src = dist + r * n;
+        for (int t = lane; t < n; t += 64) {
+            v[t] = src[t];
+            ix[t] = t;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -354,11 +376,37 @@ __global__ __launch_bounds__(256) void selection_sort_wave_kernel(long long rows
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if (FUSED) {
+        for (int t = lane; t < kk; t += 64) {
+            out[r * k + t] = v[t];
+            outi[r * k + t] = ix[t];
+        }
+        return;
+    }
     float *vo = out + r * n;
     int *io = outi + r * n;
     for (int t = lane; t < n; t += 64) {
         vo[t] = v[t];
         io[t] = ix[t];
+    }
+}
+
+// knn_point's distance matrix on its own (clouds too large for the fused kernel's LDS row): dist (b, m, n), same
+// arithmetic order as above; thread = one (query, candidate) pair, candidates fastest (coalesced stores)
+__global__ __launch_bounds__(256) void knn_point_dist_kernel(long long total, int n, int c, int m,
+                                                             const float *__restrict__ xyz1,
+                                                             const float *__restrict__ xyz2, float *__restrict__ dist) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / n;
+        const int t = (int)(e - r * n);
+        const float *q = xyz2 + r * c;
+        const float *p = xyz1 + ((r / m) * n + t) * (long long)c;
+        float acc = 0.f;
+        for (int l = 0; l < c; ++l) {
+            const float d = p[l] - q[l];
+            acc = acc + d * d;
+        }
+        dist[e] = acc;
     }
 }
 
@@ -463,14 +511,50 @@ extern "C" int pcops_selection_sort(int b, int n, int m, int k, const float *dis
         int waves = (int)(65536 / ((size_t)8 * n));
         waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
         const size_t lds = (size_t)waves * 8 * n;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_wave_kernel),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_wave_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
             return PCOPS_ERR_LAUNCH;
-        hipLaunchKernelGGL(selection_sort_wave_kernel, dim3(cdiv(rows, waves)), dim3(256), lds, as_stream(stream), rows, n,
-                           k, waves, dist, outi, out);
+        hipLaunchKernelGGL(selection_sort_wave_kernel<false>, dim3(cdiv(rows, waves)), dim3(256), lds, as_stream(stream),
+                           rows, n, k, waves, dist, outi, out, 0, 1, (const float *)nullptr, (const float *)nullptr);
         return pcops_launch_status();
     }
     hipLaunchKernelGGL(selection_sort_kernel, dim3(cdiv(rows, 64)), dim3(64), 0, as_stream(stream),
                        rows, n, k, dist, outi, out);
+    return pcops_launch_status();
+}
+
+// knn_point (pointnet2/tf_ops/grouping/tf_grouping.py:49-74): squared distances + the literal selection sort + the first
+// k columns, in one kernel (a wave per query, its distance row in LDS).  n <= 8192 (PCOPS_ERR_UNSUPPORTED beyond: build
+// the matrix with pcops_knn_point_dist and sort it with pcops_selection_sort).
+extern "C" int pcops_knn_point_supported(int n) { return n >= 1 && n <= 8192 ? 1 : 0; }
+
+extern "C" int pcops_knn_point(int b, int n, int c, int m, int k, const float *xyz1, const float *xyz2, float *val,
+                               int *idx, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0 && c >= 1);
+    PCOPS_REQUIRE_ARG(k > 0);  // tf_grouping.cpp:113
+    PCOPS_REQUIRE_SHAPE(k <= n || (long long)b * m == 0);
+    const long long rows = (long long)b * m;
+    if (rows * n == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(xyz1); PCOPS_REQUIRE_PTR(xyz2); PCOPS_REQUIRE_PTR(val); PCOPS_REQUIRE_PTR(idx);
+    if (!pcops_knn_point_supported(n)) return PCOPS_ERR_UNSUPPORTED;
+    int waves = (int)(65536 / ((size_t)8 * n));
+    waves = waves < 1 ? 1 : (waves > 4 ? 4 : waves);
+    const size_t lds = (size_t)waves * 8 * n;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(selection_sort_wave_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(selection_sort_wave_kernel<true>, dim3(cdiv(rows, waves)), dim3(256), lds, as_stream(stream), rows, n,
+                       k, waves, (const float *)nullptr, idx, val, c, m, xyz1, xyz2);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_knn_point_dist(int b, int n, int c, int m, const float *xyz1, const float *xyz2, float *dist,
+                                    pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0 && c >= 1);
+    const long long total = (long long)b * m * n;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(xyz1); PCOPS_REQUIRE_PTR(xyz2); PCOPS_REQUIRE_PTR(dist);
+    const unsigned grid = cdiv(total, 256) < 65536u ? cdiv(total, 256) : 65536u;
+    hipLaunchKernelGGL(knn_point_dist_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, n, c, m, xyz1, xyz2, dist);
     return pcops_launch_status();
 }

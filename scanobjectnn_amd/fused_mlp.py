@@ -107,7 +107,7 @@ class FusedMLPStack(torch.autograd.Function):
         for li, (w, b, gamma, beta, mm, mv) in enumerate(layers):
             # forward statistics are shifted moments around the layer's moving mean (pcops.h pcops_mlp_gemm_fwd): the
             # producer and pcops_mlp_bn_finalize get the same pivot; finalize reads it before it updates the buffer
-            piv = mm.data_ptr() if training else None
+            piv = mm.data_ptr() if (training and STAT_PIVOT) else None
             if li == 0 and gather:
                 N = C1
                 Y = None if virt else _f32((R, N), dev)
@@ -527,7 +527,7 @@ class EdgeConvPool(torch.autograd.Function):
         part = _f32((P, 2, C), dev) if training else None
         _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
                   gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part),
-                  mm.data_ptr() if training else None)       # shifted moments around the moving mean (pcops.h)
+                  mm.data_ptr() if (training and STAT_PIVOT) else None)   # shifted moments around the moving mean
         vecs = _VecArena([C], 4, dev)
         scale, shift = vecs.take(C), vecs.take(C)
         mean = rstd = None
@@ -538,7 +538,8 @@ class EdgeConvPool(torch.autograd.Function):
             if sync:
                 part, Rf = _dist.allreduce_stat_partials(part, G * S)
                 Pf = 1
-            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), mm.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), mm.data_ptr() if STAT_PIVOT else None,
+                      ws.data_ptr(), gamma.data_ptr(),
                       beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                       mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
         else:
@@ -623,6 +624,7 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
                                *_flat(layer_tensors, False))
 
 
+STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never

@@ -115,11 +115,22 @@ def knn_point(k, xyz1, xyz2):
     (tf_grouping.py:49-74: squared distances, selection sort, first k columns)."""
     xyz1 = _lib.check(xyz1.detach(), torch.float32, "xyz1", 3)
     xyz2 = _lib.check(xyz2.detach(), torch.float32, "xyz2", 3)
-    # dist[b,j,t] = sum_c (xyz1[b,t,c] - xyz2[b,j,c])^2, c ascending, uncontracted
-    d = xyz1[:, None, :, :] - xyz2[:, :, None, :]
-    dist = torch.zeros(d.shape[:3], dtype=torch.float32, device=d.device)
-    for l in range(d.shape[3]):
-        sq = d[..., l] * d[..., l]
-        dist = dist + sq
+    k = int(k)
+    if k <= 0:
+        raise ValueError("SelectionSort expects positive k")  # tf_grouping.cpp:113
+    if xyz2.shape[0] != xyz1.shape[0] or xyz2.shape[2] != xyz1.shape[2]:
+        raise ValueError("knn_point expects (b,n,c) xyz1 and (b,m,c) xyz2")
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    if k > n:
+        raise ValueError("knn_point: k = %d neighbours of %d points" % (k, n))
+    # dist[b,j,t] = sum_c (xyz1[b,t,c] - xyz2[b,j,c])^2, c ascending, uncontracted -- in the kernel
+    if _lib.load().pcops_knn_point_supported(n):
+        val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+        idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+        _lib.call("pcops_knn_point", b, n, c, m, k, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val), _lib.ptr(idx))
+        return val, idx
+    dist = torch.empty((b, m, n), dtype=torch.float32, device=xyz1.device)     # clouds beyond the fused kernel's LDS row
+    _lib.call("pcops_knn_point_dist", b, n, c, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist))
     outi, out = select_top_k(k, dist)
     return out[:, :, :k].contiguous(), outi[:, :, :k].contiguous()

@@ -89,7 +89,8 @@ def test_dense_stack_with_large_channel_means(R, S, K0, widths, pool):
             for l, p0, (mean, var, _n) in zip(layers, piv, stats):      # moving <- 0.5 moving + 0.5 batch
                 bm = 2.0 * l[4].double() - p0.double()
                 bv = 2.0 * l[5].double() - 1.0
-                assert ((bm - mean).abs() / var.sqrt()).max().item() <= 1e-5
+                # (the buffers are fp32 and this undoes a 0.5 / 0.5 blend: 4 ulp of |mean| ~ 30 on top)
+                assert ((bm - mean).abs() - 1.5e-6 * mean.abs()).max().item() <= 1e-5 * var.sqrt().min().item()
                 assert ((bv - var).abs() / var).max().item() <= 2e-5
     assert errs["warm"] <= 1e-4, errs
     assert errs["cold"] <= 2e-2 and errs["wrong"] <= 2e-2, errs        # neutral shift: still the same statistics

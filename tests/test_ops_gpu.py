@@ -225,14 +225,39 @@ def test_selection_sort_rows_of_every_size_vs_oracle(n, k):
     np.testing.assert_array_equal(N(out), ov)
 
 
-def test_knn_point_vs_oracle():
-    rng = np.random.default_rng(8)
-    x1 = rng.standard_normal((2, 150, 3)).astype(np.float32)
-    x2 = x1[:, :40].copy()
-    val, idx = tf_grouping.knn_point(12, T(x1), T(x2))
-    oval, oidx = O.knn_point(12, x1, x2)
+@pytest.mark.parametrize("b,n,m,c,k", [(2, 150, 40, 3, 12), (3, 1024, 1024, 3, 20), (1, 8192, 7, 3, 5), (2, 333, 50, 8, 16),
+                                       (1, 9000, 6, 3, 4), (2, 64, 64, 1, 64)])
+def test_knn_point_vs_oracle(b, n, m, c, k):
+    """knn_point (tf_grouping.py:49-74) with the distances computed INSIDE the selection-sort kernel (n <= 8192: no
+    (b,m,n,c) / (b,m,n) tensor), and through pcops_knn_point_dist + pcops_selection_sort beyond; values and indices bit
+    for bit against the oracle (c ascending, uncontracted), incl. lattice points whose distances tie exactly"""
+    rng = np.random.default_rng(n + k)
+    x1 = rng.standard_normal((b, n, c)).astype(np.float32)
+    x1[:, : n // 2] = np.round(x1[:, : n // 2] * 4) / 4          # a lattice half: exact ties between candidates
+    x2 = x1[:, :m].copy() if m <= n else rng.standard_normal((b, m, c)).astype(np.float32)
+    val, idx = tf_grouping.knn_point(k, T(x1), T(x2))
+    oval, oidx = O.knn_point(k, x1, x2)
+    assert val.shape == (b, m, k) and idx.dtype == torch.int32
     np.testing.assert_array_equal(N(idx), oidx)
     np.testing.assert_array_equal(N(val), oval)
+
+
+def test_knn_point_dist_matrix_vs_oracle_order():
+    """the stand-alone distance kernel == the fused kernel's rows == sum over c ascending of the squared differences"""
+    from scanobjectnn_amd import _lib
+    rng = np.random.default_rng(3)
+    x1 = rng.standard_normal((2, 500, 3)).astype(np.float32)
+    x2 = rng.standard_normal((2, 33, 3)).astype(np.float32)
+    d = torch.empty((2, 33, 500), dtype=torch.float32, device=DEV)
+    a, q = T(x1), T(x2)
+    _lib.call("pcops_knn_point_dist", 2, 500, 3, 33, _lib.ptr(a), _lib.ptr(q), _lib.ptr(d))
+    want = np.zeros((2, 33, 500), np.float32)
+    for l in range(3):
+        df = x1[:, None, :, l] - x2[:, :, None, l]
+        want = want + df * df
+    np.testing.assert_array_equal(N(d), want)
+    with pytest.raises(ValueError):
+        tf_grouping.knn_point(0, a, q)
 
 
 # ------------------------------------------------------------------ three_nn / interpolate
