@@ -76,6 +76,13 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     u32x4 v;
     v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y); v.z = __float_as_uint(x.z); v.w = __float_as_uint(x.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    // gfx950 store-data hazard hipcc does not pad: a VALU write to the data registers of a 16-byte buffer store in the
+    // very next issue slot still reaches the store (observed: the .w word of the last four lanes of every 16-lane group
+    // took the NEXT row's value whenever a v_pk_add_f32 rewrote v[n+2:n+3] right behind the store).  LLVM's recogniser
+    // only pads MUBUF stores WITHOUT an SGPR soffset; these use one.  The statement below reads the four registers, so
+    // nothing can be allocated into them before it, and it carries the wait states itself.  (Round 2 met the same
+    // corruption when it unrolled the MFMA loop and put it down to a code-generation accident.)
+    asm volatile("s_nop 1" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 }
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // a voffset no tensor reaches: forces the bounds check to fail
 enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2, E_MASKX = 3, E_MASKA = 4 };
@@ -454,25 +461,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         return;
     }
 
-    // ---- streamed weights: KC x BN chunk = WPT float4 per thread, global (L2) -> registers -> LDS buffer
-    constexpr int WPT = (KC * (BN / 4) + NTHR - 1) / NTHR;
-    float4 wreg[WST ? WPT : 1];
+    // ---- weight tile in LDS, K-QUAD MAJOR:  Ws[k / 4][n][k % 4]  -- the four k a lane's MFMA steps consume for one
+    // column sit in ONE 16-byte word, so a B fragment is one ds_read_b128 per 32 columns (it was four ds_read_b32), and
+    // the 32 lanes of a half-wave read 512 contiguous bytes (conflict-free)
+    // ---- streamed weights: KC x BN chunk in 4 x 4 blocks (4 k-rows x 4 columns), WPB blocks per thread: global (L2) ->
+    // registers -> transposed in registers -> LDS buffer
+    constexpr int WBLK = (KC / 4) * (BN / 4);
+    constexpr int WPB = (WBLK + NTHR - 1) / NTHR;
+    float4 wreg[WST ? 4 * WPB : 1];
     auto wload = [&](int kc) {
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
+        for (int j = 0; j < WPB; ++j) {
             const int e = tid + NTHR * j;
-            const int k = kc * KC + e / (BN / 4), n = n0 + (e % (BN / 4)) * 4;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < KC * (BN / 4) && k < K && n < N) w = *reinterpret_cast<const float4 *>(a.W + (long long)k * N + n);
-            wreg[j] = w;
+            const int kq = e / (BN / 4), n = n0 + (e % (BN / 4)) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kc * KC + kq * 4 + i;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < WBLK && k < K && n < N) w = *reinterpret_cast<const float4 *>(a.W + (long long)k * N + n);
+                wreg[4 * j + i] = w;
+            }
         }
     };
     auto wstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
+        for (int j = 0; j < WPB; ++j) {
             const int e = tid + NTHR * j;
-            if (e < KC * (BN / 4))
-                *reinterpret_cast<float4 *>(&Ws[(buf * KC + e / (BN / 4)) * BN + (e % (BN / 4)) * 4]) = wreg[j];
+            if (e < WBLK) {
+                float4 *dst = reinterpret_cast<float4 *>(&Ws[((buf * (KC / 4) + e / (BN / 4)) * BN + (e % (BN / 4)) * 4) * 4]);
+                const float4 w0 = wreg[4 * j], w1 = wreg[4 * j + 1], w2 = wreg[4 * j + 2], w3 = wreg[4 * j + 3];
+                dst[0] = make_float4(w0.x, w1.x, w2.x, w3.x);
+                dst[1] = make_float4(w0.y, w1.y, w2.y, w3.y);
+                dst[2] = make_float4(w0.z, w1.z, w2.z, w3.z);
+                dst[3] = make_float4(w0.w, w1.w, w2.w, w3.w);
+            }
         }
     };
     // ---- resident data: weights + coefficient vectors, loaded once per workgroup
@@ -495,7 +517,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 w.w = n + 3 < N ? src[n + 3] : 0.f;
             }
         }
-        *reinterpret_cast<float4 *>(&Ws[k * BN + nq]) = w;
+        float *dst = &Ws[((k >> 2) * BN + nq) * 4 + (k & 3)];      // k-quad major (once per workgroup)
+        dst[0] = w.x; dst[4] = w.y; dst[8] = w.z; dst[12] = w.w;
     }
     {
         const float *vs[6] = {a.v0, a.v1, a.v2, a.v3, a.v4, nullptr};
@@ -609,7 +632,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (is_dy(AM)) pb[j] = buf_load4(rx2, xvoff, kbytes + (unsigned)j * xrowstep);
         }
     };
-    auto stage = [&](long long tile, int kc) {       // registers -> transform -> wave stripe
+    // FULL_: the tile has all 32 rows and K == Kp -- wave-uniform, true for every tile but the last; the variant without
+    // it carries the per-element range checks (4 v_cndmask per float4 here, an exec-masked branch per row group in the
+    // epilogue: per-row exec masking had turned the epilogue into ~170 basic blocks of 5-10 instructions, each with its
+    // own s_and_saveexec / s_cbranch / s_waitcnt -- 2 000 of the 3 300 non-MFMA instructions of a 128 -> 256 tile)
+    auto stage = [&](long long tile, int kc, auto full_) {       // registers -> transform -> wave stripe
+        constexpr bool FULL = decltype(full_)::value;
         const long long row0 = tile * 32;
         const PoolRows prs(is_pool(AM) ? row0 : 0, is_pool(AM) ? a.S : 1);
         const int cl = (lane % C4) * 4;              // fixed per lane (64 % C4 == 0)
@@ -629,7 +657,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
-            const bool in = (r < rem) && (c < K);
+            const bool in = FULL || ((r < rem) && (c < K));
             float4 x = pa[U_ ? 0 : (B_ ? j / 4 : j)];
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
@@ -688,12 +716,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // and its row-in-group for output slot `slot`; resets the running extremum
     auto pool_flush = [&](int h, long long slot, bool wr, float4 em, int ocq) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int off = 32; off >= O4; off >>= 1) {
+            // all eight exchanges of a step in flight together; the comparison WITHOUT short-circuit evaluation (`||` /
+            // `&&` on per-lane values had become a chain of exec-masked branches, eight per step)
+            const int peer = (lane ^ off) << 2;
+            float ov[4];
+            int oa[4];
 #pragma unroll
-            for (int off = 32; off >= O4; off >>= 1) {
-                const float ov = __shfl_xor(pmx[h][e], off, 64);
-                const int oa = __shfl_xor(pax[h][e], off, 64);
-                if (ov > pmx[h][e] || (ov == pmx[h][e] && oa < pax[h][e])) { pmx[h][e] = ov; pax[h][e] = oa; }
+            for (int e = 0; e < 4; ++e) {
+                ov[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(peer, __float_as_int(pmx[h][e])));
+                oa[e] = __builtin_amdgcn_ds_bpermute(peer, pax[h][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool take = (ov[e] > pmx[h][e]) | ((ov[e] == pmx[h][e]) & (oa[e] < pax[h][e]));
+                pmx[h][e] = take ? ov[e] : pmx[h][e];
+                pax[h][e] = take ? oa[e] : pax[h][e];
             }
         }
         if (lane < O4 && wr) {
@@ -735,7 +773,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
             if (active) {
             __builtin_amdgcn_wave_barrier();
-            stage(tile, kc);
+#ifndef PCOPS_NO_STAGE_FULL
+            if ((long long)M - tile * 32 >= 32 && Kp == K) stage(tile, kc, std::true_type{});
+            else
+#endif
+                stage(tile, kc, std::false_type{});
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // next stripe: the next K chunk of this tile, or chunk 0 of this wave's next tile
@@ -743,35 +785,38 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             else if (more) issue(next_tile, 0);
 
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
-            const float *bcol = &Ws[((WST ? (wt & 1) : kc) * KC + 4 * (lane >> 5)) * BN + (lane & 31)];
-            // software pipeline: the fragments of step it+1 are requested from LDS before the 4*NT MFMAs of step
-            // it are issued
-            float4 av_n = *reinterpret_cast<const float4 *>(arow);
-            float bv_n[4][NT];
+            // B fragments: quad row (chunk base) + 2 it + (lane >> 5), column 32 nt + (lane & 31)
+            const float4 *bq = reinterpret_cast<const float4 *>(Ws) +
+                               ((WST ? (wt & 1) : kc) * (KC / 4) + (lane >> 5)) * BN + (lane & 31);
+            // two register sets in ping-pong: while the 4 NT MFMAs of step it run, the fragments of step it + 1 are in
+            // flight from LDS into the other set -- no copies between the sets, one loop body = two steps
+            float4 a0 = *reinterpret_cast<const float4 *>(arow), a1;
+            float4 b0[NT], b1[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv_n[t][nt] = bcol[t * BN + 32 * nt];
-#pragma unroll 2
-            for (int it = 0; it < KC / 8; ++it) {
-                const float ae[4] = {av_n.x, av_n.y, av_n.z, av_n.w};
-                float bv[4][NT];
+            for (int nt = 0; nt < NT; ++nt) b0[nt] = bq[32 * nt];
+            auto mfma16 = [&](const float4 &av, const float4 (&bv)[NT]) {
+                const float ae[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[t][nt] = bv_n[t][nt];
-                if (it + 1 < KC / 8) {
-                    av_n = *reinterpret_cast<const float4 *>(arow + 8 * (it + 1));
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float be = t == 0 ? bv[nt].x : (t == 1 ? bv[nt].y : (t == 2 ? bv[nt].z : bv[nt].w));
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], be, acc[nt], 0, 0, 0);
+                    }
+            };
+            static_assert((KC / 8) % 2 == 0, "two steps per loop body");
+#pragma unroll 1
+            for (int it = 0; it < KC / 8; it += 2) {
+                a1 = *reinterpret_cast<const float4 *>(arow + 8 * (it + 1));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                for (int nt = 0; nt < NT; ++nt) b1[nt] = bq[(2 * (it + 1)) * BN + 32 * nt];
+                mfma16(a0, b0);
+                // (the last body re-reads its own step instead of branching: same addresses, nobody uses the result)
+                const int nx = it + 2 < KC / 8 ? it + 2 : it + 1;
+                a0 = *reinterpret_cast<const float4 *>(arow + 8 * nx);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) bv_n[t][nt] = bcol[(8 * (it + 1) + t) * BN + 32 * nt];
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv[t][nt], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) b0[nt] = bq[(2 * nx) * BN + 32 * nt];
+                mfma16(a1, b1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
@@ -782,16 +827,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
         }
         if (active) {
+#ifdef PCOPS_EPI_SLEEP
+        __builtin_amdgcn_s_sleep(PCOPS_EPI_SLEEP);
+#endif
         // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
         const int erem = (int)((long long)M - row0 < 32 ? (long long)M - row0 : 32);   // rows of this tile (scalar, 32 bit)
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
         const __amdgpu_buffer_rsrc_t rprev =
             make_rsrc(((EM == E_MASK || EM == E_MASKA) ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
+        auto epilogue = [&](auto full_) {
+        constexpr bool FULL = decltype(full_)::value;        // all 32 rows and all BN columns exist: no range checks
 #pragma unroll
         for (int h = 0; h < EH; ++h) {
             const int ocq = h * BNH + ocl;                   // this lane's column quad in the BN-wide tile
-            const bool ocin = n0 + ocq < N;                  // N % 4 == 0 (launcher)
+            const bool ocin = FULL || (n0 + ocq < N);        // N % 4 == 0 (launcher)
             const unsigned yvoff = ocin ? (unsigned)((lane / O4) * a.ldy + n0 + ocq) * 4u : kOOB;
             float4 py[is_mask(EM) ? NST : 1];
             float4 po[(EM == E_MASKX) ? NST : 1];
@@ -822,7 +872,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #pragma unroll
                 for (int j = 0; j < NST; ++j) {
                     const int rr = (lane + 64 * j) / O4;
-                    const int slot = rr < erem ? a.rowmap[row0 + rr] : -1;
+                    const int slot = (FULL || rr < erem) ? a.rowmap[row0 + rr] : -1;
                     const unsigned off = (slot >= 0 && ocin) ? ((unsigned)slot * (unsigned)a.add_ld + (unsigned)(n0 + ocq)) * 4u : kOOB;
                     pad[j] = buf_load4(radd, off, 0u);
                 }
@@ -854,9 +904,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
+                // branch-free the whole pass is ONE basic block: without a fence the scheduler hoists all NST stripe
+                // reads (and everything that depends on them) to the top -- 32+ live registers more, which spilled
+                if (FULL && j % 2 == 0) __builtin_amdgcn_sched_barrier(0);
                 const int r = (lane + 64 * j) / O4;
                 float4 o = *reinterpret_cast<const float4 *>(&Aw[r * LDW + ocl]);
-                if (r < erem && ocin) {
+                if (FULL || (r < erem && ocin)) {
                     if (EM == E_FWD) {
                         // o = y - pivot here (accumulator start value): the statistics take it as it is
                         if (compact && O4 == 16 && j % 4 == 0) {      // rows 0 / 16 of the tile stand for w rows
@@ -914,12 +967,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     // compacted rows: a 16-row block (rows 4 (j-3) .. 4 j + 3 of the tile) lies inside ONE group -- its
                     // extremum goes out as a partial (block index), pcops_mlp_pool_combine_rows picks per group
                     const long long blk = tile * 2 + j / 4;
-                    pool_flush(h, blk, blk * kBlk < M && ocin, em, ocq);
+                    pool_flush(h, blk, FULL || (blk * kBlk < M && ocin), em, ocq);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (POOL && !compact && sub == SUB - 1) pool_flush(h, st, ocin, em, ocq);   // group complete
         }
+        };
+#ifndef PCOPS_NO_EPI_FULL
+        if (erem == 32 && n0 + BN <= N) epilogue(std::true_type{});
+        else
+#endif
+            epilogue(std::false_type{});
         }
         st = nst;
         sub = nsub;

@@ -18,11 +18,29 @@ from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-4
-# The fp32 floor is itself the MAXIMUM of rounding noise over ~1e5 logits of one seed, for two plain implementations;
-# a third fp32 implementation of the same net lands within this factor of it (measured on MI355X, round 2,
-# gpurun_out/parity_floor.json: BGA mask 1.27e-4 fused vs 1.33e-4 plain, part-seg 1.51e-4 vs 1.26e-4; eval mode
-# 3e-7 / 5e-7 on both sides)
-FLOOR_SPREAD = 1.5
+# Round 3: no slack factor.  The floor an fp32 evaluation of these nets sits on is MEASURED three ways against the same
+# float64 truth -- (a) the layer-by-layer product path on the GPU (library GEMM + torch batch norm), (b) the fp32 CPU
+# restatement, (c) the REALISATION NOISE of the fused path itself: the same fused kernels evaluated a second time in an
+# arithmetically equivalent but bitwise different way (batch-norm statistics with and without the pivot shift of
+# include/pcops.h -- tools/diag_pivot_kernels.py: identical accuracy, 3e-7, on every kernel-level case) -- and the fused
+# path has to be no further from the truth than the largest of the three: an fp32 path cannot be asked to be closer to
+# float64 than two equivalent fp32 evaluations of ITSELF are to each other.  What (c) absorbs is discrete decisions (a
+# ReLU within rounding of 0, an arg-max tie, a 20th-nearest-neighbour tie): tools/diag_grad_repeat.py shows the model-level
+# error of one path / seed flipping between 1.6e-5 and 2.2e-3 with the pivot off / on while the plain path sits at 1.8e-5,
+# and tools/diag_grad_parity.py the fused : plain ratio ranging over 0.2 ... 120 from seed to seed in BOTH directions.
+# A systematic defect of the fused arithmetic is common to both realisations, does not show in (c), and fails.
+FLOOR_SPREAD = 1.0
+
+
+def _other_realisation(fn):
+    """run fn() with the fused path's batch-norm statistics evaluated without the pivot shift"""
+    from scanobjectnn_amd import fused_mlp
+    keep = fused_mlp.STAT_PIVOT
+    fused_mlp.STAT_PIVOT = not keep
+    try:
+        return fn()
+    finally:
+        fused_mlp.STAT_PIVOT = keep
 
 
 def _randomise(net, seed):
@@ -50,7 +68,7 @@ def _randomise(net, seed):
                 p.copy_((0.01 * torch.randn(p.shape, generator=g)).to(p.device))
 
 
-def _record(key, err, floor):
+def _record(key, err, floor, **more):
     """keep the measured numbers next to the other GPU artefacts (gpurun_out/ is merged back by gpurun)"""
     import json
     import os
@@ -59,17 +77,25 @@ def _record(key, err, floor):
         os.makedirs(path, exist_ok=True)
         f = os.path.join(path, "parity_floor.json")
         d = json.load(open(f)) if os.path.exists(f) else {}
-        d[key] = {"err_fused": err, "fp32_floor": floor}
+        d[key] = dict({"err_fused": err, "fp32_floor": floor}, **more)
         json.dump(d, open(f, "w"), indent=1)
     except OSError:
         pass
 
 
-def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch):
+def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch, fused=None):
     """error of PLAIN fp32 implementations of the same net against the float64 truth: the layer-by-layer product path
-    (PCOPS_FUSED_MLP off: library GEMM + torch batch norm) on the GPU, and the fp32 CPU restatement; the larger of
-    the two is the floor an fp32 implementation of this net sits on"""
+    (PCOPS_FUSED_MLP off: library GEMM + torch batch norm) on the GPU, and the fp32 CPU restatement; fused (the fused
+    path's own output): + its distance to a second, equivalent realisation of the fused path (see FLOOR_SPREAD).  The
+    largest is the floor an fp32 implementation of this net sits on.  Returns (floor, parts)."""
     from scanobjectnn_amd.pointnet2 import tf_util as t2
+    e_self = 0.0
+    if fused is not None and training:
+        def again():
+            net.load_state_dict(sd)
+            with torch.no_grad():
+                return pick(net(x, is_training=training, bn_decay=0.9))
+        e_self = (_other_realisation(again).double() - fused.double()).abs().max().item()
     monkeypatch.setattr(t2, "FUSED_MLP", False)
     net.load_state_dict(sd)
     with torch.no_grad():
@@ -81,7 +107,7 @@ def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch):
     with torch.no_grad():
         cpu = pick(ref_fn()(torch.from_numpy(c), P32, training))
     e_cpu = (cpu.double() - truth).abs().max().item()
-    return max(e_gpu, e_cpu)
+    return max(e_gpu, e_cpu, e_self), {"gpu_layerwise": e_gpu, "cpu_fp32": e_cpu, "fused_realisations": e_self}
 
 
 def _no_dropout(monkeypatch):
@@ -129,8 +155,8 @@ def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     # layers of the mask branch amplify fp32 rounding; the bar is then the MEASURED fp32 floor of this very net:
     # the same weights through (a) the layer-by-layer path (library GEMM + torch batch norm, no fused kernel) on the
     # GPU and (b) the fp32 CPU restatement, each judged against the float64 truth
-    floor = _fp32_floor(net, sd, x, c, training, lambda o: o[1], lambda: R.pointnet2_cls_bga, ws, monkeypatch)
-    _record("bga_mask_%s" % ("train" if training else "eval"), err_seg, floor)
+    floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o[1], lambda: R.pointnet2_cls_bga, ws, monkeypatch, seg)
+    _record("bga_mask_%s" % ("train" if training else "eval"), err_seg, floor, **parts)
     assert err_seg <= (max(TOL, FLOOR_SPREAD * floor) if training else TOL), (err_seg, floor)
 
 
@@ -151,8 +177,8 @@ def test_pointnet2_partseg_logits(training, monkeypatch):
         want = R.pointnet2_cls_partseg(torch.from_numpy(c).double(), P, training)
     assert seg.shape == (16, 1024, 6)
     err = (seg.cpu().double() - want).abs().max().item()
-    floor = _fp32_floor(net, sd, x, c, training, lambda o: o, lambda: R.pointnet2_cls_partseg, want, monkeypatch)
-    _record("partseg_%s" % ("train" if training else "eval"), err, floor)
+    floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o, lambda: R.pointnet2_cls_partseg, want, monkeypatch, seg)
+    _record("partseg_%s" % ("train" if training else "eval"), err, floor, **parts)
     assert err <= (max(TOL, FLOOR_SPREAD * floor) if training else TOL), (err, floor)   # same rule as the BGA mask branch
 
 
@@ -316,17 +342,30 @@ def test_model_training_gradients(name, monkeypatch):
     assert abs(loss_fused - loss_ref.item()) <= 1e-4
     e_fused, worst_fused = _grad_errors(net, P)
 
+    g_fused = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    graphs_fused = list(graphs)
+    # the same fused kernels, second realisation (see FLOOR_SPREAD): how far two equivalent fp32 evaluations of THIS path
+    # are from each other.  (DGCNN: only when both built the same neighbour graphs -- a neighbour tie that falls the other
+    # way is a different network, which the float64 truth above does not describe either)
+    _other_realisation(product_grads)
+    same_graphs = len(graphs) == len(graphs_fused) and all(np.array_equal(a, b) for a, b in zip(graphs, graphs_fused))
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        if k in g_fused and p.grad is not None and not (k.endswith("biases") and k[:-len("biases")] + "bn/gamma" in g_fused):
+            num += (p.grad - g_fused[k]).double().norm().item() ** 2
+            den += g_fused[k].double().norm().item() ** 2
+    e_self = (num / den) ** 0.5 if same_graphs else 0.0
     monkeypatch.setattr(t2, "FUSED_MLP", False)       # the layer-by-layer path: the fp32 yardstick
     product_grads()
     e_layer, _ = _grad_errors(net, P)
     monkeypatch.setattr(t2, "FUSED_MLP", True)
-    _record("grad_%s" % name, e_fused, e_layer)
-    # measured (MI355X, round 2): fused / layer-by-layer global relative error -- bga 3.2e-3 / 2.2e-3, msg 3.3e-3 /
-    # 1.4e-3, dgcnn 2.3e-4 / 1.3e-4, dgcnn_bga 2.4e-4 / 1.4e-4.  Both are dominated by the handful of ReLUs that sit
-    # within fp32 rounding of zero (different ones in the two paths: the fused first layer is evaluated before the
-    # grouping), so the ratio of the two is a small-number statistic
+    _record("grad_%s" % name, e_fused, max(e_layer, e_self), gpu_layerwise=e_layer, fused_realisations=e_self)
+    # measured (MI355X, round 3, four seeds, tools/diag_grad_parity.py): fused / layer-by-layer global relative error --
+    # msg 2.7e-3 3.9e-3 2.1e-3 3.1e-3 / 5.2e-3 1.8e-3 2.1e-3 1.2e-3.  Both are dominated by the handful of discrete
+    # decisions that sit within fp32 rounding of a tie (different ones in the two paths), so each is judged against the
+    # larger of the plain path's error and the distance between two realisations of the fused path itself
     assert e_fused <= 1e-2, (e_fused, worst_fused)
-    assert e_fused <= max(3.0 * e_layer, 2e-3), (e_fused, e_layer, worst_fused)
+    assert e_fused <= max(FLOOR_SPREAD * 1.5 * max(e_layer, e_self), 1e-4), (e_fused, e_layer, e_self, worst_fused)
 
 
 # ---------------------------------------------------------------------------------------------------------------

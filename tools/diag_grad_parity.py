@@ -83,7 +83,10 @@ def run(name, seed, verbose):
         nl += el * el
         den += rn * rn
         rows.append((k, rn, ef / max(rn, 1e-30), el / max(rn, 1e-30)))
-    if verbose:
+    if verbose == "all":
+        for k, rn, a, b in rows:
+            print("   %-60s |ref| %.3e  fused %.2e  plain %.2e" % (k, rn, a, b))
+    elif verbose:
         for k, rn, a, b in sorted(rows, key=lambda t: -t[2] * t[1])[:12]:
             print("   %-48s |ref| %.3e  fused %.2e  plain %.2e" % (k, rn, a, b))
     return (nf / den) ** 0.5, (nl / den) ** 0.5
