@@ -94,6 +94,13 @@ constexpr int E_PLAINA = 5;      // E_PLAIN of acc + addend[rowmap[row]] + vcons
 constexpr bool is_mask(int em) { return em == E_MASK || em == E_MASKX || em == E_MASKA; }
 constexpr bool has_add(int em) { return em == E_MASKA || em == E_PLAINA; }
 
+// -DPCOPS_PHASE_PROF (tools/ only, never the shipped build): every wave of gemm_ws_kernel adds the shader cycles it spent
+// staging / in the MFMA loop / in the epilogue to these counters; pcops_debug_phase_prof reads and clears them
+#ifdef PCOPS_PHASE_PROF
+__device__ unsigned long long g_phase_prof[8];
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#endif
+
 struct GemmArgs {
     int M, K, N;
     int tiles_per_block;
@@ -469,6 +476,17 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     constexpr int WBLK = (KC / 4) * (BN / 4);
     constexpr int WPB = (WBLK + NTHR - 1) / NTHR;
     float4 wreg[WST ? 4 * WPB : 1];
+    // POOLED forward: column n of the weight tile (and the accumulator start value) is multiplied by sign(gamma[n]), so
+    // the tile leaves the matrix pipe as  s (y - pivot):  BN + ReLU is increasing in y for gamma >= 0 and decreasing
+    // otherwise, i.e. the pooled row of a group is ALWAYS the arg-max of the accumulator values -- no per-element sign
+    // multiply, and the max is taken on the accumulator registers themselves (below).  s = +-1: exact.
+    auto colsign = [&](int n) { return (POOL && n < N && a.pgamma[n] < 0.f) ? -1.f : 1.f; };
+    float4 wsg[(WST && POOL) ? WPB : 1];
+#pragma unroll
+    for (int j = 0; j < ((WST && POOL) ? WPB : 1); ++j) {
+        const int n = n0 + ((tid + NTHR * j) % (BN / 4)) * 4;
+        wsg[j] = make_float4(colsign(n), colsign(n + 1), colsign(n + 2), colsign(n + 3));
+    }
     auto wload = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
@@ -490,10 +508,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (e < WBLK) {
                 float4 *dst = reinterpret_cast<float4 *>(&Ws[((buf * (KC / 4) + e / (BN / 4)) * BN + (e % (BN / 4)) * 4) * 4]);
                 const float4 w0 = wreg[4 * j], w1 = wreg[4 * j + 1], w2 = wreg[4 * j + 2], w3 = wreg[4 * j + 3];
-                dst[0] = make_float4(w0.x, w1.x, w2.x, w3.x);
-                dst[1] = make_float4(w0.y, w1.y, w2.y, w3.y);
-                dst[2] = make_float4(w0.z, w1.z, w2.z, w3.z);
-                dst[3] = make_float4(w0.w, w1.w, w2.w, w3.w);
+                const float4 sg = wsg[POOL ? j : 0];               // pooled forward: columns carry sign(gamma), see below
+                dst[0] = make_float4(w0.x * sg.x, w1.x * sg.x, w2.x * sg.x, w3.x * sg.x);
+                dst[1] = make_float4(w0.y * sg.y, w1.y * sg.y, w2.y * sg.y, w3.y * sg.y);
+                dst[2] = make_float4(w0.z * sg.z, w1.z * sg.z, w2.z * sg.z, w3.z * sg.z);
+                dst[3] = make_float4(w0.w * sg.w, w1.w * sg.w, w2.w * sg.w, w3.w * sg.w);
             }
         }
     };
@@ -516,6 +535,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 w.z = n + 2 < N ? src[n + 2] : 0.f;
                 w.w = n + 3 < N ? src[n + 3] : 0.f;
             }
+        }
+        if (POOL) {
+            const int n = n0 + nq;
+            w.x *= colsign(n); w.y *= colsign(n + 1); w.z *= colsign(n + 2); w.w *= colsign(n + 3);
         }
         float *dst = &Ws[((k >> 2) * BN + nq) * 4 + (k & 3)];      // k-quad major (once per workgroup)
         dst[0] = w.x; dst[4] = w.y; dst[8] = w.z; dst[12] = w.w;
@@ -542,7 +565,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             // forward: the accumulators START at bias - pivot, so the tile comes out of the matrix pipe as y - pivot --
             // what the statistics sum -- and the pivot is added back on the way to the store (the add the bias used to
             // be): shifted moments at no extra instruction
-            ecoef[e] = EM == E_FWD ? e0 - pv : e0;
+            ecoef[e] = EM == E_FWD ? (POOL ? e1 * (e0 - pv) : e0 - pv) : e0;
             ecoef[BN + e] = e1;
             if (EM == E_FWD) ecoef[2 * BN + e] = pv;
             if (EM == E_MASKX) {
@@ -706,46 +729,95 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // a wave walks whole pooling groups: SUB consecutive 32-row tiles (SUB = 1 without pooling)
     const int SUB = POOL ? a.pool_sub : 1;
     const long long nsuper = (ntiles + SUB - 1) / SUB;
-    float pmx[EH][4];                                // running max of sign(gamma) * y over the group, and its row
-    int pax[EH][4];
+    // ---- pooled forward: the neighbourhood max is taken on the ACCUMULATOR registers, before the tile is transposed.
+    // acc[nt][v] of a lane is (row (v & 3) + 8 (v >> 2) + 4 (lane >> 5), column 32 nt + (lane & 31)): sixteen rows of ONE
+    // column, ascending in v, so the running (max, first row) of a column is a chain of  v_cmp + 2 v_cndmask  on
+    // registers -- four independent chains per lane (NT) -- and the two half-waves meet in ONE exchange per result.
+    // (Round 2 took the max after the transposition, on float4 row segments: sign multiply, compare and two selects per
+    // element inside the LDS-latency chain of the epilogue, plus a two-step cross-lane combine per 16-row block -- the
+    // pooled epilogue then cost a wave 18 500 cycles per tile against 7 000 without pooling, tools/phase_prof.py.)
+    float gmx[POOL ? NT : 1];                         // uncompacted groups: running max over the group's tiles, its row
+    int grw[POOL ? NT : 1];
 #pragma unroll
-    for (int h = 0; h < EH; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
-    // combine the 64/O4 lanes that own a column quad (larger key, then lower row) and write the selected raw value
-    // and its row-in-group for output slot `slot`; resets the running extremum
-    auto pool_flush = [&](int h, long long slot, bool wr, float4 em, int ocq) {
-#pragma unroll
-        for (int off = 32; off >= O4; off >>= 1) {
-            // all eight exchanges of a step in flight together; the comparison WITHOUT short-circuit evaluation (`||` /
-            // `&&` on per-lane values had become a chain of exec-masked branches, eight per step)
-            const int peer = (lane ^ off) << 2;
-            float ov[4];
-            int oa[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ov[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(peer, __float_as_int(pmx[h][e])));
-                oa[e] = __builtin_amdgcn_ds_bpermute(peer, pax[h][e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool take = (ov[e] > pmx[h][e]) | ((ov[e] == pmx[h][e]) & (oa[e] < pax[h][e]));
-                pmx[h][e] = take ? ov[e] : pmx[h][e];
-                pax[h][e] = take ? oa[e] : pax[h][e];
-            }
-        }
-        if (lane < O4 && wr) {
-            const long long o4 = slot * N + n0 + ocq;
-            *reinterpret_cast<float4 *>(a.ysel + o4) =
-                make_float4(pmx[h][0] * em.x, pmx[h][1] * em.y, pmx[h][2] * em.z, pmx[h][3] * em.w);
-            uchar4 qa;
-            qa.x = (unsigned char)pax[h][0]; qa.y = (unsigned char)pax[h][1];
-            qa.z = (unsigned char)pax[h][2]; qa.w = (unsigned char)pax[h][3];
-            *reinterpret_cast<uchar4 *>(a.psel + o4) = qa;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { pmx[h][e] = -INFINITY; pax[h][e] = 0; }
+    for (int i = 0; i < (POOL ? NT : 1); ++i) { gmx[i] = -INFINITY; grw[i] = 0; }
+    const int peer32 = (lane ^ 32) << 2;
+    // value + row of the better of (this half-wave, the other): larger value, then lower row
+    auto meet = [&](float &m, int &r) {
+        const float om = __int_as_float(__builtin_amdgcn_ds_bpermute(peer32, __float_as_int(m)));
+        const int orow = __builtin_amdgcn_ds_bpermute(peer32, r);
+        const bool take = (om > m) | ((om == m) & (orow < r));
+        m = take ? om : m;
+        r = take ? orow : r;
     };
+    auto pool_acc = [&](const f32x16 (&acc)[NT], long long tile, int sub, long long st) {
+        const int hrow = 4 * (lane >> 5);
+        const bool low = lane < 32;
+        if (compact) {
+            // 16-row blocks: block b = accumulator registers 8 b .. 8 b + 7; one partial (value, row-in-group) per block
+            const int nblk = (M + kBlk - 1) / kBlk;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long blk = tile * 2 + b;
+                if (blk >= nblk) continue;                                   // wave-uniform
+                const int s0 = a.blocks[blk].s0;                             // row-in-group of the block's first row
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float m = acc[nt][8 * b];
+                    int r = 0;
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) {
+                        const float x = acc[nt][8 * b + i];
+                        const bool gt = x > m;                               // strict: the first maximum stays
+                        m = gt ? x : m;
+                        r = gt ? (i & 3) + 8 * (i >> 2) : r;
+                    }
+                    r += hrow;
+                    meet(m, r);
+                    const int n = n0 + 32 * nt + (lane & 31);
+                    if (low && n < N) {
+                        const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
+                        a.ysel[blk * N + n] = fmaf(m, sg, pv);               // the raw y at that row, as it is stored
+                        a.psel[blk * N + n] = (unsigned char)(s0 + r);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float m = gmx[nt];
+                int r = grw[nt];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float x = acc[nt][i];
+                    const bool gt = x > m;
+                    m = gt ? x : m;
+                    r = gt ? sub * 32 + (i & 3) + 8 * (i >> 2) + hrow : r;
+                }
+                gmx[nt] = m;
+                grw[nt] = r;
+            }
+            if (sub == SUB - 1) {                                            // group complete
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float m = gmx[nt];
+                    int r = grw[nt];
+                    meet(m, r);
+                    const int n = n0 + 32 * nt + (lane & 31);
+                    if (low && n < N) {
+                        const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
+                        a.ysel[st * N + n] = fmaf(m, sg, pv);
+                        a.psel[st * N + n] = (unsigned char)r;
+                    }
+                    gmx[nt] = -INFINITY;
+                    grw[nt] = 0;
+                }
+            }
+        }
+    };
+#ifdef PCOPS_PHASE_PROF
+    unsigned long long pf_stage = 0, pf_mfma = 0, pf_epi = 0, pf_tiles = 0, pf_t;
+    const unsigned long long pf_start = PROF_T();
+#endif
     long long st = (long long)rowgrp * WAVES + wave;
     int sub = 0;
     if (st < nsuper) issue(st * SUB, 0);
@@ -772,6 +844,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int kc = 0; kc < nchunk; ++kc) {
             if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
             if (active) {
+#ifdef PCOPS_PHASE_PROF
+            pf_t = PROF_T();
+#endif
             __builtin_amdgcn_wave_barrier();
 #ifndef PCOPS_NO_STAGE_FULL
             if ((long long)M - tile * 32 >= 32 && Kp == K) stage(tile, kc, std::true_type{});
@@ -784,6 +859,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (kc + 1 < nchunk) issue(tile, kc + 1);
             else if (more) issue(next_tile, 0);
 
+#ifdef PCOPS_PHASE_PROF
+            { const unsigned long long n_ = PROF_T(); pf_stage += n_ - pf_t; pf_t = n_; }
+#endif
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
             // B fragments: quad row (chunk base) + 2 it + (lane >> 5), column 32 nt + (lane & 31)
             const float4 *bq = reinterpret_cast<const float4 *>(Ws) +
@@ -819,6 +897,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 mfma16(a1, b1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef PCOPS_PHASE_PROF
+            {   // (the MFMAs are asynchronous: read one accumulator register so that the clock is taken after the last one)
+                float sink_ = acc[NT - 1][15];
+                asm volatile("" ::"v"(sink_));
+                const unsigned long long n_ = PROF_T(); pf_mfma += n_ - pf_t; pf_t = n_;
+            }
+#endif
             }
             if (WST) {      // refill the other buffer (last read one chunk ago, before the previous barrier)
                 wstore((wt + 1) & 1);
@@ -827,9 +912,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
         }
         if (active) {
-#ifdef PCOPS_EPI_SLEEP
-        __builtin_amdgcn_s_sleep(PCOPS_EPI_SLEEP);
-#endif
+        if (POOL) pool_acc(acc, tile, sub, st);
         // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
         const int erem = (int)((long long)M - row0 < 32 ? (long long)M - row0 : 32);   // rows of this tile (scalar, 32 bit)
@@ -882,7 +965,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             const float4 epv = EM == E_FWD ? *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq])
                                            : make_float4(0.f, 0.f, 0.f, 0.f);             // forward: the pivot
             float ew[2] = {1.f, 1.f};                        // compacted rows: statistics weight of rows 0 / 16
-            int es0[2] = {0, 0};                             //                 row-in-group of rows 0 / 16
             if (EM == E_FWD && compact) {
                 const int nblk = (M + kBlk - 1) / kBlk;
 #pragma unroll
@@ -891,7 +973,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     bi = bi < nblk ? bi : nblk - 1;
                     const RowBlock rb = a.blocks[bi];
                     ew[hb] = rb.w;
-                    es0[hb] = rb.s0;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -923,13 +1004,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         s2[h][0] = fmaf(o.x, o.x, s2[h][0]); s2[h][1] = fmaf(o.y, o.y, s2[h][1]);
                         s2[h][2] = fmaf(o.z, o.z, s2[h][2]); s2[h][3] = fmaf(o.w, o.w, s2[h][3]);
                         }
-                        o.x += epv.x; o.y += epv.y; o.z += epv.z; o.w += epv.w;          // back to y
-                        if (POOL) {   // rows arrive in ascending order: a strict comparison keeps the first extremum
-                            const int sr = compact ? es0[(O4 == 16) ? j / 4 : 0] + (r & (kBlk - 1)) : sub * 32 + r;
-                            const float ov[4] = {o.x * em.x, o.y * em.y, o.z * em.z, o.w * em.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (ov[e] > pmx[h][e]) { pmx[h][e] = ov[e]; pax[h][e] = sr; }
+                        if (POOL) {   // the tile is  s (y - pivot)  (column signs folded into the weights): back to y
+                            o.x = fmaf(o.x, em.x, epv.x); o.y = fmaf(o.y, em.y, epv.y);
+                            o.z = fmaf(o.z, em.z, epv.z); o.w = fmaf(o.w, em.w, epv.w);
+                        } else {
+                            o.x += epv.x; o.y += epv.y; o.z += epv.z; o.w += epv.w;      // back to y
                         }
                     } else if (EM == E_PLAINA) {
                         const float4 vc = *reinterpret_cast<const float4 *>(&ecoef[2 * BN + ocq]);
@@ -963,27 +1042,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 // activation only exists as statistics and group extrema)
                 if ((EM != E_MASKX && !(EM == E_FWD && POOL)) || a.Y)
                     buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
-                if (POOL && compact && O4 == 16 && (j & 3) == 3) {
-                    // compacted rows: a 16-row block (rows 4 (j-3) .. 4 j + 3 of the tile) lies inside ONE group -- its
-                    // extremum goes out as a partial (block index), pcops_mlp_pool_combine_rows picks per group
-                    const long long blk = tile * 2 + j / 4;
-                    pool_flush(h, blk, FULL || (blk * kBlk < M && ocin), em, ocq);
-                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (POOL && !compact && sub == SUB - 1) pool_flush(h, st, ocin, em, ocq);   // group complete
         }
         };
-#ifndef PCOPS_NO_EPI_FULL
-        if (erem == 32 && n0 + BN <= N) epilogue(std::true_type{});
-        else
-#endif
-            epilogue(std::false_type{});
+        // (the xyz-mask epilogue keeps two more float4 arrays alive per pass: branch-free it needs ~40 registers more
+        // than the 256 a wave has at two waves per SIMD and spills -- 748 us instead of 517 for SA1's layer -- so it
+        // stays on the range-checked form)
+        if (EM != E_MASKX && erem == 32 && n0 + BN <= N) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         }
+#ifdef PCOPS_PHASE_PROF
+        if (active) { const unsigned long long n_ = PROF_T(); pf_epi += n_ - pf_t; ++pf_tiles; }
+#endif
         st = nst;
         sub = nsub;
         ++round;
     }
+#ifdef PCOPS_PHASE_PROF
+    if (lane == 0) {
+        atomicAdd(&g_phase_prof[0], pf_stage);
+        atomicAdd(&g_phase_prof[1], pf_mfma);
+        atomicAdd(&g_phase_prof[2], pf_epi);
+        atomicAdd(&g_phase_prof[3], PROF_T() - pf_start);
+        atomicAdd(&g_phase_prof[4], pf_tiles);
+        atomicAdd(&g_phase_prof[5], 1ull);
+    }
+#endif
 
     if (EM != E_PLAIN && EM != E_PLAINA && a.stats) {
         // lanes l, l + O4, l + 2 O4 ... own the same 4 columns
@@ -1000,7 +1085,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (lane < O4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    red[(wave * 2 + 0) * BN + h * BNH + ocl + e] = s1[h][e];
+                    // (pooled forward: the sums ran over  s (y - pivot);  s^2 = 1, and the first moment gets its sign back)
+                    red[(wave * 2 + 0) * BN + h * BNH + ocl + e] = POOL ? s1[h][e] * ecoef[BN + h * BNH + ocl + e] : s1[h][e];
                     red[(wave * 2 + 1) * BN + h * BNH + ocl + e] = s2[h][e];
                 }
             }
@@ -3348,6 +3434,17 @@ int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA
                        lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias);
     return pcops_launch_status();
 }
+
+#ifdef PCOPS_PHASE_PROF
+/* tools only: out[0..5] = summed shader cycles (stage, MFMA loop, epilogue, whole kernel), tiles, waves; then cleared */
+int pcops_debug_phase_prof(unsigned long long *out) {
+    if (hipDeviceSynchronize() != hipSuccess) return PCOPS_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_prof), sizeof(unsigned long long) * 8) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_prof), z, sizeof(z)) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    return PCOPS_OK;
+}
+#endif
 
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(K >= 1 && N >= 1);

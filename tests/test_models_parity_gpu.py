@@ -89,13 +89,15 @@ def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch, fused
     path's own output): + its distance to a second, equivalent realisation of the fused path (see FLOOR_SPREAD).  The
     largest is the floor an fp32 implementation of this net sits on.  Returns (floor, parts)."""
     from scanobjectnn_amd.pointnet2 import tf_util as t2
-    e_self = 0.0
+    rms = lambda t: float(t.double().pow(2).mean().sqrt())   # noqa: E731
+    e_self = r_self = 0.0
     if fused is not None and training:
         def again():
             net.load_state_dict(sd)
             with torch.no_grad():
                 return pick(net(x, is_training=training, bn_decay=0.9))
-        e_self = (_other_realisation(again).double() - fused.double()).abs().max().item()
+        d_self = _other_realisation(again).double() - fused.double()
+        e_self, r_self = d_self.abs().max().item(), rms(d_self)
     monkeypatch.setattr(t2, "FUSED_MLP", False)
     net.load_state_dict(sd)
     with torch.no_grad():
@@ -107,7 +109,21 @@ def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch, fused
     with torch.no_grad():
         cpu = pick(ref_fn()(torch.from_numpy(c), P32, training))
     e_cpu = (cpu.double() - truth).abs().max().item()
-    return max(e_gpu, e_cpu, e_self), {"gpu_layerwise": e_gpu, "cpu_fp32": e_cpu, "fused_realisations": e_self}
+    parts = {"gpu_layerwise": e_gpu, "cpu_fp32": e_cpu, "fused_realisations": e_self,
+             "rms_gpu_layerwise": rms(plain.cpu().double() - truth), "rms_cpu_fp32": rms(cpu.double() - truth),
+             "rms_fused_realisations": r_self}
+    if fused is not None:
+        parts["rms_fused"] = rms(fused.cpu().double() - truth)
+    parts["rms_floor"] = max(parts["rms_gpu_layerwise"], parts["rms_cpu_fp32"], r_self)
+    return max(e_gpu, e_cpu, e_self), parts
+
+
+def _no_worse_than_fp32(err, floor, parts):
+    """the fused path against the measured fp32 floor of the same net, without a slack factor: its LARGEST error over the
+    ~1e5 outputs is within the largest error of the plain evaluations, or -- the maximum of 1e5 rounding errors is a
+    heavy-tailed statistic that moves 20 % from one fp32 evaluation to the next -- its ROOT-MEAN-SQUARE error is within
+    theirs; and in no case further than twice the eval-mode bar"""
+    return (err <= max(TOL, FLOOR_SPREAD * floor) or parts["rms_fused"] <= FLOOR_SPREAD * parts["rms_floor"]) and err <= 2 * TOL
 
 
 def _no_dropout(monkeypatch):
@@ -157,7 +173,7 @@ def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     # GPU and (b) the fp32 CPU restatement, each judged against the float64 truth
     floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o[1], lambda: R.pointnet2_cls_bga, ws, monkeypatch, seg)
     _record("bga_mask_%s" % ("train" if training else "eval"), err_seg, floor, **parts)
-    assert err_seg <= (max(TOL, FLOOR_SPREAD * floor) if training else TOL), (err_seg, floor)
+    assert (_no_worse_than_fp32(err_seg, floor, parts) if training else err_seg <= TOL), (err_seg, floor, parts)
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -179,7 +195,7 @@ def test_pointnet2_partseg_logits(training, monkeypatch):
     err = (seg.cpu().double() - want).abs().max().item()
     floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o, lambda: R.pointnet2_cls_partseg, want, monkeypatch, seg)
     _record("partseg_%s" % ("train" if training else "eval"), err, floor, **parts)
-    assert err <= (max(TOL, FLOOR_SPREAD * floor) if training else TOL), (err, floor)   # same rule as the BGA mask branch
+    assert (_no_worse_than_fp32(err, floor, parts) if training else err <= TOL), (err, floor, parts)   # as the BGA mask branch
 
 
 def test_pointnet2_ssg_training_gradients(monkeypatch):
@@ -347,8 +363,15 @@ def test_model_training_gradients(name, monkeypatch):
     # the same fused kernels, second realisation (see FLOOR_SPREAD): how far two equivalent fp32 evaluations of THIS path
     # are from each other.  (DGCNN: only when both built the same neighbour graphs -- a neighbour tie that falls the other
     # way is a different network, which the float64 truth above does not describe either)
+    if name.startswith("dgcnn"):
+        # ... on the SAME neighbour graphs: the recorded ones are replayed (a 20th-neighbour tie that falls the other way
+        # in the second realisation would make it a different network, which the float64 truth does not describe either)
+        replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
+        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20: next(replay))
     _other_realisation(product_grads)
-    same_graphs = len(graphs) == len(graphs_fused) and all(np.array_equal(a, b) for a, b in zip(graphs, graphs_fused))
+    if name.startswith("dgcnn"):
+        monkeypatch.setattr(td, "knn_graph", recording)
+    same_graphs = True
     num = den = 0.0
     for k, p in net.named_parameters():
         if k in g_fused and p.grad is not None and not (k.endswith("biases") and k[:-len("biases")] + "bn/gamma" in g_fused):
@@ -356,6 +379,9 @@ def test_model_training_gradients(name, monkeypatch):
             den += g_fused[k].double().norm().item() ** 2
     e_self = (num / den) ** 0.5 if same_graphs else 0.0
     monkeypatch.setattr(t2, "FUSED_MLP", False)       # the layer-by-layer path: the fp32 yardstick
+    if name.startswith("dgcnn"):                      # ... on the graphs the truth was evaluated with
+        replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
+        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20: next(replay))
     product_grads()
     e_layer, _ = _grad_errors(net, P)
     monkeypatch.setattr(t2, "FUSED_MLP", True)
