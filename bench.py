@@ -372,9 +372,19 @@ def cpu_ops_baseline(seconds_budget=6.0):
     p2 = rng.random((b, m, c), dtype=np.float32)
     g2 = rng.random((b, n, c), dtype=np.float32)
     R = kind == "reference"
+    import threading
+    tls = threading.local()
+
+    def gp_out(sl):
+        # group_point writes 67 MB per reference-size batch: one buffer per worker thread, touched once -- a fresh array
+        # per call would measure the kernel's page-fault path (32 threads took 86 ms per batch against 4 ms on one core)
+        nb = len(range(*sl.indices(b)))
+        if getattr(tls, "gp", None) is None or tls.gp.shape[0] != nb:
+            tls.gp = np.zeros((nb, m, s, c), np.float32)
+        return tls.gp
     ops = {
         "query_ball_point": ((lambda sl: (O.ref_query_ball_point if R else (lambda *a: O.query_ball_point(*a)[0]))(r, s, xyz1[sl], xyz2[sl]))),
-        "group_point": (lambda sl: (O.ref_group_point if R else O.group_point)(pts[sl], idx[sl])),
+        "group_point": (lambda sl: (O.ref_group_point if R else O.group_point)(pts[sl], idx[sl], out=gp_out(sl))),
         "group_point_grad": (lambda sl: (O.ref_group_point_grad if R else O.group_point_grad)(pts[sl].shape, idx[sl], gout[sl])),
         "three_nn": (lambda sl: (O.ref_three_nn if R else O.three_nn)(xyz1[sl], xyz2[sl])),
         "three_interpolate": (lambda sl: (O.ref_three_interpolate if R else O.three_interpolate)(p2[sl], i3[sl], w[sl])),

@@ -79,11 +79,11 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
-def group_point(points, idx):
+def group_point(points, idx, out=None):
     points, idx = _f(points), _i(idx)
     b, n, c = points.shape
     _, m, s = idx.shape
-    out = np.empty((b, m, s, c), np.float32)
+    out = np.empty((b, m, s, c), np.float32) if out is None else out   # out: caller-owned buffer (bench.py's sharded CPU leg)
     lib().oracle_group_point(b, n, c, m, s, points, idx, out)
     return out
 
@@ -257,14 +257,14 @@ def ref_query_ball_point(radius, nsample, xyz1, xyz2):
     return idx
 
 
-def ref_group_point(points, idx):
+def ref_group_point(points, idx, out=None):
     I = C.c_int
     fn = _reffn("libref_grouping.so", "_Z15group_point_cpuiiiiiPKfPKiPf",
                 [I, I, I, I, I, _f32p, _i32p, _f32p])
     points, idx = _f(points), _i(idx)
     b, n, c = points.shape
     _, m, s = idx.shape
-    out = np.empty((b, m, s, c), np.float32)
+    out = np.empty((b, m, s, c), np.float32) if out is None else out   # out: caller-owned buffer (bench.py's sharded CPU leg)
     fn(b, n, c, m, s, points, idx, out)
     return out
 
