@@ -239,19 +239,25 @@ int pcops_mlp_bn_relu_apply(long long R, int C, const float *Y, const float *sca
                             float *out, pcops_stream_t stream);
 /* backward.  BN backward is folded into dY = p.G + q.Y + t with G = upstream grad masked by the ReLU.
  * relu_mask_stats: Gm = Gout*[relu(bn(Y))>0] and partial (sum Gm, sum Gm*Y): [pcops_mlp_bwd_stats_rows(R)][2][C]
- * pool_bwd_stats : the same sums for a max-pooled output, from (gpool, ysel = y at the pooled row): [..pool_stats_rows(G)][2][C]
+ * pool_bwd_stats : the same sums for a max-pooled output, from (gpool, ysel = y at the pooled row): [..pool_stats_rows(G)][2][C];
+ *                  gmasked (may be NULL) [G][C] = gpool * [relu(scale*ysel + shift) > 0], the MASKED pooled gradient --
+ *                  this is what the `gpool` argument of pcops_mlp_gemm_dgrad* / pcops_mlp_wgrad* has to be: those kernels
+ *                  place it at the arg-max rows without looking at the ReLU again (the wave-stream data gradient adds the
+ *                  one row per (group, channel) AFTER staging the dense part q.Y + t -- one multiply-add per element
+ *                  instead of byte extract, two compares, select and two multiply-adds)
  * bn_bwd_coeffs  : sums -> dgamma, dbeta, p, q, t */
 int pcops_mlp_bwd_stats_rows(long long R);
 int pcops_mlp_bwd_pool_stats_rows(long long G);
 int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float *Y, const float *scale,
                               const float *shift, float *Gm, float *stats_partial, pcops_stream_t stream);
 int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
-                             const float *shift, float *stats_partial, pcops_stream_t stream);
+                             const float *shift, float *stats_partial, float *gmasked, pcops_stream_t stream);
 int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partial, void *workspace,
                             const float *gamma, const float *mean, const float *rstd, float *dgamma,
                             float *dbeta, float *p, float *q, float *t, pcops_stream_t stream);
 /* dgrad: Gprev[M,Nout] = mask . (dY[M,K] Wt[K,Nout]); dY from (G,Y,p,q,t) or, when gpool != NULL, from the
- * pooled form (gpool, argmax, S, pool_scale, pool_shift).  Yprev != NULL: mask = [relu(bn_prev(Yprev)) > 0]
+ * pooled form (gpool = the MASKED pooled gradient of pcops_mlp_pool_bwd_stats, argmax, S, pool_scale, pool_shift).
+ * Yprev != NULL: mask = [relu(bn_prev(Yprev)) > 0]
  * and stats_partial [pcops_mlp_stats_rows(M)][2][Nout] gets (sum Gprev, sum Gprev*Yprev); Yprev == NULL: plain. */
 int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y, const float *p,
                          const float *q, const float *t, const float *gpool, const unsigned char *argmax,

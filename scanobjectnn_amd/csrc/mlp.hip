@@ -696,17 +696,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             } else if (is_dy(AM)) {
                 const float4 y = pb[j];
                 float4 g = x;
-                if (is_pool(AM)) {
+                if (U_ || B_) {
+                    // pooled form, one group per tile / per 16-row block: the p.G term has ONE row per (group, channel);
+                    // the rows get the dense part  q.Y + t  here and the few arg rows are added afterwards (below)
+                    g = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (is_pool(AM)) {
                     long long gdummy;
                     unsigned s;
-                    if (U_) s = (unsigned)(prs.s0 + r);
-                    else if (B_) s = (unsigned)(bs0[j / 4] + (r & (kBlk - 1)));
-                    else prs.split(r, glast, gdummy, s);
-                    const unsigned am = pm[U_ ? 0 : (B_ ? j / 4 : j)];
-                    g.x = ((am & 0xffu) == (unsigned)s && fmaf(y.x, c3.x, c4.x) > 0.f) ? x.x : 0.f;
-                    g.y = (((am >> 8) & 0xffu) == (unsigned)s && fmaf(y.y, c3.y, c4.y) > 0.f) ? x.y : 0.f;
-                    g.z = (((am >> 16) & 0xffu) == (unsigned)s && fmaf(y.z, c3.z, c4.z) > 0.f) ? x.z : 0.f;
-                    g.w = ((am >> 24) == (unsigned)s && fmaf(y.w, c3.w, c4.w) > 0.f) ? x.w : 0.f;
+                    prs.split(r, glast, gdummy, s);
+                    const unsigned am = pm[j];
+                    // (gpool arrives MASKED -- pcops.h: upstream gradient x [relu(bn(ysel)) > 0] -- so only the row test)
+                    g.x = ((am & 0xffu) == (unsigned)s) ? x.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == (unsigned)s) ? x.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == (unsigned)s) ? x.z : 0.f;
+                    g.w = ((am >> 24) == (unsigned)s) ? x.w : 0.f;
                 }
                 if (compact && C4 == 16 && j % 4 == 0) {
                     // rows 0 and 16 of the tile (lanes 0..15 at j = 0 / 4) open a block: dY = p.G + w (q.Y + t)
@@ -724,6 +727,32 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
             if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
+        }
+        if (U_ || B_) {
+            // the arg rows: lanes 0..15 (one per column quad) take the tile's group / its first block, lanes 16..31 the
+            // second block; each adds  p . gpool  to the stripe row the arg-max byte names, if that row is in this tile.
+            // (Per element this replaces byte extract + two compares + and + select + multiply-add of round 2 -- 1 150
+            // of the 1 540 vector instructions of a 256 -> 128 tile -- by ONE fused multiply-add; the sparse pass is ~40
+            // instructions on half a wave.)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < (B_ ? 32 : 16) && c < K) {
+                const bool second = B_ && lane >= 16;
+                const float4 gp = second ? pa[B_ ? 1 : 0] : pa[0];
+                const unsigned am = second ? pm[B_ ? 1 : 0] : pm[0];
+                const int base = B_ ? (second ? bs0[1] : bs0[0]) : prs.s0;      // row-in-group of the first row covered
+                const int span = B_ ? kBlk : 32, roff = second ? kBlk : 0;
+                const float gv[4] = {gp.x, gp.y, gp.z, gp.w};
+                const float pv[4] = {c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rel = (int)((am >> (8 * e)) & 0xffu) - base;
+                    if ((unsigned)rel < (unsigned)span && roff + rel < rem && gv[e] != 0.f) {
+                        float *dst = &Aw[(roff + rel) * LDW + cl + e];
+                        *dst = fmaf(pv[e], gv[e], *dst);
+                    }
+                }
+            }
         }
     };
     // a wave walks whole pooling groups: SUB consecutive 32-row tiles (SUB = 1 without pooling)
@@ -1481,7 +1510,8 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long G, in
                                                                  const float *__restrict__ ysel,
                                                                  const float *__restrict__ scale,
                                                                  const float *__restrict__ shift,
-                                                                 float *__restrict__ stats, int groups_per_block) {
+                                                                 float *__restrict__ stats, int groups_per_block,
+                                                                 float *__restrict__ gmasked) {
     extern __shared__ float sm[];                     // [RL][2][C]
     const int c4n = C / 4;
     const int RL = c4n >= 256 ? 1 : 256 / c4n;
@@ -1501,6 +1531,7 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long G, in
                 const float gm1 = fmaf(y.y, sc.y, sh.y) > 0.f ? gp.y : 0.f;
                 const float gm2 = fmaf(y.z, sc.z, sh.z) > 0.f ? gp.z : 0.f;
                 const float gm3 = fmaf(y.w, sc.w, sh.w) > 0.f ? gp.w : 0.f;
+                if (gmasked) *reinterpret_cast<float4 *>(gmasked + g * C + c) = make_float4(gm0, gm1, gm2, gm3);
                 a1[0] += gm0; a1[1] += gm1; a1[2] += gm2; a1[3] += gm3;
                 a2[0] = fmaf(gm0, y.x, a2[0]); a2[1] = fmaf(gm1, y.y, a2[1]);
                 a2[2] = fmaf(gm2, y.z, a2[2]); a2[3] = fmaf(gm3, y.w, a2[3]);
@@ -2014,8 +2045,6 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
         const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
         const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
         const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
-        const float4 cds = *reinterpret_cast<const float4 *>(&coefD[3 * NB + dcq]);
-        const float4 cdh = *reinterpret_cast<const float4 *>(&coefD[4 * NB + dcq]);
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
         float4 px[NA], pg[ND], py[ND];
         unsigned pm[(is_pool(DMODE)) ? ND : 1];
@@ -2123,10 +2152,11 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                     else if (B_) s = (unsigned)(bs0[B_ ? hb : 0] + (r & (kBlk - 1)));
                     else prs.split(r, glast, gdummy, s);
                     const unsigned am = pm[U_ ? 0 : (B_ ? hb : j)];
-                    g.x = ((am & 0xffu) == s && fmaf(y.x, cds.x, cdh.x) > 0.f) ? g.x : 0.f;
-                    g.y = (((am >> 8) & 0xffu) == s && fmaf(y.y, cds.y, cdh.y) > 0.f) ? g.y : 0.f;
-                    g.z = (((am >> 16) & 0xffu) == s && fmaf(y.z, cds.z, cdh.z) > 0.f) ? g.z : 0.f;
-                    g.w = ((am >> 24) == s && fmaf(y.w, cds.w, cdh.w) > 0.f) ? g.w : 0.f;
+                    // gpool arrives MASKED (pcops.h: upstream gradient x [relu(bn(ysel)) > 0]): only the row test is left
+                    g.x = ((am & 0xffu) == s) ? g.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == s) ? g.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == s) ? g.z : 0.f;
+                    g.w = ((am >> 24) == s) ? g.w : 0.f;
                 }
                 float4 d;
                 if (DMODE == A_SELFD && AMODE == A_PLAIN) {
@@ -2982,7 +3012,7 @@ int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float
 }
 
 int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
-                             const float *shift, float *stats_partial, pcops_stream_t stream) {
+                             const float *shift, float *stats_partial, float *gmasked, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(G >= 1 && C >= 4 && C % 4 == 0);
     PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(scale);
     PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(stats_partial);
@@ -2991,7 +3021,7 @@ int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float
     const size_t lds = (size_t)rl * 2 * C * sizeof(float);
     if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pool_bwd_stats_sel_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), lds,
-                       as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 16);
+                       as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 16, gmasked);
     return pcops_launch_status();
 }
 

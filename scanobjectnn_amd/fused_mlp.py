@@ -239,8 +239,11 @@ class FusedMLPStack(torch.autograd.Function):
             G = R // S
             P = lib.pcops_mlp_bwd_pool_stats_rows(G)
             part = _f32((P, 2, C), dev)
+            # gmask = the pooled gradient times the ReLU mask at the pooled rows: what the data / weight gradient kernels
+            # place at the arg-max rows (pcops.h, pcops_mlp_pool_bwd_stats)
+            gmask = _f32((G, C), dev)
             _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(),
-                      scales[-1].data_ptr(), shifts[-1].data_ptr(), part.data_ptr())
+                      scales[-1].data_ptr(), shifts[-1].data_ptr(), part.data_ptr(), gmask.data_ptr())
             Gm = None
         else:
             P = lib.pcops_mlp_bwd_stats_rows(R)
@@ -270,7 +273,7 @@ class FusedMLPStack(torch.autograd.Function):
             grads[6 * l + 2] = dgamma
             grads[6 * l + 3] = dbeta
             pooled = pool and l == L - 1
-            gp = grad_out.data_ptr() if pooled else None
+            gp = gmask.data_ptr() if pooled else None
             am = argmax.data_ptr() if pooled else None
             psc = scales[l].data_ptr() if pooled else None
             psh = shifts[l].data_ptr() if pooled else None
@@ -569,7 +572,7 @@ class EdgeConvPool(torch.autograd.Function):
         P = lib.pcops_mlp_bwd_pool_stats_rows(G)
         part = _f32((P, 2, C), dev)
         _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(), scale.data_ptr(),
-                  shift.data_ptr(), part.data_ptr())
+                  shift.data_ptr(), part.data_ptr(), None)
         vecs = _VecArena([C], 3, dev)
         p, q, t = vecs.take(C), vecs.take(C), vecs.take(C)
         dgamma, dbeta = _f32(C, dev), _f32(C, dev)
