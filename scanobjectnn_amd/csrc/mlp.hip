@@ -605,6 +605,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const unsigned yrowstep = (unsigned)(64 / O4) * (unsigned)a.ldy * 4u;
     const long long glast = is_pool(AM) ? ((long long)M - 1) / a.S : 0;
     constexpr bool U_ = AM == A_DYPOOLU;             // one pooling group per tile
+    // any other group size S >= 11: a 32-row tile meets at most FOUR groups (floor(31 / S) + 2); the 16-lane set
+    // lane / C4 keeps the (gpool, arg-max) quad of group g0 + lane / C4 and adds its arg rows after the dense staging,
+    // like U_ / B_ -- no per-row group arithmetic, one quad per lane instead of one per staged float4 (that form
+    // needed 250+ registers and spilled: DGCNN's T-Net, S = 20)
+    constexpr bool G_ = AM == A_DYPOOL;
     auto issue = [&](long long tile, int kc) {       // global -> registers, one stripe ahead, branch-free
         const long long row0 = tile * 32;
         if (compact && (is_dy(AM) || B_)) {
@@ -626,17 +631,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         }
         if (is_pool(AM) && !B_) {
             const PoolRows pr(row0, a.S);
-#pragma unroll
-            for (int j = 0; j < (U_ ? 1 : NLD); ++j) {
-                const int e = lane + 64 * j;
-                int c = (e % C4) * 4 + kc * KC;
+            {
+                int c = (lane % C4) * 4 + kc * KC;
                 c = c < K ? c : K - 4;
-                long long gi;
-                unsigned sdummy;
-                if (U_) gi = pr.g0 < glast ? pr.g0 : glast;
-                else pr.split(e / C4, glast, gi, sdummy);
-                pa[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
-                pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
+                long long gi = pr.g0 + (G_ ? lane / C4 : 0);
+                gi = gi < glast ? gi : glast;
+                pa[0] = *reinterpret_cast<const float4 *>(a.gpool + gi * K + c);
+                pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gi * K + c);
             }
         }
         const long long left = ((long long)M - row0) * a.ldx * 4;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
             const bool in = FULL || ((r < rem) && (c < K));
-            float4 x = pa[U_ ? 0 : (B_ ? j / 4 : j)];
+            float4 x = pa[(U_ || G_) ? 0 : (B_ ? j / 4 : j)];
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
                 x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
@@ -696,20 +697,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             } else if (is_dy(AM)) {
                 const float4 y = pb[j];
                 float4 g = x;
-                if (U_ || B_) {
-                    // pooled form, one group per tile / per 16-row block: the p.G term has ONE row per (group, channel);
-                    // the rows get the dense part  q.Y + t  here and the few arg rows are added afterwards (below)
+                if (is_pool(AM)) {
+                    // pooled form: the p.G term has ONE row per (group, channel); the rows get the dense part
+                    // q.Y + t  here and the few arg rows are added afterwards (below)
                     g = make_float4(0.f, 0.f, 0.f, 0.f);
-                } else if (is_pool(AM)) {
-                    long long gdummy;
-                    unsigned s;
-                    prs.split(r, glast, gdummy, s);
-                    const unsigned am = pm[j];
-                    // (gpool arrives MASKED -- pcops.h: upstream gradient x [relu(bn(ysel)) > 0] -- so only the row test)
-                    g.x = ((am & 0xffu) == (unsigned)s) ? x.x : 0.f;
-                    g.y = (((am >> 8) & 0xffu) == (unsigned)s) ? x.y : 0.f;
-                    g.z = (((am >> 16) & 0xffu) == (unsigned)s) ? x.z : 0.f;
-                    g.w = ((am >> 24) == (unsigned)s) ? x.w : 0.f;
                 }
                 if (compact && C4 == 16 && j % 4 == 0) {
                     // rows 0 and 16 of the tile (lanes 0..15 at j = 0 / 4) open a block: dY = p.G + w (q.Y + t)
@@ -728,7 +719,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             if (!in) x = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
         }
-        if (U_ || B_) {
+        if (is_pool(AM)) {
             // the arg rows: lanes 0..15 (one per column quad) take the tile's group / its first block, lanes 16..31 the
             // second block; each adds  p . gpool  to the stripe row the arg-max byte names, if that row is in this tile.
             // (Per element this replaces byte extract + two compares + and + select + multiply-add of round 2 -- 1 150
@@ -736,11 +727,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             // instructions on half a wave.)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < (B_ ? 32 : 16) && c < K) {
+            // (any group size: the 16-lane set lane / 16 takes group g0 + lane / 16, whose row s sits at tile row
+            // (lane / 16) S - s0 + s)
+            const int grp = lane / C4;
+            const bool gvalid = !G_ || prs.g0 + grp <= glast;
+            if (lane < (G_ ? 64 : (B_ ? 32 : 16)) && c < K && gvalid) {
                 const bool second = B_ && lane >= 16;
                 const float4 gp = second ? pa[B_ ? 1 : 0] : pa[0];
                 const unsigned am = second ? pm[B_ ? 1 : 0] : pm[0];
-                const int base = B_ ? (second ? bs0[1] : bs0[0]) : prs.s0;      // row-in-group of the first row covered
+                // row-in-group of the tile's (block's) first row; for G_ the tile row of the group's row 0, negated
+                const int base = B_ ? (second ? bs0[1] : bs0[0]) : (G_ ? prs.s0 - grp * a.S : prs.s0);
                 const int span = B_ ? kBlk : 32, roff = second ? kBlk : 0;
                 const float gv[4] = {gp.x, gp.y, gp.z, gp.w};
                 const float pv[4] = {c0.x, c0.y, c0.z, c0.w};
@@ -1195,6 +1191,8 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if ((reinterpret_cast<uintptr_t>(a.Y) & 15) || (reinterpret_cast<uintptr_t>(a.Yprev) & 15)) return false;
     if (is_pool(am) && ((reinterpret_cast<uintptr_t>(a.gpool) & 15) || (reinterpret_cast<uintptr_t>(a.argmax) & 3)))
         return false;
+    // pooled operand with arbitrary groups: a 32-row tile may meet at most four of them (kernel: G_)
+    if (is_pool(am) && !a.blocks && a.S % 32 != 0 && a.S < 11) return false;
     // 8 waves (two per SIMD) with 64-wide stripes; 128 output columns when the resident weight tile fits
     pl->kc = 64;
     pl->waves = 8;

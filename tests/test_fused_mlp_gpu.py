@@ -65,6 +65,12 @@ CASES = [  # (R, S, K0, widths, pool)
     # storing Y, algebraic backward with the plain-input variants (A_PLAIN operand, E_PLAINA epilogue, plain Gram)
     (64 * 256, 256, 320, [1024], True),
     (48 * 256, 256, 128, [1024], True),
+    # pooling groups that are not multiples of the 32-row tile on the wave-stream kernels: a tile meets up to four groups
+    # and adds their arg rows after the dense staging (DGCNN's T-Net: k = 20; MSG scale 0: nsample 16)
+    (4096 * 20, 20, 64, [64, 128], True),
+    (2048 * 16, 16, 32, [64, 64], True),
+    (1024 * 48, 48, 32, [64, 128], True),
+    (3000 * 11, 11, 64, [128], True),
 ]
 
 
