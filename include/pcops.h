@@ -166,6 +166,14 @@ int pcops_knn_topk(int rows, int n, int k, const float *adj, int *nn_idx,
 /* fused pairwise_distance + knn, never materialising (n,n): x (b,n,c) -> (b,n,k) */
 int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
                     pcops_stream_t stream);
+/* the same graph, with a hint: seed (b,n,k) names k DISTINCT points per query (DGCNN: the previous layer's neighbours,
+ * dgcnn/models/dgcnn.py:31-71 rebuilds the graph on every layer's features).  The largest distance to them bounds the
+ * k-th nearest distance from above, so the scan rejects everything beyond it with one compare and queues a fraction of
+ * the candidates; the selection and its tie rule are untouched -- nn_idx is bit for bit pcops_knn_graph's.  Entries
+ * outside [0, n) are clamped; duplicates among a query's seeds void the bound (caller's contract).  seed == NULL:
+ * pcops_knn_graph. */
+int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
+                           pcops_stream_t stream);
 /* get_edge_feature: x (b,n,c), nn_idx (b,n,k) -> out (b,n,k,2c) = [x_i | x_j - x_i] */
 int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn_idx,
                        float *out, pcops_stream_t stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "pcops_pairwise_distance": ([_I, _I, _I, _P, _P], True),
     "pcops_knn_topk": ([_I, _I, _I, _P, _P], True),
     "pcops_knn_graph": ([_I, _I, _I, _I, _P, _P], True),
+    "pcops_knn_graph_seeded": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_edge_feature": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_edge_feature_grad": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_mlp_gemm_fwd": ([_I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),

@@ -172,7 +172,7 @@ constexpr int kKnnQD = 12;             // queue slots per lane; a flush is due w
 
 template <int CP, int KL>
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, const float *__restrict__ x,
-                                                          int *__restrict__ nn_idx) {
+                                                          int *__restrict__ nn_idx, const int *__restrict__ seed) {
     constexpr int CH = 128;            // candidate rows per LDS chunk
     constexpr int LD = CP + 1;         // odd row stride: lanes 0..31 read 32 rows at one column without conflicts
     constexpr int NKK = CP / 2;        // MFMAs per tile
@@ -200,6 +200,49 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     if (qin)
         for (int l = 0; l < c; ++l) sq = fmaf(xb[(size_t)q * c + l], xb[(size_t)q * c + l], sq);
 
+    // SEEDED threshold (pcops_knn_graph_seeded): `seed` names k DISTINCT points per query -- in DGCNN the neighbours of the
+    // previous layer's graph.  The k-th smallest distance of the scan cannot exceed the largest distance to those k
+    // points, so every candidate beyond  tau = max_s |x_q - x_seed(s)|^2  (+ a margin for the two summation orders) is
+    // rejected by ONE compare before it reaches the queue: the sorted insertion (117 vector instructions per queued
+    // candidate) is what the selection costs, and a query that starts from a threshold near its final one queues a
+    // fraction of the ~k ln(n / k) candidates an unseeded scan does.  The result is the same list: the filter is an upper
+    // bound, selection and tie rule are untouched.
+    float tau = INFINITY;
+    if (seed != nullptr) {
+        // the two half-waves hold the same 32 queries: each takes every other seed, 16-byte loads when the rows allow
+        const int *sd = seed + ((size_t)b * n + (qin ? q : 0)) * k;
+        const bool v4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
+        float worst = 0.f, smax = 0.f;
+        for (int s = half; s < k && qin; s += 2) {
+            int j = sd[s];
+            j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+            const float *pq = xb + (size_t)q * c, *pj = xb + (size_t)j * c;
+            float d = 0.f, sj = 0.f;
+            if (v4) {
+                for (int l = 0; l < c; l += 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(pq + l);
+                    const float4 bb = *reinterpret_cast<const float4 *>(pj + l);
+                    d = fmaf(a.x - bb.x, a.x - bb.x, d); d = fmaf(a.y - bb.y, a.y - bb.y, d);
+                    d = fmaf(a.z - bb.z, a.z - bb.z, d); d = fmaf(a.w - bb.w, a.w - bb.w, d);
+                    sj = fmaf(bb.x, bb.x, sj); sj = fmaf(bb.y, bb.y, sj);
+                    sj = fmaf(bb.z, bb.z, sj); sj = fmaf(bb.w, bb.w, sj);
+                }
+            } else {
+                for (int l = 0; l < c; ++l) {
+                    const float a = pq[l], bb = pj[l];
+                    d = fmaf(a - bb, a - bb, d);
+                    sj = fmaf(bb, bb, sj);
+                }
+            }
+            worst = fmaxf(worst, d);
+            smax = fmaxf(smax, sj);
+        }
+        worst = fmaxf(worst, __shfl_xor(worst, 32, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+        // the scan evaluates (s_q - 2 <x_q, x_j>) + s_j with c-term fmaf chains: within ~4 c eps max(s_q, s_j) of the
+        // direct form above (c <= 128: 6e-5); the margin is an order of magnitude wider
+        if (qin) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
+    }
     TopK<KL> top;
     top.init();
     int nq = 0;                        // entries in this lane's queue
@@ -275,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
                 const int row0 = 32 * t + 8 * g4 + 4 * half;
                 const float4 s4 = *reinterpret_cast<const float4 *>(sc + row0);
                 const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
-                const float kth = top.v[KL - 1];
+                const float kth = fminf(top.v[KL - 1], tau);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = (sq + (-2.f * acc[4 * g4 + e])) + sv[e];
@@ -307,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
 }
 
 template <int CP, int KL>
-int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, hipStream_t st) {
+int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, const int *seed, hipStream_t st) {
     const size_t lds = (size_t)(128 * (CP + 1) + 128 + 2 * kKnnQD * 256) * sizeof(float);
     auto kern = knn_mfma_kernel<CP, KL>;
     if (lds > 48 * 1024) {
@@ -315,7 +358,7 @@ int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, hip
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)once;
     }
-    hipLaunchKernelGGL(kern, dim3(cdiv(n, 128), b), dim3(256), lds, st, n, c, k, x, nn_idx);
+    hipLaunchKernelGGL(kern, dim3(cdiv(n, 128), b), dim3(256), lds, st, n, c, k, x, nn_idx, seed);
     return pcops_launch_status();
 }
 
@@ -478,8 +521,15 @@ __global__ __launch_bounds__(256) void edge_feature_grad_kernel(long long total,
 
 }  // namespace
 
+extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
+                                      pcops_stream_t stream);
 extern "C" int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
                                pcops_stream_t stream) {
+    return pcops_knn_graph_seeded(b, n, c, k, x, nullptr, nn_idx, stream);
+}
+
+extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
+                                      pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 1);
     PCOPS_REQUIRE_ARG(k > 0 && k <= n);  // tf.nn.top_k: k must not exceed the last dimension
     if (b == 0) return PCOPS_OK;
@@ -491,8 +541,8 @@ extern "C" int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *
     if (use_mfma && k <= 32 && c <= 128) {
 #define PCOPS_KNN_CASE(CP_)                                                      \
     do {                                                                         \
-        if (k <= 20) return launch_knn_mfma<CP_, 20>(b, n, c, k, x, nn_idx, st); \
-        return launch_knn_mfma<CP_, 32>(b, n, c, k, x, nn_idx, st);              \
+        if (k <= 20) return launch_knn_mfma<CP_, 20>(b, n, c, k, x, nn_idx, seed, st); \
+        return launch_knn_mfma<CP_, 32>(b, n, c, k, x, nn_idx, seed, st);              \
     } while (0)
         if (c <= 4) PCOPS_KNN_CASE(4);
         if (c <= 16) PCOPS_KNN_CASE(16);

@@ -17,15 +17,18 @@ def placeholder_inputs(batch_size, num_point, device=None):
     return pointclouds_pl, labels_pl
 
 
-def _edge_conv(x, width, scope, k, is_training, bn_decay):
-    nn_idx = tf_util.knn_graph(x, k=k)
+def _edge_conv(x, width, scope, k, is_training, bn_decay, seed=None):
+    """-> (features (B,N,1,width), this layer's neighbour graph).  seed: the previous layer's graph -- the reference
+    rebuilds the kNN graph on every layer's features (dgcnn.py:31-71); consecutive graphs of the same points mostly
+    agree, which the kernel uses as a starting threshold (same result, tf_util.knn_graph)."""
+    nn_idx = tf_util.knn_graph(x, k=k, seed=seed)
     if tf_util.fused_ok(x, [width]):
         # EdgeConv without the (B,N,k,2C) edge tensor: first conv per point, gather + add, fused BN/ReLU/max
-        return tf_util.edge_conv_stack(x, nn_idx, [width], [scope], is_training, bn_decay)
+        return tf_util.edge_conv_stack(x, nn_idx, [width], [scope], is_training, bn_decay), nn_idx
     edge_feature = tf_util.get_edge_feature(x, nn_idx=nn_idx, k=k)
     net = tf_util.conv2d(edge_feature, width, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                          is_training=is_training, scope=scope, bn_decay=bn_decay)
-    return net.amax(dim=-2, keepdim=True)                       # (B,N,1,width)
+    return net.amax(dim=-2, keepdim=True), nn_idx               # (B,N,1,width)
 
 
 def backbone(point_cloud, is_training, bn_decay, k=20):
@@ -39,10 +42,10 @@ def backbone(point_cloud, is_training, bn_decay, k=20):
             edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
             transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
     point_cloud_transformed = torch.matmul(point_cloud, transform)
-    net1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay)
-    net2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay)
-    net3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay)
-    net4 = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay)
+    net1, g1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay, seed=nn_idx)
+    net2, g2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay, seed=g1)
+    net3, g3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay, seed=g2)
+    net4, _ = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay, seed=g3)
     cat = torch.cat([net1, net2, net3, net4], dim=-1)
     if tf_util.fused_ok(cat, [1024]):
         out_max = tf_util.conv2d_stack_global_max(cat, [1024], ['agg'], is_training, bn_decay)

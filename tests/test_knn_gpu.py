@@ -31,6 +31,31 @@ def test_knn_graph_vs_oracle(b, n, c, k):
     np.testing.assert_array_equal(N(nn), O.knn_graph(x, k))
 
 
+@pytest.mark.parametrize("b,n,c,k", [(2, 2048, 3, 20), (2, 1024, 64, 20), (1, 300, 64, 20), (2, 200, 128, 20), (2, 257, 16, 33)])
+@pytest.mark.parametrize("kind", ["previous", "random", "far", "lattice"])
+def test_seeded_knn_graph_is_the_same_graph(b, n, c, k, kind, monkeypatch):
+    """pcops_knn_graph_seeded: a hint (k distinct points per query) that starts every query from an upper bound of its
+    k-th distance.  Whatever the hint -- the graph of slightly different features (DGCNN: the previous layer), random
+    points, the k FARTHEST points, a tie-ridden lattice -- the result is bit for bit the unseeded graph / the oracle's."""
+    rng = np.random.default_rng(n * 7 + c)
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    if kind == "lattice":
+        x = (rng.integers(0, 3, (b, n, c)) * 0.5).astype(np.float32)            # exact distance ties everywhere
+    want = O.knn_graph(x, k)
+    if kind == "previous":
+        seed = O.knn_graph((x + 0.05 * rng.standard_normal(x.shape)).astype(np.float32), k)
+    elif kind == "far":
+        d = ((x[:, :, None, :].astype(np.float64) - x[:, None, :, :]) ** 2).sum(-1) if n <= 1024 else None
+        seed = (np.argsort(-d, axis=2)[:, :, :k] if d is not None
+                else np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)])).astype(np.int32)
+    else:
+        seed = np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)]).astype(np.int32)
+    monkeypatch.setattr(dg, "KNN_SEED_MAX_C", 1 << 20)          # the wrapper only takes the hint for narrow inputs
+    nn = dg.knn_graph(T(x), k=k, seed=T(seed.astype(np.int32)))
+    np.testing.assert_array_equal(N(nn), want)
+    assert torch.equal(nn, dg.knn_graph(T(x), k=k))
+
+
 def test_knn_graph_4d_input_and_lattice_ties():
     rng = np.random.default_rng(0)
     x = (rng.integers(0, 4, (2, 200, 1, 3)) * 0.25).astype(np.float32)     # heavy ties

@@ -252,9 +252,9 @@ def test_dgcnn_logits(name, training, monkeypatch):
     graphs = []
     real = td.knn_graph
 
-    def recording(point_cloud, k=20):
-        nn = real(point_cloud, k=k)
-        # the HIP graph is bit-exact w.r.t. the oracle GIVEN the same input tensor
+    def recording(point_cloud, k=20, seed=None):
+        nn = real(point_cloud, k=k, seed=seed)
+        # the HIP graph (seeded by the previous layer's, dgcnn.py) is bit-exact w.r.t. the oracle GIVEN the same input tensor
         inp = point_cloud.detach().reshape(point_cloud.shape[0], point_cloud.shape[1], -1).cpu().numpy()
         np.testing.assert_array_equal(nn.cpu().numpy(), O.knn_graph(inp, k))
         graphs.append(nn.cpu().numpy())
@@ -332,8 +332,8 @@ def test_model_training_gradients(name, monkeypatch):
     if name.startswith("dgcnn"):
         real = td.knn_graph
 
-        def recording(point_cloud, k=20):
-            nn = real(point_cloud, k=k)
+        def recording(point_cloud, k=20, seed=None):
+            nn = real(point_cloud, k=k, seed=seed)
             graphs.append(nn.cpu().numpy())
             return nn
         monkeypatch.setattr(td, "knn_graph", recording)
@@ -367,7 +367,7 @@ def test_model_training_gradients(name, monkeypatch):
         # ... on the SAME neighbour graphs: the recorded ones are replayed (a 20th-neighbour tie that falls the other way
         # in the second realisation would make it a different network, which the float64 truth does not describe either)
         replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
-        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20: next(replay))
+        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
     _other_realisation(product_grads)
     if name.startswith("dgcnn"):
         monkeypatch.setattr(td, "knn_graph", recording)
@@ -381,7 +381,7 @@ def test_model_training_gradients(name, monkeypatch):
     monkeypatch.setattr(t2, "FUSED_MLP", False)       # the layer-by-layer path: the fp32 yardstick
     if name.startswith("dgcnn"):                      # ... on the graphs the truth was evaluated with
         replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
-        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20: next(replay))
+        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
     product_grads()
     e_layer, _ = _grad_errors(net, P)
     monkeypatch.setattr(t2, "FUSED_MLP", True)

@@ -45,8 +45,8 @@ def run(name, seed, verbose):
     graphs = []
     real = td.knn_graph
     if name.startswith("dgcnn"):
-        def recording(point_cloud, k=20):
-            nn = real(point_cloud, k=k)
+        def recording(point_cloud, k=20, seed=None):
+            nn = real(point_cloud, k=k, seed=seed)
             graphs.append(nn.cpu().numpy())
             return nn
         td.knn_graph = recording
