@@ -997,9 +997,9 @@ __global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, 
             int ea[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 4; ++e) ex[e] = up[e] ? -INFINITY : INFINITY;
-            for (int s = 0; s < S; ++s) {
-                const int i = idx[g * S + s];
-                const float4 q = *reinterpret_cast<const float4 *>(Q + (b * n + i) * (long long)C + cq);
+            // the k gathered rows are independent loads: four in flight per thread (one at a time left the kernel at
+            // 0.15 of the HBM rate on L2-resident rows -- latency, not bandwidth)
+            auto take = [&](const float4 &q, int s) {
                 const float qv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1010,7 +1010,30 @@ __global__ __launch_bounds__(256) void edge_pool_fwd_kernel(long long G, int n, 
                     ex[e] = better ? qv[e] : ex[e];
                     ea[e] = better ? s : ea[e];
                 }
+            };
+            const int *ig = idx + g * S;
+            const float *Qb = Q + b * n * (long long)C + cq;
+            int s = 0;
+            constexpr int UF = 10;                                // k = 20: two rounds
+            for (; s + UF <= S; s += UF) {
+                int iu[UF];
+                float4 qu[UF];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) iu[u] = ig[s + u];
+#pragma unroll
+                for (int u = 0; u < UF; ++u) qu[u] = *reinterpret_cast<const float4 *>(Qb + iu[u] * (long long)C);
+#pragma unroll
+                for (int u = 0; u < UF; ++u) take(qu[u], s + u);
             }
+            for (; s + 4 <= S; s += 4) {
+                const int i0 = ig[s], i1 = ig[s + 1], i2 = ig[s + 2], i3 = ig[s + 3];
+                const float4 q0v = *reinterpret_cast<const float4 *>(Qb + i0 * (long long)C);
+                const float4 q1v = *reinterpret_cast<const float4 *>(Qb + i1 * (long long)C);
+                const float4 q2v = *reinterpret_cast<const float4 *>(Qb + i2 * (long long)C);
+                const float4 q3v = *reinterpret_cast<const float4 *>(Qb + i3 * (long long)C);
+                take(q0v, s); take(q1v, s + 1); take(q2v, s + 2); take(q3v, s + 3);
+            }
+            for (; s < S; ++s) take(*reinterpret_cast<const float4 *>(Qb + ig[s] * (long long)C), s);
             const float kf = (float)S;
             *reinterpret_cast<float4 *>(SQ + g * C + cq) =                       // the backward reads SQ = sum_s q
                 make_float4(fmaf(kf, qz[0], sq[0]), fmaf(kf, qz[1], sq[1]), fmaf(kf, qz[2], sq[2]), fmaf(kf, qz[3], sq[3]));
