@@ -2,6 +2,7 @@
 import torch
 
 from . import tf_util
+from ..pointnet2.tf_util import _dense
 from ..graph import constant_initializer, get_variable, variable_scope
 
 
@@ -35,9 +36,5 @@ def input_transform_net(edge_feature, is_training, bn_decay=None, K=3, is_dist=F
         weights = get_variable('weights', [256, K * K], constant_initializer(0.0))
         biases = get_variable('biases', [K * K], constant_initializer(0.0))
         eye = torch.eye(K, dtype=torch.float32, device=net.device).flatten()
-        if net.is_cuda:
-            from .. import fused_mlp
-            transform = fused_mlp.small_linear(net, weights, biases + eye)     # (B, 256) -> K*K on the small-GEMM kernel
-        else:
-            transform = torch.addmm(biases + eye, net, weights)
+        transform = _dense(net, weights, biases + eye)        # (B, 256) -> K*K: the small-GEMM kernel on the GPU (PCOPS_FC)
     return transform.view(batch_size, K, K)

@@ -89,6 +89,8 @@ class FusedMLPStack(torch.autograd.Function):
         vecs = _VecArena([l[2].shape[0] for l in layers], 4, dev)
         ws = _workspace(max(l[2].shape[0] for l in layers), dev) if training else None
         pooled_raw = pooled_parts = None
+        pool_top = False          # the pooled top layer takes the algebraic backward: decided ONCE, here (the forward
+        #                           drops Y on that decision, so the backward must not come to a different one)
         # a first layer with only the coordinate term is ARITHMETIC in three offsets per row: it is never stored, the
         # next layer and the whole backward rebuild it from off4 (16 bytes per row instead of 4 C1)
         # (with SyncBN, or a backward through eval-mode BN, the layer is materialised: its gradient shortcut assumes
@@ -146,8 +148,9 @@ class FusedMLPStack(torch.autograd.Function):
                     # gradient, not when the layer takes the algebraic backward
                     G = R // S
                     pooled_raw = (_f32((G, N), dev), torch.empty((G, N), dtype=torch.uint8, device=dev))
-                    if not need_grad or _pool_top_ok(lib, R, K, N, S, li, gather, K0, rows, virt and li == 1,
-                                                     b is not None):
+                    pool_top = need_grad and _pool_top_ok(lib, R, K, N, S, li, gather, K0, rows, virt and li == 1,
+                                                          b is not None)
+                    if not need_grad or pool_top:
                         Y = None
                     _lib.call("pcops_mlp_gemm_fwd_pool", R, K, N, S, src.data_ptr(), ld, _p(sc_prev),
                               _p(sh_prev), W2.data_ptr(), b.data_ptr(), gamma.data_ptr(), _p(Y),
@@ -213,6 +216,7 @@ class FusedMLPStack(torch.autograd.Function):
             ctx.biases = [l[1] for l in layers]
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
             ctx.rows = rows
+            ctx.pool_top = pool_top
         return out
 
     @staticmethod
@@ -314,7 +318,7 @@ class FusedMLPStack(torch.autograd.Function):
 
             K = Ws[l].shape[0]
             xyz_prev = virt and l == 1          # the layer below is the arithmetic first layer (never stored)
-            if pooled and _pool_top_ok(lib, R, K, N, S, l, gather, K0, rows, xyz_prev, ctx.biases[l] is not None):
+            if pooled and ctx.pool_top:
                 # algebraic form (pcops.h "algebraic backward of a pooled top layer"): K x K products instead of K x N
                 prev = (Ys[l - 1], scales[l - 1], shifts[l - 1]) if l > 0 else (a0, None, None)
                 Gm, part = _pool_top_backward(R, K, N, S, Ws[l], ctx.biases[l].detach(), p, q, t, grad_out, ysel,
@@ -439,6 +443,7 @@ class _SmallLinear(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # a second derivative through this node is an error, not silence
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         R, K = x.shape

@@ -80,14 +80,25 @@ def batch_norm_for_conv2d(inputs, is_training, bn_decay, scope, data_format):
     return batch_norm_template(inputs, is_training, scope, [0, 1, 2], bn_decay, data_format)
 
 
+DOUBLE_BACKWARD = False      # set True to build graphs for gradient-of-gradient uses (penalties, saliency of gradients):
+#                              the libpcops linear layers have no second derivative and are then bypassed
+
+
+def _double_backward_requested():
+    return DOUBLE_BACKWARD
+
+
 def _dense(x2d, kernel2d, biases):
     """X W + b.  Many rows into a few output columns (the per-point heads: 262 144 x 128 -> 2) is a shape the
     library GEMM runs on a handful of CUs, forward and weight gradient alike: those go through the libpcops GEMMs
     with the output padded to 4 columns."""
     rows, k = x2d.shape
     n = kernel2d.shape[1]
-    if x2d.is_cuda and FC_PCOPS and rows <= 4096 and x2d.dtype == torch.float32:
-        return fused_mlp.small_linear(x2d, kernel2d, biases)        # the classifier head (B x 1024 -> 512 -> 256 -> classes)
+    # the classifier / T-Net heads (B x 1024 -> 512 -> 256 -> classes): the regime the small-GEMM kernel was measured
+    # in (round 2, DESIGN section 8) -- a few hundred rows, K and N of a head.  Anything else keeps the library GEMM.
+    if (x2d.is_cuda and FC_PCOPS and rows <= 4096 and k <= 2048 and n <= 1024 and x2d.dtype == torch.float32
+            and not (torch.is_grad_enabled() and _double_backward_requested())):
+        return fused_mlp.small_linear(x2d, kernel2d, biases)
     if x2d.is_cuda and k % 8 == 0 and rows >= 32768 and n <= 64:
         pad = (-n) % 4
         w = F.pad(kernel2d, (0, pad)) if pad else kernel2d
