@@ -4,6 +4,7 @@ the float64 restatement."""
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import ref_models as R
@@ -123,3 +124,33 @@ def test_get_current_data_parts_keeps_points_and_part_labels_aligned():
     assert np.array_equal(prt, (cur[:, :, 0] * 6).astype(np.int32))
     for row, l in enumerate(lab):                            # every sampled point belongs to the cloud its label names
         assert all(any(np.array_equal(pt, q) for q in pcs[l]) for pt in cur[row])
+
+
+def test_evaluate_cli_flags_and_test_set_preparation(tmp_path):
+    """the evaluation command line of `pointnet2/evaluate_scenennobjects.py:27-44`: same flags and defaults; the test set
+    is centred and normalised on the host like `:81-90`; a model path that is neither a state dict nor a tensor-bundle
+    prefix is an error (no GPU needed for any of this)"""
+    from scanobjectnn_amd import data_utils as DU
+    from scanobjectnn_amd.pointnet2 import evaluate_scenennobjects as EV
+    a = EV.parse_args([])
+    assert (a.model, a.batch_size, a.num_point, a.model_path, a.dump_dir, a.num_votes, a.num_class) == \
+        ("pointnet2_cls_ssg", 1, 1024, "log/model.ckpt", "dump/", 1, 15)
+    assert a.with_bg is True and a.norm is True and a.center_data is True and a.visu is False
+    b = EV.parse_args(["--model", "dgcnn", "--num_votes", "12", "--norm", "false", "--batch_size", "32", "--normal"])
+    assert b.model == "dgcnn" and b.num_votes == 12 and b.norm is False and b.batch_size == 32
+    assert len(EV.SHAPE_NAMES) == 15 and EV.SHAPE_NAMES[0] == "bag" and EV.SHAPE_NAMES[-1] == "toilet"
+    rng = np.random.RandomState(0)
+    raw = (rng.randn(6, 40, 3) * 3.0 + 5.0).astype(np.float32)
+    lab = np.arange(6, dtype=np.int32).reshape(6, 1)
+    np.savez(tmp_path / "t.npz", data=raw, label=lab)
+    args = EV.parse_args(["--test_file", str(tmp_path / "t.npz"), "--num_point", "32"])
+    data, labels = EV.load_test_set(args)
+    np.testing.assert_array_equal(data, DU.normalize_data(DU.center_data(raw.copy())))
+    assert labels.shape == (6,) and np.sqrt((data ** 2).sum(-1)).max() <= 1.0 + 1e-6
+    args.center_data = args.norm = False
+    np.testing.assert_array_equal(EV.load_test_set(args)[0], raw)
+    with pytest.raises(FileNotFoundError):
+        EV.restore(torch.nn.Linear(2, 2), str(tmp_path / "no_such.ckpt"))
+    # accuracy bookkeeping with a class that never occurs (the reference divides by zero there)
+    acc, mean_class, per_class = EV.accuracy_summary(np.array([0, 1, 1, 3]), np.array([0, 1, 2, 3]), num_classes=5)
+    assert acc == 0.75 and np.isnan(per_class[4]) and abs(mean_class - (1 + 1 + 0 + 1) / 4.0) < 1e-12
