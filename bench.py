@@ -526,6 +526,9 @@ def main():
                     help="skip the secondary measurements (eval forward, kind=ball, rotate+jitter in the step)")
     ap.add_argument("--augment", action="store_true",
                     help="put the device-side rotate + jitter of the input pipeline (provider.py) inside the timed step")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: ONE all-reduce of the flat gradient bucket after the backward pass instead of ranges "
+                         "issued while it runs")
     ap.add_argument("--sync_bn", action="store_true", help="all-reduce the BN batch statistics over the ranks")
     ap.add_argument("--deterministic", action="store_true",
                     help="bit-reproducible backward passes (pcops_set_deterministic); reported in config, not the metric run")
@@ -568,6 +571,8 @@ def main():
     net = Model(mod.get_model, device=dev, seed=0).build(inputs["x"][:2].contiguous())
     fp = TU.FlatParams(net)
     D.broadcast_(fp.flat)                       # identical replicas
+    if not args.no_overlap:
+        fp.enable_overlap(world)                # no-op for one rank
     opt = TU.TFAdam(fp)
     global_batch = B * world
     state = {"step": 0, "augment": bool(args.augment)}
@@ -589,13 +594,16 @@ def main():
         else:
             loss = mod.get_loss(out[0], y, out[1])
         loss.backward()
-        g = fp.collect()
         if world > 1:
+            # the ranges of the flat bucket whose gradients the backward pass finished early are already travelling
+            # (FlatParams.enable_overlap); the events bracket what is left EXPOSED: the last range + the waits
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            D.allreduce_mean_(g, world)
+            fp.collect_mean(world)
             e1.record()
             ar_events.append((e0, e1))
+        else:
+            fp.collect()
         opt.step(lr)
         state["step"] = s + 1
         return loss
@@ -726,6 +734,7 @@ def main():
                    **({"shared_gpu_debug": True} if _shared_gpu_debug() else {})},
         "rccl_ranks": rccl_ranks,
         "per_rank_clouds_per_s": per_rank,
+        "allreduce_overlapped": bool(world > 1 and not args.no_overlap),   # ms below = the EXPOSED part (last range + waits)
         "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,
         "allreduce_share_of_step": (max(ar_all) / (elapsed / args.steps * 1e3)) if world > 1 else 0.0,
         "roofline": roofline,

@@ -169,7 +169,7 @@ def train(args):
     example = torch.zeros((2, args.num_point, 3), device=dev)
     kw = {"num_class": args.num_class} if args.num_class != 15 else {}
     net = Model(mod.get_model, device=dev, seed=args.seed, **kw).build(example)
-    fp = TU.FlatParams(net)
+    fp = TU.FlatParams(net).enable_overlap(world)        # N > 1: gradient ranges travel while the backward pass runs
     D.broadcast_(fp.flat)
     opt = TU.make_optimizer(args.optimizer, fp, args.momentum)
     step = 0
@@ -202,7 +202,7 @@ def train(args):
             else:
                 loss = mod.get_loss(out[0], y, out[1])
             loss.backward()
-            D.allreduce_mean_(fp.collect(), world)
+            fp.collect_mean(world)
             opt.step(lr)
             step += 1
             with torch.no_grad():

@@ -46,6 +46,7 @@ class FlatParams:
         self._zeros = torch.zeros(max(pad(p.numel()) for p in self.params), dtype=torch.float32, device=dev)
         self._gviews = []
         self._pads = []
+        self._armed = False
         off = 0
         for p in self.params:
             k = p.numel()
@@ -56,6 +57,85 @@ class FlatParams:
             self._pads.append(pad(k) - k)
             off += pad(k)
         self.numel = n
+        self._offs = []
+        off = 0
+        for p in self.params:
+            self._offs.append(off)
+            off += pad(p.numel())
+        self._buckets = None             # overlapped all-reduce (enable_overlap)
+
+    # -- gradient all-reduce overlapped with the backward pass ------------------------------------------------------
+    def enable_overlap(self, world, nbuckets=4, force=False):
+        """Cut the flat bucket into `nbuckets` contiguous ranges of about equal size (at parameter boundaries).  A range
+        is packed and its all-reduce issued ASYNCHRONOUSLY as soon as autograd has produced the gradient of its last
+        parameter -- the ranges that hold the late layers (produced first by the backward pass) travel while the
+        kernels of the early layers still run; `collect_mean()` issues what is left, waits and scales.  xGMI is
+        point-to-point and the whole bucket is 6-11 MB, so few, large ranges (latency-bound collectives) rather than
+        DDP's 25 MB default or one collective per layer.  The launch order is the order autograd finishes the ranges:
+        identical on every rank (same graph).  No-op for a single rank (force: take the path anyway -- the RCCL smoke
+        test)."""
+        import torch.distributed as dist
+        if (world <= 1 and not force) or not dist.is_initialized():
+            return self
+        target = max(1, self.numel // max(1, nbuckets))
+        self._buckets = []               # [first param, one past last param, start offset, end offset]
+        first = 0
+        for i in range(len(self.params)):
+            end = self._offs[i + 1] if i + 1 < len(self.params) else self.numel
+            if end - self._offs[first] >= target or i + 1 == len(self.params):
+                self._buckets.append((first, i + 1, self._offs[first], end))
+                first = i + 1
+        self._bucket_of = [0] * len(self.params)
+        for b, (i0, i1, _, _) in enumerate(self._buckets):
+            for i in range(i0, i1):
+                self._bucket_of[i] = b
+        self._world = world
+        self._pending = [0] * len(self._buckets)
+        self._works = []
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
+        return self
+
+    def _grad_ready(self, i):
+        if self._buckets is None or not self._armed:
+            return
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _pack(self, i0, i1, out):
+        pieces = []
+        for p, gap in zip(self.params[i0:i1], self._pads[i0:i1]):
+            pieces.append(p.grad.reshape(-1) if p.grad is not None else self._zeros[:p.numel()])
+            if gap:
+                pieces.append(self._zeros[:gap])
+        torch.cat(pieces, out=out)
+
+    def _launch(self, b):
+        import torch.distributed as dist
+        i0, i1, s, e = self._buckets[b]
+        self._pack(i0, i1, self.grad[s:e])
+        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self._pending[b] = -1            # launched
+
+    def collect_mean(self, world):
+        """after backward(): the flat gradient averaged over the ranks -- `collect()` + one all-reduce, or, with
+        `enable_overlap`, the ranges already under way plus whatever autograd did not reach."""
+        from . import dist as D
+        if self._buckets is None:
+            return D.allreduce_mean_(self.collect(), world)
+        self._armed = False
+        for b in range(len(self._buckets)):
+            if self._pending[b] >= 0:    # a parameter of this range got no gradient: zeros for it
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        del self._works[:]
+        self.grad.mul_(1.0 / self._world)
+        for p, v in zip(self.params, self._gviews):
+            p.grad = v
+        return self.grad
 
     def zero_grad(self):
         self.grad.zero_()
@@ -67,6 +147,10 @@ class FlatParams:
         adding it into a zeroed buffer (one fill + one add launch per parameter saved); `collect()` re-homes them."""
         for p in self.params:
             p.grad = None
+        if self._buckets is not None:
+            for b, (i0, i1, _, _) in enumerate(self._buckets):
+                self._pending[b] = i1 - i0
+            self._armed = True
 
     def collect(self):
         """after backward(): pack the per-parameter gradients into the flat bucket with ONE concatenation and make

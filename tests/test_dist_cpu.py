@@ -103,7 +103,7 @@ def _pointnet_setup(batch, npts):
     return pointnet_cls, net, x, y
 
 
-def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps):
+def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps, overlap=0):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -111,6 +111,9 @@ def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps):
     D.SYNC_BN = sync_bn
     mod, net, x, y = _pointnet_setup(batch, npts)
     fp = TU.FlatParams(net)
+    if overlap:
+        fp.enable_overlap(world, nbuckets=overlap)
+        assert len(fp._buckets) >= 2 and fp._buckets[0][2] == 0 and fp._buckets[-1][3] == fp.numel
     D.broadcast_(fp.flat)
     opt = TU.TFAdam(fp)
     lo, hi = D.shard_range(batch, rank, world)
@@ -118,7 +121,9 @@ def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps):
         fp.begin_step()
         logits, ep = net(x[lo:hi], is_training=True, bn_decay=0.5)
         mod.get_loss(logits, y[lo:hi], ep, reg_weight=0.0).backward()
-        D.allreduce_mean_(fp.collect(), world)
+        if overlap:
+            assert sum(1 for pend in fp._pending if pend == -1) >= len(fp._buckets) - 1   # issued DURING backward
+        fp.collect_mean(world)
         if step == 0:
             grad0 = fp.grad.tolist()
         opt.step(1e-3)
@@ -129,11 +134,11 @@ def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps):
     dist.destroy_process_group()
 
 
-def _run_model_dp(world, sync_bn, batch=8, npts=32, steps=2):
+def _run_model_dp(world, sync_bn, batch=8, npts=32, steps=2, overlap=0):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, sync_bn, batch, npts, steps))
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, sync_bn, batch, npts, steps, overlap))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -183,3 +188,31 @@ def test_model_data_parallel_local_bn_and_buffer_broadcast():
     assert torch.equal(res[0][0], res[1][0])
     assert not torch.allclose(res[0][1], res[1][1], atol=1e-6)               # shards differ -> statistics differ
     assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][2], res[0][1])
+
+
+def test_overlapped_bucket_allreduce_equals_the_single_collective():
+    """`FlatParams.enable_overlap`: the flat bucket leaves in ranges, each all-reduced asynchronously as soon as the
+    backward pass has produced it (checked: all but at most one range are under way when backward() returns) -- the
+    same averaged gradient, bit for bit, and the same parameters as the one-collective step, with and without SyncBN
+    (whose own collectives run inside the backward pass, interleaved with the ranges)."""
+    for sync_bn in (False, True):
+        plain = _run_model_dp(2, sync_bn=sync_bn)
+        over = _run_model_dp(2, sync_bn=sync_bn, overlap=3)
+        for r in range(2):
+            assert torch.equal(over[r][3], plain[r][3])                      # first step's averaged gradient
+            assert torch.equal(over[r][0], plain[r][0])                      # parameters after two Adam steps
+        assert torch.equal(over[0][0], over[1][0])
+
+
+def test_overlap_with_a_parameter_the_loss_does_not_reach():
+    """a range whose parameter never gets a gradient is issued by collect_mean() with zeros -- no hang, no stale data"""
+    net = _make_model()
+    extra = torch.nn.Linear(4, 4)                       # registered, never used
+    both = torch.nn.ModuleList([net, extra])
+    fp = TU.FlatParams(both)
+    assert fp.enable_overlap(1) is fp and fp._buckets is None          # single rank: nothing to overlap
+    fp.begin_step()
+    x = torch.randn(5, 6)
+    net(x).sum().backward()
+    g = fp.collect_mean(1)
+    assert g[-20:].abs().max().item() == 0.0 and g[:10].abs().max().item() > 0.0

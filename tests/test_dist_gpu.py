@@ -149,6 +149,7 @@ def _rccl_worker(port, q):
         mod, net, x, y = _build("ssg")
         fp = TU.FlatParams(net)
         fp.begin_step()
+        torch.manual_seed(5)                                 # (dropout masks of the head)
         mod.get_loss(net(x, is_training=True, bn_decay=0.9)[0], y).backward()
         g = fp.collect()
         before = g.clone()
@@ -162,8 +163,20 @@ def _rccl_worker(port, q):
         torch.cuda.synchronize()
         # the wrappers take the same path at world size 1 when asked to (force=True), and are no-ops otherwise
         g2 = D.allreduce_mean_(before.clone(), force=True)
+        same, same2 = bool(torch.equal(g, before)), bool(torch.equal(g2, before))
+        # the overlapped form of the same step: ranges of the bucket all-reduced asynchronously from autograd's hooks
+        # while the HIP kernels of the earlier layers still run, then waited for
+        fp.enable_overlap(1, nbuckets=4, force=True)
+        fp.begin_step()
+        torch.manual_seed(5)
+        mod.get_loss(net(x, is_training=True, bn_decay=0.9)[0], y).backward()
+        under_way = sum(1 for pend in fp._pending if pend == -1)
+        g3 = fp.collect_mean(1)
+        torch.cuda.synchronize()
         q.put({"backend": dist.get_backend(), "world": dist.get_world_size(), "bytes": g.numel() * 4,
-               "same": bool(torch.equal(g, before)), "same2": bool(torch.equal(g2, before)),
+               "ranges": len(fp._buckets), "under_way": under_way,
+               "overlap_err": float(((g3 - before).norm() / before.norm()).item()),
+               "same": same, "same2": same2,
                "max": float(t.item()), "gathered": float(out[0].item())})
     finally:
         dist.destroy_process_group()
@@ -180,3 +193,5 @@ def test_rccl_backend_initialises_and_reduces_the_flat_bucket_on_one_gpu():
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["bytes"] > 5_000_000                         # SSG's bucket: 1.47 M parameters, 5.9 MB
     assert res["same"] and res["same2"] and res["max"] == 3.25 and res["gathered"] == 3.25
+    # (same inputs and parameters as the first step; the two gradients differ by the order of the scatter atomics)
+    assert res["ranges"] >= 3 and res["under_way"] >= res["ranges"] - 1 and res["overlap_err"] <= 1e-3, res
