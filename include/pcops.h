@@ -281,6 +281,21 @@ int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const fl
                     const float *pool_scale, const float *pool_shift, float *partial, float *dW, float *db,
                     pcops_stream_t stream);
 int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t stream);
+/* Data AND weight gradient of a narrow layer in one pass (round 3): what pcops_mlp_gemm_dgrad (with Yprev) followed by
+ * pcops_mlp_wgrad (A = relu(Yprev*a_scale + a_shift)) compute for the layer  Y = relu(bn(Yprev)) W + b,  W [K][N] in its
+ * own layout (no transposed copy), with every tensor read ONCE.  The 64-wide layers of the reference's stacks are
+ * bandwidth bound in both kernels and read the same bytes twice.
+ *   pcops_mlp_bwd_fused_groups  0 when (M, K, N, S, pooled) is not taken (K <= 64, N <= 128, M >= 65536, both % 4 == 0);
+ *                               otherwise the number of partial copies: partial = groups * (K N + N) floats,
+ *                               stats_partial [groups][2][K] = (sum Gprev, sum Gprev*Yprev) -- the partial-row count to
+ *                               hand to pcops_mlp_bn_bwd_coeffs
+ *   G / Y / p / q / t / gpool / argmax / S   as pcops_mlp_gemm_dgrad
+ * Same numbers as the two-kernel path up to fp32 summation order; sums in a fixed order (deterministic). */
+int pcops_mlp_bwd_fused_groups(long long M, int K, int N, int S, int pooled);
+int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                        const float *G, const float *Y, const float *p, const float *q, const float *t,
+                        const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
+                        float *dW, float *db, float *Gprev, float *stats_partial, pcops_stream_t stream);
 /* C [M][N] = A [M][K] B [K][N], row-major with leading dimensions: the small weight x weight products and row vectors
  * around the big kernels (32 x 32 output tile per workgroup, fp32 MFMA, fixed summation order) */
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,

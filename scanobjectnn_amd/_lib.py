@@ -68,6 +68,7 @@ SIGNATURES = {
     "pcops_mlp_gemm_fwd_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_bwd_fused": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_relu_maxpool_rows": ([_LL, _I, _P, _P, _P, _P, _P, _P, _P], True),
@@ -91,6 +92,7 @@ PLAIN = {
     "pcops_mlp_bwd_stats_rows": ([_LL], _I),
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
+    "pcops_mlp_bwd_fused_groups": ([_LL, _I, _I, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_rows": ([_I, _I], _I),
     "pcops_edge_pool_stats_rows": ([_LL], _I),

@@ -1640,6 +1640,8 @@ struct WgradArgs {
     float *dbpart;           // [gridDim.z][N] partial db (written by blockIdx.x == 0)
     const RowBlock *blocks;  // compacted rows (producer/consumer kernel only), see GemmArgs
     const int *Mdev;
+    // bwd_fused_kernel only: the layer's weights, the masked data gradient it also writes, its column statistics
+    const float *W; float *Gprev; float *gstats;
 };
 
 template <int VK, int VN>
@@ -2269,6 +2271,363 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                 for (int r = quad; r < 256; r += D4) sum += sdb[r * 4 + e];
                 if (n0 + c < N) a.dbpart[(long long)grp * N + n0 + c] = sum;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Data AND weight gradient of a 64-wide layer in ONE pass over its tensors (round 3).  The two kernels of such a layer
+// are bandwidth bound and read the same bytes: SA1's 64 -> 128 layer moves 4.3 GB for the data gradient (Y, the mask
+// tensor, Gprev) and 3.2 GB for the weight gradient (Y again, the mask tensor again as the A operand).  Here the
+// producer / consumer weight-gradient kernel keeps what it has already staged -- relu(bn(Yprev)) and
+// dY = p.G + q.Y + t of a 32-row stripe -- and its consumer waves ALSO multiply the dY stripe with the resident weights:
+//   waves 4..7  PRODUCERS: HBM -> registers a stripe ahead -> LDS stripe  [32][ X (64) | raw Yprev (64) | dY (NB) ]
+//   waves 0..3  CONSUMERS: dW += X^T dY  (v_mfma_f32_32x32x2_f32, 32 x (NB/2) block per wave, as in wgrad_pc_kernel)
+//                          dX  = dY W^T  (v_mfma_f32_16x16x4_f32: two 16 x 16 blocks per wave and stripe; W sits in LDS
+//                                         n-quad major, which is how its rows lie in memory -- no transposition), then
+//                          Gprev = dX . [bn(Yprev) > 0]  straight from the accumulators, with the column sums
+//                          (sum Gprev, sum Gprev Yprev) the BN backward of the layer below needs; the mask and the
+//                          statistics read the RAW Yprev the producers left beside X -- no second trip to memory.
+// Per stripe a consumer issues 16 (NB/64) + 4 (NB/16) ... = equal matrix-pipe time for the two products (4 096 cycles at
+// NB = 128), so the pass is pipe bound at about the time of ONE of the two kernels it replaces.
+template <int TN, int DMODE>
+__global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
+    constexpr int KB = 64, NB = 64 * TN, RS = 32;
+    constexpr int LD = 2 * KB + NB + 4;                       // X | raw | dY | pad (row stride = 4 banks mod 32)
+    constexpr int A4 = KB / 4, D4 = NB / 4;
+    constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, N = a.N;
+    const long long M = a.M;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
+#ifdef PCOPS_BF_DEBUG
+    const int dbg = a.rows_per_block;          // ablation experiments (tools/ only)
+#else
+    constexpr int dbg = 0;
+#endif
+    float *coefA = lds;                        // [2][KB]  scale, shift of the layer below
+    float *coefD = coefA + 2 * KB;             // [3][NB]  p, q, t
+    float *wq = coefD + 3 * NB;                // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
+    float *buf = wq + NB * KB;                 // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][2][KB]
+
+    for (int e = tid; e < KB; e += 512) {
+        coefA[e] = e < K ? a.asc[e] : 0.f;
+        coefA[KB + e] = e < K ? a.ash[e] : 0.f;
+    }
+    for (int e = tid; e < NB; e += 512) {
+        const bool in = e < N;
+        coefD[e] = (in && a.p) ? a.p[e] : 0.f;
+        coefD[NB + e] = (in && a.q) ? a.q[e] : 0.f;
+        coefD[2 * NB + e] = (in && a.t) ? a.t[e] : 0.f;
+    }
+    for (int e = tid; e < D4 * KB; e += 512) {
+        const int nq = e / KB, k = e % KB;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && 4 * nq < N) w = *reinterpret_cast<const float4 *>(a.W + (long long)k * N + 4 * nq);   // N % 4 == 0
+        *reinterpret_cast<float4 *>(&wq[(nq * KB + k) * 4]) = w;
+    }
+    __syncthreads();
+
+    const long long nstripes = (M + RS - 1) / RS;
+    const long long cnt = grp < nstripes ? (nstripes - grp + ngrp - 1) / ngrp : 0;   // stripes of this workgroup
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const int acq = (pt % A4) * 4, dcq = (pt % D4) * 4;
+        const bool ain = acq < K, din = dcq < N;
+        const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
+        const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+        const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
+        const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
+        const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
+        float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        // TWO register sets: the loads of stripe i + 2 are in flight while stripe i + 1 is staged (one stripe ahead left
+        // 29 KB per CU in flight -- 3.0 TB/s at the latency of a loaded HBM; the kernel is otherwise matrix-pipe bound)
+        struct Regs {
+            float4 px[NA], pg[ND], py[ND];
+            unsigned pm[(is_pool(DMODE)) ? ND : 1];
+        } rs0, rs1;
+        const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acq) * 4u : kOOB;
+        const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcq) * 4u : kOOB;
+        const unsigned xstep = (unsigned)(256 / A4) * (unsigned)a.ldx * 4u;
+        const unsigned dstep = (unsigned)(256 / D4) * (unsigned)a.ldy * 4u;
+        const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
+        const int dcl = din ? dcq : 0;
+        constexpr bool U_ = DMODE == A_DYPOOLU;                // one pooling group per stripe
+        auto issue = [&](long long stripe, Regs &rg_) {
+            if (dbg & 16) return;
+            const long long row0 = stripe * RS;
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            const __amdgpu_buffer_rsrc_t rg =
+                make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                rg_.py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
+                if (is_pool(DMODE)) {
+                    if (U_) {
+                        if (j == 0) {
+                            const long long gi = pr.g0 < glast ? pr.g0 : glast;
+                            rg_.pg[0] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                            rg_.pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                        }
+                    } else {
+                        long long gi;
+                        unsigned sdummy;
+                        pr.split(pt / D4 + j * (256 / D4), glast, gi, sdummy);
+                        rg_.pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                        rg_.pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                    }
+                } else {
+                    rg_.pg[j] = buf_load4(rg, dvoff, (unsigned)j * dstep);
+                }
+            }
+        };
+        auto stage = [&](long long stripe, float *dst, const Regs &rg_) {
+            if (dbg & 8) return;
+            const long long row0 = stripe * RS;
+            const PoolRows prs(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int r = pt / A4 + j * (256 / A4);
+                float4 y = rg_.px[j], x;
+                if (!(ain && row0 + r < M)) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                x.x = fmaxf(fmaf(y.x, casc.x, cash.x), 0.f);
+                x.y = fmaxf(fmaf(y.y, casc.y, cash.y), 0.f);
+                x.z = fmaxf(fmaf(y.z, casc.z, cash.z), 0.f);
+                x.w = fmaxf(fmaf(y.w, casc.w, cash.w), 0.f);
+                if (!(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&dst[r * LD + acq]) = x;
+                *reinterpret_cast<float4 *>(&dst[r * LD + KB + acq]) = y;
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int r = pt / D4 + j * (256 / D4);
+                const float4 y = rg_.py[j];
+                float4 g = rg_.pg[U_ ? 0 : j];
+                if (is_pool(DMODE)) {
+                    long long gdummy;
+                    unsigned s;
+                    if (U_) s = (unsigned)(prs.s0 + r);
+                    else prs.split(r, glast, gdummy, s);
+                    const unsigned am = rg_.pm[U_ ? 0 : j];
+                    // gpool arrives MASKED (pcops.h, pcops_mlp_pool_bwd_stats): only the row test is left
+                    g.x = ((am & 0xffu) == s) ? g.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == s) ? g.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == s) ? g.z : 0.f;
+                    g.w = ((am >> 24) == s) ? g.w : 0.f;
+                }
+                float4 d;
+                d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
+                d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
+                d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
+                d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+                if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
+                *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + dcq]) = d;
+            }
+        };
+        if (cnt > 0) issue(grp, rs0);
+        if (cnt > 1) issue(grp + ngrp, rs1);
+        if (cnt > 0) {
+            stage(grp, buf, rs0);
+            if (cnt > 2) issue(grp + 2 * ngrp, rs0);
+        }
+        __syncthreads();                                       // stripe 0 is in buf[0]
+        // stripe i + 1 lives in set (i + 1) & 1; two stripes per loop body so that the sets are named statically
+        for (long long i = 0; i < cnt; i += 2) {
+            if (i + 1 < cnt) {
+                stage(grp + (i + 1) * ngrp, buf + RS * LD, rs1);
+                if (i + 3 < cnt) issue(grp + (i + 3) * ngrp, rs1);
+            }
+            __syncthreads();
+            if (i + 1 < cnt) {
+                if (i + 2 < cnt) {
+                    stage(grp + (i + 2) * ngrp, buf, rs0);
+                    if (i + 4 < cnt) issue(grp + (i + 4) * ngrp, rs0);
+                }
+                __syncthreads();
+            }
+        }
+        float *sdb = buf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sdb[pt * 4 + e] = dbs[e];
+        __syncthreads();
+        __syncthreads();                                       // (the consumers' statistics hand-over)
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const int ck = wave >> 1, cn = wave & 1;               // dW block: k rows 32 ck .., n columns (NB / 2) cn ..
+        const int half = lane >> 5, li = lane & 31;
+        const int rh = wave >> 1, cbp = wave & 1;              // dX blocks: rows 16 rh .., columns 32 cbp + {0, 16} ..
+        const int c16 = lane & 15, g4 = lane >> 4;
+        f32x16 accw[TN];
+        f32x4 accd[2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) accw[j][v] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) accd[b][v] = 0.f;
+        const int aoff = half * LD + ck * 32 + li;
+        const int doff = half * LD + 2 * KB + cn * TN * 32 + li;
+        const int daoff = (16 * rh + c16) * LD + 2 * KB + 4 * g4;           // + 16 J
+        const int wboff = (g4 * KB + 32 * cbp + c16) * 4;                   // + 16 b * 4, + J * 4 KB * 4
+        // this wave's slice of W (NB x 32 columns) stays in REGISTERS for the life of the workgroup: re-read from LDS per
+        // stripe it was 64 of the 154 KB of LDS reads a stripe cost -- at 128 B/clk the LDS pipe, not the matrix pipe,
+        // set the pace (measured: the kernel without any MFMA or global access still took a quarter of its time)
+        constexpr int JN = NB / 16;                            // 16-column groups of dY: one data-gradient step each
+        float4 wreg[JN][2];
+#pragma unroll
+        for (int J = 0; J < JN; ++J)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) wreg[J][b] = *reinterpret_cast<const float4 *>(&wq[wboff + 64 * b + J * 4 * KB * 4]);
+        unsigned goff[2][4];                                   // byte offsets of this lane's Gprev elements inside a stripe
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int col = 32 * cbp + 16 * b + c16;
+                goff[b][v] = col < K ? (unsigned)((16 * rh + 4 * g4 + v) * K + col) * 4u : kOOB;
+            }
+        float msc[2], msh[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            msc[b] = coefA[32 * cbp + 16 * b + c16];
+            msh[b] = coefA[KB + 32 * cbp + 16 * b + c16];
+        }
+        float pend[2][4], pyr[2][4];
+        long long prow0 = 0;
+        bool have = false;
+        auto flush = [&](int b) {         // Gprev = dX . mask, its column sums, the stores -- of the PREVIOUS stripe
+            const __amdgpu_buffer_rsrc_t rgp = make_rsrc(a.Gprev + prow0 * K, (M - prow0) * K * 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float gv = fmaf(pyr[b][v], msc[b], msh[b]) > 0.f ? pend[b][v] : 0.f;
+                s1[b] += gv;
+                s2[b] = fmaf(gv, pyr[b][v], s2[b]);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
+            }
+        };
+        __syncthreads();
+        for (long long i = 0; i < cnt; ++i) {
+            const float *sb = buf + (i & 1) * RS * LD;
+            const long long row0 = (grp + i * ngrp) * RS;
+            float av_n = sb[aoff], dv_n[TN];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 32 * y];
+            constexpr int JP = (RS / 2) / JN;                  // data-gradient steps spread over the RS / 2 row pairs
+            // every LDS fragment is requested one use AHEAD (the scheduler would otherwise sink the reads to just in
+            // front of their first use and expose the LDS latency)
+            float4 da_n = *reinterpret_cast<const float4 *>(&sb[daoff]);
+            float yr[2][4];                                    // the raw Yprev under this wave's Gprev elements
+#pragma unroll
+            for (int it = 0; it < RS / 2; ++it) {
+                const float av = av_n;
+                float dv[TN];
+#pragma unroll
+                for (int y = 0; y < TN; ++y) dv[y] = dv_n[y];
+                if (it + 1 < RS / 2) {
+                    av_n = sb[aoff + 2 * (it + 1) * LD];
+#pragma unroll
+                    for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
+                }
+                const bool dostep = it % JP == 0;
+                const int J = it / JP;
+                const float4 da = da_n;
+                if (dostep && J + 1 < JN) da_n = *reinterpret_cast<const float4 *>(&sb[daoff + 16 * (J + 1)]);
+                if (it == RS / 2 - 1) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            yr[b][v] = sb[(16 * rh + 4 * g4 + v) * LD + KB + 32 * cbp + 16 * b + c16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(dbg & 4)) {
+#pragma unroll
+                for (int y = 0; y < TN; ++y) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
+                }
+                if (dostep && !(dbg & 1)) {
+                    const float de[4] = {da.x, da.y, da.z, da.w};
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const float4 w4 = wreg[J][b];
+                            const float we = s_ == 0 ? w4.x : (s_ == 1 ? w4.y : (s_ == 2 ? w4.z : w4.w));
+                            accd[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[s_], we, accd[b], 0, 0, 0);
+                        }
+                }
+                if (have && !(dbg & 2) && (it == 1 || it == 3)) flush(it >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- Gprev rows of this stripe: handed to the NEXT stripe's loop (pend): the mask / statistics / store
+            // instructions then issue under that stripe's first MFMAs instead of leaving the matrix pipe idle between the
+            // last MFMA of a stripe and the barrier
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    pend[b][v] = accd[b][v];
+                    pyr[b][v] = yr[b][v];
+                    accd[b][v] = 0.f;
+                }
+            prow0 = row0;
+            have = true;
+            __syncthreads();
+        }
+        if (have && !(dbg & 2)) {
+            flush(0);
+            flush(1);
+        }
+        // dW partial of this workgroup: accw[y][v] = (k = 32 ck + (v&3) + 8 (v>>2) + 4 half, n = (NB/2) cn + 32 y + li)
+        float *out = a.part + (long long)grp * K * N;
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int nn = (cn * TN + y) * 32 + li;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int kk = ck * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+                if (kk < K && nn < N) out[(long long)kk * N + nn] = accw[y][v];
+            }
+        }
+        // column statistics of Gprev: the four 16-lane sets of a wave own the same columns, the two row halves (waves
+        // w, w ^ 2) meet in LDS
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            s1[b] += __shfl_xor(s1[b], 16, 64); s1[b] += __shfl_xor(s1[b], 32, 64);
+            s2[b] += __shfl_xor(s2[b], 16, 64); s2[b] += __shfl_xor(s2[b], 32, 64);
+        }
+        __syncthreads();                                       // matches the producers' db hand-over
+        float *sst = buf + 256 * 4;                            // [2 row halves][2][KB], behind the db scratch
+        if (lane < 16) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                sst[(rh * 2 + 0) * KB + 32 * cbp + 16 * b + c16] = s1[b];
+                sst[(rh * 2 + 1) * KB + 32 * cbp + 16 * b + c16] = s2[b];
+            }
+        }
+        if (a.dbpart) {
+            const float *sdb = buf;
+            for (int c = tid; c < NB; c += 256) {
+                const int quad = c >> 2, e = c & 3;
+                float sum = 0.f;
+                for (int r = quad; r < 256; r += D4) sum += sdb[r * 4 + e];
+                if (c < N) a.dbpart[(long long)grp * N + c] = sum;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * KB; i += 256) {
+            const int which = i / KB, c = i % KB;
+            if (c < K) a.gstats[((long long)grp * 2 + which) * K + c] = sst[which * KB + c] + sst[(2 + which) * KB + c];
         }
     }
 }
@@ -3298,6 +3657,81 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     // dW and db partials are adjacent ([splits][K*N] then [splits][N]): one launch sums both
     const long long L = (long long)K * N;
     hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, splits, L,
+                       partial, dW, (long long)N, a.dbpart, db);
+    return pcops_launch_status();
+}
+
+static int bwd_fused_groups(long long M, int K, int N, int S, int pooled) {
+    if (!ws_enabled() || !wgrad_pc_enabled()) return 0;
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_BWD_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    if (!on) return 0;
+    // the bandwidth-bound 64-wide layers only: wider ones are matrix-pipe bound in both kernels and gain nothing
+    if (M < 65536 || K > 64 || K % 4 != 0 || N > 128 || N % 4 != 0) return 0;
+    if (pooled && (S < 1 || S > 255)) return 0;
+    long long g = 256;
+    const long long ns = (M + 31) / 32;
+    if (g > ns) g = ns;
+    if (g >= 8) g &= ~7ll;
+    return (int)g;
+}
+
+int pcops_mlp_bwd_fused_groups(long long M, int K, int N, int S, int pooled) { return bwd_fused_groups(M, K, N, S, pooled); }
+
+int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                        const float *G, const float *Y, const float *p, const float *q, const float *t,
+                        const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
+                        float *dW, float *db, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W);
+    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(Gprev); PCOPS_REQUIRE_PTR(stats_partial);
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
+    if (gpool) PCOPS_REQUIRE_PTR(argmax);
+    const int groups = bwd_fused_groups(M, K, N, S, gpool != nullptr);
+    if (groups == 0) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Yprev) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
+        (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
+        (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return PCOPS_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_BNRELU; a.X = Yprev; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
+    a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
+#ifdef PCOPS_BF_DEBUG
+    { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
+#endif
+    const int tn = N <= 64 ? 1 : 2;
+    const int NB = 64 * tn;
+    const size_t lds = (size_t)(2 * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + 4)) * sizeof(float);
+#define PCOPS_BF_LAUNCH(TN_, DM_)                                                                          \
+    do {                                                                                                   \
+        auto kern = bwd_fused_kernel<TN_, DM_>;                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+#define PCOPS_BF_MODES(TN_)                                                                                \
+    do {                                                                                                   \
+        if (!gpool) PCOPS_BF_LAUNCH(TN_, A_DY);                                                            \
+        else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU);                                           \
+        else PCOPS_BF_LAUNCH(TN_, A_DYPOOL);                                                               \
+    } while (0)
+    if (tn == 1) PCOPS_BF_MODES(1);
+    else PCOPS_BF_MODES(2);
+#undef PCOPS_BF_MODES
+#undef PCOPS_BF_LAUNCH
+    int rc = pcops_launch_status();
+    if (rc) return rc;
+    const long long L = (long long)K * N;
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, groups, L,
                        partial, dW, (long long)N, a.dbpart, db);
     return pcops_launch_status();
 }

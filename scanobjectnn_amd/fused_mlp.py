@@ -328,6 +328,24 @@ class FusedMLPStack(torch.autograd.Function):
                 if l == 0:
                     d0 = Gm
                 continue
+            fused_groups = 0
+            if BWD_FUSED and l > 0 and not xyz_prev and rref is None and Ws[l].data_ptr() % 16 == 0:
+                # the bandwidth-bound narrow layers: data and weight gradient in ONE pass over Y / Yprev
+                fused_groups = lib.pcops_mlp_bwd_fused_groups(R, K, N, S if pooled else 0, 1 if pooled else 0)
+            if fused_groups:
+                scratch = _f32(fused_groups * (K * N + N), dev)
+                dW, db = _f32((K, N), dev), _f32(N, dev)
+                Gprev = _f32((R, K), dev)
+                P = fused_groups
+                part = _f32((P, 2, K), dev)
+                _lib.call("pcops_mlp_bwd_fused", R, K, N, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
+                          shifts[l - 1].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(),
+                          gp, am, S, Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                          Gprev.data_ptr(), part.data_ptr())
+                grads[6 * l + 0] = dW
+                grads[6 * l + 1] = db
+                Gm = Gprev
+                continue
             if l == 0:
                 src, ld, asc, ash = a0, K0, None, None
             elif not xyz_prev:
@@ -634,6 +652,7 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
 
 STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
+BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 

@@ -1,0 +1,104 @@
+"""`pcops_mlp_bwd_fused` (include/pcops.h): the data and the weight gradient of a 64-wide layer in one pass -- against
+float64 on the same inputs, and against the two-kernel path it replaces (pcops_mlp_gemm_dgrad + pcops_mlp_wgrad), for
+the materialised-gradient form and the pooled forms (one group per 32-row stripe; any group size), with a ragged tail."""
+import pytest
+import torch
+
+from scanobjectnn_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [  # (M, K, N, S)   S = 0: dense upstream gradient
+    (65536 + 32 * 5 + 13, 64, 128, 0),
+    (65536 + 77, 64, 64, 0),
+    (32 * 2100, 64, 128, 32),          # SA1's top layer: one pooling group per stripe
+    (64 * 1030, 64, 64, 64),
+    (20 * 3300, 64, 128, 20),          # any group size
+    (16 * 4200, 48, 96, 16),           # narrower than the tile in both directions
+]
+
+
+def _vec(n, g, lo=0.5):
+    return ((lo + torch.rand(n, generator=g)) * (1.0 - 2.0 * (torch.arange(n) % 3 == 1))).to(DEV)
+
+
+@pytest.mark.parametrize("M,K,N,S", CASES)
+def test_bwd_fused_against_float64_and_the_two_kernel_path(M, K, N, S):
+    lib = _lib.load()
+    groups = lib.pcops_mlp_bwd_fused_groups(M, K, N, S, 1 if S else 0)
+    assert groups > 0
+    g = torch.Generator().manual_seed(M + N)
+    Yprev = torch.randn(M, K, generator=g).to(DEV)
+    Y = torch.randn(M, N, generator=g).to(DEV)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    sc, sh = _vec(K, g), (0.3 * torch.randn(K, generator=g)).to(DEV)
+    p, q, t = _vec(N, g), 0.1 * _vec(N, g), (0.05 * torch.randn(N, generator=g)).to(DEV)
+    if S:
+        G = None
+        gpool = torch.randn(M // S, N, generator=g).to(DEV)
+        gpool[torch.rand(M // S, N, generator=g).to(DEV) < 0.3] = 0.0            # masked entries (ReLU off at the max)
+        argmax = torch.randint(0, S, (M // S, N), generator=g, dtype=torch.int32).to(torch.uint8).to(DEV)
+        Gfull = torch.zeros(M // S, S, N, dtype=torch.float64, device=DEV)
+        Gfull.scatter_(1, argmax.long().unsqueeze(1), gpool.double().unsqueeze(1))
+        Gfull = Gfull.view(M, N)
+    else:
+        G = torch.randn(M, N, generator=g).to(DEV)
+        gpool = argmax = None
+        Gfull = G.double()
+    # ---- float64 truth
+    dY = p.double() * Gfull + q.double() * Y.double() + t.double()
+    pre = Yprev.double() * sc.double() + sh.double()
+    X = pre.clamp_min(0.0)
+    want_dW, want_db = X.t() @ dY, dY.sum(0)
+    safe = pre.abs() > 1e-5                                                        # (a sign the fp32 fma may round the other way)
+    want_G = (dY @ W.double().t()) * (pre > 0)
+    want_s1, want_s2 = want_G.sum(0), (want_G * Yprev.double()).sum(0)
+
+    def ptr(x):
+        return None if x is None else x.data_ptr()
+
+    part = torch.empty(groups * (K * N + N), device=DEV)
+    dW, db = torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    Gprev = torch.full((M, K), float("nan"), device=DEV)
+    stats = torch.empty(groups, 2, K, device=DEV)
+    _lib.call("pcops_mlp_bwd_fused", M, K, N, Yprev.data_ptr(), sc.data_ptr(), sh.data_ptr(), ptr(G), Y.data_ptr(),
+              p.data_ptr(), q.data_ptr(), t.data_ptr(), ptr(gpool), ptr(argmax), S if S else 1, W.data_ptr(),
+              part.data_ptr(), dW.data_ptr(), db.data_ptr(), Gprev.data_ptr(), stats.data_ptr())
+    torch.cuda.synchronize()
+    assert not torch.isnan(Gprev).any()
+
+    def rel(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    assert rel(dW, want_dW) <= 2e-5 and rel(db, want_db) <= 2e-5
+    assert rel(torch.where(safe, Gprev.double(), want_G), want_G) <= 1e-5
+    assert rel(stats[:, 0].double().sum(0), want_s1) <= 1e-4 and rel(stats[:, 1].double().sum(0), want_s2) <= 1e-4
+
+    # ---- the two kernels it replaces, same inputs: same numbers up to summation order
+    Wt = W.t().contiguous()
+    dummy = p.data_ptr() if S else None        # (pool_scale / pool_shift of the older entry points: required, not read)
+    P = lib.pcops_mlp_stats_rows(M)
+    part2 = torch.empty(P, 2, K, device=DEV)
+    Gprev2 = torch.empty(M, K, device=DEV)
+    _lib.call("pcops_mlp_gemm_dgrad", M, N, K, ptr(G), Y.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), ptr(gpool),
+              ptr(argmax), S if S else 1, dummy, dummy, Wt.data_ptr(), Yprev.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+              Gprev2.data_ptr(), part2.data_ptr())
+    splits = lib.pcops_mlp_wgrad_splits(M, K, N)
+    scratch = torch.empty(splits * (K * N + N), device=DEV)
+    dW2, db2 = torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    _lib.call("pcops_mlp_wgrad", M, K, N, Yprev.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), ptr(G), Y.data_ptr(),
+              p.data_ptr(), q.data_ptr(), t.data_ptr(), ptr(gpool), ptr(argmax), S if S else 1, dummy, dummy,
+              scratch.data_ptr(), dW2.data_ptr(), db2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(Gprev != 0, Gprev2 != 0)                   # the same mask, element for element (same fmaf)
+    assert rel(Gprev, Gprev2.double()) <= 1e-5 and rel(dW, dW2.double()) <= 2e-5 and rel(db, db2.double()) <= 2e-5
+    assert rel(stats[:, 1].double().sum(0), part2[:, 1].double().sum(0)) <= 1e-4
+
+
+def test_bwd_fused_says_what_it_takes():
+    lib = _lib.load()
+    assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 64, 128, 32, 1) == 256
+    assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 128, 128, 32, 1) == 0      # matrix-pipe bound shapes: two kernels
+    assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 64, 256, 0, 0) == 0
+    assert lib.pcops_mlp_bwd_fused_groups(1024, 64, 64, 0, 0) == 0
