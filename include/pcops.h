@@ -296,6 +296,12 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
                         const float *G, const float *Y, const float *p, const float *q, const float *t,
                         const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
                         float *dW, float *db, float *Gprev, float *stats_partial, pcops_stream_t stream);
+/* ... over compacted rows (pcops_rows_t; M = the allocated row count, as for the other _rows entry points) */
+int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                             const float *G, const float *Y, const float *p, const float *q, const float *t,
+                             const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
+                             float *dW, float *db, float *Gprev, float *stats_partial, const pcops_rows_t *rows,
+                             pcops_stream_t stream);
 /* C [M][N] = A [M][K] B [K][N], row-major with leading dimensions: the small weight x weight products and row vectors
  * around the big kernels (32 x 32 output tile per workgroup, fp32 MFMA, fixed summation order) */
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,

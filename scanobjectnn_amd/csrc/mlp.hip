@@ -2300,7 +2300,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, N = a.N;
-    const long long M = a.M;
+    constexpr bool compact = DMODE == A_DYW || DMODE == A_DYPOOLB;      // compacted rows (block table + device row count)
+    const long long M = compact ? (long long)__builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;
     const int grp = blockIdx.x, ngrp = gridDim.x;
 #ifdef PCOPS_BF_DEBUG
     const int dbg = a.rows_per_block;          // ablation experiments (tools/ only)
@@ -2346,9 +2347,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
         // TWO register sets: the loads of stripe i + 2 are in flight while stripe i + 1 is staged (one stripe ahead left
         // 29 KB per CU in flight -- 3.0 TB/s at the latency of a loaded HBM; the kernel is otherwise matrix-pipe bound)
+        constexpr bool B_ = DMODE == A_DYPOOLB;                // compacted rows: one pooling group per 16-row block
+        constexpr int NBLK = RS / kBlk;                        // blocks per stripe
+        constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
+        static_assert(QD <= kBlk && kBlk % QD == 0, "block of row pt / D4 + j QD is (j QD) / 16");
         struct Regs {
             float4 px[NA], pg[ND], py[ND];
             unsigned pm[(is_pool(DMODE)) ? ND : 1];
+            float bw[compact ? NBLK : 1];                      // weight of the first row of each block of the stripe
+            int bs0[B_ ? NBLK : 1];
         } rs0, rs1;
         const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acq) * 4u : kOOB;
         const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcq) * 4u : kOOB;
@@ -2360,6 +2367,21 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         auto issue = [&](long long stripe, Regs &rg_) {
             if (dbg & 16) return;
             const long long row0 = stripe * RS;
+            if (compact) {
+                const long long nblk = (M + kBlk - 1) / kBlk;
+#pragma unroll
+                for (int h = 0; h < NBLK; ++h) {
+                    long long bi = stripe * NBLK + h;
+                    bi = bi < nblk ? bi : nblk - 1;
+                    const RowBlock rb = a.blocks[bi];          // wave-uniform
+                    rg_.bw[h] = rb.w;
+                    if (B_) {
+                        rg_.bs0[h] = rb.s0;
+                        rg_.pg[h] = *reinterpret_cast<const float4 *>(a.gpool + (long long)rb.g * N + dcl);
+                        rg_.pm[h] = *reinterpret_cast<const unsigned *>(a.argmax + (long long)rb.g * N + dcl);
+                    }
+                }
+            }
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
             const __amdgpu_buffer_rsrc_t rg =
@@ -2370,7 +2392,9 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 rg_.py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
-                if (is_pool(DMODE)) {
+                if (B_) {
+                    // loaded per block above
+                } else if (is_pool(DMODE)) {
                     if (U_) {
                         if (j == 0) {
                             const long long gi = pr.g0 < glast ? pr.g0 : glast;
@@ -2410,13 +2434,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             for (int j = 0; j < ND; ++j) {
                 const int r = pt / D4 + j * (256 / D4);
                 const float4 y = rg_.py[j];
-                float4 g = rg_.pg[U_ ? 0 : j];
+                const int hb = (j * QD) / kBlk;                // block of this row inside the stripe (compile time)
+                float4 g = rg_.pg[U_ ? 0 : (B_ ? hb : j)];
                 if (is_pool(DMODE)) {
                     long long gdummy;
                     unsigned s;
                     if (U_) s = (unsigned)(prs.s0 + r);
+                    else if (B_) s = (unsigned)(rg_.bs0[B_ ? hb : 0] + (r & (kBlk - 1)));
                     else prs.split(r, glast, gdummy, s);
-                    const unsigned am = rg_.pm[U_ ? 0 : j];
+                    const unsigned am = rg_.pm[U_ ? 0 : (B_ ? hb : j)];
                     // gpool arrives MASKED (pcops.h, pcops_mlp_pool_bwd_stats): only the row test is left
                     g.x = ((am & 0xffu) == s) ? g.x : 0.f;
                     g.y = (((am >> 8) & 0xffu) == s) ? g.y : 0.f;
@@ -2424,10 +2450,19 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     g.w = ((am >> 24) == s) ? g.w : 0.f;
                 }
                 float4 d;
+                if (compact && (j * QD) % kBlk == 0) {
+                    // a row that opens a block (r % 16 == 0) stands for w rows: dY = p.G + w (q.Y + t)
+                    const float w = (r & (kBlk - 1)) == 0 ? rg_.bw[compact ? hb : 0] : 1.f;
+                    d.x = fmaf(cp.x, g.x, w * fmaf(cq.x, y.x, ct.x));
+                    d.y = fmaf(cp.y, g.y, w * fmaf(cq.y, y.y, ct.y));
+                    d.z = fmaf(cp.z, g.z, w * fmaf(cq.z, y.z, ct.z));
+                    d.w = fmaf(cp.w, g.w, w * fmaf(cq.w, y.w, ct.w));
+                } else {
                 d.x = fmaf(cp.x, g.x, fmaf(cq.x, y.x, ct.x));
                 d.y = fmaf(cp.y, g.y, fmaf(cq.y, y.y, ct.y));
                 d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
                 d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
+                }
                 if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
                 dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
                 *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + dcq]) = d;
@@ -3684,6 +3719,15 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
                         const float *G, const float *Y, const float *p, const float *q, const float *t,
                         const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
                         float *dW, float *db, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+    return pcops_mlp_bwd_fused_rows(M, K, N, Yprev, a_scale, a_shift, G, Y, p, q, t, gpool, argmax, S, W, partial, dW, db,
+                                    Gprev, stats_partial, nullptr, stream);
+}
+
+int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                             const float *G, const float *Y, const float *p, const float *q, const float *t,
+                             const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
+                             float *dW, float *db, float *Gprev, float *stats_partial, const pcops_rows_t *rows,
+                             pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1);
     PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift); PCOPS_REQUIRE_PTR(Y);
     PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W);
@@ -3704,6 +3748,7 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
     a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
     a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
+    PCOPS_ROWS(a, rows);
 #ifdef PCOPS_BF_DEBUG
     { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
 #endif
@@ -3720,7 +3765,9 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
     } while (0)
 #define PCOPS_BF_MODES(TN_)                                                                                \
     do {                                                                                                   \
-        if (!gpool) PCOPS_BF_LAUNCH(TN_, A_DY);                                                            \
+        if (!gpool && a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYW);                                               \
+        else if (a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYPOOLB);                                                \
+        else if (!gpool) PCOPS_BF_LAUNCH(TN_, A_DY);                                                       \
         else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU);                                           \
         else PCOPS_BF_LAUNCH(TN_, A_DYPOOL);                                                               \
     } while (0)

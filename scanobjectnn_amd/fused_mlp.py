@@ -329,7 +329,7 @@ class FusedMLPStack(torch.autograd.Function):
                     d0 = Gm
                 continue
             fused_groups = 0
-            if BWD_FUSED and l > 0 and not xyz_prev and rref is None and Ws[l].data_ptr() % 16 == 0:
+            if BWD_FUSED and l > 0 and not xyz_prev and Ws[l].data_ptr() % 16 == 0:
                 # the bandwidth-bound narrow layers: data and weight gradient in ONE pass over Y / Yprev
                 fused_groups = lib.pcops_mlp_bwd_fused_groups(R, K, N, S if pooled else 0, 1 if pooled else 0)
             if fused_groups:
@@ -338,10 +338,10 @@ class FusedMLPStack(torch.autograd.Function):
                 Gprev = _f32((R, K), dev)
                 P = fused_groups
                 part = _f32((P, 2, K), dev)
-                _lib.call("pcops_mlp_bwd_fused", R, K, N, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
+                _lib.call("pcops_mlp_bwd_fused_rows", R, K, N, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
                           shifts[l - 1].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(),
                           gp, am, S, Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(),
-                          Gprev.data_ptr(), part.data_ptr())
+                          Gprev.data_ptr(), part.data_ptr(), rref)
                 grads[6 * l + 0] = dW
                 grads[6 * l + 1] = db
                 Gm = Gprev

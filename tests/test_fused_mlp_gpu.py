@@ -381,6 +381,7 @@ COMPACT_CASES = [  # (B, N, M, S, radius, widths, form)
     (4, 1024, 256, 64, 0.2, [64, 64, 128], "xyz_bias"),     # SA1 of the BGA config (nsample 64): arithmetic first layer
     (8, 600, 100, 48, 0.3, [64, 128], "q_xyz"),             # 3 blocks per group, two layers
     (2, 2048, 128, 128, 0.25, [32, 64, 128], "xyz_bias"),   # MSG-sized groups
+    (8, 512, 256, 64, 0.3, [64, 64, 128], "q_xyz"),         # narrow layers: one-pass data + weight gradient on compacted rows
     (8, 512, 128, 64, 2.5, [128, 128], "q_xyz"),            # every ball full: nothing to leave out, all weights 1
     (8, 512, 128, 64, 0.02, [128, 128], "q_xyz"),           # (almost) every ball holds the query alone: weights 49
 ]
