@@ -110,6 +110,9 @@ def _algo(name, a):
     if name == "pcops_mlp_bwd_fused":         # data + weight gradient in one pass: reads Yprev (K), G?, Y (N); writes Gprev (K)
         M, K, N = a[:3]
         return 4 * (2 * M * K + (1 if a[6] is None else 2) * M * N), 4 * M * K * N, "flop"
+    if name == "pcops_mlp_bwd_fused_xyz":     # ... over the xyz form: 16 bytes per row instead of Yprev, no Gprev
+        M, K, N = a[:3]
+        return 4 * (4 * M + (1 if a[7] is None else 2) * M * N), 4 * M * K * N, "flop"
     # ---- algebraic backward of a pooled top layer (pcops.h): K x K products + the arg-max rows
     if name == "pcops_mlp_gemm_dgrad_top":    # Gprev[M,Kp] = mask . (X Mq + addend rows + v): reads X, writes Gprev
         M, Kp = a[:2]

@@ -359,6 +359,14 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
  * (A = these sums, sumG / sumGY = stats_partial, B = M33 Wxyz + S^T b and S from the offset moments the forward
  * gather emits), so with xyz_stats Gprev may be NULL: the (rows, C1) gradient is neither written nor scattered. */
 int pcops_mlp_xyz_supported(int M, int C1, int N2);
+/* pcops_mlp_bwd_fused over the xyz form (round 3): pcops_mlp_wgrad_xyz + pcops_mlp_gemm_dgrad_xyz (Gprev == NULL form) in
+ * one pass -- dW, db of the layer, stats_partial [groups][2][K] and xyz_stats [groups][3][K] of the arithmetic layer
+ * below; groups = pcops_mlp_bwd_fused_groups(M, K, N, S, pooled), 0 = not taken.  W [K][N] as the forward holds it. */
+int pcops_mlp_bwd_fused_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                                 const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                                 const float *t, const float *gpool, const unsigned char *argmax, int S, const float *W,
+                                 float *partial, float *dW, float *db, float *stats_partial, float *xyz_stats,
+                                 const pcops_rows_t *rows, pcops_stream_t stream);
 int pcops_mlp_gemm_fwd_xyz(int M, int K, int N, const float *off4, const float *xyzw, const float *pro_scale,
                            const float *pro_shift, const float *W, const float *bias, float *Y,
                            float *stats_partial, const float *stat_pivot, pcops_stream_t stream);

@@ -1641,7 +1641,7 @@ struct WgradArgs {
     const RowBlock *blocks;  // compacted rows (producer/consumer kernel only), see GemmArgs
     const int *Mdev;
     // bwd_fused_kernel only: the layer's weights, the masked data gradient it also writes, its column statistics
-    const float *W; float *Gprev; float *gstats;
+    const float *W; float *Gprev; float *gstats; float *xstats;
 };
 
 template <int VK, int VN>
@@ -2290,8 +2290,10 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
 //                          statistics read the RAW Yprev the producers left beside X -- no second trip to memory.
 // Per stripe a consumer issues 16 (NB/64) + 4 (NB/16) ... = equal matrix-pipe time for the two products (4 096 cycles at
 // NB = 128), so the pass is pipe bound at about the time of ONE of the two kernels it replaces.
-template <int TN, int DMODE>
+template <int TN, int DMODE, bool XYZ>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
+    // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
+    // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
     constexpr int KB = 64, NB = 64 * TN, RS = 32;
     constexpr int LD = 2 * KB + NB + 4;                       // X | raw | dY | pad (row stride = 4 banks mod 32)
     constexpr int A4 = KB / 4, D4 = NB / 4;
@@ -2308,14 +2310,19 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
 #else
     constexpr int dbg = 0;
 #endif
-    float *coefA = lds;                        // [2][KB]  scale, shift of the layer below
-    float *coefD = coefA + 2 * KB;             // [3][NB]  p, q, t
+    constexpr int CA = XYZ ? 6 : 2;
+    float *coefA = lds;                        // [CA][KB]  scale, shift of the layer below | xyz form: w0 w1 w2 b
+    float *coefD = coefA + CA * KB;            // [3][NB]  p, q, t
     float *wq = coefD + 3 * NB;                // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
     float *buf = wq + NB * KB;                 // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][2][KB]
 
     for (int e = tid; e < KB; e += 512) {
         coefA[e] = e < K ? a.asc[e] : 0.f;
         coefA[KB + e] = e < K ? a.ash[e] : 0.f;
+        if (XYZ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) coefA[(2 + i) * KB + e] = e < K ? a.xw[i * a.xw_ld + e] : 0.f;
+        }
     }
     for (int e = tid; e < NB; e += 512) {
         const bool in = e < N;
@@ -2341,6 +2348,13 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const bool ain = acq < K, din = dcq < N;
         const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
         const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+        float4 xw0 = make_float4(0.f, 0.f, 0.f, 0.f), xw1 = xw0, xw2 = xw0, xb = xw0;
+        if (XYZ) {
+            xw0 = *reinterpret_cast<const float4 *>(&coefA[2 * KB + acq]);
+            xw1 = *reinterpret_cast<const float4 *>(&coefA[3 * KB + acq]);
+            xw2 = *reinterpret_cast<const float4 *>(&coefA[4 * KB + acq]);
+            xb = *reinterpret_cast<const float4 *>(&coefA[5 * KB + acq]);
+        }
         const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
         const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
         const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
@@ -2386,8 +2400,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
             const __amdgpu_buffer_rsrc_t rg =
                 make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            if (XYZ) {     // 16 bytes per ROW, broadcast over the A4 lanes of a row
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, (M - row0) * 16);
 #pragma unroll
-            for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+                for (int j = 0; j < NA; ++j)
+                    rg_.px[j] = buf_load4(ro, (unsigned)(pt / A4) * 16u, (unsigned)j * (256 / A4) * 16u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            }
             const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
@@ -2421,6 +2442,13 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             for (int j = 0; j < NA; ++j) {
                 const int r = pt / A4 + j * (256 / A4);
                 float4 y = rg_.px[j], x;
+                if (XYZ) {
+                    float4 o = y;
+                    if (!(row0 + r < M)) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    y = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
+                                    xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
+                    if (acq == 0) *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + NB]) = o;   // the row's offsets, beside dY
+                }
                 if (!(ain && row0 + r < M)) y = make_float4(0.f, 0.f, 0.f, 0.f);
                 x.x = fmaxf(fmaf(y.x, casc.x, cash.x), 0.f);
                 x.y = fmaxf(fmaf(y.y, casc.y, cash.y), 0.f);
@@ -2538,19 +2566,9 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             msc[b] = coefA[32 * cbp + 16 * b + c16];
             msh[b] = coefA[KB + 32 * cbp + 16 * b + c16];
         }
-        float pend[2][4], pyr[2][4];
-        long long prow0 = 0;
-        bool have = false;
-        auto flush = [&](int b) {         // Gprev = dX . mask, its column sums, the stores -- of the PREVIOUS stripe
-            const __amdgpu_buffer_rsrc_t rgp = make_rsrc(a.Gprev + prow0 * K, (M - prow0) * K * 4);
+        float sx[XYZ ? 2 : 1][3];                              // xyz form: sums of offset (x) masked gradient
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float gv = fmaf(pyr[b][v], msc[b], msh[b]) > 0.f ? pend[b][v] : 0.f;
-                s1[b] += gv;
-                s2[b] = fmaf(gv, pyr[b][v], s2[b]);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
-            }
-        };
+        for (int b = 0; b < (XYZ ? 2 : 1); ++b) sx[b][0] = sx[b][1] = sx[b][2] = 0.f;
         __syncthreads();
         for (long long i = 0; i < cnt; ++i) {
             const float *sb = buf + (i & 1) * RS * LD;
@@ -2601,27 +2619,36 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                             accd[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[s_], we, accd[b], 0, 0, 0);
                         }
                 }
-                if (have && !(dbg & 2) && (it == 1 || it == 3)) flush(it >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- Gprev rows of this stripe: handed to the NEXT stripe's loop (pend): the mask / statistics / store
-            // instructions then issue under that stripe's first MFMAs instead of leaving the matrix pipe idle between the
-            // last MFMA of a stripe and the barrier
+            // ---- Gprev rows of this stripe: mask, column sums, store (before the stripe buffer is handed back).  (Handing
+            // them to the next stripe's loop so that they issue under its first MFMAs was measured: no difference.)
+            if (!(dbg & 2)) {
+                const __amdgpu_buffer_rsrc_t rgp = make_rsrc(XYZ ? nullptr : a.Gprev + row0 * K, XYZ ? 0 : (M - row0) * K * 4);
+                float4 ofs[XYZ ? 4 : 1];
+                if (XYZ) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    pend[b][v] = accd[b][v];
-                    pyr[b][v] = yr[b][v];
-                    accd[b][v] = 0.f;
+                    for (int v = 0; v < 4; ++v)
+                        ofs[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + 2 * KB + NB]);
                 }
-            prow0 = row0;
-            have = true;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float gv = fmaf(yr[b][v], msc[b], msh[b]) > 0.f ? accd[b][v] : 0.f;
+                        s1[b] += gv;
+                        s2[b] = fmaf(gv, yr[b][v], s2[b]);
+                        if (XYZ) {
+                            sx[b][0] = fmaf(ofs[v].x, gv, sx[b][0]);
+                            sx[b][1] = fmaf(ofs[v].y, gv, sx[b][1]);
+                            sx[b][2] = fmaf(ofs[v].z, gv, sx[b][2]);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
+                        }
+                        accd[b][v] = 0.f;
+                    }
+            }
             __syncthreads();
-        }
-        if (have && !(dbg & 2)) {
-            flush(0);
-            flush(1);
         }
         // dW partial of this workgroup: accw[y][v] = (k = 32 ck + (v&3) + 8 (v>>2) + 4 half, n = (NB/2) cn + 32 y + li)
         float *out = a.part + (long long)grp * K * N;
@@ -2641,13 +2668,24 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             s1[b] += __shfl_xor(s1[b], 16, 64); s1[b] += __shfl_xor(s1[b], 32, 64);
             s2[b] += __shfl_xor(s2[b], 16, 64); s2[b] += __shfl_xor(s2[b], 32, 64);
         }
+#pragma unroll
+        for (int b = 0; b < (XYZ ? 2 : 1); ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sx[b][i] += __shfl_xor(sx[b][i], 16, 64);
+                sx[b][i] += __shfl_xor(sx[b][i], 32, 64);
+            }
         __syncthreads();                                       // matches the producers' db hand-over
-        float *sst = buf + 256 * 4;                            // [2 row halves][2][KB], behind the db scratch
+        float *sst = buf + 256 * 4;                            // [2 row halves][5][KB], behind the db scratch
         if (lane < 16) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                sst[(rh * 2 + 0) * KB + 32 * cbp + 16 * b + c16] = s1[b];
-                sst[(rh * 2 + 1) * KB + 32 * cbp + 16 * b + c16] = s2[b];
+                sst[(rh * 5 + 0) * KB + 32 * cbp + 16 * b + c16] = s1[b];
+                sst[(rh * 5 + 1) * KB + 32 * cbp + 16 * b + c16] = s2[b];
+                if (XYZ) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) sst[(rh * 5 + 2 + i) * KB + 32 * cbp + 16 * b + c16] = sx[b][i];
+                }
             }
         }
         if (a.dbpart) {
@@ -2660,9 +2698,13 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * KB; i += 256) {
+        for (int i = tid; i < (XYZ ? 5 : 2) * KB; i += 256) {
             const int which = i / KB, c = i % KB;
-            if (c < K) a.gstats[((long long)grp * 2 + which) * K + c] = sst[which * KB + c] + sst[(2 + which) * KB + c];
+            const float v = sst[which * KB + c] + sst[(5 + which) * KB + c];
+            if (c < K) {
+                if (which < 2) a.gstats[((long long)grp * 2 + which) * K + c] = v;
+                else a.xstats[((long long)grp * 3 + which - 2) * K + c] = v;
+            }
         }
     }
 }
@@ -3723,6 +3765,43 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
                                     Gprev, stats_partial, nullptr, stream);
 }
 
+static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st) {
+    const int K = a.K, N = a.N;
+    a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
+    const int tn = N <= 64 ? 1 : 2;
+    const int NB = 64 * tn;
+    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + 4)) * sizeof(float);
+    const bool pooled = a.gpool != nullptr;
+#define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
+    do {                                                                                                   \
+        auto kern = bwd_fused_kernel<TN_, DM_, X_>;                                                        \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+#define PCOPS_BF_MODES(TN_, X_)                                                                            \
+    do {                                                                                                   \
+        if (!pooled && a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYW, X_);                                          \
+        else if (a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYPOOLB, X_);                                            \
+        else if (!pooled) PCOPS_BF_LAUNCH(TN_, A_DY, X_);                                                  \
+        else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU, X_);                                       \
+        else PCOPS_BF_LAUNCH(TN_, A_DYPOOL, X_);                                                           \
+    } while (0)
+    if (tn == 1 && xyz) PCOPS_BF_MODES(1, true);
+    else if (tn == 1) PCOPS_BF_MODES(1, false);
+    else if (xyz) PCOPS_BF_MODES(2, true);
+    else PCOPS_BF_MODES(2, false);
+#undef PCOPS_BF_MODES
+#undef PCOPS_BF_LAUNCH
+    int rc = pcops_launch_status();
+    if (rc) return rc;
+    const long long L = (long long)K * N;
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, groups, L,
+                       partial, dW, (long long)N, a.dbpart, db);
+    return pcops_launch_status();
+}
+
 int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
                              const float *G, const float *Y, const float *p, const float *q, const float *t,
                              const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
@@ -3740,47 +3819,44 @@ int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, cons
         (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
         (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(argmax) & 3))
         return PCOPS_ERR_UNSUPPORTED;
-    hipStream_t st = as_stream(stream);
     WgradArgs a = {};
     a.M = M; a.K = K; a.N = N;
     a.amode = A_BNRELU; a.X = Yprev; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
     a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
     a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
-    a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
     a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
     PCOPS_ROWS(a, rows);
 #ifdef PCOPS_BF_DEBUG
     { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
 #endif
-    const int tn = N <= 64 ? 1 : 2;
-    const int NB = 64 * tn;
-    const size_t lds = (size_t)(2 * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + 4)) * sizeof(float);
-#define PCOPS_BF_LAUNCH(TN_, DM_)                                                                          \
-    do {                                                                                                   \
-        auto kern = bwd_fused_kernel<TN_, DM_>;                                                            \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
-    } while (0)
-#define PCOPS_BF_MODES(TN_)                                                                                \
-    do {                                                                                                   \
-        if (!gpool && a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYW);                                               \
-        else if (a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYPOOLB);                                                \
-        else if (!gpool) PCOPS_BF_LAUNCH(TN_, A_DY);                                                       \
-        else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU);                                           \
-        else PCOPS_BF_LAUNCH(TN_, A_DYPOOL);                                                               \
-    } while (0)
-    if (tn == 1) PCOPS_BF_MODES(1);
-    else PCOPS_BF_MODES(2);
-#undef PCOPS_BF_MODES
-#undef PCOPS_BF_LAUNCH
-    int rc = pcops_launch_status();
-    if (rc) return rc;
-    const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, groups, L,
-                       partial, dW, (long long)N, a.dbpart, db);
-    return pcops_launch_status();
+    return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream));
+}
+
+int pcops_mlp_bwd_fused_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
+                                 const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
+                                 const float *t, const float *gpool, const unsigned char *argmax, int S, const float *W,
+                                 float *partial, float *dW, float *db, float *stats_partial, float *xyz_stats,
+                                 const pcops_rows_t *rows, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 4 && K % 4 == 0 && N >= 1);
+    PCOPS_REQUIRE_PTR(off4); PCOPS_REQUIRE_PTR(xyzw); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift);
+    PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W);
+    PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(stats_partial); PCOPS_REQUIRE_PTR(xyz_stats);
+    if (!gpool) PCOPS_REQUIRE_PTR(G);
+    if (gpool) PCOPS_REQUIRE_PTR(argmax);
+    const int groups = bwd_fused_groups(M, K, N, S, gpool != nullptr);
+    if (groups == 0) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(off4) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
+        (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
+        (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return PCOPS_ERR_UNSUPPORTED;
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_XYZ; a.X = off4; a.ldx = 4; a.off4 = off4; a.xw = xyzw; a.xw_ld = K; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
+    a.W = W; a.Gprev = nullptr; a.gstats = stats_partial; a.xstats = xyz_stats;
+    PCOPS_ROWS(a, rows);
+    return bwd_fused_launch(a, true, groups, partial, dW, db, as_stream(stream));
 }
 
 int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,

@@ -329,15 +329,25 @@ class FusedMLPStack(torch.autograd.Function):
                     d0 = Gm
                 continue
             fused_groups = 0
-            if BWD_FUSED and l > 0 and not xyz_prev and Ws[l].data_ptr() % 16 == 0:
+            if BWD_FUSED and l > 0 and Ws[l].data_ptr() % 16 == 0:
                 # the bandwidth-bound narrow layers: data and weight gradient in ONE pass over Y / Yprev
                 fused_groups = lib.pcops_mlp_bwd_fused_groups(R, K, N, S if pooled else 0, 1 if pooled else 0)
             if fused_groups:
                 scratch = _f32(fused_groups * (K * N + N), dev)
                 dW, db = _f32((K, N), dev), _f32(N, dev)
-                Gprev = _f32((R, K), dev)
                 P = fused_groups
                 part = _f32((P, 2, K), dev)
+                if xyz_prev:     # the arithmetic first layer below: its masked gradient is reduced, never written
+                    xstats = _f32((P, 3, K), dev)
+                    _lib.call("pcops_mlp_bwd_fused_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(),
+                              scales[0].data_ptr(), shifts[0].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(),
+                              q.data_ptr(), t.data_ptr(), gp, am, S, Ws[l].data_ptr(), scratch.data_ptr(),
+                              dW.data_ptr(), db.data_ptr(), part.data_ptr(), xstats.data_ptr(), rref)
+                    grads[6 * l + 0] = dW
+                    grads[6 * l + 1] = db
+                    Gm = None
+                    continue
+                Gprev = _f32((R, K), dev)
                 _lib.call("pcops_mlp_bwd_fused_rows", R, K, N, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
                           shifts[l - 1].data_ptr(), Gptr, Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(),
                           gp, am, S, Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(),
