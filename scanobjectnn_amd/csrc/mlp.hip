@@ -2370,6 +2370,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             unsigned pm[(is_pool(DMODE)) ? ND : 1];
             float bw[compact ? NBLK : 1];                      // weight of the first row of each block of the stripe
             int bs0[B_ ? NBLK : 1];
+            int s0;                                            // U_: row-in-group of the stripe's first row
         } rs0, rs1;
         const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acq) * 4u : kOOB;
         const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcq) * 4u : kOOB;
@@ -2410,6 +2411,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
             }
             const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+            rg_.s0 = pr.s0;
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 rg_.py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
@@ -2434,27 +2436,32 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 }
             }
         };
-        auto stage = [&](long long stripe, float *dst, const Regs &rg_) {
+        // FULL_: all 32 rows exist and the tile is as wide as the layer -- wave-uniform, true for every stripe but the
+        // last; the other variant carries the range selects (a sixth of the producers' instructions, which compete with
+        // the consumer wave of the same SIMD for issue slots)
+        auto stage_ = [&](long long stripe, float *dst, const Regs &rg_, auto full_) {
+            constexpr bool FULL = decltype(full_)::value;
             if (dbg & 8) return;
             const long long row0 = stripe * RS;
-            const PoolRows prs(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+            constexpr bool G_ = DMODE == A_DYPOOL;             // any group size: per-row group arithmetic
+            const PoolRows prs(G_ ? row0 : 0, G_ ? a.S : 1);
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int r = pt / A4 + j * (256 / A4);
                 float4 y = rg_.px[j], x;
                 if (XYZ) {
                     float4 o = y;
-                    if (!(row0 + r < M)) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!FULL && !(row0 + r < M)) o = make_float4(0.f, 0.f, 0.f, 0.f);
                     y = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
                                     xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
                     if (acq == 0) *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + NB]) = o;   // the row's offsets, beside dY
                 }
-                if (!(ain && row0 + r < M)) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!FULL && !(ain && row0 + r < M)) y = make_float4(0.f, 0.f, 0.f, 0.f);
                 x.x = fmaxf(fmaf(y.x, casc.x, cash.x), 0.f);
                 x.y = fmaxf(fmaf(y.y, casc.y, cash.y), 0.f);
                 x.z = fmaxf(fmaf(y.z, casc.z, cash.z), 0.f);
                 x.w = fmaxf(fmaf(y.w, casc.w, cash.w), 0.f);
-                if (!(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!FULL && !(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4 *>(&dst[r * LD + acq]) = x;
                 *reinterpret_cast<float4 *>(&dst[r * LD + KB + acq]) = y;
             }
@@ -2467,7 +2474,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 if (is_pool(DMODE)) {
                     long long gdummy;
                     unsigned s;
-                    if (U_) s = (unsigned)(prs.s0 + r);
+                    if (U_) s = (unsigned)(rg_.s0 + r);
                     else if (B_) s = (unsigned)(rg_.bs0[B_ ? hb : 0] + (r & (kBlk - 1)));
                     else prs.split(r, glast, gdummy, s);
                     const unsigned am = rg_.pm[U_ ? 0 : (B_ ? hb : j)];
@@ -2491,10 +2498,14 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 d.z = fmaf(cp.z, g.z, fmaf(cq.z, y.z, ct.z));
                 d.w = fmaf(cp.w, g.w, fmaf(cq.w, y.w, ct.w));
                 }
-                if (!(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!FULL && !(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
                 dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
                 *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + dcq]) = d;
             }
+        };
+        auto stage = [&](long long stripe, float *dst, const Regs &rg_) {
+            if (stripe * RS + RS <= M && K == KB && N == NB) stage_(stripe, dst, rg_, std::true_type{});
+            else stage_(stripe, dst, rg_, std::false_type{});
         };
         if (cnt > 0) issue(grp, rs0);
         if (cnt > 1) issue(grp + ngrp, rs1);
