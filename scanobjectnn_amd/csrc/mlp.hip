@@ -84,6 +84,9 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     // corruption when it unrolled the MFMA loop and put it down to a code-generation accident.)
     asm volatile("s_nop 1" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_u32(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
 constexpr unsigned kOOB = 0x7FFFFFF0u;   // a voffset no tensor reaches: forces the bounds check to fail
 enum EMode { E_FWD = 0, E_MASK = 1, E_PLAIN = 2, E_MASKX = 3, E_MASKA = 4 };
 // E_MASKX: E_MASK with the previous layer in xyz form
@@ -404,6 +407,8 @@ struct PoolRows {
         s0 = (int)((unsigned)row0 - q * (unsigned)S_);
         invS = 1.0f / (float)S_;
     }
+    // ... from values the caller keeps up to date itself (persistent loops: no division per stripe)
+    __device__ PoolRows(long long g0_, int s0_, int S_) : g0(g0_), s0(s0_), S(S_), invS(1.0f / (float)S_) {}
     __device__ void split(int r, long long glast, long long &g, unsigned &s) const {
         const int t = s0 + r;
         const int dg = (int)(((float)t + 0.5f) * invS);
@@ -2390,14 +2395,29 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
         const int dcl = din ? dcq : 0;
         constexpr bool U_ = DMODE == A_DYPOOLU;                // one pooling group per stripe
-        auto issue = [&](long long stripe, Regs &rg_) {
+        // Stripes are issued (and staged) in ascending order, so everything a stripe's addresses depend on is kept as a
+        // RUNNING wave-uniform value -- base pointers, rows left, (group, row-in-group) of its first row -- and advanced by
+        // constants: computed from the stripe number each time (64-bit products, a division, range clamps) it was ~130
+        // scalar instructions per stripe, more than the vector work, and the producers' instructions compete with the
+        // consumer wave of their SIMD for issue slots.  A descriptor only covers the rows of ITS stripe (32-bit size).
+        const int Mi = (int)M, rstep = ngrp * RS;
+        int irow = grp * RS;                                   // first row of the next stripe to issue
+        const float *ixp = XYZ ? a.off4 + (long long)irow * 4 : a.X + (long long)irow * a.ldx;
+        const float *iyp = a.Y + (long long)irow * a.ldy;
+        const float *igp = (is_pool(DMODE) ? a.Y : a.G) + (long long)irow * a.ldy;
+        const long long xadv = (long long)rstep * (XYZ ? 4 : a.ldx), yadv = (long long)rstep * a.ldy;
+        const int Sg = is_pool(DMODE) ? a.S : 1;
+        const int dq = rstep / Sg, dr = rstep % Sg;            // (once per kernel)
+        int ig0 = irow / Sg, is0 = irow % Sg;                  // group / row-in-group of irow
+        const int nblk = compact ? (Mi + kBlk - 1) / kBlk : 0;
+        auto issue = [&](Regs &rg_) {
             if (dbg & 16) return;
-            const long long row0 = stripe * RS;
+            const int left = Mi - irow;
+            const unsigned rows_here = (unsigned)(left < RS ? left : RS);
             if (compact) {
-                const long long nblk = (M + kBlk - 1) / kBlk;
 #pragma unroll
                 for (int h = 0; h < NBLK; ++h) {
-                    long long bi = stripe * NBLK + h;
+                    int bi = irow / kBlk + h;
                     bi = bi < nblk ? bi : nblk - 1;
                     const RowBlock rb = a.blocks[bi];          // wave-uniform
                     rg_.bw[h] = rb.w;
@@ -2408,21 +2428,19 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     }
                 }
             }
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
-            const __amdgpu_buffer_rsrc_t rg =
-                make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc_u32(ixp, rows_here * (XYZ ? 16u : (unsigned)a.ldx * 4u));
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc_u32(iyp, rows_here * (unsigned)a.ldy * 4u);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc_u32(igp, rows_here * (unsigned)a.ldy * 4u);
             if (XYZ) {     // 16 bytes per ROW, broadcast over the A4 lanes of a row
-                const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, (M - row0) * 16);
 #pragma unroll
                 for (int j = 0; j < NA; ++j)
-                    rg_.px[j] = buf_load4(ro, (unsigned)(pt / A4) * 16u, (unsigned)j * (256 / A4) * 16u);
+                    rg_.px[j] = buf_load4(rx, (unsigned)(pt / A4) * 16u, (unsigned)j * (256 / A4) * 16u);
             } else {
 #pragma unroll
                 for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
             }
-            const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
-            rg_.s0 = pr.s0;
+            const PoolRows pr((long long)ig0, is0, Sg);
+            rg_.s0 = is0;
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 rg_.py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
@@ -2446,16 +2464,21 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     rg_.pg[j] = buf_load4(rg, dvoff, (unsigned)j * dstep);
                 }
             }
+            irow += rstep; ixp += xadv; iyp += yadv; igp += yadv;
+            if (is_pool(DMODE)) {
+                ig0 += dq; is0 += dr;
+                if (is0 >= Sg) { is0 -= Sg; ++ig0; }
+            }
         };
         // FULL_: all 32 rows exist and the tile is as wide as the layer -- wave-uniform, true for every stripe but the
         // last; the other variant carries the range selects (a sixth of the producers' instructions, which compete with
         // the consumer wave of the same SIMD for issue slots)
-        auto stage_ = [&](long long stripe, float *dst, const Regs &rg_, auto full_) {
+        int srow = grp * RS, sg0 = srow / Sg, ss0 = srow % Sg;  // the stripe stage() is at (same running form)
+        auto stage_ = [&](float *dst, const Regs &rg_, auto full_) {
             constexpr bool FULL = decltype(full_)::value;
             if (dbg & 8) return;
-            const long long row0 = stripe * RS;
-            constexpr bool G_ = DMODE == A_DYPOOL;             // any group size: per-row group arithmetic
-            const PoolRows prs(G_ ? row0 : 0, G_ ? a.S : 1);
+            const int row0 = srow;
+            const PoolRows prs((long long)sg0, ss0, Sg);
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int r = pt / A4 + j * (256 / A4);
@@ -2514,28 +2537,33 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + dcq]) = d;
             }
         };
-        auto stage = [&](long long stripe, float *dst, const Regs &rg_) {
-            if (stripe * RS + RS <= M && K == KB && N == NB) stage_(stripe, dst, rg_, std::true_type{});
-            else stage_(stripe, dst, rg_, std::false_type{});
+        auto stage = [&](float *dst, const Regs &rg_) {
+            if (srow + RS <= Mi && K == KB && N == NB) stage_(dst, rg_, std::true_type{});
+            else stage_(dst, rg_, std::false_type{});
+            srow += rstep;
+            if (DMODE == A_DYPOOL) {
+                sg0 += dq; ss0 += dr;
+                if (ss0 >= Sg) { ss0 -= Sg; ++sg0; }
+            }
         };
-        if (cnt > 0) issue(grp, rs0);
-        if (cnt > 1) issue(grp + ngrp, rs1);
+        if (cnt > 0) issue(rs0);
+        if (cnt > 1) issue(rs1);
         if (cnt > 0) {
-            stage(grp, buf, rs0);
-            if (cnt > 2) issue(grp + 2 * ngrp, rs0);
+            stage(buf, rs0);
+            if (cnt > 2) issue(rs0);
         }
         __syncthreads();                                       // stripe 0 is in buf[0]
         // stripe i + 1 lives in set (i + 1) & 1; two stripes per loop body so that the sets are named statically
         for (long long i = 0; i < cnt; i += 2) {
             if (i + 1 < cnt) {
-                stage(grp + (i + 1) * ngrp, buf + RS * LD, rs1);
-                if (i + 3 < cnt) issue(grp + (i + 3) * ngrp, rs1);
+                stage(buf + RS * LD, rs1);
+                if (i + 3 < cnt) issue(rs1);
             }
             __syncthreads();
             if (i + 1 < cnt) {
                 if (i + 2 < cnt) {
-                    stage(grp + (i + 2) * ngrp, buf, rs0);
-                    if (i + 4 < cnt) issue(grp + (i + 4) * ngrp, rs0);
+                    stage(buf, rs0);
+                    if (i + 4 < cnt) issue(rs0);
                 }
                 __syncthreads();
             }
@@ -3768,7 +3796,7 @@ static int bwd_fused_groups(long long M, int K, int N, int S, int pooled) {
     }();
     if (!on) return 0;
     // the bandwidth-bound 64-wide layers only: wider ones are matrix-pipe bound in both kernels and gain nothing
-    if (M < 65536 || K > 64 || K % 4 != 0 || N > 128 || N % 4 != 0) return 0;
+    if (M < 65536 || M > 0x7fffff00ll || K > 64 || K % 4 != 0 || N > 128 || N % 4 != 0) return 0;
     if (pooled && (S < 1 || S > 255)) return 0;
     long long g = 256;
     const long long ns = (M + 31) / 32;
