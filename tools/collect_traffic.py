@@ -33,7 +33,9 @@ KEYS = [
     ("wgrad_pc_kernel<2, 4, 1, 8>", None, "pcops_mlp_gram(32768, 512)"),
     ("sa_scatter_csr_kernel<32, false, 64>", None, "pcops_sa_scatter_bwd(256, 512, 128, 64, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
-    ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),
+    ("bwd_fused_kernel<2, 4, false>", None, "pcops_mlp_bwd_fused(4194304, 64, 128)"),            # round 3: one pass for ...
+    ("bwd_fused_kernel<1, 2, true>", None, "pcops_mlp_bwd_fused_xyz(4194304, 64, 64)"),
+    ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),                   # ... these four (PCOPS_BWD_FUSED=0)
     ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
     ("gemm_ws_kernel<2, 2, 3, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad_xyz(4194304, 64, 64)"),
     ("gemm_ws_kernel<2, 5, 0, 64, 8, 1, 0>", None, "pcops_mlp_gemm_fwd_xyz(4194304, 64, 64)"),
