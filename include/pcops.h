@@ -471,6 +471,12 @@ int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const fl
  * and batch-norm divisors (pcops_mlp_bn_finalize / _bn_bwd_coeffs R) stay the uncompacted count.
  * rows == NULL: exactly the entry point without the suffix.  Compacted rows need the wave-stream shapes
  * (>= 8192 rows, channel counts multiples of 8): PCOPS_ERR_UNSUPPORTED otherwise. */
+/* 1 when every launch of a grouped stack over compacted rows has a kernel for its shape (the *_rows entry points have
+ * no tiled fallback): b clouds x m groups x s slots, n source points per cloud, has_q = the first layer has a feature
+ * term (its gradient then walks the rows through the inverse index), widths [nlayers] = the layers' output widths
+ * (HOST array).  pcops_sa_scatter_rows_supported: the first layer's part of that answer. */
+int pcops_gather_stack_rows_supported(int b, int n, int m, int s, int has_q, int nlayers, const int *widths);
+int pcops_sa_scatter_rows_supported(int n, int m, int s, int c);
 unsigned long long pcops_rows_max_blocks(int b, int m, int s);
 /* builds blocks / block_start / rows from pts_cnt (b,m) of pcops_query_ball_point; s % 16 == 0.
  * blocks: 16 * pcops_rows_max_blocks(b,m,s) bytes, block_start: b*m + 1 ints, rows: 1 int. */

@@ -95,6 +95,8 @@ PLAIN = {
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
     "pcops_mlp_bwd_fused_groups": ([_LL, _I, _I, _I, _I], _I),
+    "pcops_gather_stack_rows_supported": ([_I, _I, _I, _I, _I, _I, _P], _I),
+    "pcops_sa_scatter_rows_supported": ([_I, _I, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_rows": ([_I, _I], _I),
     "pcops_edge_pool_stats_rows": ([_LL], _I),

@@ -1480,6 +1480,16 @@ int pcops_rows_plan(int b, int m, int s, const int *pts_cnt, void *blocks, int *
     return pcops_launch_status();
 }
 
+// shapes the gather (CSR) formulation of the feature gradient takes -- the only one that walks compacted rows
+static bool scatter_csr_shape(int n, int m, int s, int c) {
+    return (c == 32 || c == 64 || c == 128 || (c > 0 && c % 256 == 0)) && n <= 16384 && (long long)m * s < (1ll << 30) &&
+           2 * (size_t)n * 4 + 4096 <= 160 * 1024;
+}
+
+int pcops_sa_scatter_rows_supported(int n, int m, int s, int c) {
+    return (scatter_csr_enabled() && s % kBlk == 0 && scatter_csr_shape(n, m, s, c)) ? 1 : 0;
+}
+
 static int gather_rows_ok(const pcops_rows_t *rows, int s) {
     if (!rows) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(rows->blocks); PCOPS_REQUIRE_PTR(rows->block_start); PCOPS_REQUIRE_PTR(rows->rows);
@@ -1573,8 +1583,7 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
     }
     // gather formulation: feature gradient wanted, G materialised, no per-group output
     const int lpr = c <= 256 ? c / 4 : 64;
-    const bool csr_shape = (c == 32 || c == 64 || c == 128 || c % 256 == 0) && n <= 16384 &&
-                           (long long)m * s < (1ll << 30) && 2 * (size_t)n * 4 + 4096 <= 160 * 1024;
+    const bool csr_shape = scatter_csr_shape(n, m, s, c);
     if (rows && !(scatter_csr_enabled() && csr_shape)) return PCOPS_ERR_UNSUPPORTED;
     const bool det = pcops_get_deterministic() != 0;
     // deterministic mode: only the owner walk below adds a feature gradient in a fixed order

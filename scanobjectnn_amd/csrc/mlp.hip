@@ -3788,6 +3788,32 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     return pcops_launch_status();
 }
 
+/* 1 when EVERY launch of a grouped stack on compacted rows has a kernel for its shape -- the *_rows entry points have no
+ * tiled fallback, so a caller decides with this (and nothing else) whether to compact: group size a multiple of the
+ * 16-row block and within the 8-bit arg index, the wave-stream forward / data-gradient and the producer / consumer
+ * weight-gradient plans of every layer >= 1 (16-byte aligned operands assumed), the gather formulation of the first
+ * layer's feature gradient when the stack has a feature term (c1 = widths[0], n source points per cloud). */
+int pcops_gather_stack_rows_supported(int b, int n, int m, int s, int has_q, int nlayers, const int *widths) {
+    if (b < 1 || m < 1 || s < kBlk || s % kBlk != 0 || s > 256 || nlayers < 2 || !widths) return 0;
+    if (!ws_enabled() || !wgrad_pc_enabled()) return 0;
+    const long long M = (long long)b * m * s;
+    if (M > 0x7fffffffll) return 0;
+    for (int l = 1; l < nlayers; ++l) {
+        const int K = widths[l - 1], N = widths[l];
+        GemmArgs f = {};                 // forward: (M, K) -> (M, N)
+        f.M = (int)M; f.K = K; f.N = N; f.ldx = K; f.ldy = N;
+        GemmArgs d = {};                 // data gradient: (M, N) -> (M, K)
+        d.M = (int)M; d.K = N; d.N = K; d.ldx = N; d.ldy = K; d.S = s;
+        WsPlan pl;
+        PcWgradPlan pc;
+        if (!ws_plan(f, A_BNRELU, &pl) || !ws_plan(d, A_DY, &pl) ||
+            !wgrad_pc_plan(M, K, N, K, nullptr, nullptr, nullptr, nullptr, nullptr, &pc))
+            return 0;
+    }
+    if (has_q && !pcops_sa_scatter_rows_supported(n, m, s, widths[0])) return 0;
+    return 1;
+}
+
 static int bwd_fused_groups(long long M, int K, int N, int S, int pooled) {
     if (!ws_enabled() || !wgrad_pc_enabled()) return 0;
     static const bool on = [] {

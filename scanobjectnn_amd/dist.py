@@ -21,11 +21,15 @@ def sync_bn_active():
 
 
 def allreduce_stat_partials(part, rows):
-    """(P, 2, C) fp32 partial column sums of this rank -> ((1, 2, C) global sums, global row count).
-    The P partials are added in float64 (as the finalisation kernels do) before the all-reduce."""
+    """(P, 2, C) fp32 partial column sums of this rank -> ((2, 2, C) global sums, global row count).
+    The P partials are added in float64 (as the finalisation kernels do), all-reduced in float64, and handed back as
+    TWO fp32 partial rows -- the total rounded to fp32 and what the rounding left over -- which the finalisation kernels
+    add in float64 again: the global sums reach them with ~48 bits, like a single rank's."""
     tot = part.double().sum(dim=0, keepdim=True)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    return tot.float().contiguous(), rows * dist.get_world_size()
+    hi = tot.float()
+    lo = (tot - hi.double()).float()
+    return torch.cat([hi, lo], dim=0).contiguous(), rows * dist.get_world_size()
 
 
 def init_from_env(backend=None):

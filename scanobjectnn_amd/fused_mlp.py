@@ -164,7 +164,7 @@ class FusedMLPStack(torch.autograd.Function):
                 Pf, Rf = P, R
                 if sync:        # SyncBN: the statistics of the global batch
                     part, Rf = _dist.allreduce_stat_partials(part, R)
-                    Pf = 1
+                    Pf = part.shape[0]
                 _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), piv, ws.data_ptr(), gamma.data_ptr(),
                           beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
@@ -268,7 +268,7 @@ class FusedMLPStack(torch.autograd.Function):
                 # dY = p G + q Y + t coefficients come from the sums over the GLOBAL batch
                 gpart, Rg = _dist.allreduce_stat_partials(part, R)
                 junk = _f32(2 * N, dev)
-                _lib.call("pcops_mlp_bn_bwd_coeffs", 1, N, Rg, gpart.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
+                _lib.call("pcops_mlp_bn_bwd_coeffs", gpart.shape[0], N, Rg, gpart.data_ptr(), ws.data_ptr(), gammas[l].data_ptr(),
                           means[l].data_ptr(), rstds[l].data_ptr(), junk.data_ptr(), junk[N:].data_ptr(),
                           p.data_ptr(), q.data_ptr(), t.data_ptr())
             if not training:    # frozen statistics: no mean / variance terms in the BN backward
@@ -573,7 +573,7 @@ class EdgeConvPool(torch.autograd.Function):
             Pf, Rf = P, G * S
             if sync:
                 part, Rf = _dist.allreduce_stat_partials(part, G * S)
-                Pf = 1
+                Pf = part.shape[0]
             _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), mm.data_ptr() if STAT_PIVOT else None,
                       ws.data_ptr(), gamma.data_ptr(),
                       beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
@@ -616,7 +616,7 @@ class EdgeConvPool(torch.autograd.Function):
         if sync:        # see FusedMLPStack.backward
             gpart, Rg = _dist.allreduce_stat_partials(part, G * S)
             junk = _f32(2 * C, dev)
-            _lib.call("pcops_mlp_bn_bwd_coeffs", 1, C, Rg, gpart.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
+            _lib.call("pcops_mlp_bn_bwd_coeffs", gpart.shape[0], C, Rg, gpart.data_ptr(), ws.data_ptr(), gamma.data_ptr(),
                       mean.data_ptr(), rstd.data_ptr(), junk.data_ptr(), junk[C:].data_ptr(), p.data_ptr(),
                       q.data_ptr(), t.data_ptr())
         if not training:
@@ -671,16 +671,18 @@ def _compactable(idx, pool, L, widths, Q, Ctr, xyz, wxyz, identity_idx):
     """ball-query padding can be left out of this stack (pcops.h "compacted rows"): max-pooled gather stack of at
     least two layers without a per-group term, wave-stream sized, group size a multiple of the 16-row block"""
     B, M, S = idx.shape
-    if not (COMPACT_MIN_S and pool and not identity_idx and Ctr is None and L >= 2):
+    # policy: which stacks are worth compacting (and the forms the host code below has a compacted path for)
+    if not (COMPACT_MIN_S and pool and not identity_idx and Ctr is None and L >= 2 and S >= COMPACT_MIN_S):
         return False
-    if S < COMPACT_MIN_S or S % 16 or S > 256 or B * M * S < 32768 or any(w % 32 for w in widths):
+    if B * M * S < 32768 or any(w % 32 for w in widths) or _dist.sync_bn_active():
         return False
-    if _dist.sync_bn_active():
-        return False
-    if Q is not None:       # the feature gradient walks the compacted rows through the inverse index
-        c1, n = Q.shape[2], Q.shape[1]
-        return (c1 in (32, 64, 128) or c1 % 256 == 0) and n <= 16384
-    return wxyz is not None and L >= 3      # coordinate-only first layer: only as the arithmetic (never stored) form
+    if Q is None and not (wxyz is not None and L >= 3):
+        return False                        # coordinate-only first layer: only as the arithmetic (never stored) form
+    # support: ONE answer from the library for every launch of the stack (the *_rows entry points have no fallback)
+    import ctypes
+    n = Q.shape[1] if Q is not None else xyz.shape[1]
+    arr = (ctypes.c_int * L)(*[int(w) for w in widths])
+    return bool(_lib.load().pcops_gather_stack_rows_supported(B, n, M, S, 1 if Q is not None else 0, L, arr))
 
 
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,

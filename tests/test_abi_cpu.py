@@ -56,6 +56,31 @@ def test_argument_validation_without_gpu():
     assert lib.pcops_scatter_rows_sorted_supported(1 << 30, 64) == 0
 
 
+def test_compacted_stack_support_is_one_library_answer():
+    """`fused_mlp._compactable` asks the library whether EVERY launch of a stack on compacted rows has a kernel (the
+    *_rows entry points have no tiled fallback) instead of restating the kernels' shape conditions in Python"""
+    from scanobjectnn_amd import _lib
+    lib = _lib.load()
+
+    def q(b, n, m, s, has_q, widths):
+        arr = (ctypes.c_int * len(widths))(*widths)
+        return lib.pcops_gather_stack_rows_supported(b, n, m, s, has_q, len(widths), arr)
+
+    assert q(256, 512, 128, 64, 1, [128, 128, 256]) == 1          # SA2 of the SSG config
+    assert q(128, 2048, 512, 64, 0, [64, 64, 128]) == 1           # BGA's SA1: coordinate-only first layer
+    assert q(256, 512, 128, 60, 1, [128, 128, 256]) == 0          # groups are whole 16-row blocks
+    assert q(256, 512, 128, 512, 1, [128, 128, 256]) == 0         # 8-bit arg index
+    assert q(2, 100, 10, 64, 1, [128, 128]) == 0                  # too few rows for the wave-stream kernels
+    assert q(256, 512, 128, 64, 1, [100, 128, 256]) == 0          # the inverse-index walk wants c1 in {32, 64, 128, 256 k}
+    assert q(256, 20000, 128, 64, 1, [128, 128, 256]) == 0        # ... and the cloud's histogram in LDS
+    assert q(256, 512, 128, 64, 1, [128, 130, 256]) == 0          # K % 8 of a middle layer
+    assert lib.pcops_sa_scatter_rows_supported(512, 128, 64, 128) == 1
+    code = ("import os, ctypes; os.environ['PCOPS_GEMM_WS'] = '0'; from scanobjectnn_amd import _lib; lib = _lib.load(); "
+            "arr = (ctypes.c_int * 3)(128, 128, 256); print(lib.pcops_gather_stack_rows_supported(256, 512, 128, 64, 1, 3, arr))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert out.stdout.strip() == "0", out.stderr                  # wave-stream kernels switched off: do not compact
+
+
 def test_no_cpu_fallback():
     from scanobjectnn_amd import _lib
     from scanobjectnn_amd.pointnet2 import tf_grouping, tf_sampling
