@@ -246,6 +246,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     TopK<KL> top;
     top.init();
     int nq = 0;                        // entries in this lane's queue
+    // SHARED threshold of the two half-waves (round 3): lanes l and l ^ 32 scan the two halves of the SAME query's
+    // candidates, each with its own sorted list.  The ceil(KL/2) best of one half and the ceil(KL/2) best of the other
+    // are >= KL distinct candidates, all <= tau2 = max of the two lists' ceil(KL/2)-th values: the query's KL-th smallest
+    // distance cannot exceed tau2, and a candidate beyond it need not enter either list.  A half on its own only knows
+    // its OWN KL-th value -- with it the two lists queue ~2 KL ln(n / 2 KL) candidates per query, with tau2 about half.
+    // (<= keeps ties with the bound; the lists and the final merge are unchanged.)
+    float tau2 = INFINITY;
     auto flush = [&]() {
         const int mx = (int)wave_max_u32((unsigned)nq);
         for (int u = 0; u < mx; ++u) {
@@ -254,6 +261,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
             top.insert_ascending(d, j);
         }
         nq = 0;
+        const float hv = top.v[(KL + 1) / 2 - 1];
+        tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
     };
 
     // the candidate chunks are software pipelined: chunk i+1 travels global -> registers (16-byte loads when the rows
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = (sq + (-2.f * acc[4 * g4 + e])) + sv[e];
-                    if (d < kth) {
+                    if (d < kth && d <= tau2) {
                         qd[nq * 256 + tid] = d;
                         qj[nq * 256 + tid] = j0 + row0 + e;
                         ++nq;
