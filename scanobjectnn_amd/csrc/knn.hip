@@ -162,7 +162,9 @@ struct TopK {
 // the selection instructions of tile t, fragments preloaded a group ahead, branch-free pushes: 2482 vs 2505 us on 64
 // channels, 1090 vs 937 us on 3.  Per SIMD the time is close to (VALU + SALU + LDS instructions) x ~4.5 cycles PLUS the
 // MFMA time -- 765 instructions per 32 x 32 tile -- so fewer instructions per distance is the lever, not more overlap.
-// Two tiles per iteration with interleaved, independent MFMA chains: 2478 vs 2505 us (64 channels), 1107 vs 937 us (3).)
+// Two tiles per iteration with interleaved, independent MFMA chains: 2478 vs 2505 us (64 channels), 1107 vs 937 us (3).
+// Round 3: one compare per distance shifted into a per-lane bitmap by its carry, the distances staged in LDS, the pushes in
+// a loop over the set bits instead of sixteen exec-masked blocks: 3627 vs 2399 us -- the loop's LDS round trips are serial.)
 // Candidates that beat a lane's current k-th distance are QUEUED in LDS (slot-major, conflict free) instead of being
 // inserted at once: the per-candidate work is then one compare (+ two LDS writes for the ~5 % that pass), and the
 // sorted insertion -- 4 VALU per list slot, the expensive part -- runs for whole batches when some lane's queue
@@ -364,7 +366,7 @@ int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, con
     auto kern = knn_mfma_kernel<CP, KL>;
     if (lds > 48 * 1024) {
         static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)once;
     }
     hipLaunchKernelGGL(kern, dim3(cdiv(n, 128), b), dim3(256), lds, st, n, c, k, x, nn_idx, seed);
