@@ -471,6 +471,12 @@ int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const fl
  * and batch-norm divisors (pcops_mlp_bn_finalize / _bn_bwd_coeffs R) stay the uncompacted count.
  * rows == NULL: exactly the entry point without the suffix.  Compacted rows need the wave-stream shapes
  * (>= 8192 rows, channel counts multiples of 8): PCOPS_ERR_UNSUPPORTED otherwise. */
+/* TensorFlow-flavoured Adam on flat fp32 buffers of n floats (n % 4 == 0, 16-byte aligned), one launch:
+ *   m <- beta1 m + (1 - beta1) g;  v <- beta2 v + (1 - beta2) g^2;  p <- p - lr_t m / (sqrt(v) + epsilon)
+ * lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t) comes from the caller (tf.train.AdamOptimizer: epsilon outside the
+ * bias-corrected root; reference trainers pointnet2/train.py:165-168). */
+int pcops_adam_step(long long n, float *p, const float *g, float *m, float *v, float beta1, float beta2, float lr_t,
+                    float epsilon, pcops_stream_t stream);
 /* 1 when every launch of a grouped stack over compacted rows has a kernel for its shape (the *_rows entry points have
  * no tiled fallback): b clouds x m groups x s slots, n source points per cloud, has_q = the first layer has a feature
  * term (its gradient then walks the rows through the inverse index), widths [nlayers] = the layers' output widths

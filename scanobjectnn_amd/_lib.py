@@ -70,6 +70,7 @@ SIGNATURES = {
     "pcops_mlp_gemm_dgrad_xyz_rows": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bwd_fused": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bwd_fused_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_adam_step": ([_LL, _P, _P, _P, _P, _F, _F, _F, _F], True),
     "pcops_mlp_bwd_fused_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),

@@ -5,7 +5,9 @@ gradient buffers so that one data-parallel step is: backward -> ONE all-reduce o
 -> ONE fused optimiser update.
 """
 import math
+import os
 
+import numpy as np
 import torch
 
 BASE_LEARNING_RATE = 1e-3   # train.py:31
@@ -14,6 +16,7 @@ DECAY_RATE = 0.7            # train.py:35
 BN_INIT_DECAY = 0.5         # train.py:78
 BN_DECAY_DECAY_RATE = 0.5   # train.py:79
 BN_DECAY_CLIP = 0.99        # train.py:81
+FUSED_ADAM = os.environ.get("PCOPS_FUSED_ADAM", "1") != "0"   # device buffers: the update as one libpcops launch
 
 
 def get_learning_rate(global_step, batch_size, base_lr=BASE_LEARNING_RATE, decay_step=DECAY_STEP,
@@ -178,12 +181,27 @@ class TFAdam:
 
     @torch.no_grad()
     def step(self, lr):
+        if self.fp.flat.is_cuda and FUSED_ADAM:
+            return self._step_device(lr)
         self.t += 1
         g = self.fp.grad
-        self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
-        self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        # (1 - beta) in fp32, as TensorFlow's ApplyAdam forms it from its float32 hyper-parameter tensors: 1 - 0.999f is
+        # 0.99998713e-3, not 1e-3 -- the device kernel does the same
+        c1 = float(np.float32(1.0) - np.float32(self.b1))
+        c2 = float(np.float32(1.0) - np.float32(self.b2))
+        self.m.mul_(self.b1).add_(g, alpha=c1)
+        self.v.mul_(self.b2).addcmul_(g, g, value=c2)
         lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
         self.fp.flat.addcdiv_(self.m, self.v.sqrt().add_(self.eps), value=-lr_t)
+
+    @torch.no_grad()
+    def _step_device(self, lr):
+        """the same update as ONE libpcops launch over the flat buffers (pcops_adam_step) instead of seven elementwise ones"""
+        from . import _lib
+        self.t += 1
+        lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        _lib.call("pcops_adam_step", self.fp.numel, self.fp.flat.data_ptr(), self.fp.grad.data_ptr(), self.m.data_ptr(),
+                  self.v.data_ptr(), float(self.b1), float(self.b2), float(lr_t), float(self.eps))
 
 
 class TFMomentum:

@@ -338,3 +338,29 @@ def test_full_size_sa1_properties():
     oidx, ocnt = O.query_ball_point(0.2, 32, c[sub], N(q[sub]))
     np.testing.assert_array_equal(N(i2), oidx)
     np.testing.assert_array_equal(N(fps[sub]), O.farthest_point_sample(512, c[sub]))
+
+
+def test_adam_step_is_the_reference_update():
+    """`pcops_adam_step` (one launch) against the elementwise form of tf.train.AdamOptimizer the host code used before
+    (`train_util.TFAdam`, reference trainers `pointnet2/train.py:165-168`), three steps on a ragged flat bucket"""
+    from scanobjectnn_amd import train_util as TU
+    torch.manual_seed(3)
+    net_a = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 7)).to(DEV)
+    net_b = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 7)).to(DEV)
+    net_b.load_state_dict(net_a.state_dict())
+    fa, fb = TU.FlatParams(net_a), TU.FlatParams(net_b)
+    oa, ob = TU.TFAdam(fa), TU.TFAdam(fb)
+    assert fa.numel % 4 == 0
+    for step in range(3):
+        g = torch.randn(fa.numel, device=DEV) * (10.0 ** (step - 1))
+        fa.grad.copy_(g)
+        fb.grad.copy_(g)
+        oa.step(1e-3)                      # device launch
+        TU.FUSED_ADAM, keep = False, TU.FUSED_ADAM
+        try:
+            ob.step(1e-3)                  # seven elementwise launches
+        finally:
+            TU.FUSED_ADAM = keep
+        assert torch.allclose(oa.m, ob.m, rtol=1e-6, atol=1e-12) and torch.allclose(oa.v, ob.v, rtol=1e-6, atol=1e-20)
+        # lr-sized updates computed a few ulp apart, added to parameters of magnitude <= 0.2: one ulp of those is 1.5e-8
+        assert (fa.flat - fb.flat).abs().max().item() <= 3.1e-8
