@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(lib, s), "libpcops.so does not export %s (declared in include/pcops.h)" % s
-    assert lib.pcops_abi_version() >= 1
+    assert lib.pcops_abi_version() >= 3
     assert _lib.strerror(0) == "ok" and "null" in _lib.strerror(-1)
 
 
@@ -48,6 +48,12 @@ def test_argument_validation_without_gpu():
     assert lib.pcops_knn_graph(1, 8, 3, 9, None, None, None) == -3          # k > n
     assert lib.pcops_farthest_point_sample_workspace_bytes(32, 2048) == 0
     assert lib.pcops_mlp_stats_rows(4194304) == 512 and lib.pcops_mlp_stats_rows(100) == 1
+    assert lib.pcops_adam_step(ctypes.c_longlong(6), None, None, None, None, ctypes.c_float(0.9), ctypes.c_float(0.999),
+                               ctypes.c_float(1e-3), ctypes.c_float(1e-8), None) == -2        # n % 4 != 0
+    assert lib.pcops_adam_step(ctypes.c_longlong(8), None, None, None, None, ctypes.c_float(0.9), ctypes.c_float(0.999),
+                               ctypes.c_float(1e-3), ctypes.c_float(1e-8), None) == -1
+    assert lib.pcops_mlp_bwd_fused_groups(ctypes.c_longlong(1 << 22), 64, 128, 32, 1) in (0, 256)   # (0: PCOPS_BWD_FUSED=0)
+    assert lib.pcops_mlp_bwd_fused_groups(ctypes.c_longlong(1 << 22), 128, 128, 32, 1) == 0
     # the ordered scatter-add says what it supports (LDS-resident counting sort), callers ask before choosing it
     lim = lib.pcops_scatter_rows_sorted_max_ndst()
     assert lim == 19968
