@@ -2304,8 +2304,8 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
 //                          Gprev = dX . [bn(Yprev) > 0]  straight from the accumulators, with the column sums
 //                          (sum Gprev, sum Gprev Yprev) the BN backward of the layer below needs; the mask and the
 //                          statistics read the RAW Yprev the producers left beside X -- no second trip to memory.
-// Per stripe a consumer issues 16 (NB/64) + 4 (NB/16) ... = equal matrix-pipe time for the two products (4 096 cycles at
-// NB = 128), so the pass is pipe bound at about the time of ONE of the two kernels it replaces.
+// Per stripe a consumer issues 16 NB/64 MFMAs of 64 cycles and 4 NB/16 of 32: equal matrix-pipe time for the two products
+// (4 096 cycles at NB = 128); the pass is pipe bound at about 0.7 x the time of the two kernels it replaces.
 template <int TN, int DMODE, bool XYZ>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
@@ -2330,7 +2330,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     float *coefA = lds;                        // [CA][KB]  scale, shift of the layer below | xyz form: w0 w1 w2 b
     float *coefD = coefA + CA * KB;            // [3][NB]  p, q, t
     float *wq = coefD + 3 * NB;                // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
-    float *buf = wq + NB * KB;                 // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][2][KB]
+    float *buf = wq + NB * KB;                 // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][5][KB]
 
     for (int e = tid; e < KB; e += 512) {
         coefA[e] = e < K ? a.asc[e] : 0.f;
@@ -2375,8 +2375,9 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
         const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-        // TWO register sets: the loads of stripe i + 2 are in flight while stripe i + 1 is staged (one stripe ahead left
-        // 29 KB per CU in flight -- 3.0 TB/s at the latency of a loaded HBM; the kernel is otherwise matrix-pipe bound)
+        // TWO register sets: the loads of stripe i + 2 are in flight while stripe i + 1 is staged (57 KB per CU in flight
+        // instead of 29; measured within noise of one stripe ahead -- the kernel is matrix-pipe / issue bound -- and kept:
+        // the producers have the registers)
         constexpr bool B_ = DMODE == A_DYPOOLB;                // compacted rows: one pooling group per 16-row block
         constexpr int NBLK = RS / kBlk;                        // blocks per stripe
         constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
