@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     // its OWN KL-th value -- with it the two lists queue ~2 KL ln(n / 2 KL) candidates per query, with tau2 about half.
     // (<= keeps ties with the bound; the lists and the final merge are unchanged.)
     float tau2 = INFINITY;
+    float thr = tau;                   // d < kth && d <= tau2 && d < tau as ONE compare (the list only changes in flush)
     auto flush = [&]() {
         const int mx = (int)wave_max_u32((unsigned)nq);
         for (int u = 0; u < mx; ++u) {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
         nq = 0;
         const float hv = top.v[(KL + 1) / 2 - 1];
         tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
+        thr = fminf(fminf(top.v[KL - 1], nextafterf(tau2, INFINITY)), tau);
     };
 
     // the candidate chunks are software pipelined: chunk i+1 travels global -> registers (16-byte loads when the rows
@@ -329,11 +331,10 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
                 const int row0 = 32 * t + 8 * g4 + 4 * half;
                 const float4 s4 = *reinterpret_cast<const float4 *>(sc + row0);
                 const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
-                const float kth = fminf(top.v[KL - 1], tau);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = (sq + (-2.f * acc[4 * g4 + e])) + sv[e];
-                    if (d < kth && d <= tau2) {
+                    if (d < thr) {
                         qd[nq * 256 + tid] = d;
                         qj[nq * 256 + tid] = j0 + row0 + e;
                         ++nq;
