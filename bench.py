@@ -117,9 +117,9 @@ def _algo(name, a):
     if name == "pcops_mlp_gemm_dgrad_top":    # Gprev[M,Kp] = mask . (X Mq + addend rows + v): reads X, writes Gprev
         M, Kp = a[:2]
         return 4 * (2 * M * Kp), 2 * M * Kp * Kp, "flop"
-    if name == "pcops_mlp_gram":              # X^T X: one pass over X
+    if name == "pcops_mlp_gram":              # X^T X: one pass over X; symmetric -- the work is the upper triangle
         M, Kp = a[:2]
-        return 4 * M * Kp, 2 * M * Kp * Kp, "flop"
+        return 4 * M * Kp, M * Kp * (Kp + 1), "flop"
     if name == "pcops_mlp_pool_top_addend":   # per (group, channel) 9 bytes in, a Kp-wide weight row through L2, compact rows out
         M, Kp, N, S = a[:4]
         return (M // S) * N * 9 + 4 * (M // S) * min(S, N) * Kp + 4 * M, 2 * (M // S) * N * Kp, "flop(VALU)"

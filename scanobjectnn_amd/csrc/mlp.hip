@@ -2760,6 +2760,199 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gram matrix X^T X of a layer's input in ONE pass over X (round 3), for widths up to 320.  The tiled producer / consumer
+// kernel reads a 128-column slice of X per tile side: nine 128 x 128 tiles at K = 320 stream the 671 MB of DGCNN's
+// aggregation input more than three times over (the pass sat at ~2-3 TB/s of strided slices, 1.58 ms, and computing only
+// the upper tiles changed nothing).  Here a workgroup stages WHOLE rows -- a stripe of 32 x K -- and its four consumer
+// waves hold all 32 x 32 blocks of the UPPER triangle in accumulators (K = 320: 55 blocks, 14 per wave, 224 registers):
+// X is read once, the lower triangle is mirrored by the launcher, the MFMA work is 55 / 100 of the full square.
+struct GramArgs {
+    long long M;
+    int K, ldx;
+    const float *X, *asc, *ash;      // X = raw input; asc == NULL: plain, else relu(X asc + ash)
+    float *part;                     // [groups][K][K] partial Gram (upper 32 x 32 blocks written)
+    float *xpart;                    // [groups][K] partial column sums
+};
+
+constexpr int gram_blocks(int nbk) { return nbk * (nbk + 1) / 2; }
+// u-th block of the upper triangle in row-major order -> its block row
+constexpr int gram_row_of(int u, int nbk) {
+    int i = 0, left = u;
+    while (left >= nbk - i) { left -= nbk - i; ++i; }
+    return i;
+}
+constexpr int gram_col_of(int u, int nbk) {
+    int i = 0, left = u;
+    while (left >= nbk - i) { left -= nbk - i; ++i; }
+    return i + left;
+}
+
+// (block row, block column) of the U-th upper block as CONSTANTS -- the fragment registers must be named statically
+template <int U, int NBK>
+struct GramBlk {
+    static constexpr int i = gram_row_of(U, NBK), j = gram_col_of(U, NBK);
+};
+template <int NBK, int U0, typename AccT, int... B>
+__device__ __forceinline__ void gram_mfma_step(AccT &acc, const float (&f)[NBK], std::integer_sequence<int, B...>) {
+    ((acc[B] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[GramBlk<U0 + B, NBK>::i], f[GramBlk<U0 + B, NBK>::j], acc[B], 0, 0, 0)), ...);
+}
+template <int NBK, int U0, typename AccT, int... B>
+__device__ __forceinline__ void gram_store(const AccT &acc, float *out, int K, int half, int li,
+                                           std::integer_sequence<int, B...>) {
+    auto one = [&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        constexpr int bi = GramBlk<U0 + b, NBK>::i, bj = GramBlk<U0 + b, NBK>::j;
+        const int nn = 32 * bj + li;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int kk = 32 * bi + (v & 3) + 8 * (v >> 2) + 4 * half;
+            if (kk < K && nn < K) out[(long long)kk * K + nn] = acc[b][v];
+        }
+    };
+    (one(std::integral_constant<int, B>{}), ...);
+}
+
+template <int NBK, bool BNRELU>
+__global__ __launch_bounds__(512, 1) void gram_full_kernel(GramArgs a) {
+    constexpr int KP = 32 * NBK, RS = 32, LD = KP + 4;
+    constexpr int NU = gram_blocks(NBK), PER = (NU + 3) / 4;       // upper blocks, blocks per consumer wave
+    constexpr int K4 = KP / 4, NV = RS * K4 / 256;                   // float4 per stripe row / per producer thread
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K;
+    const long long M = a.M;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
+    float *coef = lds;                 // [2][KP]
+    float *buf = coef + 2 * KP;        // [2][RS][LD]  | afterwards: column-sum scratch [256][4]
+    for (int e = tid; e < KP; e += 512) {
+        coef[e] = (BNRELU && e < K) ? a.asc[e] : 0.f;
+        coef[KP + e] = (BNRELU && e < K) ? a.ash[e] : 0.f;
+    }
+    __syncthreads();
+    const long long nstripes = (M + RS - 1) / RS;
+    const long long cnt = grp < nstripes ? (nstripes - grp + ngrp - 1) / ngrp : 0;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers: whole rows of X
+        const int pt = tid - 256;
+        float4 px[NV];
+        float cs[NV][4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) cs[j][0] = cs[j][1] = cs[j][2] = cs[j][3] = 0.f;
+        // element e = pt + 256 j of the stripe's [RS][K4] float4 grid: row e / K4, column quad e % K4
+        auto issue = [&](long long stripe) {
+            const long long row0 = stripe * RS;
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int e = pt + 256 * j, r = e / K4, c = (e % K4) * 4;
+                px[j] = buf_load4(rx, c < K ? (unsigned)(r * a.ldx + c) * 4u : kOOB, 0u);
+            }
+        };
+        auto stage = [&](long long stripe, float *dst) {
+            const long long row0 = stripe * RS;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int e = pt + 256 * j, r = e / K4, c = (e % K4) * 4;
+                float4 x = px[j];
+                if (BNRELU) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(&coef[c]);
+                    const float4 sh = *reinterpret_cast<const float4 *>(&coef[KP + c]);
+                    x.x = fmaxf(fmaf(x.x, sc.x, sh.x), 0.f); x.y = fmaxf(fmaf(x.y, sc.y, sh.y), 0.f);
+                    x.z = fmaxf(fmaf(x.z, sc.z, sh.z), 0.f); x.w = fmaxf(fmaf(x.w, sc.w, sh.w), 0.f);
+                    if (!(c < K && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);   // (relu(shift) of a padded element)
+                }
+                cs[j][0] += x.x; cs[j][1] += x.y; cs[j][2] += x.z; cs[j][3] += x.w;
+                *reinterpret_cast<float4 *>(&dst[r * LD + c]) = x;
+            }
+        };
+        if (cnt > 0) {
+            issue(grp);
+            stage(grp, buf);
+            if (cnt > 1) issue(grp + ngrp);
+        }
+        __syncthreads();
+        for (long long i = 0; i < cnt; ++i) {
+            if (i + 1 < cnt) {
+                stage(grp + (i + 1) * ngrp, buf + ((i + 1) & 1) * RS * LD);
+                if (i + 2 < cnt) issue(grp + (i + 2) * ngrp);
+            }
+            __syncthreads();
+        }
+        // column sums: thread pt owns column quads (pt + 256 j) % K4 -- K4 divides 256 j only for some widths, so every
+        // (thread, j) pair adds into the quad's slot through LDS (once per kernel)
+        float *scr = buf;                                      // [KP]
+        for (int e = pt; e < KP; e += 256) scr[e] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = ((pt + 256 * j) % K4) * 4;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) atomicAdd(&scr[c + x], cs[j][x]);
+        }
+        __syncthreads();
+        for (int e = pt; e < K; e += 256) a.xpart[(long long)grp * K + e] = scr[e];
+    } else {
+        // ------------------------------------------------------------------ consumers: the upper blocks, PER per wave
+        const int half = lane >> 5, li = lane & 31;
+        auto run = [&](auto wv_) {
+            constexpr int WV = decltype(wv_)::value;
+            constexpr int U0 = WV * PER, U1 = (U0 + PER < NU) ? U0 + PER : NU;
+            constexpr int NB_ = U1 > U0 ? U1 - U0 : 0;
+            f32x16 acc[NB_ > 0 ? NB_ : 1];
+#pragma unroll
+            for (int b = 0; b < NB_; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[b][v] = 0.f;
+            __syncthreads();
+            for (long long i = 0; i < cnt; ++i) {
+                const float *sb = buf + (i & 1) * RS * LD + half * LD + li;
+                float fn[NBK];
+#pragma unroll
+                for (int c = 0; c < NBK; ++c) fn[c] = sb[32 * c];
+#pragma unroll
+                for (int it = 0; it < RS / 2; ++it) {
+                    float f[NBK];
+#pragma unroll
+                    for (int c = 0; c < NBK; ++c) f[c] = fn[c];
+                    if (it + 1 < RS / 2) {
+#pragma unroll
+                        for (int c = 0; c < NBK; ++c) fn[c] = sb[2 * (it + 1) * LD + 32 * c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    gram_mfma_step<NBK, U0>(acc, f, std::make_integer_sequence<int, NB_>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __syncthreads();
+            }
+            // acc[b][v]: k = 32 i + (v&3) + 8 (v>>2) + 4 half, n = 32 j + li
+            gram_store<NBK, U0>(acc, a.part + (long long)grp * K * K, K, half, li, std::make_integer_sequence<int, NB_>{});
+            __syncthreads();               // the producers' two column-sum barriers
+            __syncthreads();
+        };
+        if (wave == 0) run(std::integral_constant<int, 0>{});
+        else if (wave == 1) run(std::integral_constant<int, 1>{});
+        else if (wave == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
+    }
+}
+
+// lower triangle of a symmetric K x K result from its upper one
+__global__ __launch_bounds__(256) void mirror_lower_kernel(int K, float *__restrict__ g) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < i; j += 256) g[(long long)i * K + j] = g[(long long)j * K + i];
+}
+
+static bool gram_full_on() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_GRAM_FULL");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 struct PcWgradPlan {
     int tk, tn, kblocks, nblocks, groups;
     size_t lds;
@@ -3653,6 +3846,17 @@ int pcops_mlp_gemm_dgrad_xyz_rows(int M, int K, int Nout, const float *G, const 
 
 static int wgrad_legacy_splits(long long M, int K, int N);
 
+// workgroups (= partial copies) of the single-pass Gram kernel, 0 when it does not take the shape
+static int gram_full_groups(long long M, int K, int ldx, const void *X) {
+    if (!gram_full_on() || !ws_enabled() || M < 65536 || K > 320 || K < 32 || K % 4 != 0 || ldx % 4 != 0) return 0;
+    if (reinterpret_cast<uintptr_t>(X) & 15) return 0;
+    long long g = 256;
+    const long long ns = (M + 31) / 32;
+    if (g > ns) g = ns;
+    if (g >= 8) g &= ~7ll;
+    return (int)g;
+}
+
 int pcops_mlp_wgrad_splits(long long M, int K, int N) {
     // upper bound of the partial copies ANY of the three wgrad kernels writes for this shape (the scratch is sized
     // with it): the group counts of wgrad_pc_plan / wgrad_ws_plan before their M clamp, and the legacy split count.
@@ -3664,6 +3868,10 @@ int pcops_mlp_wgrad_splits(long long M, int K, int N) {
         int g = (tk * tn == 1 ? 512 : 256) / (kb * nb);
         if (g < 1) g = 1;
         if (g > best) best = g;
+        if (K == N) {                 // pcops_mlp_gram of this width may take the single-pass kernel: a copy per workgroup
+            const int gg = gram_full_groups(M, K, 4, nullptr);
+            if (gg > best) best = gg;
+        }
     }
     {   // wgrad_ws_plan
         int tk, tn;
@@ -4061,6 +4269,42 @@ int pcops_mlp_gram(long long M, int Kp, const float *Yprev, int ldx, const float
     PCOPS_REQUIRE_SHAPE(M >= 1 && Kp >= 1 && ldx >= Kp);
     PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(gram);
     PCOPS_REQUIRE_ARG((a_scale == nullptr) == (a_shift == nullptr));
+    const int gg = gram_full_groups(M, Kp, ldx, Yprev);
+    if (gg > 0) {
+        // one pass over X: whole rows staged, every upper 32 x 32 block in accumulators (gram_full_kernel)
+        hipStream_t st = as_stream(stream);
+        GramArgs g = {M, Kp, ldx, Yprev, a_scale, a_shift, partial, partial + (long long)gg * Kp * Kp};
+        const int nbk = (Kp + 31) / 32;
+        const size_t lds = (size_t)(2 * 32 * nbk + 2 * 32 * (32 * nbk + 4)) * sizeof(float);
+#define PCOPS_GRAM_LAUNCH(NBK_)                                                                            \
+    do {                                                                                                   \
+        auto kern = a_scale ? gram_full_kernel<NBK_, true> : gram_full_kernel<NBK_, false>;               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(gg), dim3(512), lds, st, g);                                         \
+    } while (0)
+        switch (nbk) {
+            case 1: PCOPS_GRAM_LAUNCH(1); break;
+            case 2: PCOPS_GRAM_LAUNCH(2); break;
+            case 3: PCOPS_GRAM_LAUNCH(3); break;
+            case 4: PCOPS_GRAM_LAUNCH(4); break;
+            case 5: PCOPS_GRAM_LAUNCH(5); break;
+            case 6: PCOPS_GRAM_LAUNCH(6); break;
+            case 7: PCOPS_GRAM_LAUNCH(7); break;
+            case 8: PCOPS_GRAM_LAUNCH(8); break;
+            case 9: PCOPS_GRAM_LAUNCH(9); break;
+            default: PCOPS_GRAM_LAUNCH(10); break;
+        }
+#undef PCOPS_GRAM_LAUNCH
+        int rc = pcops_launch_status();
+        if (rc) return rc;
+        const long long L = (long long)Kp * Kp;
+        hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (xsum ? cdiv(Kp, 64) : 0)), dim3(1024), 0, st, gg, L,
+                           partial, gram, (long long)Kp, g.xpart, xsum);
+        hipLaunchKernelGGL(mirror_lower_kernel, dim3(Kp), dim3(256), 0, st, Kp, gram);
+        return pcops_launch_status();
+    }
     WgradArgs a = {};
     a.M = M; a.K = Kp; a.N = Kp;
     a.amode = a_scale ? A_BNRELU : A_PLAIN; a.X = Yprev; a.ldx = ldx; a.asc = a_scale; a.ash = a_shift;

@@ -102,3 +102,32 @@ def test_bwd_fused_says_what_it_takes():
     assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 128, 128, 32, 1) == 0      # matrix-pipe bound shapes: two kernels
     assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 64, 256, 0, 0) == 0
     assert lib.pcops_mlp_bwd_fused_groups(1024, 64, 64, 0, 0) == 0
+
+
+@pytest.mark.parametrize("M,K,ld,bnrelu", [(65536 + 45, 320, 320, False), (70000, 128, 128, True), (66000, 100, 104, True),
+                                            (65536, 64, 64, False), (80000, 36, 36, True)])
+def test_single_pass_gram_against_float64(M, K, ld, bnrelu):
+    """`pcops_mlp_gram` for widths up to 320 on >= 65 536 rows: whole rows staged once, every upper 32 x 32 block in
+    accumulators, lower triangle mirrored -- X^T X and X^T 1 against float64 (plain input and relu(bn(.)) input, a row
+    stride wider than K, ragged row counts, widths that are not multiples of 32)"""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    Xs = torch.randn(M, ld, generator=g).to(DEV)
+    sc = ((0.5 + torch.rand(K, generator=g)) * (1.0 - 2.0 * (torch.arange(K) % 3 == 1))).to(DEV)
+    sh = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    X = Xs[:, :K].double()
+    if bnrelu:
+        X = (X * sc.double() + sh.double()).clamp_min(0.0)
+    want, wsum = X.t() @ X, X.sum(0)
+    splits = lib.pcops_mlp_wgrad_splits(M, K, K)
+    scratch = torch.empty(splits * (K * K + K), device=DEV)
+    gram = torch.full((K, K), float("nan"), device=DEV)
+    xsum = torch.full((K,), float("nan"), device=DEV)
+    _lib.call("pcops_mlp_gram", M, K, Xs.data_ptr(), ld, sc.data_ptr() if bnrelu else None, sh.data_ptr() if bnrelu else None,
+              scratch.data_ptr(), gram.data_ptr(), xsum.data_ptr())
+    torch.cuda.synchronize()
+    assert not torch.isnan(gram).any() and not torch.isnan(xsum).any()
+    assert torch.equal(gram, gram.t())                                              # mirrored, bit for bit
+    scale = want.abs().max().item()
+    assert (gram.double() - want).abs().max().item() <= 2e-5 * scale
+    assert (xsum.double() - wsum).abs().max().item() <= 2e-5 * max(wsum.abs().max().item(), M ** 0.5)
