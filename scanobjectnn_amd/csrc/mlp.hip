@@ -2881,19 +2881,19 @@ __global__ __launch_bounds__(512, 1) void gram_full_kernel(GramArgs a) {
             }
             __syncthreads();
         }
-        // column sums: thread pt owns column quads (pt + 256 j) % K4 -- K4 divides 256 j only for some widths, so every
-        // (thread, j) pair adds into the quad's slot through LDS (once per kernel)
-        float *scr = buf;                                      // [KP]
-        for (int e = pt; e < KP; e += 256) scr[e] = 0.f;
+        // column sums: element idx = pt + 256 j of the [RS][K4] grid always sits in column quad idx % K4 -- every (thread, j)
+        // partial goes to LDS and each column is summed by ONE thread over its RS partials in a fixed order (deterministic)
+        float *scr = buf;                                      // [256 NV][4]
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            *reinterpret_cast<float4 *>(&scr[(pt + 256 * j) * 4]) = make_float4(cs[j][0], cs[j][1], cs[j][2], cs[j][3]);
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int c = ((pt + 256 * j) % K4) * 4;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) atomicAdd(&scr[c + x], cs[j][x]);
+        for (int e = pt; e < K; e += 256) {
+            float sum = 0.f;
+            for (int idx = e >> 2; idx < 256 * NV; idx += K4) sum += scr[idx * 4 + (e & 3)];
+            a.xpart[(long long)grp * K + e] = sum;
         }
         __syncthreads();
-        for (int e = pt; e < K; e += 256) a.xpart[(long long)grp * K + e] = scr[e];
     } else {
         // ------------------------------------------------------------------ consumers: the upper blocks, PER per wave
         const int half = lane >> 5, li = lane & 31;
