@@ -913,14 +913,18 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     }
             };
             static_assert((KC / 8) % 2 == 0, "two steps per loop body");
+            // a chunk that reaches beyond K (K = 96: the second chunk holds 32 real columns and 32 of zeros) only runs the
+            // steps that have something to multiply -- wave-uniform trip count, the skipped products are exact zeros
+            const int kleft = K - kc * KC;
+            const int nit = kleft >= KC ? KC / 8 : ((kleft + 15) / 16) * 2;
 #pragma unroll 1
-            for (int it = 0; it < KC / 8; it += 2) {
+            for (int it = 0; it < nit; it += 2) {
                 a1 = *reinterpret_cast<const float4 *>(arow + 8 * (it + 1));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b1[nt] = bq[(2 * (it + 1)) * BN + 32 * nt];
                 mfma16(a0, b0);
                 // (the last body re-reads its own step instead of branching: same addresses, nobody uses the result)
-                const int nx = it + 2 < KC / 8 ? it + 2 : it + 1;
+                const int nx = it + 2 < nit ? it + 2 : it + 1;
                 a0 = *reinterpret_cast<const float4 *>(arow + 8 * nx);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b0[nt] = bq[(2 * nx) * BN + 32 * nt];
