@@ -8,6 +8,7 @@ bench.py's cpu_baseline leg.  Nothing under scanobjectnn_amd/ may import this.
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -27,12 +28,21 @@ def build(force=False):
 
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 def lib():
+    """The restatement library.  Signatures are attached ONCE, under a lock, before the handle is
+    published: bench.py's CPU leg calls these from `cores` threads at once, and a thread that saw
+    the handle before its argtypes (or re-assigned them mid-call, the round-3 race) failed with a
+    ctypes ArgumentError."""
     global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
+    if _lib is not None:
+        return _lib
+    with _load_lock:
+        if _lib is not None:
+            return _lib
+        h = C.CDLL(build())
         I, F = C.c_int, C.c_float
         sig = {
             "oracle_query_ball_point": [I, I, I, F, I, _f32p, _f32p, _i32p, _i32p],
@@ -52,9 +62,10 @@ def lib():
             "oracle_edge_feature": [I, I, I, I, _f32p, _i32p, _f32p],
         }
         for name, argtypes in sig.items():
-            fn = getattr(_lib, name)
+            fn = getattr(h, name)
             fn.argtypes = argtypes
             fn.restype = None
+        _lib = h
     return _lib
 
 
@@ -208,29 +219,38 @@ def get_edge_feature(x, nn_idx, k=20):
 _REF = os.path.join(_HERE, "_ref")
 _REF_LIBS = ("libref_grouping.so", "libref_selsort.so", "libref_interp.so")
 _ref = {}
+_ref_fns = {}
 
 
 def have_ref():
     return all(os.path.exists(os.path.join(_REF, n)) for n in _REF_LIBS)
 
 
-def _reflib(name):
-    if name not in _ref:
-        _ref[name] = C.CDLL(os.path.join(_REF, name))
-    return _ref[name]
-
-
 def _reffn(libname, mangled, argtypes):
-    fn = getattr(_reflib(libname), mangled)
-    fn.argtypes = argtypes
-    fn.restype = None
+    """One function object per symbol, its signature attached once under the load lock (every caller
+    of a symbol passes the same argtypes; re-assigning them per call raced across threads)."""
+    fn = _ref_fns.get(mangled)
+    if fn is not None:
+        return fn
+    with _load_lock:
+        fn = _ref_fns.get(mangled)
+        if fn is None:
+            if libname not in _ref:
+                _ref[libname] = C.CDLL(os.path.join(_REF, libname))
+            fn = getattr(_ref[libname], mangled)
+            fn.argtypes = argtypes
+            fn.restype = None
+            _ref_fns[mangled] = fn
     return fn
 
 
 class _silence_stdout:
     """selection_sort_cpu printf()s from inside the function (selection_sort.cpp:35-48)."""
 
+    _lock = threading.Lock()     # fd 1 is process-wide: one redirection at a time
+
     def __enter__(self):
+        self._lock.acquire()
         C.CDLL(None).fflush(None)
         self._saved = os.dup(1)
         self._null = os.open(os.devnull, os.O_WRONLY)
@@ -241,6 +261,7 @@ class _silence_stdout:
         os.dup2(self._saved, 1)
         os.close(self._null)
         os.close(self._saved)
+        self._lock.release()
 
 
 def ref_query_ball_point(radius, nsample, xyz1, xyz2):
