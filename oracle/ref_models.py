@@ -1,8 +1,9 @@
 """CPU restatement of the model-level callers: PointNet++ SA / SA-MSG
 / FP modules, the SSG / BGA / MSG classifiers, the DGCNN EdgeConv stack and its BGA variant.
 
-TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).  dtype-generic: fp32 tensors give the
-CPU baseline, fp64 tensors the high-precision truth used by the parity tests.  Independent of the product's host
+TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).  dtype- and device-generic: fp32 tensors give the
+CPU baseline, fp64 tensors the high-precision truth used by the parity tests (the bench-size and multi-seed tests
+place the float64 algebra on the GPU -- plain torch ops, the geometry still comes from the C oracle on the host).  Independent of the product's host
 code: geometry comes from the C oracle (oracle/pcops_oracle.c), dense algebra from torch-CPU fp32 ops,
 variables are looked up by the TF scope names of the reference in a plain dict
 (`layer1/conv0/weights`, `layer1/conv0/bn/{beta,gamma,moving_mean,moving_variance}`, `fc1/weights` ...).
@@ -19,6 +20,94 @@ from . import oracle as O
 EPS = 1e-3
 
 
+# ------------------------------------------------------------------------------- discrete decisions
+class Decisions:
+    """The discrete decisions of one evaluation of a network, keyed by the TF scope of the layer:
+         relu[scope] : bool (rows, C)   -- which pre-activations passed the ReLU (rows in (b, point, sample) order)
+         pool[scope] : (arg long (groups, C), active bool (groups, C)) -- for a layer whose output is max-pooled:
+                       the member the maximum was taken from (index along the pooled axis) and whether that member
+                       passed the ReLU.  (The ReLU of the other members of a pooled layer decides nothing: the
+                       maximum of relu(z) is relu of the maximum, and only the arg-max member receives gradient.)
+    A network is a smooth function of its parameters ONCE these are fixed.  An fp32 evaluation whose pre-activation
+    sits within rounding of 0 (or whose two best pool members tie within rounding) can decide differently from a
+    float64 evaluation; that is not an arithmetic error of either, but it moves gradient elements by O(1).  The
+    parity tests therefore evaluate the float64 truth a second time WITH THE DECISIONS THE PATH UNDER TEST TOOK
+    (`imposing(...)`), count and bound the decisions that differ (`report`), and compare against that."""
+
+    def __init__(self):
+        self.relu = {}
+        self.pool = {}
+
+
+_FORCE = None      # Decisions imposed on the run
+_RECORD = None     # Decisions that receives the run's own
+_REPORT = None     # {scope: {...}} how the imposed decisions differ from the run's own
+
+
+class imposing:
+    """with imposing(D=None, record=None, report=None): ref_fn(...)"""
+
+    def __init__(self, decisions=None, record=None, report=None):
+        self.new = (decisions, record, report)
+
+    def __enter__(self):
+        global _FORCE, _RECORD, _REPORT
+        self.old = (_FORCE, _RECORD, _REPORT)
+        _FORCE, _RECORD, _REPORT = self.new
+        return self
+
+    def __exit__(self, *a):
+        global _FORCE, _RECORD, _REPORT
+        _FORCE, _RECORD, _REPORT = self.old
+
+
+def _act(z, scope):
+    """ReLU of the pre-activation z of layer `scope`, with the run's own mask or an imposed one"""
+    if _FORCE is None and _RECORD is None:
+        return torch.relu(z)
+    c = z.shape[-1]
+    own = z.detach() > 0
+    if _RECORD is not None:
+        _RECORD.relu[scope] = own.reshape(-1, c)
+    m = _FORCE.relu.get(scope) if _FORCE is not None else None
+    if m is None:
+        return torch.relu(z)
+    m = m.to(z.device).reshape(z.shape)
+    if _REPORT is not None:
+        dis = m != own
+        n = int(dis.sum())
+        _REPORT[scope] = {"kind": "relu", "elements": own.numel(), "flips": n,
+                          "worst_abs_z": float(z.detach()[dis].abs().max()) if n else 0.0}
+    return z * m.to(z.dtype)
+
+
+def _act_pool(z, scope, dim):
+    """max over axis `dim` of relu(z) for the pooled layer `scope` (z = its pre-activation): the run's own arg-max /
+    activity, or imposed ones"""
+    if _FORCE is None and _RECORD is None:
+        return torch.relu(z).amax(dim=dim)
+    zd = z.detach()
+    own_max, own_arg = zd.max(dim=dim)
+    c = z.shape[-1]
+    if _RECORD is not None:
+        _RECORD.pool[scope] = (own_arg.reshape(-1, c), (own_max > 0).reshape(-1, c))
+    f = _FORCE.pool.get(scope) if _FORCE is not None else None
+    if f is None:
+        return torch.relu(z).amax(dim=dim)
+    arg, active = f[0].to(z.device).reshape(own_arg.shape), f[1].to(z.device).reshape(own_arg.shape)
+    picked = torch.gather(z, dim, arg.unsqueeze(dim)).squeeze(dim)
+    if _REPORT is not None:
+        gap = (own_max - picked.detach())                      # >= 0; 0 for the same member or an exact copy of it
+        live = active | (own_max > 0)
+        other = (gap > 0) & live
+        aflip = active != (own_max > 0)
+        _REPORT[scope] = {"kind": "pool", "elements": own_arg.numel(), "flips": int(other.sum()),
+                          "worst_gap": float(gap[other].max()) if other.any() else 0.0,
+                          "active_flips": int(aflip.sum()),
+                          "worst_abs_z": float(own_max[aflip].abs().max()) if aflip.any() else 0.0}
+    return picked * active.to(z.dtype)
+
+
 def _np(t):
     return t.detach().cpu().numpy()
 
@@ -30,7 +119,7 @@ def _idx(a):
 def batch_gather(x, idx):
     """x (B,N,C), idx (B,...) long -> (B,...,C)"""
     b = x.shape[0]
-    flat = idx.reshape(b, -1)
+    flat = idx.reshape(b, -1).to(x.device)
     out = torch.gather(x, 1, flat.unsqueeze(-1).expand(-1, -1, x.shape[2]))
     return out.reshape(*idx.shape, x.shape[2])
 
@@ -50,15 +139,18 @@ def bn(x, P, scope, training, flavour="contrib"):
     return out.reshape(x.shape)
 
 
-def dense(x, P, scope, training, use_bn=True, act=True, flavour="contrib"):
-    """1x1 conv / conv1d(1) / fully_connected: X·W + b -> BN -> ReLU (tf_util.py:120-185,327-363)"""
+def dense(x, P, scope, training, use_bn=True, act=True, flavour="contrib", pool_dim=None):
+    """1x1 conv / conv1d(1) / fully_connected: X·W + b -> BN -> ReLU (tf_util.py:120-185,327-363);
+    pool_dim: followed by the max over that axis (pointnet_util.py:127, dgcnn.py:47,84)"""
     w = P[scope + "/weights"]
     w = w.reshape(-1, w.shape[-1])
     out = x.reshape(-1, x.shape[-1]) @ w + P[scope + "/biases"]
     out = out.reshape(*x.shape[:-1], w.shape[-1])
     if use_bn:
         out = bn(out, P, scope + "/bn", training, flavour)
-    return torch.relu(out) if act else out
+    if pool_dim is not None:
+        return _act_pool(out, scope, pool_dim)
+    return _act(out, scope) if act else out
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, use_xyz=True):
@@ -78,13 +170,13 @@ def sa_module(xyz, points, npoint, radius, nsample, mlp, P, scope, training, gro
     """pointnet2/utils/pointnet_util.py:87-154 (pooling='max', mlp2=None)"""
     if group_all:
         b = xyz.shape[0]
-        new_xyz = torch.zeros((b, 1, 3), dtype=xyz.dtype)
+        new_xyz = torch.zeros((b, 1, 3), dtype=xyz.dtype, device=xyz.device)
         new_points = (xyz if points is None else torch.cat([xyz, points], 2)).unsqueeze(1)
     else:
         new_xyz, new_points, _ = sample_and_group(npoint, radius, nsample, xyz, points)
     for i in range(len(mlp)):
-        new_points = dense(new_points, P, "%s/conv%d" % (scope, i), training)
-    return new_xyz, new_points.amax(dim=2)
+        new_points = dense(new_points, P, "%s/conv%d" % (scope, i), training, pool_dim=2 if i == len(mlp) - 1 else None)
+    return new_xyz, new_points
 
 
 def sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, P, scope, training):
@@ -98,15 +190,15 @@ def sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, P, s
         if points is not None:
             g = torch.cat([batch_gather(points, idx), g], -1)
         for j in range(len(mlp_list[i])):
-            g = dense(g, P, "%s/conv%d_%d" % (scope, i, j), training)
-        outs.append(g.amax(dim=2))
+            g = dense(g, P, "%s/conv%d_%d" % (scope, i, j), training, pool_dim=2 if j == len(mlp_list[i]) - 1 else None)
+        outs.append(g)
     return new_xyz, torch.cat(outs, -1)
 
 
 def fp_module(xyz1, xyz2, points1, points2, mlp, P, scope, training):
     """pointnet2/utils/pointnet_util.py:199-229"""
     dist, idx = O.three_nn(_np(xyz1), _np(xyz2))
-    dist = torch.clamp_min(torch.from_numpy(dist).to(points2.dtype), 1e-10)
+    dist = torch.clamp_min(torch.from_numpy(dist).to(points2), 1e-10)
     inv = 1.0 / dist
     w = inv / inv.sum(dim=2, keepdim=True)
     nb = batch_gather(points2, _idx(idx))                     # (B,n,3,C)
@@ -185,25 +277,25 @@ def _dgcnn_backbone(point_cloud, P, training, k=20, nn_list=None):
     nn_list = list(nn_list) if nn_list is not None else [None] * 5
     ef = _edge_features(point_cloud, k, nn_list[0])
     t = dense(ef, P, "transform_net1/tconv1", training, flavour="moments")
-    t = dense(t, P, "transform_net1/tconv2", training, flavour="moments").amax(dim=2, keepdim=True)
-    t = dense(t, P, "transform_net1/tconv3", training, flavour="moments").amax(dim=1).reshape(b, -1)
+    t = dense(t, P, "transform_net1/tconv2", training, flavour="moments", pool_dim=2).unsqueeze(2)
+    t = dense(t, P, "transform_net1/tconv3", training, flavour="moments", pool_dim=1).reshape(b, -1)
     t = dense(t, P, "transform_net1/tfc1", training, flavour="moments")
     t = dense(t, P, "transform_net1/tfc2", training, flavour="moments")
     tr = t @ P["transform_net1/transform_XYZ/weights"] + (P["transform_net1/transform_XYZ/biases"]
-                                                          + torch.eye(3, dtype=t.dtype).flatten())
+                                                          + torch.eye(3, dtype=t.dtype, device=t.device).flatten())
     x = point_cloud @ tr.reshape(b, 3, 3)
     nets = []
     for li, scope in enumerate(("dgcnn1", "dgcnn2", "dgcnn3", "dgcnn4")):
-        x = dense(_edge_features(x, k, nn_list[li + 1]), P, scope, training, flavour="moments").amax(dim=2)
+        x = dense(_edge_features(x, k, nn_list[li + 1]), P, scope, training, flavour="moments", pool_dim=2)
         nets.append(x)
-    agg = dense(torch.cat(nets, -1), P, "agg", training, flavour="moments")       # (B,N,1024)
-    return nets, agg
+    out_max = dense(torch.cat(nets, -1), P, "agg", training, flavour="moments", pool_dim=1)   # max over the points of (B,N,1024)
+    return nets, out_max
 
 
 def dgcnn(point_cloud, P, training, nn_list=None):
     """dgcnn/models/dgcnn.py:24-102"""
-    _, agg = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
-    net = dense(agg.amax(dim=1), P, "fc1", training, flavour="moments")
+    _, out_max = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
+    net = dense(out_max, P, "fc1", training, flavour="moments")
     net = dense(net, P, "fc2", training, flavour="moments")
     return dense(net, P, "fc3", training, use_bn=False, act=False)
 
@@ -211,8 +303,7 @@ def dgcnn(point_cloud, P, training, nn_list=None):
 def dgcnn_bga(point_cloud, P, training, nn_list=None):
     """dgcnn/models/dgcnn_bga.py:27-134 -> (class_pred, seg_pred)"""
     b, n, _ = point_cloud.shape
-    nets, agg = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
-    out_max = agg.amax(dim=1)
+    nets, out_max = _dgcnn_backbone(point_cloud, P, training, nn_list=nn_list)
     net = dense(out_max, P, "fc1", training, flavour="moments")
     fc2 = dense(net, P, "fc2", training, flavour="moments")
     class_pred = dense(fc2, P, "fc3", training, use_bn=False, act=False)
@@ -256,11 +347,11 @@ def spidercnn_cls_xyz(point_cloud, P, training):
     return dense(net, P, "fc3", training, use_bn=False, act=False)
 
 
-def params_from_state_dict(sd, prefix="graph.", dtype=torch.float32):
+def params_from_state_dict(sd, prefix="graph.", dtype=torch.float32, device="cpu"):
     """product Model.state_dict() -> {tf_scope_name: cpu tensor}.  dtype=torch.float64 gives the
     high-precision "truth" the fp32 paths are judged against (every function here follows its inputs'
     dtype; the geometry oracle always sees the fp32 coordinates, which doubles hold exactly)."""
-    return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().cpu().to(dtype).clone()
+    return {k[len(prefix):] if k.startswith(prefix) else k: v.detach().to(device=device, dtype=dtype).clone()
             for k, v in sd.items()}
 
 
@@ -272,7 +363,7 @@ def _tnet(x, P, scope, training, head, k_out):
     t = dense(t, P, scope + "/tconv3", training).amax(dim=1)
     t = dense(t, P, scope + "/tfc1", training)
     t = dense(t, P, scope + "/tfc2", training)
-    out = t @ P["%s/%s/weights" % (scope, head)] + (P["%s/%s/biases" % (scope, head)] + torch.eye(k_out, dtype=t.dtype).flatten())
+    out = t @ P["%s/%s/weights" % (scope, head)] + (P["%s/%s/biases" % (scope, head)] + torch.eye(k_out, dtype=t.dtype, device=t.device).flatten())
     return out.reshape(x.shape[0], k_out, k_out)
 
 

@@ -217,6 +217,8 @@ class FusedMLPStack(torch.autograd.Function):
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
             ctx.rows = rows
             ctx.pool_top = pool_top
+            if TRACE is not None:
+                TRACE.append(ctx)
         return out
 
     @staticmethod
@@ -590,6 +592,8 @@ class EdgeConvPool(torch.autograd.Function):
         if training or need_grad:
             ctx.saved = (Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift)
             ctx.flags = (bool(training), bool(sync))
+            if TRACE is not None:
+                TRACE.append(ctx)
         return out
 
     @staticmethod
@@ -660,6 +664,10 @@ def mlp_stack(x, S, pool, training, decay, eps, unbiased, layer_tensors):
                                *_flat(layer_tensors, False))
 
 
+# Debug hook of the parity tests (tests/decisions.py): a list that receives the autograd node of every fused stack in
+# forward order, so that the discrete decisions the kernels took (ReLU masks from the raw layer outputs and BN
+# coefficients the node keeps anyway, arg-max rows of the pooled layer) can be read back.  None: nothing is recorded.
+TRACE = None
 STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)

@@ -21,9 +21,24 @@ def fused_pattern(out):
     while node is not None and not hasattr(node, "saved"):
         node = node.next_functions[0][0] if node.next_functions else None
     assert node is not None, "no fused-stack node behind this tensor"
+    return node_pattern(node)
+
+
+def _fma32(a, b, c):
+    """fp32 fused multiply-add of fp32 tensors, via float64: the product is exact, the sum is rounded to 53 bits and
+    then to 24 -- equal to the single rounding of a hardware FMA except on double-rounding ties (probability 2^-29
+    per element, and then one ulp)"""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def node_pattern(node, virtual_first_layer=False):
+    """fused_pattern() of a given FusedMLPStack / EdgeConvPool autograd node.  virtual_first_layer: also rebuild the
+    mask of an arithmetic first layer that is never stored (fused_mlp `virt`: y = fma(dz, w2, fma(dy, w1, fma(dx, w0,
+    b))) from the centred offsets the node keeps -- csrc/mlp.hip xyz_y) instead of returning None for it."""
     if len(node.saved) == 11:           # EdgeConvPool: ONE pooled layer, only the arg-max row is a discrete decision
         return [None], node.saved[5]
     Ys, scales, shifts, argmax = node.saved[7], node.saved[10], node.saved[11], node.saved[14]
+    off4, xyzw = node.saved[16], node.saved[17]
     expand = None
     rows = getattr(node, "rows", None)
     if rows is not None:
@@ -38,8 +53,18 @@ def fused_pattern(out):
         s_ar = torch.arange(S, device=idx.device).view(1, S)
         expand = (first.view(-1, 1) + torch.where(s_ar < nrow.view(-1, 1), s_ar, torch.zeros_like(s_ar))).reshape(-1)
     masks = []
-    for Y, sc, sh in zip(Ys, scales, shifts):
-        if Y is None:
+    for li, (Y, sc, sh) in enumerate(zip(Ys, scales, shifts)):
+        if Y is None and li == 0 and off4 is not None and virtual_first_layer:
+            n = xyzw.shape[1]
+            m = torch.empty((off4.shape[0], n), dtype=torch.bool, device=off4.device)
+            w0, w1, w2, b = (xyzw[i].view(1, n) for i in range(4))
+            step = max(1, (1 << 24) // n)
+            for r0 in range(0, off4.shape[0], step):
+                o = off4[r0:r0 + step]
+                y = _fma32(o[:, 2:3], w2, _fma32(o[:, 1:2], w1, _fma32(o[:, 0:1], w0, b)))
+                m[r0:r0 + step] = (y.double() * sc[:n].double() + sh[:n].double()) > 0
+            masks.append(m if expand is None else m[expand])
+        elif Y is None:
             masks.append(None)
         else:
             # the kernels decide with ONE fused multiply-add, fmaf(y, scale, shift) > 0.  In float64 the product of
@@ -138,3 +163,145 @@ def assert_grads_close(names, got, want, plain, rel=1e-3, floor_scale=None):
         err = (a.double() - b).abs().max().item()
         err_plain = (c.double() - b).abs().max().item()
         assert err <= max(rel * scale + 1e-6, 1.5 * err_plain), (name, err, err_plain, scale)
+
+
+def chunked_gather_stack(src, idx, layers, pool, go, pattern=None, dtype=torch.float64, clouds_per_chunk=8,
+                         report=None):
+    """Reference of a TRAINING-mode gather-first stack -- forward output and every gradient -- for row counts whose
+    autograd graph does not fit (DGCNN's T-Net at the benchmark size: 10.5 M rows; MSG SA1: 16.7 M rows, float64
+    activations of 8-17 GB per layer): the rows are visited in chunks of whole clouds, every chunk recomputes its
+    activations, batch-norm statistics and all reductions are accumulated across chunks, and the backward is written
+    out by hand:
+        zhat = (y - mean) rstd,  z = gamma zhat + beta,  a = mask . z
+        dz = da . mask,  dgamma = sum dz zhat,  dbeta = sum dz,  dy = gamma rstd (dz - dbeta / R - zhat dgamma / R)
+        dW_l = a_(l-1)^T dy_l,  db_l = sum dy_l,  da_(l-1) = dy_l W_l^T
+    dy of a layer needs the FULL-batch dgamma / dbeta of that layer, so the backward takes L + 1 passes over the chunks
+    (pass p finishes the sums of layer p and, with them known, the weight gradient of layer p + 1).
+    src: Q (B,N,C1) | Ctr (B,M,C1) | xyz (B,N,3) + new_xyz (B,M,3) + wxyz (3,C1) | bias (C1), each optional;
+    idx (B,M,S); layers as in run_stack (layer 0 supplies only its BN variables); go: upstream gradient, (B*M, C_L) if
+    pool else (B*M*S, C_L); pattern = (masks, argmax) imposes the activation pattern (masks[l] None: the run's own).
+    report (a dict) receives how far the imposed decisions are from this run's own, as in run_stack.
+    Validated against autograd (run_stack) by tests/test_mlp_ref_cpu.py.
+    -> (out, grads) with grads ordered [dQ, dCtr, dwxyz, dbias (those present)] + per layer [gamma, beta] for layer 0
+    and [W, b, gamma, beta] above -- the order of test_fused_mlp_gpu._gather_backward_check."""
+    B, M, S = idx.shape
+    L, R = len(layers), B * M * S
+    dev = idx.device
+    masks, argmax = pattern if pattern is not None else (None, None)
+    W = [l[0].to(dtype) for l in layers]
+    b = [l[1].to(dtype) for l in layers]
+    gam = [l[2].to(dtype) for l in layers]
+    bet = [l[3].to(dtype) for l in layers]
+    C = [g.shape[0] for g in gam]
+    mean, rstd = [None] * L, [None] * L
+    per_cloud = ("Q", "Ctr", "xyz", "new_xyz")
+    rep = {"relu_flips": 0, "worst_relu": 0.0, "worst_pool": 0.0, "pass": None} if report is not None else None
+    chunks = [(b0, min(B, b0 + clouds_per_chunk)) for b0 in range(0, B, clouds_per_chunk)]
+
+    def forward(b0, b1, upto):
+        r0, r1 = b0 * M * S, b1 * M * S
+        s = {k: (v[b0:b1] if (v is not None and k in per_cloud) else v) for k, v in src.items()}
+        ys, zh, ms, acts = [], [], [], []
+        a = None
+        for l in range(upto + 1):
+            y = (gather_first_layer(s["Q"], s["Ctr"], s["xyz"], s["new_xyz"], s["wxyz"], s["bias"], idx[b0:b1], dtype)
+                 if l == 0 else a @ W[l] + b[l])
+            ys.append(y)
+            if mean[l] is None:
+                break                                   # this layer's statistics are what the caller is collecting
+            zhat = (y - mean[l]) * rstd[l]
+            z = zhat * gam[l] + bet[l]
+            if masks is not None and masks[l] is not None and not (pool and l == L - 1):
+                m = masks[l][r0:r1]
+                if rep is not None and upto == L - 1 and rep["pass"] == L - 1:
+                    dis = m != (z > 0)
+                    n = int(dis.sum())
+                    rep["relu_flips"] += n
+                    if n:
+                        rep["worst_relu"] = max(rep["worst_relu"], z[dis].abs().max().item())
+            else:
+                m = z > 0
+            a = z * m.to(dtype)
+            zh.append(zhat)
+            ms.append(m)
+            acts.append(a)
+        return ys, zh, ms, acts
+
+    for l in range(L):                                  # statistics, layer by layer (shifted by the first chunk's mean)
+        s1 = torch.zeros(C[l], dtype=torch.float64, device=dev)
+        s2 = torch.zeros(C[l], dtype=torch.float64, device=dev)
+        piv = None
+        for b0, b1 in chunks:
+            y = forward(b0, b1, l)[0][l].double()
+            if piv is None:
+                piv = y.mean(dim=0)
+            d = y - piv
+            s1 += d.sum(dim=0)
+            s2 += (d * d).sum(dim=0)
+        m1 = s1 / R
+        mean[l] = (piv + m1).to(dtype)
+        rstd[l] = torch.rsqrt(s2 / R - m1 * m1 + EPS).to(dtype)
+
+    G = B * M
+    out = torch.empty((G if pool else R, C[-1]), dtype=dtype, device=dev)
+    dgam = [torch.zeros(c, dtype=dtype, device=dev) for c in C]
+    dbet = [torch.zeros(c, dtype=dtype, device=dev) for c in C]
+    dW = [None] + [torch.zeros_like(W[l]) for l in range(1, L)]
+    db = [None] + [torch.zeros_like(b[l]) for l in range(1, L)]
+    C1 = C[0]
+    d_first = {"Q": torch.zeros(src["Q"].shape, dtype=dtype, device=dev) if src["Q"] is not None else None,
+               "Ctr": torch.zeros(src["Ctr"].shape, dtype=dtype, device=dev) if src["Ctr"] is not None else None,
+               "wxyz": torch.zeros((3, C1), dtype=dtype, device=dev) if src["wxyz"] is not None else None,
+               "bias": torch.zeros(C1, dtype=dtype, device=dev) if src["bias"] is not None else None}
+    for p in range(L - 1, -2, -1):
+        if rep is not None:
+            rep["pass"] = p
+        for b0, b1 in chunks:
+            nb = b1 - b0
+            r0, r1, g0, g1 = b0 * M * S, b1 * M * S, b0 * M, b1 * M
+            ys, zh, ms, acts = forward(b0, b1, L - 1)
+            if pool:
+                a3 = acts[-1].view(nb * M, S, C[-1])
+                arg = (argmax[g0:g1].long() if argmax is not None else a3.argmax(dim=1)).unsqueeze(1)
+                if p == L - 1:
+                    out[g0:g1] = torch.gather(a3, 1, arg).squeeze(1)
+                    if rep is not None and argmax is not None:
+                        rep["worst_pool"] = max(rep["worst_pool"], (a3.amax(dim=1) - out[g0:g1]).abs().max().item())
+                da = torch.zeros_like(a3).scatter_(1, arg, go[g0:g1].to(dtype).unsqueeze(1)).view(-1, C[-1])
+            else:
+                if p == L - 1:
+                    out[r0:r1] = acts[-1]
+                da = go[r0:r1].to(dtype)
+            for l in range(L - 1, max(p, 0) - 1, -1):
+                dz = da * ms[l].to(dtype)
+                if l == p:
+                    dgam[l] += (dz * zh[l]).sum(dim=0)
+                    dbet[l] += dz.sum(dim=0)
+                    break
+                dy = (gam[l] * rstd[l]) * (dz - dbet[l] / R - zh[l] * (dgam[l] / R))
+                if l == 0:                              # (p == -1) the gather form's own gradients
+                    if d_first["bias"] is not None:
+                        d_first["bias"] += dy.sum(dim=0)
+                    if d_first["Ctr"] is not None:
+                        d_first["Ctr"][b0:b1] = dy.view(nb, M, S, C1).sum(dim=2)
+                    ii = idx[b0:b1].long().reshape(nb, M * S, 1)
+                    if d_first["wxyz"] is not None:
+                        off = (torch.gather(src["xyz"][b0:b1].to(dtype), 1, ii.expand(-1, -1, 3)).view(nb, M, S, 3)
+                               - src["new_xyz"][b0:b1].to(dtype).unsqueeze(2))
+                        d_first["wxyz"] += off.reshape(-1, 3).t() @ dy
+                    if d_first["Q"] is not None:
+                        d_first["Q"][b0:b1].scatter_add_(1, ii.expand(-1, -1, C1), dy.view(nb, M * S, C1))
+                    break
+                if l == p + 1:
+                    dW[l] += acts[l - 1].t() @ dy
+                    db[l] += dy.sum(dim=0)
+                da = dy @ W[l].t()
+            del ys, zh, ms, acts, da
+    grads = [d_first[k] for k in ("Q", "Ctr", "wxyz", "bias") if d_first[k] is not None]
+    for l in range(L):
+        if l > 0:
+            grads += [dW[l], db[l]]
+        grads += [dgam[l], dbet[l]]
+    if report is not None:
+        report.update({k: rep[k] for k in ("relu_flips", "worst_relu", "worst_pool")})
+    return out, [g.double() for g in grads]

@@ -6,10 +6,14 @@ different summation orders can legitimately sit 2e-4 apart through a dozen batch
 judged against the truth, not against the other.  Gradients of the training loss agree to 5e-3 of the
 gradient's max (weight gradients behind a batch norm are heavily cancelling sums).
 """
+import os
+import statistics
+
 import numpy as np
 import pytest
 import torch
 
+import decisions as DEC
 from oracle import oracle as O
 from oracle import ref_models as R
 from scanobjectnn_amd.graph import Model
@@ -18,29 +22,18 @@ from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-4
-# Round 3: no slack factor.  The floor an fp32 evaluation of these nets sits on is MEASURED three ways against the same
-# float64 truth -- (a) the layer-by-layer product path on the GPU (library GEMM + torch batch norm), (b) the fp32 CPU
-# restatement, (c) the REALISATION NOISE of the fused path itself: the same fused kernels evaluated a second time in an
-# arithmetically equivalent but bitwise different way (batch-norm statistics with and without the pivot shift of
-# include/pcops.h -- tools/diag_pivot_kernels.py: identical accuracy, 3e-7, on every kernel-level case) -- and the fused
-# path has to be no further from the truth than the largest of the three: an fp32 path cannot be asked to be closer to
-# float64 than two equivalent fp32 evaluations of ITSELF are to each other.  What (c) absorbs is discrete decisions (a
-# ReLU within rounding of 0, an arg-max tie, a 20th-nearest-neighbour tie): tools/diag_grad_repeat.py shows the model-level
-# error of one path / seed flipping between 1.6e-5 and 2.2e-3 with the pivot off / on while the plain path sits at 1.8e-5,
-# and tools/diag_grad_parity.py the fused : plain ratio ranging over 0.2 ... 120 from seed to seed in BOTH directions.
-# A systematic defect of the fused arithmetic is common to both realisations, does not show in (c), and fails.
-FLOOR_SPREAD = 1.0
-
-
-def _other_realisation(fn):
-    """run fn() with the fused path's batch-norm statistics evaluated without the pivot shift"""
-    from scanobjectnn_amd import fused_mlp
-    keep = fused_mlp.STAT_PIVOT
-    fused_mlp.STAT_PIVOT = not keep
-    try:
-        return fn()
-    finally:
-        fused_mlp.STAT_PIVOT = keep
+# Round 4: NO tolerance is derived from the fused path itself any more.  An fp32 evaluation of these
+# nets differs from float64 in two ways: (i) rounding of the arithmetic, and (ii) a handful of DISCRETE decisions that sit
+# within rounding of a tie (a ReLU at 1e-7, two pool members 5e-7 apart) and fall the other way -- each moves whole
+# gradient rows by O(1), a different handful in every path and for every seed.  (ii) is not an error of the arithmetic,
+# and instead of being absorbed into a tolerance it is now REMOVED: tests/decisions.py reads back the decisions each
+# path took (fused kernels: from the raw layer outputs / BN coefficients / arg-max rows the autograd nodes keep;
+# layer-by-layer path: from its relu / amax calls), oracle/ref_models.py evaluates the float64 truth WITH those decisions,
+# every decision that differs from the float64 run's own is counted and checked to be a rounding-level tie, and what
+# remains -- pure arithmetic error -- is compared between the fused path and the plain fp32 paths.
+TIE = 2e-4          # |float64 pre-activation| of a flipped ReLU / gap of a flipped pool member: rounding level (2 x TOL)
+GRAD_RESOLUTION = 2e-5   # relative Frobenius error below which two fp32 evaluations of these gradients are not separable
+SEEDS = [int(v) for v in os.environ.get("PCOPS_PARITY_SEEDS", "21,22,23,24,25,26,27,28").split(",")]
 
 
 def _randomise(net, seed):
@@ -71,7 +64,6 @@ def _randomise(net, seed):
 def _record(key, err, floor, **more):
     """keep the measured numbers next to the other GPU artefacts (gpurun_out/ is merged back by gpurun)"""
     import json
-    import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(path, exist_ok=True)
@@ -83,47 +75,54 @@ def _record(key, err, floor, **more):
         pass
 
 
-def _fp32_floor(net, sd, x, c, training, pick, ref_fn, truth, monkeypatch, fused=None):
-    """error of PLAIN fp32 implementations of the same net against the float64 truth: the layer-by-layer product path
-    (PCOPS_FUSED_MLP off: library GEMM + torch batch norm) on the GPU, and the fp32 CPU restatement; fused (the fused
-    path's own output): + its distance to a second, equivalent realisation of the fused path (see FLOOR_SPREAD).  The
-    largest is the floor an fp32 implementation of this net sits on.  Returns (floor, parts)."""
+def _masked_logit_errors(net, sd, x, c, pick, ref_fn, monkeypatch, fused, D_fused):
+    """Training-mode logits of the SAME net through three fp32 paths -- the fused kernels (`fused`, decisions
+    `D_fused`), the layer-by-layer product path on the GPU (library GEMM + torch batch norm) and the fp32 CPU
+    restatement -- each against the float64 truth evaluated (a) on its own decisions (`err`) and (b) WITH THE
+    DECISIONS THAT PATH TOOK (`masked`: what is left is the path's arithmetic), plus the count of decisions that differ
+    and the proof that each is a rounding-level tie.  -> {path: {...}}"""
     from scanobjectnn_amd.pointnet2 import tf_util as t2
     rms = lambda t: float(t.double().pow(2).mean().sqrt())   # noqa: E731
-    e_self = r_self = 0.0
-    if fused is not None and training:
-        def again():
-            net.load_state_dict(sd)
-            with torch.no_grad():
-                return pick(net(x, is_training=training, bn_decay=0.9))
-        d_self = _other_realisation(again).double() - fused.double()
-        e_self, r_self = d_self.abs().max().item(), rms(d_self)
+    P64 = R.params_from_state_dict(sd, dtype=torch.float64, device=DEV)    # float64 torch algebra on the GPU, C-oracle geometry
+    x64 = torch.from_numpy(c).double().to(DEV)
+    with torch.no_grad():
+        own = pick(ref_fn(x64, P64, True))
+
+    def against_truth(out, D):
+        rep = {}
+        with torch.no_grad(), R.imposing(D, None, rep):
+            forced = pick(ref_fn(x64, P64, True))
+        d_own, d_forced = out.to(own.device).double() - own, out.to(own.device).double() - forced
+        return dict(err=d_own.abs().max().item(), rms=rms(d_own), masked=d_forced.abs().max().item(),
+                    masked_rms=rms(d_forced), flips=DEC.summarise(rep, TIE))
+
+    res = {"fused": against_truth(fused, D_fused)}
+    rec = DEC.Recorder(net, DEV)
     monkeypatch.setattr(t2, "FUSED_MLP", False)
     net.load_state_dict(sd)
-    with torch.no_grad():
-        plain = pick(net(x, is_training=training, bn_decay=0.9))
+    with torch.no_grad(), rec.recording():
+        plain = pick(net(x, is_training=True, bn_decay=0.9))
     monkeypatch.setattr(t2, "FUSED_MLP", True)
     net.load_state_dict(sd)
-    e_gpu = (plain.cpu().double() - truth).abs().max().item()
+    res["gpu_layerwise"] = against_truth(plain, rec.decisions())
     P32 = R.params_from_state_dict(sd, dtype=torch.float32)
-    with torch.no_grad():
-        cpu = pick(ref_fn()(torch.from_numpy(c), P32, training))
-    e_cpu = (cpu.double() - truth).abs().max().item()
-    parts = {"gpu_layerwise": e_gpu, "cpu_fp32": e_cpu, "fused_realisations": e_self,
-             "rms_gpu_layerwise": rms(plain.cpu().double() - truth), "rms_cpu_fp32": rms(cpu.double() - truth),
-             "rms_fused_realisations": r_self}
-    if fused is not None:
-        parts["rms_fused"] = rms(fused.cpu().double() - truth)
-    parts["rms_floor"] = max(parts["rms_gpu_layerwise"], parts["rms_cpu_fp32"], r_self)
-    return max(e_gpu, e_cpu, e_self), parts
+    D32 = R.Decisions()
+    with torch.no_grad(), R.imposing(None, D32, None):
+        cpu = pick(ref_fn(torch.from_numpy(c), P32, True))
+    res["cpu_fp32"] = against_truth(cpu, D32)
+    return res
 
 
-def _no_worse_than_fp32(err, floor, parts):
-    """the fused path against the measured fp32 floor of the same net, without a slack factor: its LARGEST error over the
-    ~1e5 outputs is within the largest error of the plain evaluations, or -- the maximum of 1e5 rounding errors is a
-    heavy-tailed statistic that moves 20 % from one fp32 evaluation to the next -- its ROOT-MEAN-SQUARE error is within
-    theirs; and in no case further than twice the eval-mode bar"""
-    return (err <= max(TOL, FLOOR_SPREAD * floor) or parts["rms_fused"] <= FLOOR_SPREAD * parts["rms_floor"]) and err <= 2 * TOL
+def _assert_train_logits(key, res):
+    """Training-mode per-point logits (17 batch-normalised layers deep): the bar is max(1e-4, the plain fp32 floor)
+    and nothing else -- every path judged on the truth with ITS OWN decisions, so that a flipped ReLU in one of them
+    is not mistaken for arithmetic; the floor is the worse of the two plain fp32 evaluations of the same net."""
+    floor = max(res["gpu_layerwise"]["masked"], res["cpu_fp32"]["masked"])
+    _record(key, res["fused"]["err"], floor, **res)
+    for path, r in res.items():
+        assert r["flips"]["all_ties"], (path, r["flips"])         # every decision that differs is a rounding-level tie
+    assert res["fused"]["masked"] <= max(TOL, floor), res
+    assert res["fused"]["err"] <= 2 * TOL, res                      # and, flips included, never beyond twice the bar
 
 
 def _no_dropout(monkeypatch):
@@ -161,19 +160,27 @@ def test_pointnet2_bga_logits_and_mask(training, monkeypatch):
     _randomise(net, 6)
     P = R.params_from_state_dict(net.state_dict(), dtype=torch.float64)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
+    rec = DEC.Recorder(net, DEV)
+    if training:        # grad mode: the fused nodes only keep what a backward needs, and the decisions are read from that
+        with torch.enable_grad(), rec.recording():
+            cls, seg = net(x, is_training=True, bn_decay=0.9)
+        D_fused = rec.decisions()
+    else:
+        with torch.no_grad():
+            cls, seg = net(x, is_training=False, bn_decay=0.9)
+    cls, seg = cls.detach(), seg.detach()
     with torch.no_grad():
-        cls, seg = net(x, is_training=training, bn_decay=0.9)
         wc, ws = R.pointnet2_cls_bga(torch.from_numpy(c).double(), P, training)
     err_cls = (cls.cpu().double() - wc).abs().max().item()
     err_seg = (seg.cpu().double() - ws).abs().max().item()
     assert err_cls <= TOL
-    # eval mode (what evaluate_*.py runs) holds the 1e-4 bar outright.  With batch statistics the 17 batch-normalised
-    # layers of the mask branch amplify fp32 rounding; the bar is then the MEASURED fp32 floor of this very net:
-    # the same weights through (a) the layer-by-layer path (library GEMM + torch batch norm, no fused kernel) on the
-    # GPU and (b) the fp32 CPU restatement, each judged against the float64 truth
-    floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o[1], lambda: R.pointnet2_cls_bga, ws, monkeypatch, seg)
-    _record("bga_mask_%s" % ("train" if training else "eval"), err_seg, floor, **parts)
-    assert (_no_worse_than_fp32(err_seg, floor, parts) if training else err_seg <= TOL), (err_seg, floor, parts)
+    if not training:
+        assert err_seg <= TOL           # eval mode (what evaluate_*.py runs) holds the 1e-4 bar outright
+        return
+    # With batch statistics the 17 batch-normalised layers of the mask branch amplify fp32 rounding: the bar is
+    # max(1e-4, the MEASURED floor of plain fp32 evaluations of this very net), flipped decisions taken out on every side
+    res = _masked_logit_errors(net, sd, x, c, lambda o: o[1], R.pointnet2_cls_bga, monkeypatch, seg, D_fused)
+    _assert_train_logits("bga_mask_train", res)
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -188,14 +195,24 @@ def test_pointnet2_partseg_logits(training, monkeypatch):
     _randomise(net, 10)
     P = R.params_from_state_dict(net.state_dict(), dtype=torch.float64)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
+    rec = DEC.Recorder(net, DEV)
+    if training:
+        with torch.enable_grad(), rec.recording():
+            seg = net(x, is_training=True, bn_decay=0.9)
+        D_fused = rec.decisions()
+    else:
+        with torch.no_grad():
+            seg = net(x, is_training=False, bn_decay=0.9)
+    seg = seg.detach()
     with torch.no_grad():
-        seg = net(x, is_training=training, bn_decay=0.9)
         want = R.pointnet2_cls_partseg(torch.from_numpy(c).double(), P, training)
     assert seg.shape == (16, 1024, 6)
     err = (seg.cpu().double() - want).abs().max().item()
-    floor, parts = _fp32_floor(net, sd, x, c, training, lambda o: o, lambda: R.pointnet2_cls_partseg, want, monkeypatch, seg)
-    _record("partseg_%s" % ("train" if training else "eval"), err, floor, **parts)
-    assert (_no_worse_than_fp32(err, floor, parts) if training else err <= TOL), (err, floor, parts)   # as the BGA mask branch
+    if not training:
+        assert err <= TOL
+        return
+    res = _masked_logit_errors(net, sd, x, c, lambda o: o, R.pointnet2_cls_partseg, monkeypatch, seg, D_fused)
+    _assert_train_logits("partseg_train", res)                      # as the BGA mask branch
 
 
 def test_pointnet2_ssg_training_gradients(monkeypatch):
@@ -275,21 +292,16 @@ def test_dgcnn_logits(name, training, monkeypatch):
 
 # ---------------------------------------------------------------------------------------------------------------
 # model-level GRADIENT parity for every in-scope model (training mode, batch statistics, dropout off)
-def _grad_errors(net, P):
-    """per-tensor and global relative Frobenius error of the product gradients against the float64 restatement's.
-    Frobenius, not max: one ReLU landing on the other side of 0 than in float64 moves a single gradient element by
-    O(1) in ANY fp32 implementation (see test_pointnet2_ssg_training_gradients)."""
-    names = dict(net.named_parameters())
+def _grad_errors(got, want):
+    """global relative Frobenius error of a {name: gradient} dict against the float64 restatement's, and the worst
+    tensor.  Biases in front of a batch norm (analytically zero gradient) are left out."""
     num = den = 0.0
     worst = ("", 0.0)
-    for name, p in net.named_parameters():
-        ref = P[name[len("graph."):]].grad
-        if ref is None:
-            ref = torch.zeros_like(P[name[len("graph."):]])
-        if name.endswith("biases") and name[:-len("biases")] + "bn/gamma" in names:
-            continue          # bias in front of a batch norm: analytically zero gradient
-        got = p.grad if p.grad is not None else torch.zeros_like(p)
-        e = (got.cpu().double() - ref).norm().item()
+    for name, g in got.items():
+        ref = want[name]
+        if name.endswith("biases") and name[:-len("biases")] + "bn/gamma" in got:
+            continue
+        e = (g.to(ref.device).double() - ref).norm().item()
         r = ref.norm().item()
         if r < 1e-9:
             assert e < 1e-5, (name, e, r)
@@ -304,94 +316,123 @@ def _grad_errors(net, P):
 GRAD_MODELS = ["bga", "msg", "dgcnn", "dgcnn_bga"]
 
 
-@pytest.mark.parametrize("name", GRAD_MODELS)
-def test_model_training_gradients(name, monkeypatch):
-    """d(loss)/d(every variable) of pointnet2_cls_bga / pointnet2_cls_msg / dgcnn / dgcnn_bga against the float64
-    restatement, and against the measured floor: the SAME model through the layer-by-layer path (library GEMM +
-    torch batch norm) is judged against the same truth, and the fused path must not be further away than that."""
+def _grad_case(name, seed, monkeypatch):
+    """one (model, seed): gradients of the training loss through the fused kernels and through the layer-by-layer path,
+    each against the float64 truth on its own decisions (`e_*`) and against the float64 truth evaluated WITH THE
+    DECISIONS THAT PATH TOOK (`em_*`), and what those decisions were"""
     from scanobjectnn_amd.dgcnn import dgcnn, dgcnn_bga
     from scanobjectnn_amd.dgcnn import tf_util as td
     from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga, pointnet2_cls_msg
     from scanobjectnn_amd.pointnet2 import tf_util as t2
-    _no_dropout(monkeypatch)
     mod, ref, n_pts, has_mask = {
         "bga": (pointnet2_cls_bga, R.pointnet2_cls_bga, 1024, True),
         "msg": (pointnet2_cls_msg, R.pointnet2_cls_msg, 1024, False),
         "dgcnn": (dgcnn, R.dgcnn, 256, False),
         "dgcnn_bga": (dgcnn_bga, R.dgcnn_bga, 256, True)}[name]
     B = 16
-    c = synth_clouds(B, n_pts, seed=21)
-    y = torch.from_numpy(synth_labels(B, seed=21))
-    mask = torch.from_numpy(synth_masks(B, n_pts, seed=21)) if has_mask else None
+    c = synth_clouds(B, n_pts, seed=seed)
+    y = torch.from_numpy(synth_labels(B, seed=seed))
+    mask = torch.from_numpy(synth_masks(B, n_pts, seed=seed)) if has_mask else None
     x = torch.from_numpy(c).to(DEV)
-    net = Model(mod.get_model, device=DEV, seed=6).build(x)
-    _randomise(net, 12)
+    net = Model(mod.get_model, device=DEV, seed=seed - 15).build(x)
+    _randomise(net, seed - 9)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-
+    rec = DEC.Recorder(net, DEV)
+    is_dg = name.startswith("dgcnn")
     graphs = []
-    if name.startswith("dgcnn"):
-        real = td.knn_graph
+    real = td.knn_graph
 
-        def recording(point_cloud, k=20, seed=None):
-            nn = real(point_cloud, k=k, seed=seed)
-            graphs.append(nn.cpu().numpy())
-            return nn
-        monkeypatch.setattr(td, "knn_graph", recording)
+    def recording(point_cloud, k=20, seed=None):
+        nn = real(point_cloud, k=k, seed=seed)
+        graphs.append(nn.cpu().numpy())
+        return nn
 
     def product_grads():
         net.load_state_dict(sd)
         net.zero_grad(set_to_none=True)
-        del graphs[:]
-        out = net(x, is_training=True, bn_decay=0.9)
+        with rec.recording():
+            out = net(x, is_training=True, bn_decay=0.9)
         loss = (mod.get_loss(out[0], out[1], y.to(DEV), mask.to(DEV))[0] if has_mask
                 else mod.get_loss(out[0], y.to(DEV)))
         loss.backward()
-        return loss.item()
+        return (loss.item(), rec.decisions(),
+                {k[len("graph."):]: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
 
-    loss_fused = product_grads()
-    P = {k: v.requires_grad_(v.is_floating_point())
-         for k, v in R.params_from_state_dict(sd, dtype=torch.float64).items()}
-    kw = {"nn_list": list(graphs)} if name.startswith("dgcnn") else {}
-    want = ref(torch.from_numpy(c).double(), P, True, **kw)
-    loss_ref = (mod.get_loss(want[0], want[1], y, mask)[0] if has_mask else mod.get_loss(want, y))
-    loss_ref.backward()
-    assert abs(loss_fused - loss_ref.item()) <= 1e-4
-    e_fused, worst_fused = _grad_errors(net, P)
-
-    g_fused = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
-    graphs_fused = list(graphs)
-    # the same fused kernels, second realisation (see FLOOR_SPREAD): how far two equivalent fp32 evaluations of THIS path
-    # are from each other.  (DGCNN: only when both built the same neighbour graphs -- a neighbour tie that falls the other
-    # way is a different network, which the float64 truth above does not describe either)
-    if name.startswith("dgcnn"):
-        # ... on the SAME neighbour graphs: the recorded ones are replayed (a 20th-neighbour tie that falls the other way
-        # in the second realisation would make it a different network, which the float64 truth does not describe either)
-        replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
-        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
-    _other_realisation(product_grads)
-    if name.startswith("dgcnn"):
+    if is_dg:
         monkeypatch.setattr(td, "knn_graph", recording)
-    same_graphs = True
-    num = den = 0.0
-    for k, p in net.named_parameters():
-        if k in g_fused and p.grad is not None and not (k.endswith("biases") and k[:-len("biases")] + "bn/gamma" in g_fused):
-            num += (p.grad - g_fused[k]).double().norm().item() ** 2
-            den += g_fused[k].double().norm().item() ** 2
-    e_self = (num / den) ** 0.5 if same_graphs else 0.0
-    monkeypatch.setattr(t2, "FUSED_MLP", False)       # the layer-by-layer path: the fp32 yardstick
-    if name.startswith("dgcnn"):                      # ... on the graphs the truth was evaluated with
+    loss_fused, D_fused, g_fused = product_grads()
+    graphs_fused = list(graphs)
+    # the layer-by-layer path (library GEMM + torch batch norm): the fp32 yardstick.  DGCNN: on the neighbour graphs of the
+    # fused run (which the truth is evaluated with too -- a 20th-neighbour tie that falls the other way is a different
+    # network; the graphs themselves are bit-exact against the oracle, test_dgcnn_logits / test_knn_gpu.py)
+    monkeypatch.setattr(t2, "FUSED_MLP", False)
+    if is_dg:
         replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
         monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
-    product_grads()
-    e_layer, _ = _grad_errors(net, P)
+    _, D_layer, g_layer = product_grads()
     monkeypatch.setattr(t2, "FUSED_MLP", True)
-    _record("grad_%s" % name, e_fused, max(e_layer, e_self), gpu_layerwise=e_layer, fused_realisations=e_self)
-    # measured (MI355X, round 3, four seeds, tools/diag_grad_parity.py): fused / layer-by-layer global relative error --
-    # msg 2.7e-3 3.9e-3 2.1e-3 3.1e-3 / 5.2e-3 1.8e-3 2.1e-3 1.2e-3.  Both are dominated by the handful of discrete
-    # decisions that sit within fp32 rounding of a tie (different ones in the two paths), so each is judged against the
-    # larger of the plain path's error and the distance between two realisations of the fused path itself
-    assert e_fused <= 1e-2, (e_fused, worst_fused)
-    assert e_fused <= max(FLOOR_SPREAD * 1.5 * max(e_layer, e_self), 1e-4), (e_fused, e_layer, e_self, worst_fused)
+    monkeypatch.setattr(td, "knn_graph", real)
+
+    kw = {"nn_list": graphs_fused} if is_dg else {}
+
+    def truth(D=None, record=None, report=None):
+        # float64 autograd of the restatement: torch algebra on the GPU, geometry from the C oracle
+        P = {k: v.requires_grad_(v.is_floating_point())
+             for k, v in R.params_from_state_dict(sd, dtype=torch.float64, device=DEV).items()}
+        with R.imposing(D, record, report):
+            want = ref(torch.from_numpy(c).double().to(DEV), P, True, **kw)
+        loss = (mod.get_loss(want[0], want[1], y.to(DEV), mask.to(DEV))[0] if has_mask else mod.get_loss(want, y.to(DEV)))
+        loss.backward()
+        return loss.item(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in P.items()
+                             if v.is_floating_point() and k in g_fused}
+
+    D64 = R.Decisions()
+    loss_ref, g64 = truth(record=D64)
+    assert abs(loss_fused - loss_ref) <= 1e-4
+    out = {"seed": seed}
+    for path, D, g in (("fused", D_fused, g_fused), ("layer", D_layer, g_layer)):
+        # the read-back covers exactly the layers of the network, each with the kind of decision it has
+        assert set(D.relu) == set(D64.relu) and set(D.pool) == set(D64.pool), \
+            (path, sorted(set(D.relu) ^ set(D64.relu)), sorted(set(D.pool) ^ set(D64.pool)))
+        rep = {}
+        _, g64_forced = truth(D, report=rep)
+        e, worst = _grad_errors(g, g64)
+        em, worst_m = _grad_errors(g, g64_forced)
+        out.update({"e_" + path: e, "em_" + path: em, "worst_" + path: worst, "worst_masked_" + path: worst_m,
+                    "flips_" + path: DEC.summarise(rep, TIE)})
+    return out
+
+
+@pytest.mark.parametrize("name", GRAD_MODELS)
+def test_model_training_gradients(name, monkeypatch):
+    """d(loss)/d(every variable) of pointnet2_cls_bga / pointnet2_cls_msg / dgcnn / dgcnn_bga against float64 autograd of
+    the restatement, over len(SEEDS) >= 8 seeds (weights, BN state, clouds, labels all re-drawn).  Per seed:
+      * the decisions each path took are read back; those that differ from the float64 run's are COUNTED and each must be
+        a rounding-level tie (float64 pre-activation / pool gap <= TIE);
+      * with the float64 truth evaluated on the path's own decisions, the fused kernels' gradient error -- now purely
+        arithmetic -- must be within 1.5x the layer-by-layer path's (library GEMM + torch batch norm) or at the fp32
+        resolution of these sums;
+    and over the seeds the median UNMASKED ratio fused : layer-by-layer must be <= 2 (flips hit both paths alike).
+    No bar involves a second evaluation of the fused path (round 3's `fused_realisations` is gone)."""
+    _no_dropout(monkeypatch)
+    cases = [_grad_case(name, seed, monkeypatch) for seed in SEEDS]
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(path, exist_ok=True)
+        f = os.path.join(path, "parity_flips.json")
+        d = json.load(open(f)) if os.path.exists(f) else {}
+        d["grad_" + name] = {"tie": TIE, "seeds": cases,
+                             "median_unmasked_ratio": statistics.median(c["e_fused"] / c["e_layer"] for c in cases),
+                             "max_masked_ratio": max(c["em_fused"] / c["em_layer"] for c in cases)}
+        json.dump(d, open(f, "w"), indent=1)
+    except OSError:
+        pass
+    for c in cases:
+        assert c["flips_fused"]["all_ties"] and c["flips_layer"]["all_ties"], c
+        assert c["em_fused"] <= max(1.5 * c["em_layer"], GRAD_RESOLUTION), c
+        assert c["e_fused"] <= 1e-2, c                    # absolute ceiling, flips included (ADVICE r3)
+    assert statistics.median(c["e_fused"] / c["e_layer"] for c in cases) <= 2.0, cases
 
 
 # ---------------------------------------------------------------------------------------------------------------
