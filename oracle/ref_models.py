@@ -98,13 +98,16 @@ def _act_pool(z, scope, dim):
     picked = torch.gather(z, dim, arg.unsqueeze(dim)).squeeze(dim)
     if _REPORT is not None:
         gap = (own_max - picked.detach())                      # >= 0; 0 for the same member or an exact copy of it
-        live = active | (own_max > 0)
-        other = (gap > 0) & live
+        other = (gap > 0) & active                             # an ACTIVE imposed member that is not this run's maximum
         aflip = active != (own_max > 0)
+        # an activity flip is a tie when the deciding value sits at 0 in this run: the imposed member's value if the imposed
+        # decision is "active"; this run's own maximum if it is "inactive" (the imposed member is then arbitrary -- every
+        # member ties at relu(.) = 0 -- and its gap to the maximum means nothing)
+        za = torch.where(active, picked.detach(), own_max).abs()
         _REPORT[scope] = {"kind": "pool", "elements": own_arg.numel(), "flips": int(other.sum()),
                           "worst_gap": float(gap[other].max()) if other.any() else 0.0,
                           "active_flips": int(aflip.sum()),
-                          "worst_abs_z": float(own_max[aflip].abs().max()) if aflip.any() else 0.0}
+                          "worst_abs_z": float(za[aflip].max()) if aflip.any() else 0.0}
     return picked * active.to(z.dtype)
 
 

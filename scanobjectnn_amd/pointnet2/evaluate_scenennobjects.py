@@ -198,8 +198,9 @@ def evaluate(args):
     dev = torch.device("cuda", args.gpu)
     torch.cuda.set_device(dev)
     if args.model.endswith("_bga") or args.model.endswith("_partseg"):
-        raise SystemExit("evaluate_scenennobjects.py evaluates classifiers; mask / part models have their own metrics "
-                         "(eval_seg_one_epoch / eval_partseg_one_epoch)")
+        raise SystemExit("evaluate_scenennobjects.py evaluates classifiers; the background-aware models have their own "
+                         "command line, as in the reference: python -m scanobjectnn_amd.pointnet2."
+                         "evaluate_seg_scenennobjects (part models: eval_partseg_one_epoch)")
     mod = importlib.import_module(MODELS[args.model])
     names = [l.rstrip() for l in open(args.shape_names)] if args.shape_names else \
         (SHAPE_NAMES if args.num_class == 15 else ["class%d" % i for i in range(args.num_class)])

@@ -230,6 +230,8 @@ def train(args):
         rec = {"epoch": epoch, "mean_loss": loss_sum / max(nb, 1), "train_acc": correct / max(seen, 1),
                "eval_acc": ev["accuracy"], "eval_avg_class_acc": ev["avg_class_acc"],
                "clouds_per_s": nb * args.batch_size / (time.time() - t0)}
+        if "seg_accuracy" in ev:                 # BGA models: the mask accuracy of `train_seg.py:330`
+            rec["eval_seg_acc"] = ev["seg_accuracy"]
         log.append(rec)
         if rank == 0:
             print(json.dumps(rec), flush=True)

@@ -29,11 +29,15 @@ def _rot_y(angles):
     return torch.stack([torch.stack([c, z, s], -1), torch.stack([z, o, z], -1), torch.stack([-s, z, c], -1)], -2)
 
 
-def rotate_point_cloud(batch_data, generator=None):
-    """random rotation about the up axis, one angle per cloud (provider.py:34-52)"""
+def rotate_point_cloud(batch_data, generator=None, angles=None):
+    """random rotation about the up axis, one angle per cloud (provider.py:34-52).  angles: (B,) the per-cloud angles
+    instead of fresh draws (the reference draws `np.random.uniform() * 2 * np.pi` per cloud, :45)"""
     x, np_in = _as_tensor(batch_data)
-    ang = torch.rand(x.shape[0], generator=generator, device=x.device if generator is None or
-                     generator.device == x.device else generator.device).to(x.device) * (2 * math.pi)
+    if angles is not None:       # given angles: cos / sin in float64 like the reference's NumPy matrix (:46-50), then cast
+        ang = torch.as_tensor(angles, dtype=torch.float64, device=x.device)
+    else:
+        ang = torch.rand(x.shape[0], generator=generator, device=x.device if generator is None or
+                         generator.device == x.device else generator.device).to(x.device) * (2 * math.pi)
     out = torch.bmm(x[..., :3].reshape(x.shape[0], -1, 3), _rot_y(ang).to(x.dtype))
     return _ret(out, np_in)
 
@@ -41,18 +45,22 @@ def rotate_point_cloud(batch_data, generator=None):
 def rotate_point_cloud_by_angle(batch_data, rotation_angle):
     """fixed rotation about the up axis (provider.py:121-138) -- the vote rotations of the evaluation loop"""
     x, np_in = _as_tensor(batch_data)
-    ang = torch.full((1,), float(rotation_angle), dtype=x.dtype, device=x.device)
+    ang = torch.full((1,), float(rotation_angle), dtype=torch.float64, device=x.device)   # float64 matrix (:130-134), cast
     out = x.clone()
-    out[..., :3] = x[..., :3] @ _rot_y(ang)[0]
+    out[..., :3] = x[..., :3] @ _rot_y(ang)[0].to(x.dtype)
     return _ret(out, np_in)
 
 
-def jitter_point_cloud(batch_data, sigma=0.01, clip=0.05, generator=None):
-    """per-point clipped Gaussian jitter (provider.py:189-200)"""
+def jitter_point_cloud(batch_data, sigma=0.01, clip=0.05, generator=None, noise=None):
+    """per-point clipped Gaussian jitter (provider.py:189-200).  noise: the standard-normal draws (same shape) instead
+    of fresh ones (the reference draws `np.random.randn(B, N, C)`, :198)"""
     assert clip > 0
     x, np_in = _as_tensor(batch_data)
-    gdev = generator.device if generator is not None else x.device
-    noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=x.dtype).to(x.device)
+    if noise is not None:
+        noise = torch.as_tensor(noise, dtype=x.dtype, device=x.device)
+    else:
+        gdev = generator.device if generator is not None else x.device
+        noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=x.dtype).to(x.device)
     return _ret(x + torch.clamp(sigma * noise, -clip, clip), np_in)
 
 

@@ -112,3 +112,55 @@ def test_evaluate_cli_from_a_tensor_bundle(tmp_path):
     r = EV.eval_one_epoch(net, cur, lab, 8, num_votes=3, device=DEV)
     assert np.array_equal(r["pred"], ev["pred"])
     assert [l.split(", ")[1] for l in lines] == [EV.SHAPE_NAMES[i] for i in lab]
+
+
+@pytest.mark.parametrize("name", ["pointnet2_cls_bga", "dgcnn_bga"])
+def test_evaluate_seg_cli_from_a_tensor_bundle(name, tmp_path):
+    """`pointnet2/evaluate_seg_scenennobjects.py:33-53,179-340` end to end for both background-aware models: restore
+    from a tensor bundle, 2 votes, class + mask metrics, outputs on disk; the same protocol by hand gives the same
+    predictions (file order, first num_point points, masks binarised, logits of both heads summed over the votes)"""
+    import importlib
+    from scanobjectnn_amd import data_utils as DU
+    from scanobjectnn_amd import provider
+    from scanobjectnn_amd.pointnet2 import evaluate_seg_scenennobjects as EVS
+    from scanobjectnn_amd.pointnet2.train import MODELS
+    from scanobjectnn_amd.synth import synth_masks
+    mod = importlib.import_module(MODELS[name])
+    n_pts = 256 if name.startswith("dgcnn") else 512
+    raw = synth_clouds(12, n_pts + 64, seed=31) * 2.0 + 0.7       # NOT centred / normalised: the CLI has to do it
+    labels = synth_labels(12, seed=31)
+    parts = synth_masks(12, n_pts + 64, seed=31) * 3 - 1         # raw masks: -1 = background, 2 = an object part id
+    np.savez(tmp_path / "test.npz", data=raw, label=labels, mask=parts)
+    net = Model(mod.get_model, device=DEV, seed=5).build(torch.zeros((2, n_pts, 3), device=DEV))
+    _randomise(net, 9)
+    prefix = str(tmp_path / "model.ckpt")
+    _indep_bundle(prefix, _tf_names(net.state_dict(), ema_shadow=name.startswith("dgcnn")))
+    dump = tmp_path / "dump"
+    args = EVS.parse_args(["--model", name, "--num_point", str(n_pts), "--batch_size", "4", "--num_votes", "2",
+                           "--model_path", prefix, "--test_file", str(tmp_path / "test.npz"), "--dump_dir", str(dump)])
+    ev = EVS.evaluate(args)
+    assert ev["pred"].shape == (12,) and ev["seg_pred"].shape == (12, n_pts)
+    assert 0.0 <= ev["accuracy"] <= 1.0 and 0.0 <= ev["seg_accuracy"] <= 1.0 and np.isfinite(ev["mean_loss"])
+    lines = open(dump / "pred_label.txt").read().splitlines()
+    assert len(lines) == 12 and [l.split(", ")[1] for l in lines] == [EVS.SHAPE_NAMES[i] for i in labels]
+    log = open(dump / "log_evaluate.txt").read()
+    for key in ("Model restored.", "total seen: 12", "eval mean loss:", "eval accuracy:", "eval avg class acc:",
+                "seg accuracy: %f" % ev["seg_accuracy"], "toilet:"):
+        assert key in log, key
+    # by hand
+    data = DU.normalize_data(DU.center_data(raw.copy()))[:, :n_pts]
+    mask = DU.convert_to_binary_mask(parts)[:, :n_pts]
+    assert set(np.unique(mask)) <= {0, 1}
+    cls_pred, seg_pred = [], []
+    with torch.no_grad():
+        for lo in range(0, 12, 4):
+            pts = torch.from_numpy(data[lo:lo + 4]).to(DEV)
+            c = s = 0
+            for v in range(2):
+                cp, sp = net(provider.rotate_point_cloud_by_angle(pts, v / 2.0 * np.pi * 2).contiguous(), is_training=False)
+                c, s = c + cp, s + sp
+            cls_pred.append(c.argmax(1).cpu().numpy())
+            seg_pred.append(s.argmax(2).cpu().numpy())
+    assert np.array_equal(np.concatenate(cls_pred), ev["pred"])
+    assert np.array_equal(np.concatenate(seg_pred), ev["seg_pred"])
+    assert ev["seg_accuracy"] == (np.concatenate(seg_pred) == mask).sum() / (12.0 * n_pts)

@@ -154,3 +154,44 @@ def test_evaluate_cli_flags_and_test_set_preparation(tmp_path):
     # accuracy bookkeeping with a class that never occurs (the reference divides by zero there)
     acc, mean_class, per_class = EV.accuracy_summary(np.array([0, 1, 1, 3]), np.array([0, 1, 2, 3]), num_classes=5)
     assert acc == 0.75 and np.isnan(per_class[4]) and abs(mean_class - (1 + 1 + 0 + 1) / 4.0) < 1e-12
+
+
+def test_seg_evaluation_metrics_toy_fixture():
+    """`evaluate_seg_scenennobjects.py:332-340` on a hand-computed case, and the vote loop (`:211-236`) on a stub model:
+    class logits and per-point mask logits are SUMMED over the votes before the argmax; seg accuracy = correct points /
+    (seen clouds * points); only whole batches are evaluated (`:203`)."""
+    import torch
+    from scanobjectnn_amd.pointnet2 import evaluate_seg_scenennobjects as EVS
+    # 4 clouds x 5 points; class predictions 3 of 4 right; masks: 20 points, 14 right
+    labels = np.array([0, 1, 1, 2])
+    cls = np.array([0, 1, 2, 2])
+    masks = np.array([[1, 1, 0, 0, 1], [0, 0, 0, 1, 1], [1, 1, 1, 1, 1], [0, 1, 0, 1, 0]])
+    seg = np.array([[1, 1, 0, 0, 0], [0, 0, 1, 1, 1], [1, 1, 1, 0, 0], [0, 1, 0, 0, 1]])
+    s = EVS.seg_summary(cls, labels, seg, masks, num_classes=3)
+    assert s["accuracy"] == 0.75 and s["seg_accuracy"] == 14 / 20.0
+    np.testing.assert_allclose(s["per_class"], [1.0, 0.5, 1.0])
+    assert abs(s["avg_class_acc"] - (1.0 + 0.5 + 1.0) / 3) < 1e-12
+
+    # vote loop: a stub whose logits depend on the rotation so that single votes disagree with the sum
+    calls = []
+
+    def net(pts, is_training):
+        assert is_training is False
+        calls.append(pts.clone())
+        b, n, _ = pts.shape
+        first = len(calls) % 2 == 1                      # vote 0 / vote 1 of each batch
+        cp = torch.zeros(b, 3)
+        cp[:, 0] = 1.0 if first else 0.0                 # vote 0 says class 0 (margin 1) ...
+        cp[:, 2] = 0.0 if first else 3.0                 # ... vote 1 says class 2 (margin 3): the SUM says 2
+        sp = torch.zeros(b, n, 2)
+        sp[:, :, 1] = 2.0 if first else -1.0             # vote 0: object (+2), vote 1: background (-1): the sum says 1
+        return cp, sp
+    data = np.random.default_rng(0).standard_normal((5, 6, 3)).astype(np.float32)      # 5 clouds, batch 2 -> 4 seen
+    ev = EVS.eval_seg_votes(net, data, np.array([2, 2, 0, 2, 1]), np.ones((5, 6), np.int32), 2, num_votes=2, device="cpu",
+                            num_classes=3, loss_fn=lambda cp, sp, y, mk: torch.tensor(1.5))
+    assert len(calls) == 4 and ev["pred"].tolist() == [2, 2, 2, 2] and ev["label"].tolist() == [2, 2, 0, 2]
+    assert ev["accuracy"] == 0.75 and ev["seg_accuracy"] == 1.0 and ev["seg_pred"].shape == (4, 6)
+    assert abs(ev["mean_loss"] - 1.5) < 1e-12           # sum over votes of loss * batch / votes, over seen clouds
+    # vote 1 sees the cloud rotated by pi about the up axis: x and z change sign, y stays
+    np.testing.assert_allclose(calls[1][..., 1].numpy(), data[:2, :, 1], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(calls[1][..., 0].numpy(), -data[:2, :, 0], rtol=0, atol=1e-6)
