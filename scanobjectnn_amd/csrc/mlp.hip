@@ -293,6 +293,17 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
 
             const float *arow = &As[(wave * 32 + (lane & 31)) * kLdA + 4 * (lane >> 5)];
             const float *bcol = &Bs[(4 * (lane >> 5)) * BN + (lane & 31)];
+            // BLOCKED summation over K (round 4): every 32-wide K chunk is summed into its own accumulator (a 32-term
+            // fmaf chain) and the chunk sums are added up -- the rounding error of a dot product then grows like
+            // sqrt(32 + K / 32) instead of sqrt(K) of one K-long chain (K = 512: 3.3x smaller).  These are the small-row
+            // layers (group_all stacks, FP stacks, heads of small batches) whose output feeds a batch norm over a few
+            // hundred rows, where a library GEMM with its K split was measurably more accurate than the single chain
+            // (tools/diag_stage_noise.py: +8 % RMS error from layer3 on); the extra 16 NT adds per chunk are free here.
+            f32x16 part[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) part[i][v] = 0.f;
 #pragma unroll
             for (int it = 0; it < kBK / 8; ++it) {
                 const float4 av = *reinterpret_cast<const float4 *>(arow + 8 * it);
@@ -302,10 +313,14 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const float bv = bcol[(8 * it + t) * BN + 32 * nt];
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv, acc[nt], 0, 0, 0);
+                        part[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ae[t], bv, part[nt], 0, 0, 0);
                     }
                 }
             }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][v] += part[i][v];
         }
 
         // ------------------------------------------------------------------ epilogue
