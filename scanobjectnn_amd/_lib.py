@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCOPS_LIB") or os.path.join(_HERE, "libpcops.so")      # PCOPS_LIB: A/B runs of two builds
 
 _I, _F, _P, _U64, _LL = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong, C.c_longlong
+ABI_VERSION = 3      # pcops_abi_version() of the library this binding matches (include/pcops.h), checked in load()
 
 # name -> (argtypes without the trailing stream, has_stream)
 SIGNATURES = {
@@ -172,6 +173,12 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = restype
+    got = int(lib.pcops_abi_version())
+    if got != ABI_VERSION:
+        # the signatures above are positional: a stale or newer library would take the wrong arguments SILENTLY (round 3
+        # inserted stat_pivot mid-signature in five entry points) -- refuse it instead
+        raise PcopsError("%s reports ABI version %d, this binding is written for %d: rebuild it "
+                         "(make -C scanobjectnn_amd/csrc)" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -26,6 +26,31 @@ extern "C" int pcops_get_deterministic(void);     // abi.hip: bit-reproducible b
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// Asymmetric STATIC wave priority (round 4; MI355X_MICROARCH.md "Two waves per SIMD").  Two co-resident waves that run
+// the same [MFMA chain | VALU phase] loop at equal priority settle in LOCKSTEP: both contend for the matrix pipe (each
+// chain takes twice as long), then both contend for the VALU issue slots -- time = MFMA + VALU, nothing overlaps,
+// exactly the "matrix-pipe busy + 4.5 x other instructions" the round-2/3 counters showed.  With the odd wave slot of
+// every SIMD at priority 1 its chain runs unimpeded while the partner waits, and from then on one wave's VALU phase
+// sits under the other's MFMA chain.  PCOPS_WAVE_PRIO (compile time, A/B builds through PCOPS_LIB): bit 0 = the
+// single-role kernels (gemm_ws, knn_mfma) by hardware wave slot, bit 1 = the consumer (MFMA) waves of the producer /
+// consumer kernels.
+#ifndef PCOPS_WAVE_PRIO
+#define PCOPS_WAVE_PRIO 0
+#endif
+__device__ __forceinline__ void wave_prio_stagger() {
+#if PCOPS_WAVE_PRIO & 1
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.wave_id: slot on the SIMD
+    if (slot & 1) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+__device__ __forceinline__ void wave_prio_consumer(bool consumer) {
+#if PCOPS_WAVE_PRIO & 2
+    if (consumer) __builtin_amdgcn_s_setprio(1);
+#else
+    (void)consumer;
+#endif
+}
+
 // unsigned max across the 64 lanes of a wave, wave-uniform result.  DPP row shifts + the two gfx9 row broadcasts
 // (a max-"scan" whose last lane holds the total): 6 VALU instructions and one v_readlane, no LDS round trips.
 // (The bpermute butterfly this replaces cost 12 ds_bpermute with ~100 cycles of latency each per 64-bit key --

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     constexpr int LD = CP + 1;         // odd row stride: lanes 0..31 read 32 rows at one column without conflicts
     constexpr int NKK = CP / 2;        // MFMAs per tile
     constexpr int QD = kKnnQD;
+    wave_prio_stagger();
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cs = lds;                   // [CH][LD]
     float *sc = cs + CH * LD;          // [CH]   (16-byte aligned: CH * LD is a multiple of 4)

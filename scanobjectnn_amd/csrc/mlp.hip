@@ -435,6 +435,7 @@ struct PoolRows {
 
 template <int NT, int AM, int EM, int KC, int WAVES, int EH, int VAR>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs a) {
+    wave_prio_stagger();
     // WAVES waves per workgroup (4: one per SIMD, 8: two per SIMD so that one wave's staging / epilogue hides under
     // its partner's MFMA phase); EH: the epilogue transposes the accumulator tile in EH column passes so that the
     // wave stripe only needs max(KC, BN/EH) columns.
@@ -2018,6 +2019,7 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    wave_prio_consumer(wave < 4);
     const int K = a.K, N = a.N;
     constexpr bool compact = DMODE == A_DYW || DMODE == A_DYPOOLB;      // compacted rows (block table + device row count)
     const long long M = compact ? (long long)__builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;
@@ -2336,6 +2338,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    wave_prio_consumer(wave < 4);
     const int K = a.K, N = a.N;
     constexpr bool compact = DMODE == A_DYW || DMODE == A_DYPOOLB;      // compacted rows (block table + device row count)
     const long long M = compact ? (long long)__builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;

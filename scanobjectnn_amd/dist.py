@@ -20,13 +20,36 @@ def sync_bn_active():
     return SYNC_BN and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def allreduce_stat_partials(part, rows):
+_STAT_GROUP = None
+
+
+def stat_group():
+    """The communicator of the SyncBN statistics: its own process group, so that the small, latency-critical
+    all-reduces inside forward / backward do not queue behind the multi-MB gradient ranges that
+    `FlatParams.enable_overlap` issues on the default group from autograd hooks.  Created at the first use,
+    which every rank reaches at the same point of the same graph."""
+    global _STAT_GROUP
+    if _STAT_GROUP is None:
+        _STAT_GROUP = dist.new_group()
+    return _STAT_GROUP
+
+
+def allreduce_stat_partials(part, rows, pivot=None):
     """(P, 2, C) fp32 partial column sums of this rank -> ((2, 2, C) global sums, global row count).
     The P partials are added in float64 (as the finalisation kernels do), all-reduced in float64, and handed back as
     TWO fp32 partial rows -- the total rounded to fp32 and what the rounding left over -- which the finalisation kernels
-    add in float64 again: the global sums reach them with ~48 bits, like a single rank's."""
+    add in float64 again: the global sums reach them with ~48 bits, like a single rank's.
+    pivot (C,): the partials are SHIFTED moments, sum (y - pivot) and sum (y - pivot)^2 (pcops.h).  Each rank's pivot is
+    its own moving mean, and nothing guarantees those are bit-identical across ranks (per-rank restore, buffers broadcast
+    only at epoch ends), so the shift is taken out in float64 BEFORE the all-reduce -- the caller then finalises the
+    returned sums with no pivot."""
     tot = part.double().sum(dim=0, keepdim=True)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if pivot is not None:
+        c = tot.shape[-1]
+        p = pivot.detach().double()[:c]
+        tot[0, 1] += 2.0 * p * tot[0, 0] + float(rows) * p * p
+        tot[0, 0] += float(rows) * p
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=stat_group())
     hi = tot.float()
     lo = (tot - hi.double()).float()
     return torch.cat([hi, lo], dim=0).contiguous(), rows * dist.get_world_size()
@@ -94,7 +117,7 @@ def sync_batch_stats(flat):
     import torch.distributed.nn.functional as dfn
     n = flat.shape[0]
     s = torch.stack([flat.sum(dim=0), (flat * flat).sum(dim=0)])
-    s = dfn.all_reduce(s, op=dist.ReduceOp.SUM)
+    s = dfn.all_reduce(s, op=dist.ReduceOp.SUM, group=stat_group())
     total = n * dist.get_world_size()
     mean = s[0] / total
     var = (s[1] / total - mean * mean).clamp_min(0.0)

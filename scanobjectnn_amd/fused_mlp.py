@@ -161,11 +161,11 @@ class FusedMLPStack(torch.autograd.Function):
             scale, shift = vecs.take(N), vecs.take(N)
             if training:
                 mean, rstd = vecs.take(N), vecs.take(N)
-                Pf, Rf = P, R
-                if sync:        # SyncBN: the statistics of the global batch
-                    part, Rf = _dist.allreduce_stat_partials(part, R)
-                    Pf = part.shape[0]
-                _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), piv, ws.data_ptr(), gamma.data_ptr(),
+                Pf, Rf, piv_fin = P, R, piv
+                if sync:        # SyncBN: the statistics of the global batch (the rank's pivot taken out before the exchange)
+                    part, Rf = _dist.allreduce_stat_partials(part, R, mm if piv is not None else None)
+                    Pf, piv_fin = part.shape[0], None
+                _lib.call("pcops_mlp_bn_finalize", Pf, N, Rf, part.data_ptr(), piv_fin, ws.data_ptr(), gamma.data_ptr(),
                           beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())
                 means.append(mean)
@@ -572,11 +572,11 @@ class EdgeConvPool(torch.autograd.Function):
         if training:
             mean, rstd = vecs.take(C), vecs.take(C)
             ws = _workspace(C, dev)
-            Pf, Rf = P, G * S
+            Pf, Rf, piv_fin = P, G * S, (mm.data_ptr() if STAT_PIVOT else None)
             if sync:
-                part, Rf = _dist.allreduce_stat_partials(part, G * S)
-                Pf = part.shape[0]
-            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), mm.data_ptr() if STAT_PIVOT else None,
+                part, Rf = _dist.allreduce_stat_partials(part, G * S, mm if STAT_PIVOT else None)
+                Pf, piv_fin = part.shape[0], None
+            _lib.call("pcops_mlp_bn_finalize", Pf, C, Rf, part.data_ptr(), piv_fin,
                       ws.data_ptr(), gamma.data_ptr(),
                       beta.data_ptr(), float(eps), float(decay), int(unbiased), mm.data_ptr(), mv.data_ptr(),
                       mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr())

@@ -80,6 +80,8 @@ class FlatParams:
         import torch.distributed as dist
         if (world <= 1 and not force) or not dist.is_initialized():
             return self
+        if getattr(self, "_hooks_registered", False):
+            return self                  # hooks are permanent: a second registration would count every gradient twice
         target = max(1, self.numel // max(1, nbuckets))
         self._buckets = []               # [first param, one past last param, start offset, end offset]
         first = 0
@@ -97,6 +99,7 @@ class FlatParams:
         self._works = []
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._grad_ready(i))
+        self._hooks_registered = True
         return self
 
     def _grad_ready(self, i):

@@ -146,8 +146,11 @@ def _rccl_worker(port, q):
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     try:
+        from scanobjectnn_amd import _lib
+        _lib.load().pcops_set_deterministic(1)               # ordered sums: the two steps below must agree BIT FOR BIT
         mod, net, x, y = _build("ssg")
         fp = TU.FlatParams(net)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
         fp.begin_step()
         torch.manual_seed(5)                                 # (dropout masks of the head)
         mod.get_loss(net(x, is_training=True, bn_decay=0.9)[0], y).backward()
@@ -167,6 +170,7 @@ def _rccl_worker(port, q):
         # the overlapped form of the same step: ranges of the bucket all-reduced asynchronously from autograd's hooks
         # while the HIP kernels of the earlier layers still run, then waited for
         fp.enable_overlap(1, nbuckets=4, force=True)
+        net.load_state_dict(sd)                              # the first step moved the BN moving statistics (= the pivots)
         fp.begin_step()
         torch.manual_seed(5)
         mod.get_loss(net(x, is_training=True, bn_decay=0.9)[0], y).backward()
@@ -193,5 +197,7 @@ def test_rccl_backend_initialises_and_reduces_the_flat_bucket_on_one_gpu():
     assert res["backend"] == "nccl" and res["world"] == 1
     assert res["bytes"] > 5_000_000                         # SSG's bucket: 1.47 M parameters, 5.9 MB
     assert res["same"] and res["same2"] and res["max"] == 3.25 and res["gathered"] == 3.25
-    # (same inputs and parameters as the first step; the two gradients differ by the order of the scatter atomics)
-    assert res["ranges"] >= 3 and res["under_way"] >= res["ranges"] - 1 and res["overlap_err"] <= 1e-3, res
+    # same inputs, parameters and BN state as the first step, deterministic kernels: the overlapped step's gradient is
+    # the single-collective step's, bit for bit (round 3 allowed 1e-3 here -- the two steps then differed by their scatter
+    # atomics AND by the batch-norm pivots the first step had moved, enough for a ReLU to fall the other way)
+    assert res["ranges"] >= 3 and res["under_way"] >= res["ranges"] - 1 and res["overlap_err"] == 0.0, res
