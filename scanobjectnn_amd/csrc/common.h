@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -15,7 +17,11 @@
     do { if (!(cond)) return PCOPS_ERR_BAD_ARGUMENT; } while (0)
 
 static inline int pcops_launch_status() {
-    return hipGetLastError() == hipSuccess ? PCOPS_OK : PCOPS_ERR_LAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return PCOPS_OK;
+    static const bool verbose = getenv("PCOPS_DEBUG_LAUNCH") != nullptr;      // what HIP said, on stderr
+    if (verbose) fprintf(stderr, "libpcops: launch failed: %s (%s)\n", hipGetErrorString(e), hipGetErrorName(e));
+    return PCOPS_ERR_LAUNCH;
 }
 
 static inline hipStream_t as_stream(pcops_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -375,6 +375,248 @@ int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, con
     return pcops_launch_status();
 }
 
+// ------------------------------------------------------------------ fused kNN graph, fp16 pre-filter (round 4)
+// Measured on this chip (tools/ubench/mfma_valu_coexec.hip, profiles/r04_ubench_mfma_valu_coexec.txt): MFMA time and VALU
+// time ADD on a SIMD -- for v_mfma_f32_32x32x2_f32 and for the 16-bit MFMAs alike, with one wave per SIMD or two, clustered
+// or interleaved, and a static priority split between the two waves of a SIMD changes nothing (profiles/
+// r04_wave_prio_ab.txt).  So knn_mfma_kernel's 64-channel tile costs its 2048 matrix cycles PLUS ~2700 cycles of selection,
+// and the matrix part cannot hide.  What can shrink is the matrix part itself: the exact fp32 distance is only needed for
+// the few candidates that can still enter a top-k list.
+//   * every 32 x 32 tile is first evaluated in FP16 on v_mfma_f32_32x32x16_f16 -- 4 instructions of 32 cycles instead of 32
+//     of 64 for 64 channels (1/16 of the matrix time).  fp16 rounding of both operands moves a product by <= 2^-10 |x y|,
+//     the distance by <= 2^-10 (s_i + s_j) (Cauchy-Schwarz + AM-GM); with the fp32 accumulation of the MFMA, the rounding of
+//     the test itself and fp16 underflow:  |d_exact - d_fp16| <= A (s_i + s_j) + B,  A = 1.1e-3, B = 1e-6.
+//   * a candidate is REJECTED iff  d_fp16 - A (s_i + s_j) - B > thr  (thr = the lane's current bound on its k-th distance,
+//     as in knn_mfma_kernel) -- then d_exact > thr as well, and knn_mfma_kernel would not have queued it either.  The test is
+//     one fma and one compare per pair:  fma(-2, acc, (1 - A) s_j)  >  thr - (1 - A) s_i + B.  Anything non-finite (a
+//     feature beyond the fp16 range) fails the '>' and is kept.
+//   * survivors (j only) wait in a per-lane LDS list; when a list fills or the candidate chunk is about to leave LDS, each
+//     lane evaluates the EXACT distance of its survivors -- the contract's fmaf chain over c on the VALU, query row in
+//     registers, candidate row from the fp32 copy of the chunk -- and inserts it in its sorted list exactly as
+//     knn_mfma_kernel's flush does (ascending index order, strict '<').  Same lists, same merge, same indices: bit-exact
+//     w.r.t. the oracle (tests/test_knn_gpu.py, test_bench_size_gpu.py run through this kernel).
+// Workgroup: 8 waves (two per SIMD) = 256 queries on one candidate chunk; 32 queries per wave, two half-waves per
+// query as in knn_mfma_kernel (shared bound tau2).  c == 64 (DGCNN's feature
+// graphs), k <= 20; everything else takes knn_mfma_kernel.
+typedef _Float16 f16x8k __attribute__((ext_vector_type(8)));
+constexpr int kKnnPD = 32;             // pending survivors per lane; checked once per 32-row tile (<= 16 new entries each)
+constexpr float kKnnA = 1.1e-3f, kKnnB = 1e-6f;
+
+#ifdef PCOPS_KNN_STATS
+__device__ unsigned long long g_knn_stats[4];    // pairs tested, survivors, exact distances below the bound, process rounds
+#endif
+
+template <int KL>
+__global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const float *__restrict__ x,
+                                                         int *__restrict__ nn_idx) {
+    constexpr int CP = 64, CH = 128, LD = CP + 4;      // fp32 chunk row stride: 16-byte aligned rows
+    constexpr int LH = CP + 8;                         // fp16 chunk row stride in halves (144 B: conflict-free b128 reads)
+    constexpr int PD = kKnnPD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cs = lds;                                   // [CH][LD]   fp32 candidates (exact distances, squared norms)
+    float *sc = cs + CH * LD;                          // [CH]       s_j
+    float *su = sc + CH;                               // [CH]       (1 - A) s_j
+    int *pj = reinterpret_cast<int *>(su + CH);        // [PD][512]  pending survivors
+    _Float16 *chh = reinterpret_cast<_Float16 *>(pj + PD * 512);   // [CH][LH]  fp16 candidates (the filter's A operand)
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, li = lane & 31;
+    const float *xb = x + (size_t)b * n * CP;
+    const int q = blockIdx.x * 256 + wave * 32 + li;      // 8 waves = 256 queries share one candidate chunk
+    const bool qin = q < n;
+
+    // the query row: fp32 in registers (exact distances) and fp16 B fragments (channels 16 kk + 8 half .. + 7)
+    float xq[CP];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(xb + (size_t)(qin ? q : 0) * CP);
+#pragma unroll
+        for (int l4 = 0; l4 < CP / 4; ++l4) {
+            const float4 v = qin ? src[l4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[4 * l4] = v.x; xq[4 * l4 + 1] = v.y; xq[4 * l4 + 2] = v.z; xq[4 * l4 + 3] = v.w;
+        }
+    }
+    float sq = 0.f;
+#pragma unroll
+    for (int l = 0; l < CP; ++l) sq = fmaf(xq[l], xq[l], sq);
+    f16x8k bh[CP / 16];
+#pragma unroll
+    for (int kk = 0; kk < CP / 16; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // (both half-waves hold the whole row; the fragment of a lane is the half-wave's 8 channels of every 16)
+            const float lo = xq[16 * kk + e], hi = xq[16 * kk + 8 + e];
+            bh[kk][e] = (_Float16)(half ? hi : lo);
+        }
+    const float sqa = (1.f - kKnnA) * sq;
+    constexpr float kF16Safe = 6.0e4f;                 // |x| <= 6e4 converts to a finite fp16 with relative error 2^-11
+    int big = 0;
+    bool filter_off = false;
+#pragma unroll
+    for (int l = 0; l < CP; ++l) big |= (int)!(fabsf(xq[l]) <= kF16Safe);
+
+    TopK<KL> top;
+    top.init();
+    int nq = 0;
+    float tau2 = INFINITY, thr = INFINITY, tp = INFINITY;
+#ifdef PCOPS_KNN_STATS
+    unsigned st_surv = 0, st_acc = 0, st_rounds = 0;
+#endif
+    int j0 = 0;
+    constexpr int NQ4 = CH * (CP / 4);                  // float4 per chunk
+    constexpr int NV = NQ4 / 512;                       // float4 per thread per chunk (4)
+    float4 pre[NV];
+    auto fetch = [&](int j0n) {
+        const int tnn = min(CH, n - j0n);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e4 = tid + 512 * u;
+            const int r = e4 / (CP / 4), l = (e4 - r * (CP / 4)) * 4;
+            pre[u] = r < tnn ? *reinterpret_cast<const float4 *>(xb + (size_t)(j0n + r) * CP + l)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (n > 0) fetch(0);
+    for (j0 = 0; j0 < n; j0 += CH) {
+        const int tn = min(CH, n - j0);
+        __syncthreads();                                // every wave has processed its survivors of the previous chunk
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e4 = tid + 512 * u;
+            const int r = e4 / (CP / 4), l = (e4 - r * (CP / 4)) * 4;
+            *reinterpret_cast<float4 *>(cs + r * LD + l) = pre[u];
+            typedef _Float16 f16x4k __attribute__((ext_vector_type(4)));
+            f16x4k h;
+            h[0] = (_Float16)pre[u].x; h[1] = (_Float16)pre[u].y; h[2] = (_Float16)pre[u].z; h[3] = (_Float16)pre[u].w;
+            *reinterpret_cast<f16x4k *>(chh + r * LH + l) = h;
+            big |= (int)!(fabsf(pre[u].x) <= kF16Safe) | (int)!(fabsf(pre[u].y) <= kF16Safe) |
+                   (int)!(fabsf(pre[u].z) <= kF16Safe) | (int)!(fabsf(pre[u].w) <= kF16Safe);
+        }
+        // a feature beyond the fp16 range (or a NaN) anywhere in this chunk or in this workgroup's queries: the error bound
+        // of the filter does not hold -- from here on nothing is rejected (tp = +inf), every pair takes the exact path
+        if (__syncthreads_or(big)) { filter_off = true; tp = INFINITY; }
+        big = 0;
+        if (j0 + CH < n) fetch(j0 + CH);
+        if (tid < CH) {
+            float s = 0.f;
+#pragma unroll 16
+            for (int l = 0; l < CP; ++l) s = fmaf(cs[tid * LD + l], cs[tid * LD + l], s);
+            s = tid < tn ? s : INFINITY;                // rows beyond the cloud: never a neighbour
+            sc[tid] = s;
+            su[tid] = (1.f - kKnnA) * s;
+        }
+        __syncthreads();
+        const int ntile = (tn + 31) / 32;
+        for (int t = 0; t < ntile; ++t) {
+            f32x16k acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            const _Float16 *arow = chh + (32 * t + li) * LH + 8 * half;
+#pragma unroll
+            for (int kk = 0; kk < CP / 16; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8k *>(arow + 16 * kk), bh[kk], acc, 0, 0, 0);
+            // acc[v]: candidate row 32 t + (v&3) + 8 (v>>2) + 4 half, query li
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int row0 = 32 * t + 8 * g4 + 4 * half;
+                const float4 u4 = *reinterpret_cast<const float4 *>(su + row0);
+                const float uv[4] = {u4.x, u4.y, u4.z, u4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float val = fmaf(-2.f, acc[4 * g4 + e], uv[e]);
+                    if (!(val > tp)) {
+                        pj[nq * 512 + tid] = j0 + row0 + e;
+                        ++nq;
+                    }
+                }
+            }
+            // a list could overflow in the next tile, or these were the chunk's last rows (they leave LDS at the next
+            // barrier).  Checked once per tile, after the accumulators are dead: inside the row groups the exact chain's
+            // registers came on top of them and spilled
+            const bool last = t == ntile - 1;
+            if (__any(nq > PD - 16) || (last && __any(nq > 0))) {
+#ifdef PCOPS_KNN_STATS
+                st_surv += (unsigned)nq;
+#endif
+                {
+                const int mx = (int)wave_max_u32((unsigned)nq);
+                for (int u = 0; u < mx; ++u) {
+                    const bool live = u < nq;
+                    const int j = live ? pj[u * 512 + tid] : j0;
+                    const int rr = j - j0;
+                    const float *row = cs + rr * LD;
+                    float inner = 0.f;
+#pragma unroll
+                    for (int l16 = 0; l16 < CP / 16; ++l16) {          // four 16-byte reads in flight, then their 16 chain steps
+                        float4 v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(row + 16 * l16 + 4 * i);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            inner = fmaf(xq[16 * l16 + 4 * i], v[i].x, inner);
+                            inner = fmaf(xq[16 * l16 + 4 * i + 1], v[i].y, inner);
+                            inner = fmaf(xq[16 * l16 + 4 * i + 2], v[i].z, inner);
+                            inner = fmaf(xq[16 * l16 + 4 * i + 3], v[i].w, inner);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);             // (all sixteen reads hoisted to the top cost 21 spilled registers)
+                    }
+                    float d = (sq + (-2.f * inner)) + sc[rr];
+                    d = live ? d : INFINITY;
+#ifdef PCOPS_KNN_STATS
+                    st_acc += (live && d < thr) ? 1u : 0u;
+#endif
+                    top.insert_ascending(d, j);
+                }
+#ifdef PCOPS_KNN_STATS
+                st_rounds += (lane == 0) ? (unsigned)mx : 0u;
+#endif
+                nq = 0;
+                const float hv = top.v[(KL + 1) / 2 - 1];
+                tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
+                thr = fminf(top.v[KL - 1], nextafterf(tau2, INFINITY));
+                tp = filter_off ? INFINITY : (thr - sqa) + kKnnB;   // reject iff  fma(-2, acc, su_j) > tp
+                }
+            }
+        }
+    }
+#ifdef PCOPS_KNN_STATS
+    atomicAdd(&g_knn_stats[1], (unsigned long long)st_surv);
+    atomicAdd(&g_knn_stats[2], (unsigned long long)st_acc);
+    atomicAdd(&g_knn_stats[3], (unsigned long long)st_rounds);
+    if (tid == 0) atomicAdd(&g_knn_stats[0], (unsigned long long)256 * n);
+#endif
+
+    // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
+#pragma unroll
+    for (int s = 0; s < KL; ++s) {
+        const float pv = __shfl(top.v[s], li + 32, 64);
+        const int pi = __shfl(top.ix[s], li + 32, 64);
+        if (half == 0) top.insert_lex(pv, pi);
+    }
+    if (half == 0 && qin) {
+        int *o = nn_idx + ((size_t)b * n + q) * k;
+#pragma unroll
+        for (int s = 0; s < KL; ++s)
+            if (s < k) o[s] = top.ix[s];
+    }
+}
+
+static bool knn_f16_enabled() {
+    static const bool on = [] { const char *e = getenv("PCOPS_KNN_F16"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+int launch_knn_f16(int b, int n, int k, const float *x, int *nn_idx, hipStream_t st) {
+    constexpr int CP = 64, CH = 128;
+    const size_t lds = (size_t)(CH * (CP + 4) + 2 * CH + kKnnPD * 512) * sizeof(float) + (size_t)CH * (CP + 8) * 2;
+    auto kern = knn_f16_kernel<20>;
+    // (the kernel also has 256 bytes of STATIC LDS -- __syncthreads_or -- so asking for the full 160 KB is refused)
+    static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)once;
+    hipLaunchKernelGGL(kern, dim3(cdiv(n, 256), b), dim3(512), lds, st, n, k, x, nn_idx);
+    return pcops_launch_status();
+}
+
 // ------------------------------------------------------------------ materialised path
 // pairwise_distance: 64x64 output tile per workgroup, 4x4 outputs per lane, channel chunks of
 // CK staged in LDS; the fmaf chains run c-ascending across chunks.
@@ -551,6 +793,11 @@ extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x
     PCOPS_REQUIRE_SHAPE(b <= 65535);
     hipStream_t st = as_stream(stream);
     static const bool use_mfma = [] { const char *e = getenv("PCOPS_KNN_MFMA"); return !(e && e[0] == '0'); }();
+    // 64-channel graphs (DGCNN's feature graphs): fp16 pre-filter on the 16-bit matrix pipe + exact distances of the
+    // survivors (knn_f16_kernel above); rows must be 16-byte aligned
+    if (use_mfma && knn_f16_enabled() && c == 64 && k <= 20 && seed == nullptr && n >= 256 &&
+        (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        return launch_knn_f16(b, n, k, x, nn_idx, st);
     if (use_mfma && k <= 32 && c <= 128) {
 #define PCOPS_KNN_CASE(CP_)                                                      \
     do {                                                                         \
@@ -571,6 +818,18 @@ extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x
     if (c <= 128) return launch_knn_graph<128>(b, n, c, k, x, nn_idx, st);
     return PCOPS_ERR_UNSUPPORTED;
 }
+
+#ifdef PCOPS_KNN_STATS
+// diagnostics build only (tools/build_variant.sh knnstats "-DPCOPS_KNN_STATS=1"): counters of knn_f16_kernel since the
+// last call -- pairs tested, survivors of the fp16 filter, exact distances below the lane's bound, processing rounds
+extern "C" int pcops_knn_debug_stats(unsigned long long *out4) {
+    if (hipDeviceSynchronize() != hipSuccess) return PCOPS_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_knn_stats), 4 * sizeof(unsigned long long)) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stats), z, sizeof(z)) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    return PCOPS_OK;
+}
+#endif
 
 extern "C" int pcops_pairwise_distance(int b, int n, int c, const float *x, float *adj,
                                        pcops_stream_t stream) {

@@ -11,9 +11,13 @@ OBJ=/tmp/pcops_variant_$NAME
 mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function $EXTRA"
 pids=()
+echo "$EXTRA" > $OBJ/flags.new
+if ! cmp -s $OBJ/flags.new $OBJ/flags 2>/dev/null; then rm -f $OBJ/*.o; cp $OBJ/flags.new $OBJ/flags; fi
 for f in abi sampling grouping interpolate knn mlp gather; do
-  /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o &
-  pids+=($!)
+  if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ $SRC/common.h -nt $OBJ/$f.o ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o &
+    pids+=($!)
+  fi
 done
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/scanobjectnn_amd/libpcops_$NAME.so $OBJ/*.o
