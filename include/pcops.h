@@ -169,9 +169,13 @@ int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
 /* the same graph, with a hint: seed (b,n,k) names k DISTINCT points per query (DGCNN: the previous layer's neighbours,
  * dgcnn/models/dgcnn.py:31-71 rebuilds the graph on every layer's features).  The largest distance to them bounds the
  * k-th nearest distance from above, so the scan rejects everything beyond it with one compare and queues a fraction of
- * the candidates; the selection and its tie rule are untouched -- nn_idx is bit for bit pcops_knn_graph's.  Entries
- * outside [0, n) are clamped; duplicates among a query's seeds void the bound (caller's contract).  seed == NULL:
- * pcops_knn_graph. */
+ * the candidates; the selection and its tie rule are untouched -- nn_idx is bit for bit pcops_knn_graph's.  The
+ * precondition is CHECKED per query: a seed row with an entry outside [0, n) or with a repeated entry names fewer than k
+ * distinct points and is ignored (that query is scanned without a bound) -- nn_idx is pcops_knn_graph's for ANY seed.
+ * seed == NULL: pcops_knn_graph.
+ * (c == 64, k <= 20, no seed, 16-byte aligned x: the pairs are first evaluated in fp16 on the 16-bit matrix pipe and
+ * only those whose fp16 distance minus a rigorous error bound can still enter a list get the exact fp32 distance --
+ * same indices, csrc/knn.hip knn_f16_kernel; PCOPS_KNN_F16=0 keeps the fp32-MFMA kernel.) */
 int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
                            pcops_stream_t stream);
 /* get_edge_feature: x (b,n,c), nn_idx (b,n,k) -> out (b,n,k,2c) = [x_i | x_j - x_i] */

@@ -216,9 +216,29 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
         const int *sd = seed + ((size_t)b * n + (qin ? q : 0)) * k;
         const bool v4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15) == 0);
         float worst = 0.f, smax = 0.f;
+        // PRECONDITION (pcops.h): k distinct in-range indices per row.  It is CHECKED: a row with an index outside [0, n)
+        // or with a repeated index does not bound the k-th distance (fewer than k distinct points), so it gives no bound
+        // at all (tau stays +inf) instead of a clamped / too small one that would silently drop true neighbours
+        bool seed_ok = true;
+        int mine[(KL + 1) / 2];
+#pragma unroll
+        for (int u = 0; u < (KL + 1) / 2; ++u) {
+            const int s = half + 2 * u;
+            mine[u] = (s < k && qin) ? sd[s] : -1 - u - 64 * half;          // distinct negative fillers beyond k
+            if (s < k && qin && (mine[u] < 0 || mine[u] >= n)) seed_ok = false;
+        }
+#pragma unroll
+        for (int u = 0; u < (KL + 1) / 2; ++u) {
+#pragma unroll
+            for (int w = u + 1; w < (KL + 1) / 2; ++w) seed_ok = seed_ok && (mine[u] != mine[w]);
+            const int theirs = __shfl_xor(mine[u], 32, 64);                 // the partner half-wave's seeds of this query
+#pragma unroll
+            for (int w = 0; w < (KL + 1) / 2; ++w) seed_ok = seed_ok && (theirs != mine[w]);
+        }
+        seed_ok = seed_ok && (__shfl_xor((int)seed_ok, 32, 64) != 0);
         for (int s = half; s < k && qin; s += 2) {
             int j = sd[s];
-            j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+            j = j < 0 ? 0 : (j >= n ? n - 1 : j);                           // (address safety only; such a row is rejected above)
             const float *pq = xb + (size_t)q * c, *pj = xb + (size_t)j * c;
             float d = 0.f, sj = 0.f;
             if (v4) {
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
         smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
         // the scan evaluates (s_q - 2 <x_q, x_j>) + s_j with c-term fmaf chains: within ~4 c eps max(s_q, s_j) of the
         // direct form above (c <= 128: 6e-5); the margin is an order of magnitude wider
-        if (qin) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
+        if (qin && seed_ok) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
     }
     TopK<KL> top;
     top.init();

@@ -32,7 +32,7 @@ def test_knn_graph_vs_oracle(b, n, c, k):
 
 
 @pytest.mark.parametrize("b,n,c,k", [(2, 2048, 3, 20), (2, 1024, 64, 20), (1, 300, 64, 20), (2, 200, 128, 20), (2, 257, 16, 33)])
-@pytest.mark.parametrize("kind", ["previous", "random", "far", "lattice"])
+@pytest.mark.parametrize("kind", ["previous", "random", "far", "lattice", "duplicates", "out_of_range"])
 def test_seeded_knn_graph_is_the_same_graph(b, n, c, k, kind, monkeypatch):
     """pcops_knn_graph_seeded: a hint (k distinct points per query) that starts every query from an upper bound of its
     k-th distance.  Whatever the hint -- the graph of slightly different features (DGCNN: the previous layer), random
@@ -50,10 +50,37 @@ def test_seeded_knn_graph_is_the_same_graph(b, n, c, k, kind, monkeypatch):
                 else np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)])).astype(np.int32)
     else:
         seed = np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)]).astype(np.int32)
+    if kind == "duplicates":        # a row that repeats an index names < k distinct points -- its bound is void and
+        seed[:, ::2, 1] = seed[:, ::2, 0]                        # must be IGNORED, not trusted (every other query, nearest twice)
+        seed[:, ::2, :] = O.knn_graph(x, k)[:, ::2, :1]          # ... and the whole row = the nearest point, k times
+    if kind == "out_of_range":
+        seed[:, ::3, k // 2] = n + 5
+        seed[:, 1::3, 0] = -1
     monkeypatch.setattr(dg, "KNN_SEED_MAX_C", 1 << 20)          # the wrapper only takes the hint for narrow inputs
     nn = dg.knn_graph(T(x), k=k, seed=T(seed.astype(np.int32)))
     np.testing.assert_array_equal(N(nn), want)
     assert torch.equal(nn, dg.knn_graph(T(x), k=k))
+
+
+@pytest.mark.parametrize("case", ["huge", "nan_free_mixed", "tiny", "ties"])
+def test_knn_graph_fp16_filter_edge_inputs(case):
+    """the 64-channel graph kernel pre-filters in fp16 (csrc/knn.hip knn_f16_kernel): features beyond the fp16 range, far
+    below its normal range, wildly mixed magnitudes and exact ties must all give the oracle's indices -- the filter only
+    ever REJECTS on a rigorous bound and switches itself off where the bound does not hold"""
+    rng = np.random.default_rng(17)
+    b, n, c, k = 2, 512, 64, 20
+    x = rng.standard_normal((b, n, c)).astype(np.float32)
+    if case == "huge":
+        x *= 3.0e5                                               # |x| > 65504: fp16 overflows -> the filter turns itself off
+    elif case == "nan_free_mixed":
+        x[:, ::7] *= 1.0e5                                       # a few far outliers among O(1) points
+        x[:, 1::7] *= 1.0e-6
+    elif case == "tiny":
+        x *= 1.0e-6                                              # fp16 subnormals / flush to zero
+    else:
+        x = (rng.integers(0, 2, (b, n, c)) * 0.5).astype(np.float32)   # many exactly equal distances
+    nn = dg.knn_graph(T(x), k=k)
+    np.testing.assert_array_equal(N(nn), O.knn_graph(x, k))
 
 
 def test_knn_graph_4d_input_and_lattice_ties():
