@@ -228,3 +228,26 @@ def test_msg_logits_at_bench_size_eval():
     _randomise(net, 5)
     worst = _eval_logits_against_chunked_truth(net, x, c, lambda xx, P, tr: R.pointnet2_cls_msg(xx, P, tr), 16)
     assert worst <= 1e-4, worst
+
+
+def test_bga_logits_and_mask_at_bench_size_eval():
+    """config 4 (pointnet2_cls_bga, 1024 clouds over 8 GPUs = 128 x 2048 per GPU): class logits AND per-point mask logits of
+    one GPU's full batch, eval mode, <= 1e-4 against the float64 restatement (SA1 with nsample 64 on compacted rows, the three
+    FP stacks on 65 536 / 16 384 / 262 144 rows)"""
+    from test_models_parity_gpu import _randomise
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_bga as m
+    c = synth_clouds(128, 2048, seed=1234)
+    x = torch.from_numpy(c).to(DEV)
+    net = Model(m.get_model, device=DEV, seed=1).build(x[:2].contiguous())
+    _randomise(net, 5)
+    P = R.params_from_state_dict(net.state_dict(), dtype=torch.float64, device=DEV)
+    with torch.no_grad():
+        cls, seg = net(x, is_training=False)
+    worst_c = worst_s = 0.0
+    for lo in range(0, 128, 16):
+        with torch.no_grad():
+            wc, ws = R.pointnet2_cls_bga(torch.from_numpy(c[lo:lo + 16]).double().to(DEV), P, False)
+        worst_c = max(worst_c, (cls[lo:lo + 16].double() - wc).abs().max().item())
+        worst_s = max(worst_s, (seg[lo:lo + 16].double() - ws).abs().max().item())
+    assert seg.shape == (128, 2048, 2)
+    assert worst_c <= 1e-4 and worst_s <= 1e-4, (worst_c, worst_s)

@@ -44,7 +44,7 @@ def _grads(mod, net, x, y):
     return torch.cat([p.grad.reshape(-1) for _, p in sorted(net.named_parameters()) if p.grad is not None])
 
 
-def _worker(rank, world, port, name, sync, q):
+def _worker(rank, world, port, name, sync, q, perturb=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -54,6 +54,11 @@ def _worker(rank, world, port, name, sync, q):
     torch.cuda.set_device(0)
     D.SYNC_BN = sync
     mod, net, x, y = _build(name)
+    if perturb:       # every rank its OWN moving means (= the pivots of its shifted BN moments): a per-rank restore / resume
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                if k.endswith("moving_mean"):
+                    v.add_(0.01 * (rank + 1))        # (small against the layers' spread: the pivots stay warm, §4.4)
     import torch.nn.functional as F
     F.dropout = lambda x, p=0.5, training=True, inplace=False: x      # per-rank masks would not add up to one process's
     lo, hi = D.shard_range(B, rank, world)
@@ -66,11 +71,11 @@ def _worker(rank, world, port, name, sync, q):
     dist.destroy_process_group()
 
 
-def _run_ranks(name, sync):
+def _run_ranks(name, sync, perturb=False):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, sync, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, sync, q, perturb)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
@@ -109,6 +114,22 @@ def test_sync_bn_two_ranks_equal_one_process_on_the_whole_batch(name, monkeypatc
     else:
         for r in res:
             assert ((r[1] - wbufs).norm() / wbufs.norm()).item() <= btol, ((r[1] - wbufs).norm() / wbufs.norm()).item()
+
+
+def test_sync_bn_does_not_depend_on_the_ranks_holding_the_same_pivots(monkeypatch):
+    """under SyncBN the shifted moments sum (y - pivot_rank) were all-reduced and finalised with the LOCAL
+    pivot -- right only while every rank's moving mean is bit-identical, which nothing enforced.  Now each rank takes its
+    pivot out in float64 before the exchange (dist.allreduce_stat_partials): with DIFFERENT moving means per rank the
+    all-reduced gradient is still the single process's on the whole batch.  (Offsets of 0.01 / 0.02: finalised with the local
+    pivot the global mean of every layer would be off by +-0.005, i.e. by 0.5 ... 10 % of a standard deviation.)"""
+    res = _run_ranks("ssg", True, perturb=True)
+    _no_dropout(monkeypatch)
+    mod, net, x, y = _build("ssg")
+    want = _grads(mod, net, x, y).cpu()
+    assert torch.equal(res[0][0], res[1][0])
+    err = (res[0][0] - want).norm().item() / want.norm().item()
+    assert err <= 2e-3, err
+    assert not torch.allclose(res[0][1], res[1][1])          # the ranks really had different moving means
 
 
 def test_without_sync_bn_the_ranks_keep_their_own_statistics():
