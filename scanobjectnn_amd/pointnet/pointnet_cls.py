@@ -5,7 +5,8 @@ import torch
 import torch.nn.functional as F
 
 from ..graph import variable_scope
-from . import tf_util
+from ..dgcnn import tf_util      # the `tf.nn.moments` + EMA batch-norm flavour of `pointnet/utils/tf_util.py:455-490` IS the one
+#                                   `dgcnn/utils/tf_util.py:462-499` copies (biased variance in the moving average too): one layer module
 from .transform_nets import feature_transform_net, input_transform_net
 
 NUM_CLASSES = 15

@@ -3,7 +3,8 @@ feature_transform_net :53-95).  Pure dense layers (no custom kernel), runs on an
 import torch
 
 from ..graph import constant_initializer, get_variable, variable_scope
-from . import tf_util
+from ..dgcnn import tf_util      # the `tf.nn.moments` + EMA batch-norm flavour of `pointnet/utils/tf_util.py:455-490` IS the one
+#                                   `dgcnn/utils/tf_util.py:462-499` copies (biased variance in the moving average too): one layer module
 
 
 def _trunk(net, num_point, is_training, bn_decay, first_kernel):
