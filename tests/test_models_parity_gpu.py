@@ -379,6 +379,27 @@ def _grad_case(name, seed, monkeypatch):
     loss_ref, g64 = truth(record=D64)
     assert abs(loss_fused - loss_ref) <= 1e-4
     out = {"seed": seed}
+    if is_dg:
+        # the third kind of discrete decision: the neighbour graphs.  The truth above is evaluated ON the product's graphs
+        # (each bit-exact against the oracle given its input tensor: test_dgcnn_logits, test_knn_gpu.py); here they are
+        # compared with the graphs the float64 run builds on ITS OWN features -- rows (cloud, point) whose neighbour SET
+        # differs are counted per graph: a 20th-neighbour near-tie decided the other way by a 1e-7 feature difference
+        own_graphs = []
+        real_knn = O.knn_graph
+
+        def rec_knn(xx, k):
+            g = real_knn(xx, k)
+            own_graphs.append(g)
+            return g
+        monkeypatch.setattr(O, "knn_graph", rec_knn)
+        with torch.no_grad():
+            ref(torch.from_numpy(c).double().to(DEV), R.params_from_state_dict(sd, dtype=torch.float64, device=DEV), True)
+        monkeypatch.setattr(O, "knn_graph", real_knn)
+        assert len(own_graphs) == len(graphs_fused) == 5
+        out["graph_rows_differing"] = [int((np.sort(a, -1) != np.sort(b, -1)).any(-1).sum())
+                                       for a, b in zip(own_graphs, graphs_fused)]
+        out["graph_rows"] = int(graphs_fused[0].shape[0] * graphs_fused[0].shape[1])
+        assert sum(out["graph_rows_differing"]) <= 0.01 * 5 * out["graph_rows"], out       # few, and only near-ties can differ
     for path, D, g in (("fused", D_fused, g_fused), ("layer", D_layer, g_layer)):
         # the read-back covers exactly the layers of the network, each with the kind of decision it has
         assert set(D.relu) == set(D64.relu) and set(D.pool) == set(D64.pool), \
