@@ -428,7 +428,7 @@ __device__ unsigned long long g_knn_stats[4];    // pairs tested, survivors, exa
 
 template <int KL>
 __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const float *__restrict__ x,
-                                                         int *__restrict__ nn_idx) {
+                                                         int *__restrict__ nn_idx, const int *__restrict__ seed) {
     constexpr int CP = 64, CH = 128, LD = CP + 4;      // fp32 chunk row stride: 16-byte aligned rows
     constexpr int LH = CP + 8;                         // fp16 chunk row stride in halves (144 B: conflict-free b128 reads)
     constexpr int PD = kKnnPD;
@@ -474,10 +474,60 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
 #pragma unroll
     for (int l = 0; l < CP; ++l) big |= (int)!(fabsf(xq[l]) <= kF16Safe);
 
+    // SEEDED start (pcops_knn_graph_seeded, as in knn_mfma_kernel): k distinct points per query -- DGCNN: the previous
+    // layer's neighbours -- bound the k-th distance from above by the largest exact distance to them.  Here a survivor
+    // costs an exact 64-channel distance AND an insertion, so a query that starts from a bound near its final one saves
+    // far more than the k / 2 exact distances per half-wave the bound costs.  Invalid rows (out of range / repeated
+    // index) give no bound.
+    float tau = INFINITY;
+    if (seed != nullptr) {
+        const int *sd = seed + ((size_t)b * n + (qin ? q : 0)) * k;
+        bool seed_ok = true;
+        int mine[(KL + 1) / 2];
+#pragma unroll
+        for (int u = 0; u < (KL + 1) / 2; ++u) {
+            const int s_ = half + 2 * u;
+            mine[u] = (s_ < k && qin) ? sd[s_] : -1 - u - 64 * half;
+            if (s_ < k && qin && (mine[u] < 0 || mine[u] >= n)) seed_ok = false;
+        }
+#pragma unroll
+        for (int u = 0; u < (KL + 1) / 2; ++u) {
+#pragma unroll
+            for (int w = u + 1; w < (KL + 1) / 2; ++w) seed_ok = seed_ok && (mine[u] != mine[w]);
+            const int theirs = __shfl_xor(mine[u], 32, 64);
+#pragma unroll
+            for (int w = 0; w < (KL + 1) / 2; ++w) seed_ok = seed_ok && (theirs != mine[w]);
+        }
+        seed_ok = seed_ok && (__shfl_xor((int)seed_ok, 32, 64) != 0);
+        float worst = 0.f, smax = 0.f;
+#pragma unroll 1
+        for (int u = 0; u < (KL + 1) / 2; ++u) {
+            const int s_ = half + 2 * u;
+            if (!(s_ < k && qin)) continue;
+            int j = mine[u];
+            j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+            const float4 *pj4 = reinterpret_cast<const float4 *>(xb + (size_t)j * CP);
+            float d = 0.f, sj = 0.f;
+#pragma unroll
+            for (int l4 = 0; l4 < CP / 4; ++l4) {
+                const float4 v = pj4[l4];
+                const float e0 = xq[4 * l4] - v.x, e1 = xq[4 * l4 + 1] - v.y, e2 = xq[4 * l4 + 2] - v.z, e3 = xq[4 * l4 + 3] - v.w;
+                d = fmaf(e0, e0, d); d = fmaf(e1, e1, d); d = fmaf(e2, e2, d); d = fmaf(e3, e3, d);
+                sj = fmaf(v.x, v.x, sj); sj = fmaf(v.y, v.y, sj); sj = fmaf(v.z, v.z, sj); sj = fmaf(v.w, v.w, sj);
+            }
+            worst = fmaxf(worst, d);
+            smax = fmaxf(smax, sj);
+        }
+        worst = fmaxf(worst, __shfl_xor(worst, 32, 64));
+        smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+        // the scan's distance (s_q - 2 <x_q, x_j>) + s_j is within ~4 c eps max(s_q, s_j) of the direct form above; the margin
+        // is an order of magnitude wider (as in knn_mfma_kernel)
+        if (qin && seed_ok) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
+    }
     TopK<KL> top;
     top.init();
     int nq = 0;
-    float tau2 = INFINITY, thr = INFINITY, tp = INFINITY;
+    float tau2 = INFINITY, thr = tau, tp = (tau - sqa) + kKnnB;
 #ifdef PCOPS_KNN_STATS
     unsigned st_surv = 0, st_acc = 0, st_rounds = 0;
 #endif
@@ -592,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
                 nq = 0;
                 const float hv = top.v[(KL + 1) / 2 - 1];
                 tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
-                thr = fminf(top.v[KL - 1], nextafterf(tau2, INFINITY));
+                thr = fminf(fminf(top.v[KL - 1], nextafterf(tau2, INFINITY)), tau);
                 tp = filter_off ? INFINITY : (thr - sqa) + kKnnB;   // reject iff  fma(-2, acc, su_j) > tp
                 }
             }
@@ -625,7 +675,7 @@ static bool knn_f16_enabled() {
     return on;
 }
 
-int launch_knn_f16(int b, int n, int k, const float *x, int *nn_idx, hipStream_t st) {
+int launch_knn_f16(int b, int n, int k, const float *x, int *nn_idx, const int *seed, hipStream_t st) {
     constexpr int CP = 64, CH = 128;
     const size_t lds = (size_t)(CH * (CP + 4) + 2 * CH + kKnnPD * 512) * sizeof(float) + (size_t)CH * (CP + 8) * 2;
     auto kern = knn_f16_kernel<20>;
@@ -633,7 +683,7 @@ int launch_knn_f16(int b, int n, int k, const float *x, int *nn_idx, hipStream_t
     static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)once;
-    hipLaunchKernelGGL(kern, dim3(cdiv(n, 256), b), dim3(512), lds, st, n, k, x, nn_idx);
+    hipLaunchKernelGGL(kern, dim3(cdiv(n, 256), b), dim3(512), lds, st, n, k, x, nn_idx, seed);
     return pcops_launch_status();
 }
 
@@ -815,9 +865,8 @@ extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x
     static const bool use_mfma = [] { const char *e = getenv("PCOPS_KNN_MFMA"); return !(e && e[0] == '0'); }();
     // 64-channel graphs (DGCNN's feature graphs): fp16 pre-filter on the 16-bit matrix pipe + exact distances of the
     // survivors (knn_f16_kernel above); rows must be 16-byte aligned
-    if (use_mfma && knn_f16_enabled() && c == 64 && k <= 20 && seed == nullptr && n >= 256 &&
-        (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        return launch_knn_f16(b, n, k, x, nn_idx, st);
+    if (use_mfma && knn_f16_enabled() && c == 64 && k <= 20 && n >= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        return launch_knn_f16(b, n, k, x, nn_idx, seed, st);
     if (use_mfma && k <= 32 && c <= 128) {
 #define PCOPS_KNN_CASE(CP_)                                                      \
     do {                                                                         \

@@ -141,7 +141,7 @@ def knn(adj_matrix, k=20):
 
 
 KNN_SEED = os.environ.get("PCOPS_KNN_SEED", "1") != "0"
-KNN_SEED_MAX_C = int(os.environ.get("PCOPS_KNN_SEED_MAX_C", "16"))
+KNN_SEED_MAX_C = int(os.environ.get("PCOPS_KNN_SEED_MAX_C", "64"))
 
 
 def knn_graph(point_cloud, k=20, seed=None):
@@ -154,9 +154,10 @@ def knn_graph(point_cloud, k=20, seed=None):
         raise ValueError("input must have at least k columns")
     out = torch.empty((b, n, k), dtype=torch.int32, device=x.device)
     # measured at the DGCNN config (B = 256, N = 2048, k = 20, MI355X): coordinate graphs 905 -> 613 us with the previous
-    # graph as the hint; 64-channel graphs 2445 -> 2750 us (the k seed rows cost 20 x 256 bytes of gathers per query and
-    # the previous layer's neighbours are not close enough in the next layer's feature space to pay for them) -- so the
-    # hint is taken for narrow inputs only
+    # graph as the hint.  64-channel graphs: on the fp32-MFMA kernel the hint LOST (round 3: 2445 -> 2750 us, the k seed
+    # rows cost more than the queue entries they saved); on round 4's fp16-filter kernel every survivor costs an exact
+    # 64-channel distance plus an insertion and the hint WINS (1720 -> 1555 us, profiles/r04_knn_seed_ab.txt), so it is
+    # taken up to 64 channels (PCOPS_KNN_SEED_MAX_C; wider inputs run the fp32-MFMA kernel, where it does not pay)
     if (seed is not None and KNN_SEED and c <= KNN_SEED_MAX_C and tuple(seed.shape) == (b, n, k)
             and seed.dtype == torch.int32):
         _lib.call("pcops_knn_graph_seeded", b, n, c, k, _lib.ptr(x), _lib.ptr(seed.contiguous()), _lib.ptr(out))
