@@ -142,6 +142,8 @@ def knn(adj_matrix, k=20):
 
 KNN_SEED = os.environ.get("PCOPS_KNN_SEED", "1") != "0"
 KNN_SEED_MAX_C = int(os.environ.get("PCOPS_KNN_SEED_MAX_C", "64"))
+KNN_SEED_FORCE = False       # tests: take the hint whatever the shape (every seeded kernel variant is then exercised)
+KNN_F16 = os.environ.get("PCOPS_KNN_F16", "1") != "0"      # (mirrors the library's switch: csrc/knn.hip knn_f16_enabled)
 
 
 def knn_graph(point_cloud, k=20, seed=None):
@@ -157,8 +159,10 @@ def knn_graph(point_cloud, k=20, seed=None):
     # graph as the hint.  64-channel graphs: on the fp32-MFMA kernel the hint LOST (round 3: 2445 -> 2750 us, the k seed
     # rows cost more than the queue entries they saved); on round 4's fp16-filter kernel every survivor costs an exact
     # 64-channel distance plus an insertion and the hint WINS (1720 -> 1555 us, profiles/r04_knn_seed_ab.txt), so it is
-    # taken up to 64 channels (PCOPS_KNN_SEED_MAX_C; wider inputs run the fp32-MFMA kernel, where it does not pay)
-    if (seed is not None and KNN_SEED and c <= KNN_SEED_MAX_C and tuple(seed.shape) == (b, n, k)
+    # taken for narrow inputs (<= 16 channels) and for exactly the shape that kernel takes (64 channels, k <= 20); anything
+    # else would run the fp32-MFMA kernel, where it does not pay
+    pays = KNN_SEED_FORCE or c <= 16 or (c == 64 and k <= 20 and n >= 256 and KNN_F16)
+    if (seed is not None and KNN_SEED and c <= KNN_SEED_MAX_C and pays and tuple(seed.shape) == (b, n, k)
             and seed.dtype == torch.int32):
         _lib.call("pcops_knn_graph_seeded", b, n, c, k, _lib.ptr(x), _lib.ptr(seed.contiguous()), _lib.ptr(out))
     else:

@@ -56,7 +56,8 @@ def test_seeded_knn_graph_is_the_same_graph(b, n, c, k, kind, monkeypatch):
     if kind == "out_of_range":
         seed[:, ::3, k // 2] = n + 5
         seed[:, 1::3, 0] = -1
-    monkeypatch.setattr(dg, "KNN_SEED_MAX_C", 1 << 20)          # the wrapper only takes the hint for narrow inputs
+    monkeypatch.setattr(dg, "KNN_SEED_MAX_C", 1 << 20)          # the wrapper only takes the hint where it pays ...
+    monkeypatch.setattr(dg, "KNN_SEED_FORCE", True)             # ... here every seeded kernel variant is exercised
     nn = dg.knn_graph(T(x), k=k, seed=T(seed.astype(np.int32)))
     np.testing.assert_array_equal(N(nn), want)
     assert torch.equal(nn, dg.knn_graph(T(x), k=k))
