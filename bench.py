@@ -75,9 +75,9 @@ def _algo(name, a):
     if name in ("pcops_three_interpolate", "pcops_three_interpolate_grad"):
         b, m, c, n = a[:4] if name == "pcops_three_interpolate" else (a[0], a[3], a[2], a[1])
         return b * (4 * m * c + 24 * n + 4 * n * c), 0, ""
-    if name == "pcops_knn_graph":
+    if name in ("pcops_knn_graph", "pcops_knn_graph_seeded"):      # (seeded: + the hint's k indices per query)
         b, n, c, k = a[:4]
-        return b * (4 * n * c + 4 * n * k), 2 * b * n * n * c, "flop"
+        return b * (4 * n * c + 4 * n * k * (2 if name.endswith("seeded") else 1)), 2 * b * n * n * c, "flop"
     if name in ("pcops_edge_feature", "pcops_edge_feature_grad"):
         b, n, c, k = a[:4]
         return b * (4 * n * c + 4 * n * k + 8 * n * k * c), 0, ""
@@ -165,7 +165,7 @@ def _algo(name, a):
 
 _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcops_group_point": 5,
            "pcops_group_point_grad": 5, "pcops_three_interpolate": 4, "pcops_three_interpolate_grad": 4,
-           "pcops_knn_graph": 4, "pcops_edge_feature": 4, "pcops_edge_feature_grad": 4,
+           "pcops_knn_graph": 4, "pcops_knn_graph_seeded": 4, "pcops_edge_feature": 4, "pcops_edge_feature_grad": 4,
            "pcops_selection_sort": 4, "pcops_pairwise_distance": 3, "pcops_knn_topk": 3,
            "pcops_sa_gather_fwd": 5, "pcops_sa_scatter_bwd": 5, "pcops_mlp_bn_finalize": 3,
            "pcops_mlp_bn_bwd_coeffs": 3, "pcops_mlp_bn_relu_apply": 2, "pcops_mlp_relu_mask_stats": 2,
