@@ -128,7 +128,9 @@ def test_sync_bn_does_not_depend_on_the_ranks_holding_the_same_pivots(monkeypatc
     want = _grads(mod, net, x, y).cpu()
     assert torch.equal(res[0][0], res[1][0])
     err = (res[0][0] - want).norm().item() / want.norm().item()
-    assert err <= 2e-3, err
+    # measured 1.3e-3 (6e-4 with equal pivots: ReLU flips between two fp32 evaluations); finalised with the
+    # LOCAL pivot the layers' means would be off by 0.5 ... 10 % of a standard deviation and the gradient by tens of per cent
+    assert err <= 3e-3, err
     assert not torch.allclose(res[0][1], res[1][1])          # the ranks really had different moving means
 
 
