@@ -216,3 +216,49 @@ def test_overlap_with_a_parameter_the_loss_does_not_reach():
     net(x).sum().backward()
     g = fp.collect_mean(1)
     assert g[-20:].abs().max().item() == 0.0 and g[:10].abs().max().item() > 0.0
+
+
+def _stat_worker(rank, world, port, q):
+    """each rank: shifted-moment partials of ITS shard about ITS OWN pivot -> dist.allreduce_stat_partials(part, rows, pivot)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    y = 3.0 + 0.5 * torch.randn(64, 5, generator=g)                  # the whole batch; |mean| = 6 sigma
+    rows = 64 // world
+    mine = y[rank * rows:(rank + 1) * rows]
+    pivot = torch.full((5,), 2.5 + 0.4 * rank)                       # a DIFFERENT pivot on every rank
+    d = mine - pivot
+    # P = 4 partial rows of (sum (y - pivot), sum (y - pivot)^2), fp32 like the kernels'
+    part = torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in d.chunk(4)]).float()
+    glob, total = D.allreduce_stat_partials(part, rows, pivot)
+    s = glob.double().sum(0)                                          # (2, C): plain sums of the GLOBAL batch, no pivot left
+    q.put((rank, total, s.tolist()))
+    D.dist.barrier()
+    D.dist.destroy_process_group()
+
+
+def test_sync_bn_statistics_with_a_different_pivot_on_every_rank():
+    """the SyncBN exchange must not assume that all ranks hold the same pivot (moving mean).  Every rank takes its
+    own pivot out of its shifted moments in float64 before the all-reduce (which runs on the statistics' own process
+    group): what comes back are the plain sums of the global batch -- mean and variance right to 1e-6 although the ranks'
+    pivots differ by 0.4 and the data sit 6 sigma from the origin."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stat_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    y = (3.0 + 0.5 * torch.randn(64, 5, generator=g)).double()
+    for _, total, s in res:
+        assert total == 64
+        s = torch.tensor(s, dtype=torch.float64)
+        mean = s[0] / total
+        var = s[1] / total - mean * mean
+        assert torch.allclose(mean, y.mean(0), rtol=0, atol=1e-6)
+        assert torch.allclose(var, y.var(0, unbiased=False), rtol=1e-5, atol=1e-7)
