@@ -195,3 +195,35 @@ def test_seg_evaluation_metrics_toy_fixture():
     # vote 1 sees the cloud rotated by pi about the up axis: x and z change sign, y stays
     np.testing.assert_allclose(calls[1][..., 1].numpy(), data[:2, :, 1], rtol=0, atol=1e-6)
     np.testing.assert_allclose(calls[1][..., 0].numpy(), -data[:2, :, 0], rtol=0, atol=1e-6)
+
+
+def test_seg_evaluate_cli_flags_and_test_set_preparation(tmp_path):
+    """`pointnet2/evaluate_seg_scenennobjects.py:33-55`: the flags and defaults of the BGA evaluation; the test set is
+    loaded WITH masks, the masks binarised (-1 -> 0, parts -> 1, `:84`), the clouds centred and normalised on the host
+    (`:86-90`) -- no GPU needed for any of this"""
+    from scanobjectnn_amd import data_utils as DU
+    from scanobjectnn_amd.pointnet2 import evaluate_seg_scenennobjects as EVS
+    a = EVS.parse_args([])
+    assert (a.model, a.batch_size, a.num_point, a.seg_weight, a.model_path, a.dump_dir, a.num_votes) == \
+        ("pointnet2_cls_bga", 1, 1024, 0.5, "log/model.ckpt", "dump/", 1)
+    assert a.with_bg is True and a.norm is True and a.center_data is True and a.visu is False
+    b = EVS.parse_args(["--model", "dgcnn_bga", "--num_votes", "12", "--seg_weight", "0.25", "--center_data", "no", "--normal"])
+    assert b.model == "dgcnn_bga" and b.num_votes == 12 and b.seg_weight == 0.25 and b.center_data is False
+    with pytest.raises(SystemExit):
+        EVS.parse_args(["--model", "pointnet2_cls_ssg"])             # a classifier has the other command line
+    rng = np.random.RandomState(1)
+    raw = (rng.randn(5, 48, 3) * 2.0 - 4.0).astype(np.float32)
+    lab = np.arange(5, dtype=np.int32)
+    parts = rng.randint(-1, 3, (5, 48)).astype(np.int32)
+    np.savez(tmp_path / "t.npz", data=raw, label=lab, mask=parts)
+    args = EVS.parse_args(["--test_file", str(tmp_path / "t.npz"), "--num_point", "32"])
+    data, labels, masks = EVS.load_test_set(args)
+    np.testing.assert_array_equal(data, DU.normalize_data(DU.center_data(raw.copy())))
+    assert labels.shape == (5,) and set(np.unique(masks)) <= {0, 1} and np.array_equal(masks == 0, parts == -1)
+    # the evaluation view: file order, the FIRST num_point points (shuffle=False, :196)
+    cur, l2, m2 = DU.get_current_data_withmask_h5(data, labels, masks, 32, shuffle=False)
+    assert np.array_equal(cur, data[:, :32]) and np.array_equal(m2, masks[:, :32]) and np.array_equal(l2, labels)
+    # synthetic fallback (no --test_file): clouds, labels and binary masks of the requested size
+    args = EVS.parse_args(["--num_point", "64", "--synthetic_clouds", "6"])
+    d, l, m = EVS.load_test_set(args)
+    assert d.shape[0] == 6 and d.shape[1] >= 64 and l.shape == (6,) and m.shape == d.shape[:2] and set(np.unique(m)) <= {0, 1}
