@@ -269,6 +269,12 @@ int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partia
                             float *dbeta, float *p, float *q, float *t, pcops_stream_t stream);
 /* dgrad: Gprev[M,Nout] = mask . (dY[M,K] Wt[K,Nout]); dY from (G,Y,p,q,t) or, when gpool != NULL, from the
  * pooled form (gpool = the MASKED pooled gradient of pcops_mlp_pool_bwd_stats, argmax, S, pool_scale, pool_shift).
+ * CONTRACT since ABI version 3: gpool must ALREADY carry the ReLU mask of the pooled rows (pass the `gmasked` output of
+ * pcops_mlp_pool_bwd_stats, never the raw upstream gradient) -- the dgrad / wgrad / scatter kernels no longer test
+ * relu(pool_scale * y + pool_shift) themselves; pool_scale / pool_shift are still REQUIRED non-NULL with a pooled form
+ * (argument validation, and room to move the test back) but are not read.  A caller written against version 2 that passes
+ * the raw gradient gets wrong gradients for inactive pooled rows: compare pcops_abi_version() first (the Python binding
+ * refuses a mismatch, _lib.load()).
  * Yprev != NULL: mask = [relu(bn_prev(Yprev)) > 0]
  * and stats_partial [pcops_mlp_stats_rows(M)][2][Nout] gets (sum Gprev, sum Gprev*Yprev); Yprev == NULL: plain. */
 int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y, const float *p,
