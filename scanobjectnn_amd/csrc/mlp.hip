@@ -1208,6 +1208,14 @@ static bool ws_stream256_enabled() {
     return on;
 }
 
+static bool ws_n96_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_WS_N96");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
@@ -1233,9 +1241,14 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
     if (pl->wst) {
         const int nc = ws_ncoef(am);
         if (a.N > 64 && ws_lds_bytes_streamed(Kp, 64, 128, 8, 2, nc) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
+        if (pl->bn == 128 && a.N <= 96 && ws_n96_enabled()) { pl->bn = 96; pl->eh = 3; }
         pl->lds = ws_lds_bytes_streamed(Kp, pl->kc, pl->bn, pl->waves, pl->eh, nc);
     } else {
         if (a.N > 64 && ws_lds_bytes(Kp, 64, 128, 8, 2) <= 160 * 1024) { pl->bn = 128; pl->eh = 2; }
+        // 65..96 output columns (MSG's 64 -> 96 -> 128 scale): THREE 32-column accumulator blocks instead of four -- a
+        // quarter of the matrix-pipe work of the 128-wide tile was on zero columns; the epilogue then runs three
+        // 32-column passes
+        if (pl->bn == 128 && a.N <= 96 && ws_n96_enabled()) { pl->bn = 96; pl->eh = 3; }
         pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
     }
     if (pl->lds > 160 * 1024) return false;
@@ -1267,6 +1280,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
+    else if (pl.bn == 96) PCOPS_WS_LAUNCH(3, 3);
     else PCOPS_WS_LAUNCH(2, 1);
 #undef PCOPS_WS_LAUNCH
     return pcops_launch_status();
@@ -2008,8 +2022,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_ws_kernel(WgradArgs a) {
 // Stripes are double buffered and handed over with ONE workgroup barrier per stripe.  Per 32-row stripe a consumer
 // issues 16 TK TN MFMAs (64 cycles each) while the producers need a few hundred VALU cycles: the kernel is MFMA
 // bound for K >= 128 and HBM bound for the 64-wide layers.
-template <int TK, int TN, int AMODE, int DMODE>
+// K96 (65..96 input channels against 65..128 gradient columns -- MSG's 96 -> 128 layer): the staged tile keeps its 128 +
+// 128 columns (the producers' lane mapping wants 256 % (KB / 4) == 0; channels >= K are never requested and arrive as
+// zeros), but the four consumers split the OUTPUT as 96 x 32 each (three A blocks against one dY block) instead of
+// 64 x 64: no wave multiplies the empty fourth block -- 3 MFMAs per row pair and wave instead of 4.
+template <int TK, int TN, int AMODE, int DMODE, bool K96 = false>
 __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(WgradArgs a) {
+    static_assert(!K96 || (TK == 2 && TN == 2), "96-channel consumer layout: 128 + 128 staged columns");
     constexpr int KB = 64 * TK, NB = 64 * TN, LD = KB + NB;
     // rows per stripe: the small tiles get longer stripes (fewer barriers) unless the pooled form wants stripes that
     // stay inside one 32-row-aligned group
@@ -2241,46 +2260,47 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
         __syncthreads();
     } else {
         // ------------------------------------------------------------------ consumers
-        constexpr int CN = 2;
+        constexpr int CN = K96 ? 4 : 2;                        // consumers across the dY columns
+        constexpr int KX = K96 ? 3 : TK, NY = K96 ? 1 : TN;    // 32 x 32 blocks of a consumer: KX of A against NY of dY
         const int ck = wave / CN, cn = wave % CN;
         const int half = lane >> 5, li = lane & 31;
-        f32x16 acc[TK][TN];
+        f32x16 acc[KX][NY];
 #pragma unroll
-        for (int i = 0; i < TK; ++i)
+        for (int i = 0; i < KX; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < NY; ++j)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-        const int aoff = half * LD + ck * TK * 32 + li;
-        const int doff = half * LD + KB + cn * TN * 32 + li;
+        const int aoff = half * LD + ck * KX * 32 + li;
+        const int doff = half * LD + KB + cn * NY * 32 + li;
         __syncthreads();
         for (long long i = 0; i < cnt; ++i) {
             const float *sb = buf + (i & 1) * RS * LD;
-            float av_n[TK], dv_n[TN];
+            float av_n[KX], dv_n[NY];
 #pragma unroll
-            for (int x = 0; x < TK; ++x) av_n[x] = sb[aoff + 32 * x];
+            for (int x = 0; x < KX; ++x) av_n[x] = sb[aoff + 32 * x];
 #pragma unroll
-            for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 32 * y];
+            for (int y = 0; y < NY; ++y) dv_n[y] = sb[doff + 32 * y];
 #pragma unroll
             for (int it = 0; it < RS / 2; ++it) {
-                float av[TK], dv[TN];
+                float av[KX], dv[NY];
 #pragma unroll
-                for (int x = 0; x < TK; ++x) av[x] = av_n[x];
+                for (int x = 0; x < KX; ++x) av[x] = av_n[x];
 #pragma unroll
-                for (int y = 0; y < TN; ++y) dv[y] = dv_n[y];
+                for (int y = 0; y < NY; ++y) dv[y] = dv_n[y];
                 if (it + 1 < RS / 2) {
 #pragma unroll
-                    for (int x = 0; x < TK; ++x) av_n[x] = sb[aoff + 2 * (it + 1) * LD + 32 * x];
+                    for (int x = 0; x < KX; ++x) av_n[x] = sb[aoff + 2 * (it + 1) * LD + 32 * x];
 #pragma unroll
-                    for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
+                    for (int y = 0; y < NY; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
                 }
                 // the next row pair's fragments are REQUESTED before this pair's MFMAs issue (the scheduler would
                 // otherwise sink the reads to just in front of their first use and expose the LDS latency)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int x = 0; x < TK; ++x)
+                for (int x = 0; x < KX; ++x)
 #pragma unroll
-                    for (int y = 0; y < TN; ++y)
+                    for (int y = 0; y < NY; ++y)
                         acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], dv[y], acc[x][y], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2289,13 +2309,13 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
         // acc[x][y][v]: A channel 32 x + (v&3) + 8 (v>>2) + 4 half, dY channel 32 y + li  (of this consumer's block)
         float *out = a.part + (long long)grp * K * N;
 #pragma unroll
-        for (int x = 0; x < TK; ++x)
+        for (int x = 0; x < KX; ++x)
 #pragma unroll
-            for (int y = 0; y < TN; ++y) {
-                const int nn = n0 + (cn * TN + y) * 32 + li;
+            for (int y = 0; y < NY; ++y) {
+                const int nn = n0 + (cn * NY + y) * 32 + li;
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const int kk = k0 + (ck * TK + x) * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+                    const int kk = k0 + (ck * KX + x) * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
                     if (kk < K && nn < N) out[(long long)kk * N + nn] = acc[x][y][v];
                 }
             }
@@ -2327,7 +2347,9 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
 //                          statistics read the RAW Yprev the producers left beside X -- no second trip to memory.
 // Per stripe a consumer issues 16 NB/64 MFMAs of 64 cycles and 4 NB/16 of 32: equal matrix-pipe time for the two products
 // (4 096 cycles at NB = 128); the pass is pipe bound at about 0.7 x the time of the two kernels it replaces.
-template <int TN, int DMODE, bool XYZ>
+// NSK (N <= NB - 32, MSG's 64 -> 96 layer on the 128-column tile): the consumers skip what only multiplies the zero
+// columns -- the dW block of dY columns >= N and the data-gradient steps over them (wave-uniform tests on N).
+template <int TN, int DMODE, bool XYZ, bool NSK = false>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
     // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
@@ -2615,6 +2637,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const int aoff = half * LD + ck * 32 + li;
         const int doff = half * LD + 2 * KB + cn * TN * 32 + li;
         const int daoff = (16 * rh + c16) * LD + 2 * KB + 4 * g4;           // + 16 J
+        const int nyw = NSK ? (N - cn * TN * 32 + 31) / 32 : TN;            // dW blocks of this wave with real columns
+        const int jreal = NSK ? (N + 15) / 16 : NB / 16;                    // data-gradient steps with real columns
         const int wboff = (g4 * KB + 32 * cbp + c16) * 4;                   // + 16 b * 4, + J * 4 KB * 4
         // this wave's slice of W (NB x 32 columns) stays in REGISTERS for the life of the workgroup: re-read from LDS per
         // stripe it was 64 of the 154 KB of LDS reads a stripe cost -- at 128 B/clk the LDS pipe, not the matrix pipe,
@@ -2679,9 +2703,10 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(dbg & 4)) {
 #pragma unroll
-                for (int y = 0; y < TN; ++y) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
+                for (int y = 0; y < TN; ++y)
+                    if (!NSK || y < nyw) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
                 }
-                if (dostep && !(dbg & 1)) {
+                if (dostep && (!NSK || J < jreal) && !(dbg & 1)) {
                     const float de[4] = {da.x, da.y, da.z, da.w};
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
@@ -2977,8 +3002,17 @@ static bool gram_full_on() {
 
 struct PcWgradPlan {
     int tk, tn, kblocks, nblocks, groups;
+    bool k96;        // 65..96 input channels: the 96 x 32 consumer layout (wgrad_pc_kernel)
     size_t lds;
 };
+
+static bool wgrad_k96_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_WGRAD_K96");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 
 static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
                           const void *gpool, const void *argmax, PcWgradPlan *pl, bool narrow = false) {
@@ -2991,6 +3025,7 @@ static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, con
     pl->tk = K <= 64 ? 1 : 2;
     pl->tn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
     if (narrow && pl->tn == 4 && (N + 127) / 128 * 128 < (N + 255) / 256 * 256) pl->tn = 2;   // less padding (N = 320)
+    pl->k96 = K > 64 && K <= 96 && pl->tn == 2 && wgrad_k96_enabled();
     const int KB = 64 * pl->tk, NB = 64 * pl->tn;
     pl->kblocks = (K + KB - 1) / KB;
     pl->nblocks = (N + NB - 1) / NB;
@@ -3944,14 +3979,15 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
         const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
 #define PCOPS_PC_LAUNCH(TK_, TN_, AM_, DM_)                                                                \
     do {                                                                                                   \
-        auto kern = wgrad_pc_kernel<TK_, TN_, AM_, DM_>;                                                   \
+        auto kern = wgrad_pc_kernel<TK_, TN_, AM_, DM_, K96_>;                                                \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
             return PCOPS_ERR_LAUNCH;                                                                       \
         hipLaunchKernelGGL(kern, grid, dim3(512), pc.lds, st, a);                                          \
     } while (0)
-#define PCOPS_PC_MODES(TK_, TN_)                                                                           \
+#define PCOPS_PC_MODES(TK_, TN_, K96V_)                                                                    \
     do {                                                                                                   \
+        constexpr bool K96_ = K96V_;                                                                       \
         if (a.dmode == A_SELFD && a.amode == A_PLAIN) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_SELFD);         \
         else if (a.dmode == A_SELFD) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_SELFD);                         \
         else if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW); \
@@ -3970,12 +4006,13 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
         else if (a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLU);                             \
         else PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOL);                                                 \
     } while (0)
-        if (pc.tk == 1 && pc.tn == 1) PCOPS_PC_MODES(1, 1);
-        else if (pc.tk == 1 && pc.tn == 2) PCOPS_PC_MODES(1, 2);
-        else if (pc.tk == 1) PCOPS_PC_MODES(1, 4);
-        else if (pc.tn == 1) PCOPS_PC_MODES(2, 1);
-        else if (pc.tn == 2) PCOPS_PC_MODES(2, 2);
-        else PCOPS_PC_MODES(2, 4);
+        if (pc.tk == 1 && pc.tn == 1) PCOPS_PC_MODES(1, 1, false);
+        else if (pc.tk == 1 && pc.tn == 2) PCOPS_PC_MODES(1, 2, false);
+        else if (pc.tk == 1) PCOPS_PC_MODES(1, 4, false);
+        else if (pc.tn == 1) PCOPS_PC_MODES(2, 1, false);
+        else if (pc.tn == 2 && pc.k96) PCOPS_PC_MODES(2, 2, true);
+        else if (pc.tn == 2) PCOPS_PC_MODES(2, 2, false);
+        else PCOPS_PC_MODES(2, 4, false);
 #undef PCOPS_PC_MODES
 #undef PCOPS_PC_LAUNCH
     } else if (a.amode == A_XYZ) {
@@ -4079,9 +4116,14 @@ static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, 
     const int NB = 64 * tn;
     const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + 4)) * sizeof(float);
     const bool pooled = a.gpool != nullptr;
+    static const bool nsk_on = [] {
+        const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
+        return !(e && e[0] == '0');
+    }();
+    const bool nsk = nsk_on && tn == 2 && N <= 96;
 #define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
     do {                                                                                                   \
-        auto kern = bwd_fused_kernel<TN_, DM_, X_>;                                                        \
+        auto kern = (TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>;                                                      \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
             return PCOPS_ERR_LAUNCH;                                                                       \

@@ -16,6 +16,8 @@ CASES = [  # (M, K, N, S)   S = 0: dense upstream gradient
     (64 * 1030, 64, 64, 64),
     (20 * 3300, 64, 128, 20),          # any group size
     (16 * 4200, 48, 96, 16),           # narrower than the tile in both directions
+    (65536 + 32 * 3 + 5, 64, 96, 0),   # MSG's 64 -> 96 layer: the zero fourth column block is skipped
+    (128 * 520, 64, 80, 128),          # ... a ragged third block
 ]
 
 

@@ -71,6 +71,11 @@ CASES = [  # (R, S, K0, widths, pool)
     (2048 * 16, 16, 32, [64, 64], True),
     (1024 * 48, 48, 32, [64, 128], True),
     (3000 * 11, 11, 64, [128], True),
+    # 96-wide layers (MSG's 64 -> 96 -> 128 scale): three 32-column blocks in the forward / data-gradient kernels, the
+    # 96 x 32 consumer layout of the weight gradient, the one-pass backward without the zero columns
+    (1024 * 32 * 2 + 64, 32, 32, [64, 96, 128], True),
+    (70000 + 19, 1, 64, [96, 128], False),         # ... ragged tail, dense upstream gradient
+    (2048 * 16, 16, 64, [96, 128], True),          # ... groups that are not tile multiples
 ]
 
 
@@ -257,6 +262,7 @@ GATHER_CASES = [  # (B, N, M, S, widths, pool)
     (8, 512, 256, 32, [64, 64, 128], True),
     (4, 512, 128, 64, [64, 128], False),
     (3, 700, 130, 96, [32, 64, 64], True),      # ragged tail tile, 3 tiles per pooling group
+    (2, 1024, 168, 128, [64, 96, 128], True),   # MSG scale 2: arithmetic first layer into a 96-wide one, compacted rows
 ]
 
 
