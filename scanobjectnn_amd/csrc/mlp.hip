@@ -453,6 +453,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     constexpr int NLD = KC / 8;                    // float4 per lane per 32 x KC operand stripe
     constexpr int O4 = BNH / 4;                    // float4 per output row per pass
     constexpr int NST = BNH / 8;                   // float4 per lane per pass
+    static_assert(O4 % 4 == 0 && 64 % O4 == 0, "epilogue pass: whole rows per step, whole steps per 16-row block");
     constexpr int NCOEF = (AM == A_PLAIN) ? 0 : (AM == A_BNRELU ? 2 : (AM == A_DY ? 3 : (AM == A_XYZ ? 6 : 5)));
     constexpr int NTHR = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1043,8 +1044,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 if (FULL || (r < erem && ocin)) {
                     if (EM == E_FWD) {
                         // o = y - pivot here (accumulator start value): the statistics take it as it is
-                        if (compact && O4 == 16 && j % 4 == 0) {      // rows 0 / 16 of the tile stand for w rows
-                            const float w = lane < 16 ? ew[j / 4] : 1.f;
+                        // rows 0 / 16 of the tile stand for w rows.  A pass step covers 64 / O4 rows: a 16-row block opens
+                        // every O4 / 4 steps, in the lanes of the step's first row
+                        if (compact && j % (O4 / 4) == 0) {
+                            const float w = lane < O4 ? ew[j / (O4 / 4)] : 1.f;
                             const float4 wo = make_float4(w * o.x, w * o.y, w * o.z, w * o.w);
                             s1[h][0] += wo.x; s1[h][1] += wo.y; s1[h][2] += wo.z; s1[h][3] += wo.w;
                             s2[h][0] = fmaf(wo.x, o.x, s2[h][0]); s2[h][1] = fmaf(wo.y, o.y, s2[h][1]);

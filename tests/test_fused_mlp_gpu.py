@@ -388,6 +388,8 @@ COMPACT_CASES = [  # (B, N, M, S, radius, widths, form)
     (8, 600, 100, 48, 0.3, [64, 128], "q_xyz"),             # 3 blocks per group, two layers
     (2, 2048, 128, 128, 0.25, [32, 64, 128], "xyz_bias"),   # MSG-sized groups
     (8, 512, 256, 64, 0.3, [64, 64, 128], "q_xyz"),         # narrow layers: one-pass data + weight gradient on compacted rows
+    (4, 1024, 128, 128, 0.25, [64, 96, 128], "xyz_bias"),   # MSG's 96-wide scale (three-block tiles, weighted statistics)
+    (4, 1024, 128, 64, 0.22, [64, 96], "q_xyz"),            # ... a pooled 96-wide top layer behind a stored first layer
     (8, 512, 128, 64, 2.5, [128, 128], "q_xyz"),            # every ball full: nothing to leave out, all weights 1
     (8, 512, 128, 64, 0.02, [128, 128], "q_xyz"),           # (almost) every ball holds the query alone: weights 49
 ]
