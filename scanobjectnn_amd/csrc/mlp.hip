@@ -31,6 +31,21 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> three bf16 pieces, x = h + m + l up to 2^-25 |x| (each residual is exact in fp32; round-to-nearest pieces carry
+// their own signs, so 3 x 8 significant bits cover the 24 of the operand).  Products of two pieces are exact in fp32.
+__device__ __forceinline__ void split3(const float4 &x0, const float4 &x1, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)x[e];
+        const float r1 = x[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+}
 
 constexpr int kBM = 128;   // rows per tile (4 waves x 32)
 constexpr int kBK = 32;    // K chunk
@@ -444,7 +459,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     //     2: weights STREAMED -- K chunks of KC rows double-buffered in LDS, refilled from L2 by the whole workgroup
     //        while the MFMAs of the current chunk run; all waves then walk the chunks in lockstep (one workgroup
     //        barrier per chunk), which is what K > 256 costs
-    constexpr bool POOL = VAR == 1 || VAR == 3, WST = VAR == 2 || VAR == 3;   // 3: pooled epilogue AND streamed weights
+    //  +4: the product on the 16-bit matrix pipe with SPLIT operands: each fp32 operand as three
+    //      bf16 pieces, six of the nine partial products on v_mfma_f32_32x32x16_bf16 (6/16 of the fp32 pipe time), the
+    //      h.h products in the tile's accumulators and the five small ones in a second set that is added once per tile --
+    //      the large accumulator is rounded K/16 times instead of K/2, a third of the fp32 chain's error (measured,
+    //      tools/ubench/gemm_bf16x3.hip).  The weight pieces sit in LDS in fragment order (6 bytes per element), the
+    //      operand stripe stays fp32 and is split in registers on the way to the matrix pipe (every element is read by
+    //      exactly one lane, so the split costs the same there as at staging time and needs no second stripe).
+    constexpr bool BF3 = (VAR & 4) != 0;
+    constexpr bool POOL = (VAR & 3) == 1 || (VAR & 3) == 3, WST = (VAR & 3) == 2 || (VAR & 3) == 3;   // 3: pooled AND streamed
     constexpr int BN = NT * 32;
     constexpr int NTH = NT / EH;                   // accumulator tiles per epilogue pass
     constexpr int BNH = BN / EH;                   // columns per epilogue pass
@@ -468,9 +491,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     const int Kp = nchunk * KC;
     constexpr int CROWS = WST ? (NCOEF > 0 ? NCOEF : 1) : 6;
     constexpr bool B_ = AM == A_DYPOOLB;             // two pooling blocks per tile
-    static_assert(!B_ || KC == 64, "block-wise pooled operand: row = lane / 16 + 4 j");
-    float *Ws = lds;                                        // [Kp][BN], or [2][KC][BN] when streamed
-    float *coef = Ws + (size_t)(WST ? 2 * KC : Kp) * BN;    // [CROWS][Kp]
+    static_assert(KC == 64 || KC == 32, "stripe rows of 16 or 8 float4");
+    static_assert(!BF3 || KC % 16 == 0, "split operands: 16 k per matrix instruction");
+    float *Ws = lds;                                        // [Kp][BN], or [2][KC][BN] when streamed (BF3: 6 bytes / element)
+    float *coef = Ws + (size_t)(WST ? 2 * KC : Kp) * BN * (BF3 ? 3 : 2) / 2;    // [CROWS][Kp]
+    bf16x8 *Wf = reinterpret_cast<bf16x8 *>(lds);           // BF3: [3 pieces][KSW k-steps][NT][64 lanes] fragments of 8 bf16
+    const int KSW = (WST ? 2 * KC : Kp) / 16;
     float *ecoef = coef + CROWS * Kp;                       // [6][BN]: bias | (mask scale, mask shift) | xyz-form w0 w1 w2 b
     float *Aw = ecoef + 6 * BN + wave * 32 * LDW;           // [32][LDW] per wave
     float *red = ecoef + 6 * BN + WAVES * 32 * LDW;         // [WAVES][2][BN]
@@ -497,7 +523,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // registers -> transposed in registers -> LDS buffer
     constexpr int WBLK = (KC / 4) * (BN / 4);
     constexpr int WPB = (WBLK + NTHR - 1) / NTHR;
-    float4 wreg[WST ? 4 * WPB : 1];
+    float4 wreg[(WST && !BF3) ? 4 * WPB : 1];
+    // split operands: a chunk is (KC / 16) NT 64 fragments of 8 k x 1 column, FPB per thread: global (L2) -> registers ->
+    // three bf16 pieces -> LDS buffer, already in the order the matrix instruction reads them
+    constexpr int FR = (KC / 16) * NT * 64;
+    constexpr int FPB = (FR + NTHR - 1) / NTHR;
+    float wfr[(WST && BF3) ? 8 * FPB : 1];
     // POOLED forward: column n of the weight tile (and the accumulator start value) is multiplied by sign(gamma[n]), so
     // the tile leaves the matrix pipe as  s (y - pivot):  BN + ReLU is increasing in y for gamma >= 0 and decreasing
     // otherwise, i.e. the pooled row of a group is ALWAYS the arg-max of the accumulator values -- no per-element sign
@@ -509,7 +540,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const int n = n0 + ((tid + NTHR * j) % (BN / 4)) * 4;
         wsg[j] = make_float4(colsign(n), colsign(n + 1), colsign(n + 2), colsign(n + 3));
     }
+    float wsgf[(WST && POOL && BF3) ? FPB : 1];
+#pragma unroll
+    for (int j = 0; j < ((WST && POOL && BF3) ? FPB : 1); ++j) {
+        const int f = tid + NTHR * j;
+        wsgf[j] = colsign(n0 + 32 * ((f >> 6) % NT) + (f & 31));
+    }
     auto wload = [&](int kc) {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int j = 0; j < FPB; ++j) {
+                const int f = tid + NTHR * j;
+                const int ln = f & 63, nt = (f >> 6) % NT, ksl = f / (64 * NT);
+                const int n = n0 + 32 * nt + (ln & 31);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kc * KC + 16 * ksl + 8 * (ln >> 5) + e;
+                    wfr[8 * j + e] = (f < FR && k < K && n < N) ? a.W[(long long)k * N + n] : 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
             const int e = tid + NTHR * j;
@@ -524,6 +575,25 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         }
     };
     auto wstore = [&](int buf) {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int j = 0; j < FPB; ++j) {
+                const int f = tid + NTHR * j;
+                const int ln = f & 63, nt = (f >> 6) % NT, ksl = f / (64 * NT);
+                if (f < FR) {
+                    const float sg = POOL ? wsgf[POOL ? j : 0] : 1.f;         // pooled forward: columns carry sign(gamma)
+                    bf16x8 h, m, l;
+                    split3(make_float4(wfr[8 * j] * sg, wfr[8 * j + 1] * sg, wfr[8 * j + 2] * sg, wfr[8 * j + 3] * sg),
+                           make_float4(wfr[8 * j + 4] * sg, wfr[8 * j + 5] * sg, wfr[8 * j + 6] * sg, wfr[8 * j + 7] * sg),
+                           h, m, l);
+                    const int at = ((buf * (KC / 16) + ksl) * NT + nt) * 64 + ln;
+                    Wf[at] = h;
+                    Wf[KSW * NT * 64 + at] = m;
+                    Wf[2 * KSW * NT * 64 + at] = l;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < WPB; ++j) {
             const int e = tid + NTHR * j;
@@ -543,7 +613,23 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         wload(0);
         wstore(0);
     }
-    for (int e = tid; e < (WST ? 0 : Kp * (BN / 4)); e += NTHR) {
+    for (int f = tid; f < ((BF3 && !WST) ? KSW * NT * 64 : 0); f += NTHR) {
+        const int ln = f & 63, nt = (f >> 6) % NT, ks = f / (64 * NT);
+        const int n = n0 + 32 * nt + (ln & 31);
+        const float sg = colsign(n);
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * ks + 8 * (ln >> 5) + e;
+            x[e] = (k < K && n < N) ? a.W[(long long)k * N + n] * sg : 0.f;
+        }
+        bf16x8 h, m, l;
+        split3(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), h, m, l);
+        Wf[f] = h;
+        Wf[KSW * NT * 64 + f] = m;
+        Wf[2 * KSW * NT * 64 + f] = l;
+    }
+    for (int e = tid; e < ((WST || BF3) ? 0 : Kp * (BN / 4)); e += NTHR) {
         const int k = e / (BN / 4), nq = (e % (BN / 4)) * 4;
         float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K) {
@@ -704,7 +790,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int j = 0; j < NLD; ++j) {
             const int r = (lane + 64 * j) / C4;
             const bool in = FULL || ((r < rem) && (c < K));
-            float4 x = pa[(U_ || G_) ? 0 : (B_ ? j / 4 : j)];
+            float4 x = pa[(U_ || G_) ? 0 : (B_ ? j / (C4 / 4) : j)];     // (a 16-row block = C4 / 4 staging steps)
             if (AM == A_BNRELU) {
                 x.x = fmaxf(fmaf(x.x, c0.x, c1.x), 0.f);
                 x.y = fmaxf(fmaf(x.y, c0.y, c1.y), 0.f);
@@ -724,9 +810,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     // q.Y + t  here and the few arg rows are added afterwards (below)
                     g = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                if (compact && C4 == 16 && j % 4 == 0) {
-                    // rows 0 and 16 of the tile (lanes 0..15 at j = 0 / 4) open a block: dY = p.G + w (q.Y + t)
-                    const float w = lane < 16 ? bw[j / 4] : 1.f;
+                if (compact && j % (C4 / 4) == 0) {
+                    // rows 0 and 16 of the tile (the first C4 lanes of every C4 / 4-th step) open a block:
+                    // dY = p.G + w (q.Y + t)
+                    const float w = lane < C4 ? bw[j / (C4 / 4)] : 1.f;
                     x.x = fmaf(c0.x, g.x, w * fmaf(c1.x, y.x, c2.x));
                     x.y = fmaf(c0.y, g.y, w * fmaf(c1.y, y.y, c2.y));
                     x.z = fmaf(c0.z, g.z, w * fmaf(c1.z, y.z, c2.z));
@@ -742,8 +829,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             *reinterpret_cast<float4 *>(&Aw[r * LDW + cl]) = x;
         }
         if (is_pool(AM)) {
-            // the arg rows: lanes 0..15 (one per column quad) take the tile's group / its first block, lanes 16..31 the
-            // second block; each adds  p . gpool  to the stripe row the arg-max byte names, if that row is in this tile.
+            // the arg rows: lanes 0..C4-1 (one per column quad) take the tile's group / its first block, the next C4 lanes
+            // the second block; each adds  p . gpool  to the stripe row the arg-max byte names, if that row is in this tile.
             // (Per element this replaces byte extract + two compares + and + select + multiply-add of round 2 -- 1 150
             // of the 1 540 vector instructions of a 256 -> 128 tile -- by ONE fused multiply-add; the sparse pass is ~40
             // instructions on half a wave.)
@@ -753,8 +840,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             // (lane / 16) S - s0 + s)
             const int grp = lane / C4;
             const bool gvalid = !G_ || prs.g0 + grp <= glast;
-            if (lane < (G_ ? 64 : (B_ ? 32 : 16)) && c < K && gvalid) {
-                const bool second = B_ && lane >= 16;
+            if (lane < (G_ ? 4 * C4 : (B_ ? 2 * C4 : C4)) && c < K && gvalid) {
+                const bool second = B_ && lane >= C4;
                 const float4 gp = second ? pa[B_ ? 1 : 0] : pa[0];
                 const unsigned am = second ? pm[B_ ? 1 : 0] : pm[0];
                 // row-in-group of the tile's (block's) first row; for G_ the tile row of the group's row 0, negated
@@ -887,6 +974,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][v] = EM == E_FWD ? ecoef[32 * i + (lane & 31)] : 0.f;   // bias - pivot
+        f32x16 sm[BF3 ? NT : 1];                        // split operands: the sum of the small partial products
+#pragma unroll
+        for (int i = 0; i < (BF3 ? NT : 1); ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sm[i][v] = 0.f;
 
         for (int kc = 0; kc < nchunk; ++kc) {
             if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
@@ -909,6 +1001,45 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 #ifdef PCOPS_PHASE_PROF
             { const unsigned long long n_ = PROF_T(); pf_stage += n_ - pf_t; pf_t = n_; }
 #endif
+            if constexpr (BF3) {
+                // split operands: a step is 16 k -- the lane's eight stripe values of its row (two ds_read_b128) split into
+                // three bf16 pieces, the weight pieces as 16-byte fragments, six matrix instructions per column block.  The
+                // fragments of one weight piece are requested while the products of the previous one issue.
+                const float *arow = &Aw[(lane & 31) * LDW + 8 * (lane >> 5)];
+                const bf16x8 *wf = Wf + ((WST ? (wt & 1) : kc) * (KC / 16)) * NT * 64 + lane;
+                const int pst = KSW * NT * 64;                       // piece stride (fragments)
+                const int kleft = K - kc * KC;
+                const int nstep = kleft >= KC ? KC / 16 : (kleft + 15) / 16;
+#pragma unroll
+                for (int st_ = 0; st_ < KC / 16; ++st_) {
+                    if (st_ < nstep) {
+                        const float4 x0 = *reinterpret_cast<const float4 *>(arow + 16 * st_);
+                        const float4 x1 = *reinterpret_cast<const float4 *>(arow + 16 * st_ + 4);
+                        bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bh[nt] = wf[(st_ * NT + nt) * 64];
+                        bf16x8 ah, am, al;
+                        split3(x0, x1, ah, am, al);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bm[nt] = wf[pst + (st_ * NT + nt) * 64];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], sm[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[nt], sm[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) bl[nt] = wf[2 * pst + (st_ * NT + nt) * 64];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[nt], sm[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[nt], sm[nt], 0, 0, 0);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], sm[nt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
             // B fragments: quad row (chunk base) + 2 it + (lane >> 5), column 32 nt + (lane & 31)
             const float4 *bq = reinterpret_cast<const float4 *>(Ws) +
@@ -948,6 +1079,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 mfma16(a1, b1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
 #ifdef PCOPS_PHASE_PROF
             {   // (the MFMAs are asynchronous: read one accumulator register so that the clock is taken after the last one)
                 float sink_ = acc[NT - 1][15];
@@ -963,6 +1095,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
         }
         if (active) {
+        if constexpr (BF3) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i] += sm[i];
+        }
         if (POOL) pool_acc(acc, tile, sub, st);
         // ---- epilogue: accumulators -> stripe (transposed, EH column passes) -> 16-byte row-segment stores
         const long long row0 = tile * 32;
@@ -1186,8 +1322,24 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
 struct WsPlan {
     int kc, bn, waves, eh, ncb, gy;
     bool wst;        // weights streamed (K > 256)
+    bool bf3;        // split operands on the 16-bit matrix pipe (kernel: VAR + 4)
     size_t lds;
 };
+
+// split-operand form: weights as three bf16 pieces (6 bytes per element), 32-wide operand stripes, 32-column epilogue passes
+static size_t ws_lds_bytes_bf3(int Kp, int bn, int waves, bool wst, int ncoef) {
+    const int ldw = 32 + 4;
+    const int crows = wst ? (ncoef > 0 ? ncoef : 1) : 6;
+    return (size_t)((wst ? 2 * 32 : Kp) * bn * 3 / 2 + crows * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
+}
+
+static int ws_bf3_mode() {       // PCOPS_GEMM_BF3 = 0: off, 1: on, 2 (default): on where the weight pieces stay resident
+    static const int mode = [] {
+        const char *e = getenv("PCOPS_GEMM_BF3");
+        return e ? atoi(e) : 2;
+    }();
+    return mode;
+}
 
 static int ws_ncoef(int am) { return am == A_PLAIN ? 0 : (am == A_BNRELU ? 2 : (am == A_DY ? 3 : (am == A_XYZ ? 6 : 5))); }
 
@@ -1219,7 +1371,10 @@ static bool ws_n96_enabled() {
     return on;
 }
 
-static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
+// fwd: the launch is a forward product (E_FWD epilogue) -- the only one the split-operand form is built for: the data
+// gradients of the same shapes are bandwidth bound (measured: 557 vs 556 us for SA2's 128 -> 128) and their variants
+// need more registers than a wave has at two waves per SIMD
+static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
     if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
     if (a.K > 256 && (am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
@@ -1254,6 +1409,21 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl) {
         if (pl->bn == 128 && a.N <= 96 && ws_n96_enabled()) { pl->bn = 96; pl->eh = 3; }
         pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
     }
+    pl->bf3 = false;
+    if (fwd && ws_bf3_mode() && pl->bn != 96 && !(reinterpret_cast<uintptr_t>(a.W) & 3)) {
+        const int Kp3 = (a.K + 31) / 32 * 32;
+        const int nc = ws_ncoef(am);
+        const int bn3 = a.N > 64 ? 128 : 64;
+        bool wst3 = ws_lds_bytes_bf3(Kp3, bn3, 8, false, nc) > 160 * 1024;
+        if (wst3 && (am == A_XYZ || ws_bf3_mode() == 2)) wst3 = false, pl->bf3 = false;
+        else pl->bf3 = true;
+        if (pl->bf3 && ws_lds_bytes_bf3(Kp3, bn3, 8, wst3, nc) <= 160 * 1024) {
+            pl->kc = 32; pl->bn = bn3; pl->eh = bn3 / 32; pl->wst = wst3;
+            pl->lds = ws_lds_bytes_bf3(Kp3, bn3, 8, wst3, nc);
+        } else {
+            pl->bf3 = false;
+        }
+    }
     if (pl->lds > 160 * 1024) return false;
     pl->ncb = (a.N + pl->bn - 1) / pl->bn;
     const long long ntiles = (((long long)a.M + 31) / 32 + (a.pool_sub > 1 ? a.pool_sub - 1 : 0)) /
@@ -1282,6 +1452,28 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
+    if constexpr (EM == E_FWD) {
+    if (pl.bf3) {
+#define PCOPS_WS3_LAUNCH(NT_, EH_)                                                                    \
+    do {                                                                                              \
+        const bool pool_ = EM == E_FWD && a.pool_sub > 0;                                             \
+        auto kern = (pl.wst && pool_) ? gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, ((AM == A_XYZ || EM != E_FWD) ? 4 : 7)> \
+                    : pl.wst ? gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, (AM == A_XYZ ? 4 : 6)>            \
+                    : pool_ ? gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, (EM == E_FWD ? 5 : 4)>              \
+                            : gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, 4>;                                 \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+            return PCOPS_ERR_LAUNCH;                                                                  \
+        a.nrowgrp = pl.gy;                                                                            \
+        const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
+        hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
+    } while (0)
+        if (pl.bn == 128) PCOPS_WS3_LAUNCH(4, 4);
+        else PCOPS_WS3_LAUNCH(2, 2);
+#undef PCOPS_WS3_LAUNCH
+        return pcops_launch_status();
+    }
+    }
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
     else if (pl.bn == 96) PCOPS_WS_LAUNCH(3, 3);
     else PCOPS_WS_LAUNCH(2, 1);
@@ -1304,7 +1496,7 @@ static bool ws_enabled() {
 template <int AM, int EM>
 int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (ws_enabled() && ws_plan(a, AM, &pl)) {
+    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD)) {
         int rc;
         if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
         else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
@@ -3500,7 +3692,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
 template <int AM, int EM>
 static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (!(ws_enabled() && ws_plan(a, AM, &pl))) return PCOPS_ERR_UNSUPPORTED;
+    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD))) return PCOPS_ERR_UNSUPPORTED;
     int rc;
     if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
     else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);

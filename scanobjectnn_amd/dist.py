@@ -14,10 +14,18 @@ import torch.distributed as dist
 # statistics at the global batch size.  Off: statistics are per rank (plain data parallelism) and the moving
 # averages differ between ranks until `broadcast_buffers_` is called (the trainers do so before every checkpoint).
 SYNC_BN = False
+# Test hook: a SINGLE process takes the kernel forms of the SyncBN mode (statistics finalised from the exchanged sums, no
+# compacted rows, a stored first layer) with the exchange itself left out -- the reference a multi-rank SyncBN run is
+# compared with row for row (tests/test_dist_gpu.py): what then differs is the exchange and nothing else.
+SYNC_FORMS_LOCAL = False
+
+
+def _multi_rank():
+    return dist.is_initialized() and dist.get_world_size() > 1
 
 
 def sync_bn_active():
-    return SYNC_BN and dist.is_initialized() and dist.get_world_size() > 1
+    return SYNC_BN and (_multi_rank() or SYNC_FORMS_LOCAL)
 
 
 _STAT_GROUP = None
@@ -49,10 +57,11 @@ def allreduce_stat_partials(part, rows, pivot=None):
         p = pivot.detach().double()[:c]
         tot[0, 1] += 2.0 * p * tot[0, 0] + float(rows) * p * p
         tot[0, 0] += float(rows) * p
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=stat_group())
+    if _multi_rank():
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=stat_group())
     hi = tot.float()
     lo = (tot - hi.double()).float()
-    return torch.cat([hi, lo], dim=0).contiguous(), rows * dist.get_world_size()
+    return torch.cat([hi, lo], dim=0).contiguous(), rows * (dist.get_world_size() if _multi_rank() else 1)
 
 
 def init_from_env(backend=None):
@@ -117,8 +126,9 @@ def sync_batch_stats(flat):
     import torch.distributed.nn.functional as dfn
     n = flat.shape[0]
     s = torch.stack([flat.sum(dim=0), (flat * flat).sum(dim=0)])
-    s = dfn.all_reduce(s, op=dist.ReduceOp.SUM, group=stat_group())
-    total = n * dist.get_world_size()
+    if _multi_rank():
+        s = dfn.all_reduce(s, op=dist.ReduceOp.SUM, group=stat_group())
+    total = n * (dist.get_world_size() if _multi_rank() else 1)
     mean = s[0] / total
     var = (s[1] / total - mean * mean).clamp_min(0.0)
     return mean, var, total

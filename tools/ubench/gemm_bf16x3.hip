@@ -26,8 +26,12 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &h, bf16x8 &m
 }
 
 // W pieces in LDS, fragment order: Wf[piece][ks][nt][lane] = 8 bf16 (k = 16 ks + 8 (lane / 32) + e, column 32 nt + lane % 32)
-template <int K>
-__global__ __launch_bounds__(512, 2) void gemm_bf16x3(long long M, int N, const float *__restrict__ A, const float *__restrict__ W,
+// MODE 0: one accumulator per column block, the six products of a 16-k step back to back (smallest first)
+//      1: TWO accumulators per block -- the h.h products alone in one, the five small ones in the other, added at the end
+//      2: one accumulator, the h.h product FIRST in every step
+//      3: two accumulators, all NINE products (the three extra ones with the small ones)
+template <int K, int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3(long long M, int N, const float *__restrict__ A, const float *__restrict__ W,
                                                    float *__restrict__ Y) {
     constexpr int KS = K / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -50,11 +54,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3(long long M, int N, const 
     for (long long t = (long long)blockIdx.x * 8 + wave; t < ntiles; t += (long long)gridDim.x * 8) {
         const long long row = t * 32 + (lane & 31);
         const float *ar = A + (row < M ? row : M - 1) * K + 8 * (lane >> 5);
-        f32x16 acc[4];
+        f32x16 acc[4], sm[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+            for (int v = 0; v < 16; ++v) acc[i][v] = sm[i][v] = 0.f;
         float4 p0 = *reinterpret_cast<const float4 *>(ar), p1 = *reinterpret_cast<const float4 *>(ar + 4);
 #pragma unroll 2
         for (int ks = 0; ks < KS; ++ks) {
@@ -71,27 +75,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16x3(long long M, int N, const 
                 bm[nt] = Wf[(1 * KS + ks) * 256 + nt * 64 + lane];
                 bl[nt] = Wf[(2 * KS + ks) * 256 + nt * 64 + lane];
             }
-            // six partial products, smallest first; the four column blocks are independent accumulators: no MFMA waits
-            // for the one before it
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[nt], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nt], acc[nt], 0, 0, 0);
+#define MM(A_, B_, C_) _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) C_[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[nt], C_[nt], 0, 0, 0)
+            if (MODE == 0) {
+                MM(al, bh, acc); MM(ah, bl, acc); MM(am, bm, acc); MM(am, bh, acc); MM(ah, bm, acc); MM(ah, bh, acc);
+            } else if (MODE == 1) {
+                MM(al, bh, sm); MM(ah, bl, sm); MM(am, bm, sm); MM(am, bh, sm); MM(ah, bm, sm); MM(ah, bh, acc);
+            } else if (MODE == 2) {
+                MM(ah, bh, acc); MM(ah, bm, acc); MM(am, bh, acc); MM(am, bm, acc); MM(ah, bl, acc); MM(al, bh, acc);
+            } else {
+                MM(al, bl, sm); MM(al, bm, sm); MM(am, bl, sm);
+                MM(al, bh, sm); MM(ah, bl, sm); MM(am, bm, sm); MM(am, bh, sm); MM(ah, bm, sm); MM(ah, bh, acc);
+            }
+#undef MM
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const long long r = t * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
-                if (r < M) Y[r * N + n0 + 32 * nt + (lane & 31)] = acc[nt][v];
+                if (r < M) Y[r * N + n0 + 32 * nt + (lane & 31)] = (MODE == 1 || MODE == 3) ? acc[nt][v] + sm[nt][v] : acc[nt][v];
             }
     }
 }
@@ -144,28 +146,38 @@ void run(long long M, int N) {
     hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
     const dim3 grid(512, N / 128), blk(256);
     const size_t lds3 = (size_t)3 * (K / 16) * 256 * 16, ldsf = (size_t)K * 128 * 4;
-    hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3<K, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3<K, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3<K, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_bf16x3<K, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     std::vector<float> y3((size_t)64 * N), yf((size_t)64 * N);
-    for (int which = 0; which < 2; ++which) {
+    static const char *names[5] = {"bf16x3, 6 products", "bf16x3, 6, two accum.", "bf16x3, 6, h.h first", "bf16x3, 9, two accum.", "fp32 MFMA"};
+    const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 5;
+    const int only = getenv("ONLY") ? atoi(getenv("ONLY")) : -1;      // one variant, many repetitions: clock / power polling
+    for (int which = 0; which < 5; ++which) {
+        if (only >= 0 && which != only) continue;
         auto launch = [&]() {
-            if (which == 0) hipLaunchKernelGGL(gemm_bf16x3<K>, dim3(256, N / 128), dim3(512), lds3, 0, M, N, A, W, Y);
+            if (which == 0) hipLaunchKernelGGL((gemm_bf16x3<K, 0>), dim3(256, N / 128), dim3(512), lds3, 0, M, N, A, W, Y);
+            else if (which == 1) hipLaunchKernelGGL((gemm_bf16x3<K, 1>), dim3(256, N / 128), dim3(512), lds3, 0, M, N, A, W, Y);
+            else if (which == 2) hipLaunchKernelGGL((gemm_bf16x3<K, 2>), dim3(256, N / 128), dim3(512), lds3, 0, M, N, A, W, Y);
+            else if (which == 3) hipLaunchKernelGGL((gemm_bf16x3<K, 3>), dim3(256, N / 128), dim3(512), lds3, 0, M, N, A, W, Y);
             else hipLaunchKernelGGL(gemm_f32<K>, grid, blk, ldsf, 0, M, N, A, W, Y);
         };
         launch();
         hipDeviceSynchronize();
-        hipMemcpy(which == 0 ? y3.data() : yf.data(), Y, (size_t)64 * N * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(y3.data(), Y, (size_t)64 * N * 4, hipMemcpyDeviceToHost);
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        for (int r = 0; r < 5; ++r) launch();
+        for (int r = 0; r < reps; ++r) launch();
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        ms /= 5;
+        ms /= reps;
         double num = 0, den = 0;
-        const std::vector<float> &y = which == 0 ? y3 : yf;
+        const std::vector<float> &y = y3;
         for (int r = 0; r < 64; ++r)
             for (int n = 0; n < N; ++n) {
                 double ex = 0;
@@ -175,7 +187,7 @@ void run(long long M, int N) {
             }
         const double flop = 2.0 * M * K * N, bytes = 4.0 * M * (K + N);
         printf("M=%lld K=%d N=%d  %-22s %8.1f us  %6.1f TF/s-equivalent (%.2f of the 157.3 fp32 MFMA peak)  %5.2f TB/s  rel. RMS error %.2e\n",
-               M, K, N, which == 0 ? "bf16x3, 6 products" : "fp32 MFMA", ms * 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3,
+               M, K, N, names[which], ms * 1e3, flop / ms / 1e9, flop / ms / 1e9 / 157.3,
                bytes / ms / 1e9, sqrt(num / den));
     }
     hipFree(A); hipFree(W); hipFree(Y);
