@@ -1333,10 +1333,10 @@ static size_t ws_lds_bytes_bf3(int Kp, int bn, int waves, bool wst, int ncoef) {
     return (size_t)((wst ? 2 * 32 : Kp) * bn * 3 / 2 + crows * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
 }
 
-static int ws_bf3_mode() {       // PCOPS_GEMM_BF3 = 0: off, 1: on, 2 (default): on where the weight pieces stay resident
+static int ws_bf3_mode() {       // PCOPS_GEMM_BF3 = 0: off, 1 (default): on, 2: only where the weight pieces stay resident
     static const int mode = [] {
         const char *e = getenv("PCOPS_GEMM_BF3");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 1;
     }();
     return mode;
 }
