@@ -33,6 +33,20 @@ from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks  # no
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3   # f32 vector == f32-input MFMA peak
+BF16_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA peak (16 x the f32-input rate, MI355X_MICROARCH.md)
+# kernels whose product runs on the bf16 matrix pipe with split operands: six bf16 products per
+# fp32 product, so their matrix-pipe fraction is 6 x the algorithmic flops over the bf16 peak (= flops / (157.3 x 16 / 6))
+SPLIT_OPERAND_KERNELS = ("pcops_mlp_gemm_fwd", "pcops_mlp_gemm_fwd_pool", "pcops_mlp_gemm_fwd_xyz",
+                         "pcops_mlp_gemm_fwd_rows", "pcops_mlp_gemm_fwd_pool_rows", "pcops_mlp_gemm_fwd_xyz_rows")
+
+
+def _mfma_frac(d):
+    """fraction of the matrix pipe's peak a kernel's ALGORITHMIC flops stand for on the pipe it runs on"""
+    if d["work_unit"] != "flop":
+        return 0.0
+    if d["kernel"] in SPLIT_OPERAND_KERNELS and os.environ.get("PCOPS_GEMM_BF3", "1") != "0" and d.get("split_operands", True):
+        return 6.0 * d["gwork_s"] / 1e3 / BF16_PEAK_TFLOPS
+    return d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS
 MEASURED_F32_MFMA_TFLOPS = 155.0   # tools/ubench/mfma_peak.hip on this chip (operands in registers, 2.37 GHz)
 MEASURED_HBM_GBS = 6290.0          # MI355X_MICROARCH.md: float4 copy, 79 % of spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9    # 256 CUs x 4 SIMD-32 at 2.4 GHz = 78.6 T fp32 lane-ops/s
@@ -480,13 +494,12 @@ def side_model(name, dev, steps=10, warmup=3):
     if ks:
         d = ks[0]
         hbm = d["gbs"] / HBM_PEAK_GBS
-        mf = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
+        mf = _mfma_frac(d)
         res["dominant"] = {"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / 3.0,
                            "bound": "mfma" if mf > hbm else "hbm", "frac": max(mf, hbm), "hbm_frac": hbm, "mfma_frac": mf,
                            "share_of_step": d["ms"] / 3.0 / (el / steps * 1e3)}
         res["kernels"] = [{"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / 3.0,
-                           "bound_frac": max(d["gbs"] / HBM_PEAK_GBS,
-                                             d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0)}
+                           "bound_frac": max(d["gbs"] / HBM_PEAK_GBS, _mfma_frac(d))}
                           for d in ks[:6]]
     del net, fp, opt, x
     gc.collect()
@@ -704,11 +717,13 @@ def main():
     value = global_batch * args.steps / elapsed
     for d in kernels:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
-        d["mfma_frac"] = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
+        d["mfma_frac"] = _mfma_frac(d)
+        d["pipe"] = ("bf16 x 6 (split operands)" if d["work_unit"] == "flop" and d["kernel"] in SPLIT_OPERAND_KERNELS
+                     and os.environ.get("PCOPS_GEMM_BF3", "1") != "0" else ("f32 mfma" if d["work_unit"] == "flop" else None))
         d["bound_frac"] = max(d["hbm_frac"], d["mfma_frac"])
     for d in dom_live:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
-        d["mfma_frac"] = d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS if d["work_unit"] == "flop" else 0.0
+        d["mfma_frac"] = _mfma_frac(d)
     dom = dom_live[0] if dom_live else (kernels[0] if kernels else None)      # measured inside the timed region
     roofline = None
     if dom is not None:
@@ -716,7 +731,11 @@ def main():
         # kernels; for the MFMA GEMMs whichever of (algorithmic bytes / 8 TB/s, flops / 157.3 TF/s) is larger
         hbm_frac, mfma_frac = dom["hbm_frac"], dom["mfma_frac"]
         traffic = _measured_traffic(dom)
-        if mfma_frac > hbm_frac:
+        split = dom["kernel"] in SPLIT_OPERAND_KERNELS and os.environ.get("PCOPS_GEMM_BF3", "1") != "0"
+        if mfma_frac > hbm_frac and split:       # six bf16 products per algorithmic fp32 product, on the bf16 pipe
+            roofline = {"bound": "mfma", "achieved": 6.0 * dom["gwork_s"] / 1e3, "peak": BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": mfma_frac, "traffic": traffic, "pipe": "bf16 x 6 (split operands)"}
+        elif mfma_frac > hbm_frac:
             roofline = {"bound": "mfma", "achieved": dom["gwork_s"] / 1e3, "peak": F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": mfma_frac, "traffic": traffic}
         else:
@@ -729,7 +748,8 @@ def main():
                          "share_of_step": dom["ms"] / (elapsed * 1e3),
                          # ceilings measured on this chip (tools/ubench, MI355X_MICROARCH.md): what `peak` is in practice
                          "peak_measured": {"mfma_f32_tflops": MEASURED_F32_MFMA_TFLOPS, "hbm_gbs": MEASURED_HBM_GBS},
-                         "frac_of_measured_peak": (dom["gwork_s"] / 1e3 / MEASURED_F32_MFMA_TFLOPS
+                         "frac_of_measured_peak": (mfma_frac if (mfma_frac > hbm_frac and split) else
+                                                   dom["gwork_s"] / 1e3 / MEASURED_F32_MFMA_TFLOPS
                                                    if mfma_frac > hbm_frac else dom["gbs"] / MEASURED_HBM_GBS)})
     line = {
         "metric": "point-clouds/sec fwd+bwd at B×2048×3, 15-cls" if not args.forward_only
@@ -754,7 +774,7 @@ def main():
         "kernels_pass": "separate untimed pass of %d steps with every launch bracketed by HIP events; the timed region "
                         "brackets the dominant kernel only (roofline)" % profile_steps,
         "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit",
-                                        "hbm_frac", "mfma_frac", "bound_frac")} for d in kernels[:24]],
+                                        "hbm_frac", "mfma_frac", "bound_frac", "pipe")} for d in kernels[:24]],
     }
     if extras:
         line["extras"] = extras

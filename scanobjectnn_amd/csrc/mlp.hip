@@ -1410,7 +1410,9 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
         pl->lds = ws_lds_bytes(Kp, pl->kc, pl->bn, pl->waves, pl->eh);
     }
     pl->bf3 = false;
-    if (fwd && ws_bf3_mode() && pl->bn != 96 && !(reinterpret_cast<uintptr_t>(a.W) & 3)) {
+    static const int bf3_kmin = [] { const char *e = getenv("PCOPS_GEMM_BF3_KMIN"); return e ? atoi(e) : 0; }();
+    static const int bf3_kmax = [] { const char *e = getenv("PCOPS_GEMM_BF3_KMAX"); return e ? atoi(e) : 1 << 30; }();
+    if (fwd && ws_bf3_mode() && pl->bn != 96 && !(reinterpret_cast<uintptr_t>(a.W) & 3) && a.K >= bf3_kmin && a.K <= bf3_kmax) {
         const int Kp3 = (a.K + 31) / 32 * 32;
         const int nc = ws_ncoef(am);
         const int bn3 = a.N > 64 ? 128 : 64;
