@@ -1412,10 +1412,10 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
     pl->bf3 = false;
     static const int bf3_kmin = [] { const char *e = getenv("PCOPS_GEMM_BF3_KMIN"); return e ? atoi(e) : 0; }();
     static const int bf3_kmax = [] { const char *e = getenv("PCOPS_GEMM_BF3_KMAX"); return e ? atoi(e) : 1 << 30; }();
-    if (fwd && ws_bf3_mode() && pl->bn != 96 && !(reinterpret_cast<uintptr_t>(a.W) & 3) && a.K >= bf3_kmin && a.K <= bf3_kmax) {
+    if (fwd && ws_bf3_mode() && !(reinterpret_cast<uintptr_t>(a.W) & 3) && a.K >= bf3_kmin && a.K <= bf3_kmax) {
         const int Kp3 = (a.K + 31) / 32 * 32;
         const int nc = ws_ncoef(am);
-        const int bn3 = a.N > 64 ? 128 : 64;
+        const int bn3 = a.N > 96 ? 128 : (a.N > 64 ? (ws_n96_enabled() ? 96 : 128) : 64);
         bool wst3 = ws_lds_bytes_bf3(Kp3, bn3, 8, false, nc) > 160 * 1024;
         if (wst3 && (am == A_XYZ || ws_bf3_mode() == 2)) wst3 = false, pl->bf3 = false;
         else pl->bf3 = true;
@@ -1471,6 +1471,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
         if (pl.bn == 128) PCOPS_WS3_LAUNCH(4, 4);
+        else if (pl.bn == 96) PCOPS_WS3_LAUNCH(3, 3);
         else PCOPS_WS3_LAUNCH(2, 2);
 #undef PCOPS_WS3_LAUNCH
         return pcops_launch_status();
