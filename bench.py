@@ -33,11 +33,84 @@ from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks  # no
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_PEAK_TFLOPS = 157.3   # f32 vector == f32-input MFMA peak
+BOOST_MHZ = 2400.0         # the clock the peaks below are quoted at
 BF16_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA peak (16 x the f32-input rate, MI355X_MICROARCH.md)
 # kernels whose product runs on the bf16 matrix pipe with split operands: six bf16 products per
 # fp32 product, so their matrix-pipe fraction is 6 x the algorithmic flops over the bf16 peak (= flops / (157.3 x 16 / 6))
 SPLIT_OPERAND_KERNELS = ("pcops_mlp_gemm_fwd", "pcops_mlp_gemm_fwd_pool", "pcops_mlp_gemm_fwd_xyz",
                          "pcops_mlp_gemm_fwd_rows", "pcops_mlp_gemm_fwd_pool_rows", "pcops_mlp_gemm_fwd_xyz_rows")
+
+
+class ClockPoller:
+    """Shader clock and socket power of the busiest GPU while the timed region runs (rank 0; a host thread reading the
+    amdgpu hwmon files at ~100 Hz, rocm-smi as the fallback).  Context for `roofline.frac`, which is priced against the
+    peak at the part's boost clock: dense bf16 matrix work makes the chip clock down."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.freq = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"))
+        self.samples, self.stop_flag, self.source = [], False, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read_sysfs(self):
+        best = None
+        for f in self.freq:
+            try:
+                mhz = int(open(f).read()) / 1e6
+                d = os.path.dirname(f)
+                pw = None
+                for name in ("power1_average", "power1_input"):
+                    if os.path.exists(os.path.join(d, name)):
+                        pw = int(open(os.path.join(d, name)).read()) / 1e6
+                        break
+                if pw is not None and (best is None or pw > best[1]):
+                    best = (mhz, pw)
+            except (OSError, ValueError):
+                continue
+        return best
+
+    def _read_smi(self):
+        import re
+        import subprocess
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+        pw = [float(v) for v in re.findall(r"Power \(W\): ([\d.]+)", out)]
+        ck = [int(v) for v in re.findall(r"sclk clock level: \d+: \((\d+)Mhz\)", out)]
+        if not pw or len(pw) != len(ck):
+            return None
+        i = max(range(len(pw)), key=lambda j: pw[j])
+        return (float(ck[i]), pw[i])
+
+    def _run(self):
+        reader = self._read_sysfs if self.freq and self._read_sysfs() else self._read_smi
+        self.source = "amdgpu hwmon (freq1_input, power1_average), ~100 Hz" if reader == self._read_sysfs else "rocm-smi"
+        while not self.stop_flag:
+            try:
+                v = reader()
+            except Exception:
+                v = None
+            if v:
+                self.samples.append(v)
+            if reader == self._read_sysfs:
+                time.sleep(0.01)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop_flag = True
+        self.thread.join(timeout=10)
+
+    def summary(self):
+        busy = [v for v in self.samples if v[1] > 500.0] or self.samples
+        if not busy:
+            return None
+        ck, pw = sorted(v[0] for v in busy), sorted(v[1] for v in busy)
+        return {"sclk_mhz": sum(ck) / len(ck), "power_w": sum(pw) / len(pw),
+                "sclk_mhz_min_median_max": [ck[0], ck[len(ck) // 2], ck[-1]],
+                "power_w_min_median_max": [pw[0], pw[len(pw) // 2], pw[-1]],
+                "samples": len(busy), "source": self.source, "boost_mhz": BOOST_MHZ}
 
 
 def _mfma_frac(d):
@@ -671,7 +744,13 @@ def main():
     profile_steps = max(3, min(10, args.steps))
     _, _, _, kernels = measure(step, profile_steps, args.warmup, True)
     dom_key = (kernels[0]["kernel"], kernels[0]["shape"]) if kernels else None
-    elapsed, local_elapsed, host_elapsed, dom_live = measure(step, args.steps, args.warmup, dom_key is not None, dom_key)
+    clock = None
+    if rank == 0 and not os.environ.get("PCOPS_BENCH_NO_CLOCK"):
+        with ClockPoller() as poller:
+            elapsed, local_elapsed, host_elapsed, dom_live = measure(step, args.steps, args.warmup, dom_key is not None, dom_key)
+        clock = poller.summary()
+    else:
+        elapsed, local_elapsed, host_elapsed, dom_live = measure(step, args.steps, args.warmup, dom_key is not None, dom_key)
     ar_ms = [a.elapsed_time(b) for a, b in ar_events]
     per_rank = D.gather_floats(B * args.steps / local_elapsed, dev)      # every rank's own clouds/s
     ar_all = D.gather_floats(sum(ar_ms) / max(len(ar_ms), 1), dev)
@@ -745,6 +824,10 @@ def main():
                          "launches": dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"],
                          "algorithmic_flops_per_launch": dom["work"] if dom["work_unit"] == "flop" else None,
                          "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
+                         # `frac` is priced at the boost clock; the same launch against the peak at the clock the chip
+                         # actually held over the timed region (matrix-bound kernels only: HBM does not follow sclk)
+                         "frac_at_measured_clock": (roofline["frac"] * BOOST_MHZ / clock["sclk_mhz"]
+                                                    if clock and roofline["bound"] == "mfma" else None),
                          "share_of_step": dom["ms"] / (elapsed * 1e3),
                          # ceilings measured on this chip (tools/ubench, MI355X_MICROARCH.md): what `peak` is in practice
                          "peak_measured": {"mfma_f32_tflops": MEASURED_F32_MFMA_TFLOPS, "hbm_gbs": MEASURED_HBM_GBS},
@@ -770,6 +853,7 @@ def main():
         "allreduce_ms_per_step": max(ar_all) if world > 1 else 0.0,
         "allreduce_share_of_step": (max(ar_all) / (elapsed / args.steps * 1e3)) if world > 1 else 0.0,
         "roofline": roofline,
+        "clock": clock,
         "kernels_steps": profile_steps,
         "kernels_pass": "separate untimed pass of %d steps with every launch bracketed by HIP events; the timed region "
                         "brackets the dominant kernel only (roofline)" % profile_steps,

@@ -24,22 +24,28 @@ OUT = os.path.join(ROOT, "gpurun_out")
 KEYS = [
     # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
     ("gemm_ws_kernel<4, 6, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
-    ("wgrad_pc_kernel<2, 4, 1, 6>", None, "pcops_mlp_wgrad(2097152, 128, 256, 'compacted')"),
-    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),   # + per-block pooling
+    ("wgrad_pc_kernel<2, 4, 1, 6, false>", None, "pcops_mlp_wgrad(2097152, 128, 256, 'compacted')"),
+    # round 4: the forward products run as the split-operand variants (KC = 32, EH = 4, VAR + 4); the fp32 names are
+    # kept for PCOPS_GEMM_BF3=0 runs
+    ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 5>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),   # + per-block pooling
+    ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 4>", 512 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 128, 'compacted')"),
+    ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 5>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
+    ("gemm_ws_kernel<2, 5, 0, 32, 8, 2, 4>", None, "pcops_mlp_gemm_fwd_xyz(4194304, 64, 64)"),
+    ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 1024 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 256, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 0>", 512 * 512, "pcops_mlp_gemm_fwd(2097152, 128, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 2, 1, 64, 8, 2, 0>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128, 'compacted')"),
-    ("wgrad_pc_kernel<2, 2, 1, 7>", None, "pcops_mlp_wgrad(2097152, 128, 128, 'compacted')"),
+    ("wgrad_pc_kernel<2, 2, 1, 7, false>", None, "pcops_mlp_wgrad(2097152, 128, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 4, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad_top(32768, 512)"),
-    ("wgrad_pc_kernel<2, 4, 1, 8>", None, "pcops_mlp_gram(32768, 512)"),
+    ("wgrad_pc_kernel<2, 4, 1, 8, false>", None, "pcops_mlp_gram(32768, 512)"),
     ("sa_scatter_csr_kernel<32, false, 64>", None, "pcops_sa_scatter_bwd(256, 512, 128, 64, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
-    ("bwd_fused_kernel<2, 4, false>", None, "pcops_mlp_bwd_fused(4194304, 64, 128)"),            # round 3: one pass for ...
-    ("bwd_fused_kernel<1, 2, true>", None, "pcops_mlp_bwd_fused_xyz(4194304, 64, 64)"),
-    ("wgrad_pc_kernel<1, 2, 1, 4>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),                   # ... these four (PCOPS_BWD_FUSED=0)
+    ("bwd_fused_kernel<2, 4, false, false>", None, "pcops_mlp_bwd_fused(4194304, 64, 128)"),            # round 3: one pass for ...
+    ("bwd_fused_kernel<1, 2, true, false>", None, "pcops_mlp_bwd_fused_xyz(4194304, 64, 64)"),
+    ("wgrad_pc_kernel<1, 2, 1, 4, false>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),                   # ... these four (PCOPS_BWD_FUSED=0)
     ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
     ("gemm_ws_kernel<2, 2, 3, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad_xyz(4194304, 64, 64)"),
     ("gemm_ws_kernel<2, 5, 0, 64, 8, 1, 0>", None, "pcops_mlp_gemm_fwd_xyz(4194304, 64, 64)"),
-    ("wgrad_pc_kernel<1, 1, 5, 2>", None, "pcops_mlp_wgrad_xyz(4194304, 64, 64)"),
+    ("wgrad_pc_kernel<1, 1, 5, 2, false>", None, "pcops_mlp_wgrad_xyz(4194304, 64, 64)"),
     ("qbp_kernel<1, 32>", 512 * 1024, "pcops_query_ball_point(256, 2048, 512, 0.2, 32)"),
     ("fps_kernel<256, 8, true>", 256 * 256, "pcops_farthest_point_sample(256, 2048, 512)"),
 ]
