@@ -205,7 +205,13 @@ int pcops_edge_feature_grad_central(int b, int n, int c, int k, const float *gra
  *            sums, and  E[y^2] - mean^2  on fp32 partial sums loses |mean|^2 / var digits.  Any per-channel estimate of
  *            the mean within a few standard deviations -- the layer's moving mean is the natural one -- removes that:
  *            the shift is algebraically neutral (pcops_mlp_bn_finalize adds it back to the mean), every producer of
- *            forward statistics (this family, pcops_sa_gather_fwd, pcops_edge_pool_fwd) takes the same argument. */
+ *            forward statistics (this family, pcops_sa_gather_fwd, pcops_edge_pool_fwd) takes the same argument.
+ *            ARITHMETIC of the product (rows >= 8192, K a multiple of 8): fp32 in, fp32 out, evaluated on the bf16 matrix
+ *            pipe with both operands split into three bf16 pieces (x = h + m + l to 2^-25 |x|; six exact partial
+ *            products, the h.h products accumulated apart from the small ones) -- relative RMS error of an output ~5e-8
+ *            ... 7e-8 for K = 64 ... 128, a third of a K-long fp32 fmaf chain's; it is NOT bit-identical to such a chain
+ *            (environment PCOPS_GEMM_BF3=0 selects the fp32 matrix pipe, which is).  An infinite input gives NaN (inf - inf
+ *            in the split) where the chain gives inf; NaN stays NaN. */
 int pcops_mlp_stats_rows(int M);
 unsigned long long pcops_mlp_reduce_workspace_bytes(int N);
 int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float *pro_scale,

@@ -17,8 +17,11 @@
 //   wgrad dW_l = A_{l-1}^T dY_l, db_l = 1^T dY_l         both operands rebuilt in registers from the raw
 //                                                        tensors, fragment-shaped straight from HBM
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, k ascending within a chunk) -- no
-// reduced precision anywhere.  Tiles: 128 rows x (64|128) cols per workgroup of 4 waves, K in chunks
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, k ascending within a chunk) for the data and weight
+// gradients and the small-row kernels; the FORWARD products of the wave-stream kernel run on the bf16 matrix pipe with
+// every fp32 operand split into three bf16 pieces (six exact partial products, the large ones accumulated apart from the
+// small ones: a third of the fp32 chain's rounding error; PCOPS_GEMM_BF3=0 takes the fp32 pipe) --
+// no reduced-precision RESULT anywhere.  Tiles: 128 rows x (64|128) cols per workgroup of 4 waves, K in chunks
 // of 32 staged through LDS with 16-byte reads; the A fragment uses the "label permutation" trick: a
 // lane reads 4 consecutive k of its row with ONE ds_read_b128 and feeds them to 4 MFMAs whose k labels
 // are matched on the B side, so no transpose is ever needed.
