@@ -2534,6 +2534,342 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad with SPLIT OPERANDS on the bf16 matrix pipe (round 4): dW = A^T dY reduces over ROWS, so a
+// matrix instruction wants, per lane, eight consecutive rows of ONE channel.  The producers therefore hand the stripe
+// over TRANSPOSED and already split: T[piece][column slot][row] in bf16, three pieces per operand; a lane of a consumer
+// reads its fragment (8 rows x 1 column) with one ds_read_b128 per piece.
+//   waves 4..7  PRODUCERS: lane (cq = column quad, rg = group of FOUR CONSECUTIVE rows): 16-byte loads of rows 4 rg .. 4 rg + 3
+//               (a row of 128 channels is read by 32 lanes: coalesced), transform as in wgrad_pc_kernel, split, and per
+//               column and piece ONE 8-byte store of the four rows.  Column c of an operand lives in slot
+//               32 (c % 4) + c / 4: the 32 lanes of a row then write 32 consecutive slots (80 bytes apart: two passes
+//               for 64 lanes x 8 bytes, the minimum), and a consumer block of 32 slots holds the channels 4 m + e --
+//               a permutation that only shows in the index arithmetic of the final store.
+//   waves 0..3  CONSUMERS: 2 x 2 blocks of 32 x 32 each; per 16 rows and block pair six v_mfma_f32_32x32x16_bf16 -- the
+//               h.h product into the block's accumulator, the five small ones into a second set that is added once at
+//               the end (the large accumulator is then rounded once per 16 rows instead of once per 2: a long reduction
+//               -- 8 192 rows per workgroup at SA2's size -- is where that matters most).
+// Tile 128 x 128 (K or N beyond: more workgroups along y / z; the other operand is then read once per block).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3x4(float v0, float v1, float v2, float v3, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    const float x[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)x[e];
+        const float r1 = x[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+}
+
+template <int AMODE, int DMODE>
+__global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
+    constexpr int KB = 128, NB = 128, RS = 32;
+    constexpr int RSP = 40;                    // bf16 per slot: 32 rows + 8 (80 bytes: 16-byte aligned, 5 x 16 -> b128 reads of
+                                               // 16 consecutive slots fall into 16 different 16-byte bank groups)
+    constexpr int SLOTS = KB + NB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, N = a.N;
+    constexpr bool compact = DMODE == A_DYW || DMODE == A_DYPOOLB;
+    const long long M = compact ? (long long)__builtin_amdgcn_readfirstlane(*a.Mdev) : a.M;
+    const int k0 = blockIdx.y * KB, n0 = blockIdx.z * NB;
+    const int grp = blockIdx.x, ngrp = gridDim.x;
+    float *coefA = lds;                        // [6][KB]
+    float *coefD = coefA + 6 * KB;             // [5][NB]
+    __bf16 *T = reinterpret_cast<__bf16 *>(coefD + 5 * NB);    // [2][3][SLOTS][RSP]   | afterwards: db scratch [256][4]
+
+    for (int e = tid; e < KB; e += 512) {
+        const int k = k0 + e;
+        const bool in = k < K;
+        coefA[e] = (AMODE != A_PLAIN && in) ? a.asc[k] : 0.f;
+        coefA[KB + e] = (AMODE != A_PLAIN && in) ? a.ash[k] : 0.f;
+        if (AMODE == A_XYZ) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) coefA[(2 + i) * KB + e] = in ? a.xw[i * a.xw_ld + k] : 0.f;
+        }
+    }
+    for (int e = tid; e < NB; e += 512) {
+        const int n = n0 + e;
+        const bool in = n < N;
+        coefD[e] = (in && a.p) ? a.p[n] : 0.f;
+        coefD[NB + e] = (in && a.q) ? a.q[n] : 0.f;
+        coefD[2 * NB + e] = (in && a.t) ? a.t[n] : 0.f;
+        coefD[3 * NB + e] = (is_pool(DMODE) && in) ? a.dsc[n] : 0.f;
+        coefD[4 * NB + e] = (is_pool(DMODE) && in) ? a.dsh[n] : 0.f;
+    }
+    __syncthreads();
+
+    const long long nstripes = (M + RS - 1) / RS;
+    const long long cnt = grp < nstripes ? (nstripes - grp + ngrp - 1) / ngrp : 0;   // stripes of this workgroup
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const int cq = pt & 31, rg = pt >> 5;                 // column quad; rows 4 rg .. 4 rg + 3 of the stripe
+        const int acq = cq * 4, dcq = cq * 4;
+        const bool ain = k0 + acq < K, din = n0 + dcq < N;    // K % 4 == 0 and N % 4 == 0 (launcher)
+        const int acl = ain ? k0 + acq : 0, dcl = din ? n0 + dcq : 0;
+        const float4 casc = *reinterpret_cast<const float4 *>(&coefA[acq]);
+        const float4 cash = *reinterpret_cast<const float4 *>(&coefA[KB + acq]);
+        float4 xw0 = make_float4(0.f, 0.f, 0.f, 0.f), xw1 = xw0, xw2 = xw0, xb = xw0;
+        if (AMODE == A_XYZ) {
+            xw0 = *reinterpret_cast<const float4 *>(&coefA[2 * KB + acq]);
+            xw1 = *reinterpret_cast<const float4 *>(&coefA[3 * KB + acq]);
+            xw2 = *reinterpret_cast<const float4 *>(&coefA[4 * KB + acq]);
+            xb = *reinterpret_cast<const float4 *>(&coefA[5 * KB + acq]);
+        }
+        const float4 cp = *reinterpret_cast<const float4 *>(&coefD[dcq]);
+        const float4 cqv = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
+        const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
+        float dbs[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 px[4], pg[4], py[4];
+        unsigned pm[(is_pool(DMODE)) ? 4 : 1];
+        const unsigned xvoff = ain ? (unsigned)((4 * rg) * a.ldx + acl) * 4u : kOOB;
+        const unsigned dvoff = din ? (unsigned)((4 * rg) * a.ldy + dcl) * 4u : kOOB;
+        const unsigned xstep = (unsigned)a.ldx * 4u, dstep = (unsigned)a.ldy * 4u;
+        const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
+        constexpr bool U_ = DMODE == A_DYPOOLU;               // one pooling group per stripe
+        constexpr bool B_ = DMODE == A_DYPOOLB;               // compacted rows: one pooling group per 16-row block
+        constexpr bool G_ = DMODE == A_DYPOOL;                // any group size: per-row group arithmetic
+        const int hb = rg >> 2;                               // the 16-row block this lane's four rows lie in
+        float bw = 1.f;                                       // weight of that block's first row
+        int bs0 = 0, us0 = 0;
+        auto issue = [&](long long stripe) {
+            const long long row0 = stripe * RS;
+            if (compact) {
+                const long long nblk = (M + kBlk - 1) / kBlk;
+                long long bi = stripe * (RS / kBlk) + hb;
+                bi = bi < nblk ? bi : nblk - 1;
+                const RowBlock rb = a.blocks[bi];
+                bw = rb.w;
+                if (B_) {
+                    bs0 = rb.s0;
+                    pg[0] = *reinterpret_cast<const float4 *>(a.gpool + (long long)rb.g * N + dcl);
+                    pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + (long long)rb.g * N + dcl);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.Y + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            const __amdgpu_buffer_rsrc_t rgs =
+                make_rsrc((is_pool(DMODE) ? a.Y : a.G) + row0 * a.ldy, (M - row0) * a.ldy * 4);
+            if (AMODE == A_XYZ) {     // 16 bytes per ROW, broadcast over the 32 lanes of a row
+                const __amdgpu_buffer_rsrc_t ro = make_rsrc(a.off4 + row0 * 4, (M - row0) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) px[j] = buf_load4(ro, (unsigned)(4 * rg) * 16u, (unsigned)j * 16u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            }
+            const PoolRows pr(is_pool(DMODE) ? row0 : 0, is_pool(DMODE) ? a.S : 1);
+            us0 = pr.s0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                py[j] = buf_load4(ry, dvoff, (unsigned)j * dstep);
+                if (B_) {
+                    // loaded per block above
+                } else if (is_pool(DMODE)) {
+                    if (U_) {
+                        if (j == 0) {
+                            const long long gi = pr.g0 < glast ? pr.g0 : glast;
+                            pg[0] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                            pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                        }
+                    } else {
+                        long long gi;
+                        unsigned sdummy;
+                        pr.split(4 * rg + j, glast, gi, sdummy);
+                        pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
+                        pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
+                    }
+                } else if (DMODE != A_SELFD) {
+                    pg[j] = buf_load4(rgs, dvoff, (unsigned)j * dstep);
+                }
+            }
+        };
+        // four rows x four columns of one operand -> three pieces, one 8-byte store per column and piece
+        auto put = [&](const float4 (&v)[4], __bf16 *tbuf, int slot0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bf16x4 h, m, l;
+                split3x4(e == 0 ? v[0].x : (e == 1 ? v[0].y : (e == 2 ? v[0].z : v[0].w)),
+                         e == 0 ? v[1].x : (e == 1 ? v[1].y : (e == 2 ? v[1].z : v[1].w)),
+                         e == 0 ? v[2].x : (e == 1 ? v[2].y : (e == 2 ? v[2].z : v[2].w)),
+                         e == 0 ? v[3].x : (e == 1 ? v[3].y : (e == 2 ? v[3].z : v[3].w)), h, m, l);
+                __bf16 *dst = tbuf + (slot0 + 32 * e + cq) * RSP + 4 * rg;
+                *reinterpret_cast<bf16x4 *>(dst) = h;
+                *reinterpret_cast<bf16x4 *>(dst + SLOTS * RSP) = m;
+                *reinterpret_cast<bf16x4 *>(dst + 2 * SLOTS * RSP) = l;
+            }
+        };
+        auto stage_ = [&](long long stripe, __bf16 *tbuf, auto full_) {
+            constexpr bool FULL = decltype(full_)::value;
+            const long long row0 = stripe * RS;
+            const PoolRows prs(G_ ? row0 : 0, G_ ? a.S : 1);
+            float4 ax[4], dd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * rg + j;
+                float4 x = px[j];
+                if (AMODE == A_XYZ) {
+                    const float4 o = x;
+                    x = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
+                                    xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
+                }
+                if (AMODE != A_PLAIN) {
+                    x.x = fmaxf(fmaf(x.x, casc.x, cash.x), 0.f);
+                    x.y = fmaxf(fmaf(x.y, casc.y, cash.y), 0.f);
+                    x.z = fmaxf(fmaf(x.z, casc.z, cash.z), 0.f);
+                    x.w = fmaxf(fmaf(x.w, casc.w, cash.w), 0.f);
+                }
+                if (!FULL && !(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                ax[j] = x;
+            }
+            put(ax, tbuf, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * rg + j;
+                const float4 y = py[j];
+                float4 g = DMODE == A_SELFD ? make_float4(0.f, 0.f, 0.f, 0.f) : pg[(U_ || B_) ? 0 : j];
+                if (is_pool(DMODE)) {
+                    long long gdummy;
+                    unsigned s;
+                    if (U_) s = (unsigned)(us0 + r);
+                    else if (B_) s = (unsigned)(bs0 + (r & (kBlk - 1)));
+                    else prs.split(r, glast, gdummy, s);
+                    const unsigned am = pm[(U_ || B_) ? 0 : j];
+                    // gpool arrives MASKED (pcops.h: upstream gradient x [relu(bn(ysel)) > 0]): only the row test is left
+                    g.x = ((am & 0xffu) == s) ? g.x : 0.f;
+                    g.y = (((am >> 8) & 0xffu) == s) ? g.y : 0.f;
+                    g.z = (((am >> 16) & 0xffu) == s) ? g.z : 0.f;
+                    g.w = ((am >> 24) == s) ? g.w : 0.f;
+                }
+                float4 d;
+                if (DMODE == A_SELFD && AMODE == A_PLAIN) {
+                    d = y;
+                } else if (DMODE == A_SELFD) {
+                    d.x = fmaxf(fmaf(y.x, cqv.x, ct.x), 0.f);
+                    d.y = fmaxf(fmaf(y.y, cqv.y, ct.y), 0.f);
+                    d.z = fmaxf(fmaf(y.z, cqv.z, ct.z), 0.f);
+                    d.w = fmaxf(fmaf(y.w, cqv.w, ct.w), 0.f);
+                } else if (compact && j == 0) {
+                    // a row that opens a block (r % 16 == 0): dY = p.G + w (q.Y + t)
+                    const float w = (rg & 3) == 0 ? bw : 1.f;
+                    d.x = fmaf(cp.x, g.x, w * fmaf(cqv.x, y.x, ct.x));
+                    d.y = fmaf(cp.y, g.y, w * fmaf(cqv.y, y.y, ct.y));
+                    d.z = fmaf(cp.z, g.z, w * fmaf(cqv.z, y.z, ct.z));
+                    d.w = fmaf(cp.w, g.w, w * fmaf(cqv.w, y.w, ct.w));
+                } else {
+                    d.x = fmaf(cp.x, g.x, fmaf(cqv.x, y.x, ct.x));
+                    d.y = fmaf(cp.y, g.y, fmaf(cqv.y, y.y, ct.y));
+                    d.z = fmaf(cp.z, g.z, fmaf(cqv.z, y.z, ct.z));
+                    d.w = fmaf(cp.w, g.w, fmaf(cqv.w, y.w, ct.w));
+                }
+                if (!FULL && !(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
+                dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
+                dd[j] = d;
+            }
+            put(dd, tbuf, KB);
+        };
+        auto stage = [&](long long stripe, __bf16 *tbuf) {
+            if (stripe * RS + RS <= M && k0 + KB <= K && n0 + NB <= N) stage_(stripe, tbuf, std::true_type{});
+            else stage_(stripe, tbuf, std::false_type{});
+        };
+        if (cnt > 0) {
+            issue(grp);
+            stage(grp, T);
+            if (cnt > 1) issue(grp + ngrp);
+        }
+        __syncthreads();                                       // stripe 0 is in buffer 0
+        for (long long i = 0; i < cnt; ++i) {
+            if (i + 1 < cnt) {
+                stage(grp + (i + 1) * ngrp, T + ((i + 1) & 1) * 3 * SLOTS * RSP);
+                if (i + 2 < cnt) issue(grp + (i + 2) * ngrp);
+            }
+            __syncthreads();
+        }
+        // column sums of dY: lanes pt, pt + 32, ... own the same 4 columns
+        float *sdb = reinterpret_cast<float *>(T);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sdb[pt * 4 + e] = dbs[e];
+        __syncthreads();
+    } else {
+        // ------------------------------------------------------------------ consumers
+        const int ck = wave >> 1, cn = wave & 1;
+        const int half = lane >> 5, li = lane & 31;
+        f32x16 acc[2][2], sm[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] = sm[i][j][v] = 0.f;
+        const int aslot = (2 * ck) * 32 + li, dslot = KB + (2 * cn) * 32 + li;      // + 32 x / + 32 y
+        __syncthreads();
+        for (long long i = 0; i < cnt; ++i) {
+            const __bf16 *tb = T + (i & 1) * 3 * SLOTS * RSP;
+#pragma unroll
+            for (int s = 0; s < RS / 16; ++s) {
+                const int ro = 16 * s + 8 * half;
+                bf16x8 ah[2], am[2], al[2], dh[2], dm[2], dl[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const __bf16 *p0 = tb + (aslot + 32 * x) * RSP + ro;
+                    ah[x] = *reinterpret_cast<const bf16x8 *>(p0);
+                    am[x] = *reinterpret_cast<const bf16x8 *>(p0 + SLOTS * RSP);
+                    al[x] = *reinterpret_cast<const bf16x8 *>(p0 + 2 * SLOTS * RSP);
+                }
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    const __bf16 *p0 = tb + (dslot + 32 * y) * RSP + ro;
+                    dh[y] = *reinterpret_cast<const bf16x8 *>(p0);
+                    dm[y] = *reinterpret_cast<const bf16x8 *>(p0 + SLOTS * RSP);
+                    dl[y] = *reinterpret_cast<const bf16x8 *>(p0 + 2 * SLOTS * RSP);
+                }
+                // one product at a time over the four blocks: consecutive matrix instructions never share an accumulator
+#define PCOPS_MMX(A_, D_, C_)                                                                              \
+    _Pragma("unroll") for (int x = 0; x < 2; ++x) _Pragma("unroll") for (int y = 0; y < 2; ++y)            \
+        C_[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x], D_[y], C_[x][y], 0, 0, 0)
+                PCOPS_MMX(al, dh, sm);
+                PCOPS_MMX(ah, dl, sm);
+                PCOPS_MMX(am, dm, sm);
+                PCOPS_MMX(am, dh, sm);
+                PCOPS_MMX(ah, dm, sm);
+                PCOPS_MMX(ah, dh, acc);
+#undef PCOPS_MMX
+            }
+            __syncthreads();
+        }
+        // acc[x][y][v]: A slot 32 (2 ck + x) + m with m = (v&3) + 8 (v>>2) + 4 half  ->  channel 4 m + (2 ck + x);
+        //               dY slot 32 (2 cn + y) + li                                     ->  column  4 li + (2 cn + y)
+        float *out = a.part + (long long)grp * K * N;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const int nn = n0 + 4 * li + 2 * cn + y;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int kk = k0 + 4 * ((v & 3) + 8 * (v >> 2) + 4 * half) + 2 * ck + x;
+                    if (kk < K && nn < N) out[(long long)kk * N + nn] = acc[x][y][v] + sm[x][y][v];
+                }
+            }
+        __syncthreads();                                       // matches the producers' db hand-over
+        if (blockIdx.y == 0 && a.dbpart) {
+            const float *sdb = reinterpret_cast<const float *>(T);
+            for (int c = tid; c < NB; c += 256) {
+                const int quad = c >> 2, e = c & 3;
+                float sum = 0.f;
+                for (int r = quad; r < 256; r += 32) sum += sdb[r * 4 + e];
+                if (n0 + c < N) a.dbpart[(long long)grp * N + n0 + c] = sum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Data AND weight gradient of a 64-wide layer in ONE pass over its tensors (round 3).  The two kernels of such a layer
 // are bandwidth bound and read the same bytes: SA1's 64 -> 128 layer moves 4.3 GB for the data gradient (Y, the mask
 // tensor, Gprev) and 3.2 GB for the weight gradient (Y again, the mask tensor again as the A operand).  Here the
@@ -3241,6 +3577,36 @@ static bool wgrad_pc_plan(long long M, int K, int N, int ldx, const void *X, con
     const int rs = pl->tk * pl->tn <= 2 ? 64 : 32;
     pl->lds = (size_t)(6 * KB + 5 * NB + 2 * rs * (KB + NB)) * sizeof(float);
     return pl->lds <= 160 * 1024;
+}
+
+struct Bf3WgradPlan {
+    int kblocks, nblocks, groups;
+    size_t lds;
+};
+
+// split-operand weight gradient (wgrad_bf3_kernel): the large layers wider than 64 on both sides
+static bool wgrad_bf3_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
+                           const void *gpool, const void *argmax, Bf3WgradPlan *pl) {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_WGRAD_BF3");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || M < 32768 || K <= 64 || N <= 64) return false;
+    if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
+        (reinterpret_cast<uintptr_t>(Y) & 15) || (reinterpret_cast<uintptr_t>(gpool) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return false;
+    pl->kblocks = (K + 127) / 128;
+    pl->nblocks = (N + 127) / 128;
+    int groups = 256 / (pl->kblocks * pl->nblocks);
+    if (groups < 1) groups = 1;
+    const long long maxg = (M + 31) / 32;
+    if (groups > maxg) groups = (int)maxg;
+    if (groups >= 8) groups &= ~7;
+    pl->groups = groups;
+    pl->lds = (size_t)(6 * 128 + 5 * 128) * sizeof(float) + (size_t)2 * 3 * 256 * 40 * 2;
+    return true;
 }
 
 static bool wgrad_pc_enabled() {
@@ -4172,7 +4538,32 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     const bool self = a.dmode == A_SELFD;
     if (self && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, true)))
         return PCOPS_ERR_UNSUPPORTED;            // Gram matrix: producer/consumer kernel only
-    if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, self) &&
+    Bf3WgradPlan b3;
+    if (ws_enabled() && wgrad_pc_enabled() && !self && a.amode != A_XYZ &&
+        wgrad_bf3_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &b3)) {
+        splits = b3.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(b3.groups, b3.kblocks, b3.nblocks);
+#define PCOPS_B3_LAUNCH(AM_, DM_)                                                                          \
+    do {                                                                                                   \
+        auto kern = wgrad_bf3_kernel<AM_, DM_>;                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(512), b3.lds, st, a);                                          \
+    } while (0)
+        if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYW);
+        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYW);
+        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLB);
+        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLB);
+        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_B3_LAUNCH(A_BNRELU, A_DY);
+        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLU);
+        else if (a.amode == A_BNRELU) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOL);
+        else if (a.dmode == A_DY) PCOPS_B3_LAUNCH(A_PLAIN, A_DY);
+        else if (a.S % 32 == 0) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLU);
+        else PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOL);
+#undef PCOPS_B3_LAUNCH
+    } else if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, self) &&
         (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks || self ||
          !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
         splits = pc.groups;
