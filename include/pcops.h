@@ -289,7 +289,11 @@ int pcops_mlp_gemm_dgrad(int M, int K, int Nout, const float *G, const float *Y,
                          const float *Yprev, const float *prev_scale, const float *prev_shift, float *Gprev,
                          float *stats_partial, pcops_stream_t stream);
 /* wgrad: dW[K,N] = A^T dY, db[N] (may be NULL) = 1^T dY; A = X or relu(X*a_scale + a_shift); dY as above.
- * partial: caller scratch of pcops_mlp_wgrad_splits(M,K,N) * (K*N + N) floats. */
+ * partial: caller scratch of pcops_mlp_wgrad_splits(M,K,N) * (K*N + N) floats.
+ * ARITHMETIC (round 4): layers wider than 64 on both sides with >= 32 768 rows are reduced on the bf16 matrix pipe with
+ * split operands (three bf16 pieces per fp32 value, six exact partial products, the large ones accumulated apart from the
+ * small ones): fp32 in, fp32 out, 1.5e-7 ... 2.2e-7 relative RMS against float64 where the fp32-pipe kernel makes
+ * 2.1e-7 ... 4.0e-7; not bit-identical to it (environment PCOPS_WGRAD_BF3=0 selects the fp32 pipe). */
 int pcops_mlp_wgrad_splits(long long M, int K, int N);
 int pcops_mlp_wgrad(long long M, int K, int N, const float *X, int ldx, const float *a_scale,
                     const float *a_shift, const float *G, const float *Y, const float *p, const float *q,

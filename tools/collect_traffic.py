@@ -24,6 +24,9 @@ OUT = os.path.join(ROOT, "gpurun_out")
 KEYS = [
     # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
     ("gemm_ws_kernel<4, 6, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
+    # round 4: SA2's two weight gradients run as ONE template instantiation of the split-operand kernel with equal grid
+    # sizes (128 x 1 x 2 and 256 x 1 x 1 workgroups): the counters cannot tell them apart, the entry is their average
+    ("wgrad_bf3_kernel<1, 6>", None, "pcops_mlp_wgrad(2097152, 128, 128|256, 'compacted') [two launches averaged]"),
     ("wgrad_pc_kernel<2, 4, 1, 6, false>", None, "pcops_mlp_wgrad(2097152, 128, 256, 'compacted')"),
     # round 4: the forward products run as the split-operand variants (KC = 32, EH = 4, VAR + 4); the fp32 names are
     # kept for PCOPS_GEMM_BF3=0 runs
