@@ -113,11 +113,24 @@ class ClockPoller:
                 "samples": len(busy), "source": self.source, "boost_mhz": BOOST_MHZ}
 
 
+def _split_operands(d):
+    """does this launch run on the bf16 matrix pipe with split operands (csrc/mlp.hip: ws_plan's forward rule,
+    wgrad_bf3_plan)?"""
+    if d["work_unit"] != "flop":
+        return False
+    if d["kernel"] in SPLIT_OPERAND_KERNELS:
+        return os.environ.get("PCOPS_GEMM_BF3", "1") != "0" and d["shape"][0] >= 8192
+    if d["kernel"] == "pcops_mlp_wgrad":
+        m, k, n = d["shape"][:3]
+        return os.environ.get("PCOPS_WGRAD_BF3", "1") != "0" and m >= 32768 and k > 64 and n > 64
+    return False
+
+
 def _mfma_frac(d):
     """fraction of the matrix pipe's peak a kernel's ALGORITHMIC flops stand for on the pipe it runs on"""
     if d["work_unit"] != "flop":
         return 0.0
-    if d["kernel"] in SPLIT_OPERAND_KERNELS and os.environ.get("PCOPS_GEMM_BF3", "1") != "0" and d.get("split_operands", True):
+    if _split_operands(d):
         return 6.0 * d["gwork_s"] / 1e3 / BF16_PEAK_TFLOPS
     return d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS
 MEASURED_F32_MFMA_TFLOPS = 155.0   # tools/ubench/mfma_peak.hip on this chip (operands in registers, 2.37 GHz)
@@ -797,8 +810,7 @@ def main():
     for d in kernels:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
         d["mfma_frac"] = _mfma_frac(d)
-        d["pipe"] = ("bf16 x 6 (split operands)" if d["work_unit"] == "flop" and d["kernel"] in SPLIT_OPERAND_KERNELS
-                     and os.environ.get("PCOPS_GEMM_BF3", "1") != "0" else ("f32 mfma" if d["work_unit"] == "flop" else None))
+        d["pipe"] = "bf16 x 6 (split operands)" if _split_operands(d) else ("f32 mfma" if d["work_unit"] == "flop" else None)
         d["bound_frac"] = max(d["hbm_frac"], d["mfma_frac"])
     for d in dom_live:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
@@ -810,7 +822,7 @@ def main():
         # kernels; for the MFMA GEMMs whichever of (algorithmic bytes / 8 TB/s, flops / 157.3 TF/s) is larger
         hbm_frac, mfma_frac = dom["hbm_frac"], dom["mfma_frac"]
         traffic = _measured_traffic(dom)
-        split = dom["kernel"] in SPLIT_OPERAND_KERNELS and os.environ.get("PCOPS_GEMM_BF3", "1") != "0"
+        split = _split_operands(dom)
         if mfma_frac > hbm_frac and split:       # six bf16 products per algorithmic fp32 product, on the bf16 pipe
             roofline = {"bound": "mfma", "achieved": 6.0 * dom["gwork_s"] / 1e3, "peak": BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": mfma_frac, "traffic": traffic, "pipe": "bf16 x 6 (split operands)"}
