@@ -262,3 +262,26 @@ def test_sync_bn_statistics_with_a_different_pivot_on_every_rank():
         var = s[1] / total - mean * mean
         assert torch.allclose(mean, y.mean(0), rtol=0, atol=1e-6)
         assert torch.allclose(var, y.var(0, unbiased=False), rtol=1e-5, atol=1e-7)
+
+
+def test_sync_forms_without_a_process_group(monkeypatch):
+    """dist.SYNC_FORMS_LOCAL (the single-process reference of tests/test_dist_gpu.py): SyncBN's code paths are active, the
+    exchange is the identity -- the shifted partials come back as un-shifted sums of this process's rows, split into an
+    fp32 head and the float64 remainder, and the row count is the local one"""
+    monkeypatch.setattr(D, "SYNC_BN", True)
+    assert not D.sync_bn_active()
+    monkeypatch.setattr(D, "SYNC_FORMS_LOCAL", True)
+    assert D.sync_bn_active()
+    g = torch.Generator().manual_seed(1)
+    rows, c = 1000, 12
+    y = torch.randn(rows, c, generator=g, dtype=torch.float64) * 3.0 + 5.0
+    piv = torch.randn(c, generator=g).float() + 5.0
+    chunks = y.view(10, 100, c)
+    part = torch.stack([torch.stack([(ch - piv.double()).sum(0), ((ch - piv.double()) ** 2).sum(0)]) for ch in chunks]).float()
+    out, n = D.allreduce_stat_partials(part, rows, piv)
+    assert n == rows and out.shape == (2, 2, c)
+    tot = out.double().sum(0)
+    assert torch.allclose(tot[0], y.sum(0), rtol=1e-6) and torch.allclose(tot[1], (y * y).sum(0), rtol=1e-6)
+    mean, var, total = D.sync_batch_stats(y.float())
+    assert total == rows and torch.allclose(mean.double(), y.mean(0), atol=1e-5)
+    assert torch.allclose(var.double(), y.var(0, unbiased=False), rtol=1e-4)
