@@ -126,6 +126,13 @@ def _split_operands(d):
     return False
 
 
+def _half_split(d):
+    """the one-pass backward: its dW half on the fp32 pipe, its dX half on the bf16 pipe with split operands
+    (bwd_fused_kernel<..., DX3>)"""
+    return (d["work_unit"] == "flop" and d["kernel"] in ("pcops_mlp_bwd_fused", "pcops_mlp_bwd_fused_xyz")
+            and os.environ.get("PCOPS_BWD_FUSED_DX3", "1") != "0")
+
+
 def _mfma_frac(d):
     """fraction of the matrix pipe's peak a kernel's ALGORITHMIC flops stand for on the pipe it runs on"""
     if d["work_unit"] != "flop":
@@ -133,6 +140,19 @@ def _mfma_frac(d):
     if _split_operands(d):
         return 6.0 * d["gwork_s"] / 1e3 / BF16_PEAK_TFLOPS
     return d["gwork_s"] / 1e3 / F32_PEAK_TFLOPS
+
+
+def _pipe_busy(d):
+    """share of the launch the matrix pipe is busy at its nominal rate: the fp32 part of the flops at the fp32 rate, the
+    split-operand part six-fold at the bf16 rate"""
+    if d["work_unit"] != "flop":
+        return None
+    tf = d["gwork_s"] / 1e3
+    if _split_operands(d):
+        return 6.0 * tf / BF16_PEAK_TFLOPS
+    if _half_split(d):
+        return 0.5 * tf / F32_PEAK_TFLOPS + 0.5 * 6.0 * tf / BF16_PEAK_TFLOPS
+    return tf / F32_PEAK_TFLOPS
 MEASURED_F32_MFMA_TFLOPS = 155.0   # tools/ubench/mfma_peak.hip on this chip (operands in registers, 2.37 GHz)
 MEASURED_HBM_GBS = 6290.0          # MI355X_MICROARCH.md: float4 copy, 79 % of spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9    # 256 CUs x 4 SIMD-32 at 2.4 GHz = 78.6 T fp32 lane-ops/s
@@ -810,7 +830,9 @@ def main():
     for d in kernels:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
         d["mfma_frac"] = _mfma_frac(d)
-        d["pipe"] = "bf16 x 6 (split operands)" if _split_operands(d) else ("f32 mfma" if d["work_unit"] == "flop" else None)
+        d["pipe"] = ("bf16 x 6 (split operands)" if _split_operands(d) else
+                     "f32 mfma (dW) + bf16 x 6 (dX)" if _half_split(d) else ("f32 mfma" if d["work_unit"] == "flop" else None))
+        d["pipe_busy_frac"] = _pipe_busy(d)
         d["bound_frac"] = max(d["hbm_frac"], d["mfma_frac"])
     for d in dom_live:
         d["hbm_frac"] = d["gbs"] / HBM_PEAK_GBS
@@ -836,6 +858,11 @@ def main():
                          "launches": dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"],
                          "algorithmic_flops_per_launch": dom["work"] if dom["work_unit"] == "flop" else None,
                          "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
+                         # which pipe(s) the launch's products run on, and the share of the launch the matrix pipe is busy
+                         # at its nominal rate (`frac` prices the ALGORITHMIC fp32 flops against the fp32-input peak)
+                         "pipe": ("f32 mfma (dW) + bf16 x 6 (dX)" if _half_split(dom) else
+                                  "bf16 x 6 (split operands)" if split else "f32 mfma"),
+                         "pipe_busy_frac": _pipe_busy(dom),
                          # `frac` is priced at the boost clock; the same launch against the peak at the clock the chip
                          # actually held over the timed region (matrix-bound kernels only: HBM does not follow sclk)
                          "frac_at_measured_clock": (roofline["frac"] * BOOST_MHZ / clock["sclk_mhz"]
@@ -870,7 +897,7 @@ def main():
         "kernels_pass": "separate untimed pass of %d steps with every launch bracketed by HIP events; the timed region "
                         "brackets the dominant kernel only (roofline)" % profile_steps,
         "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit",
-                                        "hbm_frac", "mfma_frac", "bound_frac", "pipe")} for d in kernels[:24]],
+                                        "hbm_frac", "mfma_frac", "bound_frac", "pipe", "pipe_busy_frac")} for d in kernels[:24]],
     }
     if extras:
         line["extras"] = extras

@@ -2886,7 +2886,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
 // (4 096 cycles at NB = 128); the pass is pipe bound at about 0.7 x the time of the two kernels it replaces.
 // NSK (N <= NB - 32, MSG's 64 -> 96 layer on the 128-column tile): the consumers skip what only multiplies the zero
 // columns -- the dW block of dY columns >= N and the data-gradient steps over them (wave-uniform tests on N).
-template <int TN, int DMODE, bool XYZ, bool NSK = false>
+// DX3: the data-gradient half (dX = dY W^T, a reduction over the dY columns) on the bf16 matrix pipe with split operands
+// (DESIGN.md section 4.10): its A operand is the row-major dY the stripe already holds -- a lane reads eight consecutive
+// columns of its row and splits them in registers -- and the wave's W slice is split once into register-resident pieces;
+// per 32 dY columns six v_mfma_f32_16x16x32_bf16 per 16 x 16 block instead of eight v_mfma_f32_16x16x4_f32 of twice the
+// length (768 instead of 2 048 matrix cycles per stripe and wave, ~700 cycles of split arithmetic in exchange), the h.h
+// products in the block's accumulator, the small ones in a second one.  The dW half stays on the fp32 pipe (its operands
+// would have to be staged transposed).
+template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
     // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
@@ -3173,19 +3180,39 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             for (int v = 0; v < 4; ++v) accd[b][v] = 0.f;
         const int aoff = half * LD + ck * 32 + li;
         const int doff = half * LD + 2 * KB + cn * TN * 32 + li;
-        const int daoff = (16 * rh + c16) * LD + 2 * KB + 4 * g4;           // + 16 J
+        const int daoff = (16 * rh + c16) * LD + 2 * KB + (DX3 ? 8 : 4) * g4;   // + 16 J (split operands: + 32 J, and + 4)
         const int nyw = NSK ? (N - cn * TN * 32 + 31) / 32 : TN;            // dW blocks of this wave with real columns
-        const int jreal = NSK ? (N + 15) / 16 : NB / 16;                    // data-gradient steps with real columns
+        const int jreal = NSK ? (DX3 ? (N + 31) / 32 : (N + 15) / 16) : (DX3 ? NB / 32 : NB / 16);   // steps with real columns
         const int wboff = (g4 * KB + 32 * cbp + c16) * 4;                   // + 16 b * 4, + J * 4 KB * 4
         // this wave's slice of W (NB x 32 columns) stays in REGISTERS for the life of the workgroup: re-read from LDS per
         // stripe it was 64 of the 154 KB of LDS reads a stripe cost -- at 128 B/clk the LDS pipe, not the matrix pipe,
         // set the pace (measured: the kernel without any MFMA or global access still took a quarter of its time)
-        constexpr int JN = NB / 16;                            // 16-column groups of dY: one data-gradient step each
-        float4 wreg[JN][2];
+        constexpr int JN = DX3 ? NB / 32 : NB / 16;            // column groups of dY (16, split operands: 32): one data-gradient step each
+        float4 wreg[DX3 ? 1 : JN][2];
+        bf16x8 wph[DX3 ? JN : 1][2], wpm[DX3 ? JN : 1][2], wpl[DX3 ? JN : 1][2];      // DX3: the slice as three bf16 pieces
+        f32x4 smd[2];                                          // DX3: the small partial products of the two blocks
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) smd[b][v] = 0.f;
+        if constexpr (DX3) {
+            // B operand of v_mfma_f32_16x16x32_bf16: lane (c16, g4) = output column 32 cbp + 16 b + c16 (row kk of W), eight
+            // consecutive dY columns 32 J + 8 g4 .. + 7 = two n-quads of the staging layout wq[n / 4][k][n % 4]
+#pragma unroll
+            for (int J = 0; J < JN; ++J)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int kk = 32 * cbp + 16 * b + c16, nq = 8 * J + 2 * g4;
+                    const float4 f0 = *reinterpret_cast<const float4 *>(&wq[(nq * KB + kk) * 4]);
+                    const float4 f1 = *reinterpret_cast<const float4 *>(&wq[((nq + 1) * KB + kk) * 4]);
+                    split3(f0, f1, wph[J][b], wpm[J][b], wpl[J][b]);
+                }
+        } else {
 #pragma unroll
         for (int J = 0; J < JN; ++J)
 #pragma unroll
             for (int b = 0; b < 2; ++b) wreg[J][b] = *reinterpret_cast<const float4 *>(&wq[wboff + 64 * b + J * 4 * KB * 4]);
+        }
         unsigned goff[2][4];                                   // byte offsets of this lane's Gprev elements inside a stripe
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -3214,6 +3241,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             // every LDS fragment is requested one use AHEAD (the scheduler would otherwise sink the reads to just in
             // front of their first use and expose the LDS latency)
             float4 da_n = *reinterpret_cast<const float4 *>(&sb[daoff]);
+            float4 da2_n = DX3 ? *reinterpret_cast<const float4 *>(&sb[daoff + 4]) : da_n;     // split operands: columns + 4 .. + 7
             float yr[2][4];                                    // the raw Yprev under this wave's Gprev elements
 #pragma unroll
             for (int it = 0; it < RS / 2; ++it) {
@@ -3228,8 +3256,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 }
                 const bool dostep = it % JP == 0;
                 const int J = it / JP;
-                const float4 da = da_n;
-                if (dostep && J + 1 < JN) da_n = *reinterpret_cast<const float4 *>(&sb[daoff + 16 * (J + 1)]);
+                const float4 da = da_n, da2 = da2_n;
+                if (dostep && J + 1 < JN) {
+                    da_n = *reinterpret_cast<const float4 *>(&sb[daoff + (DX3 ? 32 : 16) * (J + 1)]);
+                    if (DX3) da2_n = *reinterpret_cast<const float4 *>(&sb[daoff + 32 * (J + 1) + 4]);
+                }
                 if (it == RS / 2 - 1) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
@@ -3244,15 +3275,33 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     if (!NSK || y < nyw) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
                 }
                 if (dostep && (!NSK || J < jreal) && !(dbg & 1)) {
+                    if constexpr (DX3) {
+                        bf16x8 eh, em, el;
+                        split3(da, da2, eh, em, el);
+                        const int Jc = J < JN ? J : 0;          // (J is a compile-time constant of the unrolled loop)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, wph[Jc][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wpl[Jc][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, wpm[Jc][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, wph[Jc][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wpm[Jc][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) accd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wph[Jc][b], accd[b], 0, 0, 0);
+                    } else {
                     const float de[4] = {da.x, da.y, da.z, da.w};
 #pragma unroll
                     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            const float4 w4 = wreg[J][b];
+                            const float4 w4 = wreg[DX3 ? 0 : J][b];
                             const float we = s_ == 0 ? w4.x : (s_ == 1 ? w4.y : (s_ == 2 ? w4.z : w4.w));
                             accd[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(de[s_], we, accd[b], 0, 0, 0);
                         }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -3270,7 +3319,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const float gv = fmaf(yr[b][v], msc[b], msh[b]) > 0.f ? accd[b][v] : 0.f;
+                        const float gv = fmaf(yr[b][v], msc[b], msh[b]) > 0.f ? (DX3 ? accd[b][v] + smd[b][v] : accd[b][v]) : 0.f;
+                        if (DX3) smd[b][v] = 0.f;
                         s1[b] += gv;
                         s2[b] = fmaf(gv, yr[b][v], s2[b]);
                         if (XYZ) {
@@ -4713,9 +4763,15 @@ static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, 
         return !(e && e[0] == '0');
     }();
     const bool nsk = nsk_on && tn == 2 && N <= 96;
+    static const bool dx3 = [] {
+        const char *e = getenv("PCOPS_BWD_FUSED_DX3");
+        return !(e && e[0] == '0');
+    }();
 #define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
     do {                                                                                                   \
-        auto kern = (TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>;                                                      \
+        auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
+                                              : bwd_fused_kernel<TN_, DM_, X_, false, true>)                    \
+                        : ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>);                                                      \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
             return PCOPS_ERR_LAUNCH;                                                                       \
