@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-# (kernel-name fragment, total grid threads or None) -> bench.py key.  Template arguments:
+# (kernel-name fragment -- a SUBSTRING, trailing template arguments may be left open --, total grid threads or None) -> bench.py key.  Template arguments:
 # gemm_ws_kernel<NT, AM, EM, KC, WAVES, EH, VAR>, wgrad_pc_kernel<TK, TN, AMODE, DMODE>
 KEYS = [
     # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
@@ -42,8 +42,8 @@ KEYS = [
     ("wgrad_pc_kernel<2, 4, 1, 8, false>", None, "pcops_mlp_gram(32768, 512)"),
     ("sa_scatter_csr_kernel<32, false, 64>", None, "pcops_sa_scatter_bwd(256, 512, 128, 64, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 1, 0, 64, 8, 2, 1>", 512 * 512, "pcops_mlp_gemm_fwd_pool(4194304, 64, 128, 32)"),
-    ("bwd_fused_kernel<2, 4, false, false>", None, "pcops_mlp_bwd_fused(4194304, 64, 128)"),            # round 3: one pass for ...
-    ("bwd_fused_kernel<1, 2, true, false>", None, "pcops_mlp_bwd_fused_xyz(4194304, 64, 64)"),
+    ("bwd_fused_kernel<2, 4, false, false", None, "pcops_mlp_bwd_fused(4194304, 64, 128)"),            # round 3: one pass for ...
+    ("bwd_fused_kernel<1, 2, true, false", None, "pcops_mlp_bwd_fused_xyz(4194304, 64, 64)"),
     ("wgrad_pc_kernel<1, 2, 1, 4, false>", None, "pcops_mlp_wgrad(4194304, 64, 128)"),                   # ... these four (PCOPS_BWD_FUSED=0)
     ("gemm_ws_kernel<2, 4, 1, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad(4194304, 128, 64)"),
     ("gemm_ws_kernel<2, 2, 3, 64, 8, 1, 0>", None, "pcops_mlp_gemm_dgrad_xyz(4194304, 64, 64)"),
