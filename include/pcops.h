@@ -310,7 +310,11 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
  *                               stats_partial [groups][2][K] = (sum Gprev, sum Gprev*Yprev) -- the partial-row count to
  *                               hand to pcops_mlp_bn_bwd_coeffs
  *   G / Y / p / q / t / gpool / argmax / S   as pcops_mlp_gemm_dgrad
- * Same numbers as the two-kernel path up to fp32 summation order; sums in a fixed order (deterministic). */
+ * Same numbers as the two-kernel path up to rounding; sums in a fixed order (deterministic).  ARITHMETIC (round 4): the
+ * data gradient dX = dY W^T is evaluated on the bf16 matrix pipe with split operands (three bf16 pieces per fp32 value,
+ * six exact partial products, the large ones accumulated apart from the small ones): fp32 in, fp32 out, no less accurate
+ * than the fp32 chain, not bit-identical to it (environment PCOPS_BWD_FUSED_DX3=0 selects the fp32 pipe); the weight
+ * gradient half runs on the fp32 pipe. */
 int pcops_mlp_bwd_fused_groups(long long M, int K, int N, int S, int pooled);
 int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
                         const float *G, const float *Y, const float *p, const float *q, const float *t,
