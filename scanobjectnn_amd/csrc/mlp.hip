@@ -37,7 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // fp32 -> three bf16 pieces, x = h + m + l up to 2^-25 |x| (each residual is exact in fp32; round-to-nearest pieces carry
-// their own signs, so 3 x 8 significant bits cover the 24 of the operand).  Products of two pieces are exact in fp32.
+// their own signs, so 3 x 8 significant bits cover the 24 of the operand; below 2^-100 the residuals turn denormal and the
+// identity holds to an absolute 2^-133 instead).  Products of two pieces are exact in fp32.  (tests/test_split_operands_cpu.py)
 __device__ __forceinline__ void split3(const float4 &x0, const float4 &x1, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
