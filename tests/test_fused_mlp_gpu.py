@@ -76,6 +76,10 @@ CASES = [  # (R, S, K0, widths, pool)
     (1024 * 32 * 2 + 64, 32, 32, [64, 96, 128], True),
     (70000 + 19, 1, 64, [96, 128], False),         # ... ragged tail, dense upstream gradient
     (2048 * 16, 16, 64, [96, 128], True),          # ... groups that are not tile multiples
+    # a pooled top layer WIDER than 64 on both sides behind groups that are not stripe multiples: the per-row group
+    # arithmetic of the split-operand weight gradient (four consecutive rows per producer lane)
+    (2048 * 20, 20, 32, [128, 128], True),
+    (1100 * 48, 48, 16, [96, 128], True),
 ]
 
 
