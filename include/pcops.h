@@ -62,6 +62,14 @@ int pcops_farthest_point_sample(int b, int n, int m, const float *inp, float *te
                                 int *out, pcops_stream_t stream);
 unsigned long long pcops_farthest_point_sample_workspace_bytes(int b, int n);
 
+/* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)   sampling/tf_sampling.cpp:65, kernels sampling/tf_sampling_g.cu:7-103,
+ * launcher :197-200.  inp_p (b,n) non-negative weights, inp_r (b,m) numbers in [0,1] -> out (b,m) int32: the smallest
+ * index whose cumulative weight is >= inp_r * total.  `temp` is the reference's (b,n) scratch (tf_sampling.cpp:86) and
+ * receives the row cumsum; its fp32 association is the reference's (groups of four, up-/down-sweep over the group
+ * totals, compensated carry across 8192-element chunks), so `out` is bit-identical, boundary cases included. */
+int pcops_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp,
+                      int *out, pcops_stream_t stream);
+
 /* gatherpointLauncher(b,n,m,inp,idx,out)   sampling/tf_sampling.cpp:125, :172-181 */
 int pcops_gather_point(int b, int n, int m, const float *inp, const int *idx,
                        float *out, pcops_stream_t stream);
@@ -421,6 +429,12 @@ int pcops_mlp_wgrad_xyz(long long M, int K, int N, const float *off4, const floa
  * moments (may be NULL; needs the coordinate term): float [pcops_sa_gather_stats_rows(b*m)][9] partial sums of
  * (dx dx, dx dy, dx dz, dy dy, dy dz, dz dz, dx, dy, dz) -- see pcops_mlp_gemm_dgrad_xyz. */
 int pcops_sa_gather_stats_rows(long long groups);
+/* rows of stats_partial a pcops_sa_gather_fwd(_rows) call of this form writes: the Q + Ctr form with a stored Y runs on
+ * the 64-channel-slice kernel of csrc/edgeconv.hip (one row per 64 groups) when the shape fits; everything else writes
+ * pcops_sa_gather_stats_rows(b*m) rows.  has_q / has_ctr: the term is present; other_terms: any of Wxyz, bias, off4,
+ * moments; compacted: a pcops_rows_t is passed. */
+int pcops_sa_gather_fwd_stats_rows(int b, int n, int m, int s, int c, int has_q, int has_ctr, int other_terms,
+                                   int compacted);
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
                         float *off4, float *stats_partial, const float *stat_pivot, float *moments,

@@ -51,6 +51,8 @@ def lib():
             "oracle_selection_sort": [I, I, I, I, _f32p, _i32p, _f32p],
             "oracle_knn_point": [I, I, I, I, I, _f32p, _f32p, _f32p, _i32p],
             "oracle_farthest_point_sample": [I, I, I, _f32p, _i32p],
+            "oracle_cumsum": [I, I, _f32p, _f32p],
+            "oracle_prob_sample": [I, I, I, _f32p, _f32p, _f32p, _i32p],
             "oracle_gather_point": [I, I, I, _f32p, _i32p, _f32p],
             "oracle_gather_point_grad": [I, I, I, _f32p, _i32p, _f32p],
             "oracle_three_nn": [I, I, I, _f32p, _f32p, _f32p, _i32p],
@@ -133,6 +135,26 @@ def farthest_point_sample(npoint, inp):
     out = np.zeros((b, npoint), np.int32)
     lib().oracle_farthest_point_sample(b, n, npoint, inp, out)
     return out
+
+
+def cumsum(inp):
+    """(b,n) f32 -> (b,n) f32, the association of tf_sampling_g.cu:7-81."""
+    inp = _f(inp)
+    b, n = inp.shape
+    out = np.zeros((b, n), np.float32)
+    lib().oracle_cumsum(b, n, inp, out)
+    return out
+
+
+def prob_sample(inp, inpr, return_temp=False):
+    """inp (b,ncategory) weights, inpr (b,npoints) uniforms -> (b,npoints) i32 (tf_sampling.py:14-23)."""
+    inp, inpr = _f(inp), _f(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = np.zeros((b, n), np.float32)
+    out = np.zeros((b, m), np.int32)
+    lib().oracle_prob_sample(b, n, m, inp, inpr, temp, out)
+    return (out, temp) if return_temp else out
 
 
 def gather_point(inp, idx):

@@ -18,7 +18,7 @@
  *     three_nn, three_interpolate, three_interpolate_grad
  *   parity unpinned (no CPU code / not runnable in the reference; the
  *   restatement of the CUDA kernel or of the TF call sequence IS the pin):
- *     pts_cnt of query_ball_point, farthest_point_sample, gather_point(+grad),
+ *     pts_cnt of query_ball_point, farthest_point_sample, gather_point(+grad), prob_sample,
  *     pairwise_distance / knn / get_edge_feature (TensorFlow 1.10, absent).
  */
 #include <math.h>
@@ -198,6 +198,83 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *inp,
         }
     }
     free(temp);
+}
+
+/* sampling/tf_sampling_g.cu:7-81 (cumsumKernel).  An inclusive fp32 prefix sum of each row whose ASSOCIATION is part of
+ * the contract, because prob_sample's integer output is read off these values: per chunk of 8192 elements, (1) groups of
+ * four are summed serially -- v1, v1+v2, (v1+v2)+v3, (v3+v4)+(v1+v2) (:19-33); a ragged last group is the serial sum of
+ * what exists, replicated (:34-44) -- (2) the group totals go through a work-efficient up-sweep / down-sweep (:46-67)
+ * which leaves S[p] = T(aligned 2^u block ending at p) + S[p - 2^u], u = ctz(p + 1), T = balanced tree, (3) every element
+ * of group g > 0 adds S[g-1] (:69-77), (4) the chunk is offset by a compensated running sum carried across chunks
+ * (:79-85).  The thread/block indices of the CUDA kernel do not enter the result: every LDS slot has one writer per
+ * level.  Restated as those four steps, sequentially. */
+void oracle_cumsum(int b, int n, const float *inp, float *out) {
+    enum { CHUNK = 8192 };
+    float *b4 = (float *)malloc(sizeof(float) * CHUNK);
+    float *tot = (float *)malloc(sizeof(float) * (CHUNK / 4));
+    for (int i = 0; i < b; ++i) {
+        const float *x = inp + (size_t)i * n;
+        float *y = out + (size_t)i * n;
+        float runningsum = 0.f, runningsum2 = 0.f;
+        for (int j = 0; j < n; j += CHUNK) {
+            const int len = n - j < CHUNK ? n - j : CHUNK;     /* n24_i */
+            const int len4 = (len + 3) & ~3;                   /* n24   */
+            const int n2 = len4 >> 2;
+            for (int k = 0; k < len; k += 4) {
+                if (k + 3 < len) {
+                    float v1 = x[j + k], v2 = x[j + k + 1], v3 = x[j + k + 2], v4 = x[j + k + 3];
+                    v2 += v1;
+                    v4 += v3;
+                    v3 += v2;
+                    v4 += v2;
+                    b4[k] = v1; b4[k + 1] = v2; b4[k + 2] = v3; b4[k + 3] = v4;
+                    tot[k >> 2] = v4;
+                } else {
+                    float v = 0.f;
+                    for (int k2 = k; k2 < len; ++k2) { v += x[j + k2]; b4[k2] = v; }
+                    for (int k2 = len; k2 < len4; ++k2) b4[k2] = v;
+                    tot[k >> 2] = v;
+                }
+            }
+            int u = 0;
+            for (; (2 << u) <= n2; ++u)
+                for (int k = 0; k < (n2 >> (u + 1)); ++k)
+                    tot[(((k << 1) + 2) << u) - 1] += tot[(((k << 1) + 1) << u) - 1];
+            for (--u; u >= 0; --u)
+                for (int k = 0; k < ((n2 - (1 << u)) >> (u + 1)); ++k)
+                    tot[(((k << 1) + 3) << u) - 1] += tot[(((k << 1) + 2) << u) - 1];
+            for (int k = 4; k < len4; k += 4) {
+                const float p = tot[(k >> 2) - 1];
+                b4[k] += p; b4[k + 1] += p; b4[k + 2] += p; b4[k + 3] += p;
+            }
+            for (int k = 0; k < len; ++k) y[j + k] = b4[k] + runningsum;
+            const float t = tot[n2 - 1] + runningsum2;
+            const float r2 = runningsum + t;
+            runningsum2 = t - (r2 - runningsum);
+            runningsum = r2;
+        }
+    }
+    free(b4);
+    free(tot);
+}
+
+/* sampling/tf_sampling_g.cu:83-103 (binarysearchKernel) behind probsampleLauncher (:197-200): q = r * cumsum[n-1] (one
+ * fp32 product), then a descending power-of-two walk from n-1 to the SMALLEST index whose cumulative value is >= q.
+ * inp_p (b,n) weights, inp_r (b,m) uniform numbers -> temp (b,n) = the cumsum above, out (b,m) int32. */
+void oracle_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out) {
+    oracle_cumsum(b, n, inp_p, temp);
+    int base = 1;
+    while (base < n) base <<= 1;
+    for (int i = 0; i < b; ++i) {
+        const float *d = temp + (size_t)i * n;
+        for (int j = 0; j < m; ++j) {
+            const float q = inp_r[(size_t)i * m + j] * d[n - 1];
+            int r = n - 1;
+            for (int k = base; k >= 1; k >>= 1)
+                if (r >= k && d[r - k] >= q) r -= k;
+            out[(size_t)i * m + j] = r;
+        }
+    }
 }
 
 /* sampling/tf_sampling_g.cu:172-181 */

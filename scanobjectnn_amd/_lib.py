@@ -19,6 +19,7 @@ ABI_VERSION = 3      # pcops_abi_version() of the library this binding matches (
 # name -> (argtypes without the trailing stream, has_stream)
 SIGNATURES = {
     "pcops_farthest_point_sample": ([_I, _I, _I, _P, _P, _P], True),
+    "pcops_prob_sample": ([_I, _I, _I, _P, _P, _P, _P], True),
     "pcops_gather_point": ([_I, _I, _I, _P, _P, _P], True),
     "pcops_gather_point_grad": ([_I, _I, _I, _P, _P, _P], True),
     "pcops_query_ball_point": ([_I, _I, _I, _F, _I, _P, _P, _P, _P], True),
@@ -100,6 +101,7 @@ PLAIN = {
     "pcops_gather_stack_rows_supported": ([_I, _I, _I, _I, _I, _I, _P], _I),
     "pcops_sa_scatter_rows_supported": ([_I, _I, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
+    "pcops_sa_gather_fwd_stats_rows": ([_I] * 9, _I),
     "pcops_sa_scatter_rows": ([_I, _I], _I),
     "pcops_edge_pool_stats_rows": ([_LL], _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),

@@ -1,0 +1,22 @@
+// edgeconv.h -- internal interface of edgeconv.hip (round-5 gather / scatter kernels of the DGCNN path) to the C-ABI
+// launchers in gather.hip.  Not part of include/pcops.h: the entry points keep their signatures, these are the kernels
+// they dispatch to when the shape fits (64-channel slices, whole 64-group chunks; ec_*_supported).
+#pragma once
+#include <hip/hip_runtime.h>
+
+bool ec_enabled();
+bool ec_fwd_supported(int b, int n, int m, int s, int c);
+bool ec_bwd_supported(int b, int n, int m, int s, int c);
+int ec_stats_rows(long long G);      // partial-statistics rows the forward kernels write: one per 64 groups
+// pooled EdgeConv layer (pcops_edge_pool_fwd): SQ, qsel, arg, shifted moments
+int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
+                     float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st);
+// stored first layer of a gather stack, Y = Q[idx] + Ctr (pcops_sa_gather_fwd_rows in its Q + Ctr form)
+int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, float *Y,
+                  float *stats, const float *pivot, hipStream_t st);
+// inverse index of idx into `workspace` (order | start), then the owner walk over it
+int ec_csr_build(int b, int n, int m, int s, const int *idx, void *workspace, hipStream_t st);
+int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const float *p,
+            const float *q, const float *t, const void *workspace, float *dQ, hipStream_t st);
+int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const int *idx,
+                const float *p, const float *q, const float *t, float *dCtr, hipStream_t st);

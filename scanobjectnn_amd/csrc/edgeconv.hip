@@ -1,0 +1,497 @@
+// edgeconv.hip -- round 5: the gather / scatter family of the DGCNN path rebuilt around three measured facts
+// (profiles/r04_pmc_insts_dgcnn.txt, profiles/r05_pmc_traffic_detail_dgcnn_before.json):
+//   * the round-2..4 kernels (gather.hip: edge_pool_fwd, edge_pool_bwd_dense, sa_gather_fwd, sa_scatter_*) were bound by
+//     INSTRUCTION ISSUE, not by HBM: 13 VALU instructions per gathered element where the arithmetic needs 4.5 -- 64-bit
+//     address products per neighbour, an unsigned division per list entry and lane, every lane of a group re-loading the
+//     group's indices, both directions of the extremum evaluated and selected per element;
+//   * they moved 4.1x (forward) and 4x (dense backward) their algorithmic bytes: consecutive workgroups of one cloud were
+//     dealt round-robin to the 8 XCDs, so every XCD's L2 re-fetched every cloud's Q / Ctr rows;
+//   * the T-Net's scatter read Y1 (2.7 GB) only to form  sum q.Y1  -- which is  q (cnt_i Q[i] + sum Ctr[g])  exactly as
+//     in the EdgeConv layer, i.e. a walk over L2-resident rows.
+// What is here:
+//   ec_fwd_kernel<MODE, UP>   y[g,s,:] = Q[idx[g,s],:] + Ctr[g,:]  in 64-channel slices, a 16-lane set per group:
+//                             MODE 0 the pooled EdgeConv layer (group sums, extremum + first arg, shifted moments),
+//                             MODE 1 the stored first layer of a gather stack (rows of Y + shifted moments).
+//                             The group's byte offsets are staged once per workgroup in LDS (pre-multiplied), a gather is
+//                             one 32-bit VALU add + one bounds-checked buffer load, the statistics are packed fp32.
+//   ec_csr_build_kernel       inverse index per cloud: packed (group << 8 | slot) entries sorted by source point.
+//   ec_walk_kernel<HAS_G>     owner walk of the inverse index: sum of the Ctr rows (and, T-Net, of the G rows) that
+//                             reference a point; entries beyond a list read out of bounds (zeros), no per-entry branch.
+//   ec_tnet_ctr_kernel        per-group output of the T-Net's scatter:  dCtr = p sum_s G + q (sum_s Q[idx] + k Ctr) + k t.
+// Work is numbered (cloud, slice, chunk) and workgroups are mapped to it XCD-contiguously: a cloud's rows are fetched by
+// ONE L2.  Dispatch placement is a speed assumption only (MI355X_MICROARCH.md "Workgroup dispatch"); nothing is shared
+// between workgroups.
+#include "common.h"
+#include "edgeconv.h"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int ec_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ec_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ec_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    const ec_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ unsigned ec_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+}
+
+// workgroup `bid` of `nwg` runs on XCD bid % 8 (observed): renumber so that every XCD owns a CONTIGUOUS range of the
+// virtual ids (bijective for any nwg)
+__device__ __forceinline__ unsigned ec_xcd_contiguous(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+constexpr int kGB = 64;          // groups (forward) / points (walk) per workgroup
+constexpr int kSets = 16;        // 16-lane sets per 256-thread workgroup: one group / point each, four rounds
+
+struct FwdArgs {
+    int b, n, m, S, C;
+    const float *Q, *Ctr;
+    const int *idx;
+    const float *gamma;          // MODE 0: direction of the extremum
+    float *SQ, *qsel;            // MODE 0
+    unsigned char *arg;          // MODE 0
+    float *Y;                    // MODE 1
+    float *stats;                // [b * m / 64][2][C] or NULL
+    const float *pivot;          // shifted moments around this vector (or NULL: 0)
+};
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+// MODE 0, per (group, channel):  sq = sum_s (q - qz), sq2 = sum_s (q - qz)^2 around the sample row qz = Q[0,0,:] (the
+// formulas of gather.hip edge_pool_fwd_kernel, kept so that the statistics are the same numbers), ex = max_s sg.q and the
+// FIRST s attaining it (sg = -1 where gamma < 0: BN + ReLU is then decreasing and the pooled row is the minimum).
+// MODE 1, per row: y = Ctr + q stored, d = y - pivot, s1 += d, s2 += d^2 (gather.hip sa_gather_fwd_kernel).
+template <int MODE, bool UP>
+__device__ __forceinline__ void ec_fwd_groups(const FwdArgs &a, const unsigned *offs, long long g0, int set, int quad,
+                                              unsigned tq, __amdgpu_buffer_rsrc_t rq, int ch, f2 (&s1)[2], f2 (&s2)[2]) {
+    const int S = a.S, C = a.C;
+    const float kf = (float)S;
+    f2 sg[2] = {{1.f, 1.f}, {1.f, 1.f}};
+    f2 qz[2] = {{0.f, 0.f}, {0.f, 0.f}}, cz[2] = {{0.f, 0.f}, {0.f, 0.f}}, pv[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (MODE == 0) {
+        if (!UP) {
+            const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + ch);
+            sg[0] = f2{ga.x < 0.f ? -1.f : 1.f, ga.y < 0.f ? -1.f : 1.f};
+            sg[1] = f2{ga.z < 0.f ? -1.f : 1.f, ga.w < 0.f ? -1.f : 1.f};
+        }
+        if (a.stats) {
+            const float4 q0 = *reinterpret_cast<const float4 *>(a.Q + ch);
+            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.pivot) p4 = *reinterpret_cast<const float4 *>(a.pivot + ch);
+            qz[0] = f2{q0.x, q0.y}; qz[1] = f2{q0.z, q0.w};
+            cz[0] = f2{q0.x - p4.x, q0.y - p4.y}; cz[1] = f2{q0.z - p4.z, q0.w - p4.w};
+        }
+    } else if (a.stats && a.pivot) {
+        const float4 p4 = *reinterpret_cast<const float4 *>(a.pivot + ch);
+        pv[0] = f2{p4.x, p4.y}; pv[1] = f2{p4.z, p4.w};
+    }
+#pragma unroll 1
+    for (int r = 0; r < kGB / kSets; ++r) {
+        const int gl = set + kSets * r;
+        const long long g = g0 + gl;
+        const float4 c4 = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+        const f2 ct[2] = {{c4.x, c4.y}, {c4.z, c4.w}};
+        f2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}}, sq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float ex[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int ea[4] = {0, 0, 0, 0};
+        float *yrow = MODE == 1 ? a.Y + g * S * (long long)C + ch : nullptr;
+        const unsigned *og = offs + gl * S;
+        auto take = [&](const float4 &q, int s) {
+            const f2 qa = f2{q.x, q.y}, qb = f2{q.z, q.w};
+            if (MODE == 0) {
+                const f2 da = qa - qz[0], db = qb - qz[1];
+                sq[0] += da; sq[1] += db;
+                sq2[0] = __builtin_elementwise_fma(da, da, sq2[0]);
+                sq2[1] = __builtin_elementwise_fma(db, db, sq2[1]);
+                const f2 va = UP ? qa : qa * sg[0], vb = UP ? qb : qb * sg[1];
+                const float v[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool better = v[e] > ex[e];             // strict: the first extremum keeps the slot
+                    ea[e] = better ? s : ea[e];                   // (two selects on one compare: fmaxf would add a
+                    ex[e] = better ? v[e] : ex[e];                //  canonicalising multiply per loaded register pair)
+                }
+            } else {
+                const f2 ya = ct[0] + qa, yb = ct[1] + qb;
+                *reinterpret_cast<float4 *>(yrow + (long long)s * C) = make_float4(ya.x, ya.y, yb.x, yb.y);
+                const f2 da = ya - pv[0], db = yb - pv[1];
+                s1[0] += da; s1[1] += db;
+                s2[0] = __builtin_elementwise_fma(da, da, s2[0]);
+                s2[1] = __builtin_elementwise_fma(db, db, s2[1]);
+            }
+        };
+        int s = 0;
+        if ((S & 3) == 0) {
+            for (; s + 8 <= S; s += 8) {
+                const uint4 o0 = *reinterpret_cast<const uint4 *>(og + s), o1 = *reinterpret_cast<const uint4 *>(og + s + 4);
+                const float4 q0 = ec_load4(rq, o0.x + tq), q1 = ec_load4(rq, o0.y + tq), q2 = ec_load4(rq, o0.z + tq),
+                             q3 = ec_load4(rq, o0.w + tq), q4 = ec_load4(rq, o1.x + tq), q5 = ec_load4(rq, o1.y + tq),
+                             q6 = ec_load4(rq, o1.z + tq), q7 = ec_load4(rq, o1.w + tq);
+                take(q0, s); take(q1, s + 1); take(q2, s + 2); take(q3, s + 3);
+                take(q4, s + 4); take(q5, s + 5); take(q6, s + 6); take(q7, s + 7);
+            }
+            for (; s + 4 <= S; s += 4) {
+                const uint4 o0 = *reinterpret_cast<const uint4 *>(og + s);
+                const float4 q0 = ec_load4(rq, o0.x + tq), q1 = ec_load4(rq, o0.y + tq), q2 = ec_load4(rq, o0.z + tq),
+                             q3 = ec_load4(rq, o0.w + tq);
+                take(q0, s); take(q1, s + 1); take(q2, s + 2); take(q3, s + 3);
+            }
+        }
+        for (; s < S; ++s) take(ec_load4(rq, og[s] + tq), s);
+        if (MODE == 0) {
+            *reinterpret_cast<float4 *>(a.SQ + g * C + ch) =
+                make_float4(fmaf(kf, qz[0].x, sq[0].x), fmaf(kf, qz[0].y, sq[0].y), fmaf(kf, qz[1].x, sq[1].x),
+                            fmaf(kf, qz[1].y, sq[1].y));
+            *reinterpret_cast<float4 *>(a.qsel + g * C + ch) =
+                UP ? make_float4(ex[0], ex[1], ex[2], ex[3])
+                   : make_float4(ex[0] * sg[0].x, ex[1] * sg[0].y, ex[2] * sg[1].x, ex[3] * sg[1].y);
+            uchar4 a4;
+            a4.x = (unsigned char)ea[0]; a4.y = (unsigned char)ea[1]; a4.z = (unsigned char)ea[2]; a4.w = (unsigned char)ea[3];
+            *reinterpret_cast<uchar4 *>(a.arg + g * C + ch) = a4;
+            if (a.stats) {
+                const f2 k2 = f2{kf, kf};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2 cv = ct[h] + cz[h];
+                    s1[h] += __builtin_elementwise_fma(k2, cv, sq[h]);
+                    s2[h] += __builtin_elementwise_fma(cv, __builtin_elementwise_fma(k2, cv, sq[h] + sq[h]), sq2[h]);
+                }
+            }
+        }
+    }
+    (void)quad;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ec_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ec_sm[];      // offsets [64][S] | statistics [16][2][64]
+    const int S = a.S, C = a.C;
+    const int H = C >> 6, P = a.m / kGB;
+    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)(H * P));
+    const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
+    const int h = rem / P, chunk = rem - h * P;
+    const long long g0 = (long long)b * a.m + (long long)chunk * kGB;
+    const int tid = threadIdx.x, set = tid >> 4, quad = tid & 15;
+    const int ch = h * 64 + quad * 4;
+    // byte offsets of the gathered rows, relative to Q: ((b n + idx) C + h 64) * 4 -- one LDS word per (group, slot)
+    const int *ig = a.idx + g0 * S;
+    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)C + (unsigned)h * 64u) * 4u;
+    const unsigned c4 = (unsigned)C * 4u;
+    for (int e = tid; e < kGB * S; e += 256) ec_sm[e] = (unsigned)ig[e] * c4 + base;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * C * 4));
+    const unsigned tq = (unsigned)quad * 16u;
+    f2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    bool up = true;
+    if (MODE == 0) {
+        const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + ch);
+        up = !(ga.x < 0.f) && !(ga.y < 0.f) && !(ga.z < 0.f) && !(ga.w < 0.f);
+        up = __all(up) != 0;                                               // wave-uniform: one loop body per wave
+    }
+    if (up) ec_fwd_groups<MODE, true>(a, ec_sm, g0, set, quad, tq, rq, ch, s1, s2);
+    else ec_fwd_groups<MODE, false>(a, ec_sm, g0, set, quad, tq, rq, ch, s1, s2);
+    if (a.stats == nullptr) return;
+    float *sm = reinterpret_cast<float *>(ec_sm + kGB * S);
+    {
+        float *d = sm + set * 128 + quad * 4;
+        *reinterpret_cast<float4 *>(d) = make_float4(s1[0].x, s1[0].y, s1[1].x, s1[1].y);
+        *reinterpret_cast<float4 *>(d + 64) = make_float4(s2[0].x, s2[0].y, s2[1].x, s2[1].y);
+    }
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < kSets; ++l) t += sm[l * 128 + tid];
+        const int which = tid >> 6, c = tid & 63;
+        const long long row = (long long)b * P + chunk;
+        a.stats[(row * 2 + which) * C + h * 64 + c] = t;
+    }
+}
+
+// ---- inverse index ------------------------------------------------------------------------------------------------
+// order [b][m S] u32: (group << 8 | slot) of every grouped row, sorted by the source point it references (within a list
+// in the order the slots were handed out: no particular order);  start [b][n + 1]: list boundaries.
+// One workgroup per cloud; the rows are read 16 bytes per lane, the group of a row comes from ONE division per four rows.
+__global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S, const int *__restrict__ idx,
+                                                            unsigned *__restrict__ order, int *__restrict__ start) {
+    extern __shared__ int ec_si[];              // cnt / cursor [n] | scan scratch [1024]
+    int *cnt = ec_si, *sc = ec_si + n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int mS = m * S;
+    const int *ib = idx + (long long)b * mS;
+    for (int i = tid; i < n; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const int n4 = mS >> 2;
+    for (int e4 = tid; e4 < n4; e4 += 1024) {
+        const int4 v = *reinterpret_cast<const int4 *>(ib + 4 * e4);
+        atomicAdd(&cnt[v.x], 1); atomicAdd(&cnt[v.y], 1); atomicAdd(&cnt[v.z], 1); atomicAdd(&cnt[v.w], 1);
+    }
+    for (int e = 4 * n4 + tid; e < mS; e += 1024) atomicAdd(&cnt[ib[e]], 1);
+    __syncthreads();
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; ++i) local += cnt[i];
+    sc[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? sc[tid - off] : 0;
+        __syncthreads();
+        sc[tid] += v;
+        __syncthreads();
+    }
+    int run = sc[tid] - local;
+    int *sb = start + (long long)b * (n + 1);
+    for (int i = i0; i < i1; ++i) {
+        const int c = cnt[i];
+        cnt[i] = run;                            // the bin becomes the list's cursor
+        sb[i] = run;
+        run += c;
+    }
+    if (tid == 0) sb[n] = mS;
+    __syncthreads();
+    unsigned *ob = order + (long long)b * mS;
+    for (int e4 = tid; e4 < n4; e4 += 1024) {
+        const int4 v = *reinterpret_cast<const int4 *>(ib + 4 * e4);
+        const int e = 4 * e4;
+        int g = e / S, s = e - g * S;
+        const int vi[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ob[atomicAdd(&cnt[vi[u]], 1)] = ((unsigned)g << 8) | (unsigned)s;
+            if (++s == S) { s = 0; ++g; }
+        }
+    }
+    for (int e = 4 * n4 + tid; e < mS; e += 1024) {
+        const int g = e / S;
+        ob[atomicAdd(&cnt[ib[e]], 1)] = ((unsigned)g << 8) | (unsigned)(e - g * S);
+    }
+}
+
+// ---- owner walk ---------------------------------------------------------------------------------------------------
+//   HAS_G = false (EdgeConv, after the arg-row kernel initialised dQ):  dQ[b,i,:] += q (cnt Q[i] + sum Ctr[g]) + cnt t
+//   HAS_G = true  (first layer of a gather stack):  dQ[b,i,:] = p sum G[g,s] + q (cnt Q[i] + sum Ctr[g]) + cnt t
+// A 16-lane set per source point and 64-channel slice, four list entries in flight; an entry beyond the list is the
+// sentinel (m << 8), whose rows lie outside the cloud-sized buffer resources and read as zeros.
+struct WalkArgs {
+    int b, n, m, S, C;
+    const float *Q, *Ctr, *G;
+    const float *p, *q, *t;
+    const unsigned *order;
+    const int *start;
+    float *dQ;
+};
+
+template <bool HAS_G>
+__global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
+    const int C = a.C, S = a.S;
+    const int H = C >> 6, P = (a.n + kGB - 1) / kGB;
+    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)(H * P));
+    const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
+    const int h = rem / P, chunk = rem - h * P;
+    const int tid = threadIdx.x, set = tid >> 4, quad = tid & 15;
+    const int ch = h * 64 + quad * 4;
+    const unsigned c4 = (unsigned)C * 4u, tq = ((unsigned)h * 64u + (unsigned)quad * 4u) * 4u;
+    const int mS = a.m * S;
+    const __amdgpu_buffer_rsrc_t rc = ec_rsrc(a.Ctr + (long long)b * a.m * C, (unsigned)a.m * c4);
+    const __amdgpu_buffer_rsrc_t rg = ec_rsrc(HAS_G ? a.G + (long long)b * mS * C : a.Ctr, HAS_G ? (unsigned)mS * c4 : 0u);
+    const __amdgpu_buffer_rsrc_t ro = ec_rsrc(a.order + (long long)b * mS, (unsigned)mS * 4u);
+    const int *sb = a.start + (long long)b * (a.n + 1);
+    const float4 cq = *reinterpret_cast<const float4 *>(a.q + ch);
+    const float4 ct = *reinterpret_cast<const float4 *>(a.t + ch);
+    float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_G) cp = *reinterpret_cast<const float4 *>(a.p + ch);
+    const unsigned sentinel = (unsigned)a.m << 8;
+#pragma unroll 1
+    for (int r = 0; r < kGB / kSets; ++r) {
+        const int i = chunk * kGB + set + kSets * r;
+        if (i >= a.n) break;
+        const int k0 = sb[i], k1 = sb[i + 1];
+        f2 ac[2] = {{0.f, 0.f}, {0.f, 0.f}}, ag[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        for (int k = k0; k < k1; k += 4) {
+            unsigned w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = ec_load1(ro, (unsigned)(k + u) * 4u);     // beyond the cloud's list: 0 ...
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = k + u < k1 ? w[u] : sentinel;             // ... beyond this list: sentinel
+            float4 cc[4], gg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned g = w[u] >> 8;
+                cc[u] = ec_load4(rc, g * c4 + tq);
+                if (HAS_G) gg[u] = ec_load4(rg, (g * (unsigned)S + (w[u] & 255u)) * c4 + tq);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ac[0] += f2{cc[u].x, cc[u].y}; ac[1] += f2{cc[u].z, cc[u].w};
+                if (HAS_G) { ag[0] += f2{gg[u].x, gg[u].y}; ag[1] += f2{gg[u].z, gg[u].w}; }
+            }
+        }
+        const long long pt = (long long)b * a.n + i;
+        const float kf = (float)(k1 - k0);
+        const float4 qi = *reinterpret_cast<const float4 *>(a.Q + pt * C + ch);
+        float4 *dst = reinterpret_cast<float4 *>(a.dQ + pt * C + ch);
+        float4 d;
+        d.x = fmaf(cq.x, fmaf(kf, qi.x, ac[0].x), kf * ct.x);
+        d.y = fmaf(cq.y, fmaf(kf, qi.y, ac[0].y), kf * ct.y);
+        d.z = fmaf(cq.z, fmaf(kf, qi.z, ac[1].x), kf * ct.z);
+        d.w = fmaf(cq.w, fmaf(kf, qi.w, ac[1].y), kf * ct.w);
+        if (HAS_G) {
+            d.x = fmaf(cp.x, ag[0].x, d.x); d.y = fmaf(cp.y, ag[0].y, d.y);
+            d.z = fmaf(cp.z, ag[1].x, d.z); d.w = fmaf(cp.w, ag[1].y, d.w);
+        } else {
+            const float4 o = *dst;
+            d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w;
+        }
+        *dst = d;
+    }
+}
+
+// ---- per-group output of the T-Net's scatter ------------------------------------------------------------------------
+//   dCtr[g,:] = sum_s dY[g,s,:],  dY = p G + q (Q[idx] + Ctr[g]) + t   =>   p sum_s G[g,s] + q (sum_s Q[idx[g,s]] + k Ctr[g]) + k t
+// the G rows of a group are one contiguous run (streamed), the Q rows are L2 gathers exactly as in the forward.
+struct CtrArgs {
+    int b, n, m, S, C;
+    const float *Q, *Ctr, *G;
+    const int *idx;
+    const float *p, *q, *t;
+    float *dCtr;
+};
+
+__global__ __launch_bounds__(256) void ec_tnet_ctr_kernel(CtrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ec_sm[];      // offsets [64][S]
+    const int S = a.S, C = a.C;
+    const int H = C >> 6, P = a.m / kGB;
+    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)(H * P));
+    const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
+    const int h = rem / P, chunk = rem - h * P;
+    const long long g0 = (long long)b * a.m + (long long)chunk * kGB;
+    const int tid = threadIdx.x, set = tid >> 4, quad = tid & 15;
+    const int ch = h * 64 + quad * 4;
+    const int *ig = a.idx + g0 * S;
+    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)C + (unsigned)h * 64u) * 4u;
+    const unsigned c4 = (unsigned)C * 4u;
+    for (int e = tid; e < kGB * S; e += 256) ec_sm[e] = (unsigned)ig[e] * c4 + base;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * C * 4));
+    const unsigned tq = (unsigned)quad * 16u;
+    const float4 cp = *reinterpret_cast<const float4 *>(a.p + ch);
+    const float4 cq = *reinterpret_cast<const float4 *>(a.q + ch);
+    const float4 ct = *reinterpret_cast<const float4 *>(a.t + ch);
+    const float kf = (float)S;
+#pragma unroll 1
+    for (int r = 0; r < kGB / kSets; ++r) {
+        const int gl = set + kSets * r;
+        const long long g = g0 + gl;
+        const unsigned *og = ec_sm + gl * S;
+        const float *grow = a.G + g * S * (long long)C + ch;
+        f2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}}, sgm[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {
+            float4 qv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                qv[u] = ec_load4(rq, og[s + u] + tq);
+                gv[u] = *reinterpret_cast<const float4 *>(grow + (long long)(s + u) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sq[0] += f2{qv[u].x, qv[u].y}; sq[1] += f2{qv[u].z, qv[u].w};
+                sgm[0] += f2{gv[u].x, gv[u].y}; sgm[1] += f2{gv[u].z, gv[u].w};
+            }
+        }
+        for (; s < S; ++s) {
+            const float4 qv = ec_load4(rq, og[s] + tq);
+            const float4 gv = *reinterpret_cast<const float4 *>(grow + (long long)s * C);
+            sq[0] += f2{qv.x, qv.y}; sq[1] += f2{qv.z, qv.w};
+            sgm[0] += f2{gv.x, gv.y}; sgm[1] += f2{gv.z, gv.w};
+        }
+        const float4 c4v = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+        float4 d;
+        d.x = fmaf(cp.x, sgm[0].x, fmaf(cq.x, fmaf(kf, c4v.x, sq[0].x), kf * ct.x));
+        d.y = fmaf(cp.y, sgm[0].y, fmaf(cq.y, fmaf(kf, c4v.y, sq[0].y), kf * ct.y));
+        d.z = fmaf(cp.z, sgm[1].x, fmaf(cq.z, fmaf(kf, c4v.z, sq[1].x), kf * ct.z));
+        d.w = fmaf(cp.w, sgm[1].y, fmaf(cq.w, fmaf(kf, c4v.w, sq[1].y), kf * ct.w));
+        *reinterpret_cast<float4 *>(a.dCtr + g * C + ch) = d;
+    }
+}
+
+bool ec_shape_ok(int b, int n, int m, int s, int c) {
+    // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q / the cloud's G rows
+    return c >= 64 && c % 64 == 0 && m >= kGB && m % kGB == 0 && s >= 1 && s <= 128 && n >= 1 &&
+           (long long)b * n * c * 4 < (1ll << 32) && ((long long)m * s + 256) * c * 4 < (1ll << 32) && m < (1 << 23) &&
+           (long long)b * (c / 64) * ((n + kGB - 1) / kGB) < (1ll << 31) && (long long)b * (c / 64) * (m / kGB) < (1ll << 31);
+}
+
+}  // namespace
+
+bool ec_enabled() {
+    static const bool on = [] { const char *e = getenv("PCOPS_EDGECONV_R5"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+bool ec_fwd_supported(int b, int n, int m, int s, int c) { return ec_enabled() && ec_shape_ok(b, n, m, s, c); }
+
+int ec_stats_rows(long long G) { return (int)((G + kGB - 1) / kGB); }
+
+int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
+                     float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st) {
+    FwdArgs a = {b, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel, arg, nullptr, stats, pivot};
+    const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
+    const size_t lds = ((size_t)kGB * s + kSets * 128) * sizeof(float);
+    hipLaunchKernelGGL(ec_fwd_kernel<0>, dim3(grid), dim3(256), lds, st, a);
+    return pcops_launch_status();
+}
+
+int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, float *Y,
+                  float *stats, const float *pivot, hipStream_t st) {
+    FwdArgs a = {b, n, m, s, c, Q, Ctr, idx, nullptr, nullptr, nullptr, nullptr, Y, stats, pivot};
+    const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
+    const size_t lds = ((size_t)kGB * s + kSets * 128) * sizeof(float);
+    hipLaunchKernelGGL(ec_fwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    return pcops_launch_status();
+}
+
+bool ec_bwd_supported(int b, int n, int m, int s, int c) {
+    return ec_enabled() && ec_shape_ok(b, n, m, s, c) && n <= 16384 && s <= 256;
+}
+
+// workspace: order (b m s u32) | start (b (n + 1) int32) -- inside what pcops_sa_scatter_workspace_bytes asks for
+int ec_csr_build(int b, int n, int m, int s, const int *idx, void *workspace, hipStream_t st) {
+    unsigned *order = static_cast<unsigned *>(workspace);
+    int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
+    const size_t lds = ((size_t)n + 1024) * sizeof(int);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(ec_csr_build_kernel, dim3(b), dim3(1024), lds, st, n, m, s, idx, order, start);
+    return pcops_launch_status();
+}
+
+int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const float *p,
+            const float *q, const float *t, const void *workspace, float *dQ, hipStream_t st) {
+    const unsigned *order = static_cast<const unsigned *>(workspace);
+    const int *start = reinterpret_cast<const int *>(order + (size_t)b * m * s);
+    WalkArgs a = {b, n, m, s, c, Q, Ctr, G, p, q, t, order, start, dQ};
+    const unsigned grid = (unsigned)((long long)b * (c / 64) * ((n + kGB - 1) / kGB));
+    if (G) hipLaunchKernelGGL(ec_walk_kernel<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ec_walk_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+    return pcops_launch_status();
+}
+
+int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const int *idx,
+                const float *p, const float *q, const float *t, float *dCtr, hipStream_t st) {
+    CtrArgs a = {b, n, m, s, c, Q, Ctr, G, idx, p, q, t, dCtr};
+    const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
+    hipLaunchKernelGGL(ec_tnet_ctr_kernel, dim3(grid), dim3(256), (size_t)kGB * s * sizeof(unsigned), st, a);
+    return pcops_launch_status();
+}

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "edgeconv.h"
 
 namespace {
 
@@ -1536,6 +1537,17 @@ static int gather_rows_ok(const pcops_rows_t *rows, int s) {
     return PCOPS_OK;
 }
 
+// the Q + Ctr form with a stored Y (the T-Net's first layer, dgcnn/models/transform_nets.py:18) runs on edgeconv.hip's
+// forward kernel, which writes one row of partial statistics per 64 groups
+static bool gather_fwd_is_ec(int b, int n, int m, int s, int c, bool has_q, bool has_ctr, bool other_terms, bool compacted) {
+    return has_q && has_ctr && !other_terms && !compacted && ec_fwd_supported(b, n, m, s, c);
+}
+int pcops_sa_gather_fwd_stats_rows(int b, int n, int m, int s, int c, int has_q, int has_ctr, int other_terms, int compacted) {
+    if (gather_fwd_is_ec(b, n, m, s, c, has_q != 0, has_ctr != 0, other_terms != 0, compacted != 0))
+        return ec_stats_rows((long long)b * m);
+    return pcops_sa_gather_stats_rows((long long)b * m);
+}
+
 int pcops_sa_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *xyz,
                         const float *new_xyz, const float *Wxyz, const float *bias, const int *idx, float *Y,
                         float *off4, float *stats_partial, const float *stat_pivot, float *moments,
@@ -1561,6 +1573,9 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
     PCOPS_REQUIRE_ARG(Q != nullptr || Wxyz != nullptr);
     if (off4 || moments) PCOPS_REQUIRE_PTR(Wxyz);
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
+    if (gather_fwd_is_ec(b, n, m, s, c, Q != nullptr, Ctr != nullptr, Wxyz != nullptr || bias != nullptr || off4 != nullptr ||
+                         moments != nullptr, rows != nullptr) && Y != nullptr)
+        return ec_gather_fwd(b, n, m, s, c, Q, Ctr, idx, Y, stats_partial, stat_pivot, as_stream(stream));
     const int rl = 256 / (c / 4);
     const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
@@ -1619,6 +1634,16 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
         PCOPS_REQUIRE_SHAPE(s <= 256);
     } else {
         PCOPS_REQUIRE_PTR(G);
+    }
+    if (!rows && !gpool && G && dQ && dCtr && fwd_Q && fwd_Ctr && !fwd_Wxyz && !fwd_bias && !wp && workspace &&
+        !pcops_get_deterministic() && ec_bwd_supported(b, n, m, s, c)) {
+        // round 5 (edgeconv.hip), the Q + Ctr form:  sum over the rows of a point of  q Y  is  q (cnt Q[i] + sum Ctr[g]),
+        // so Y is not read at all and G is read twice (streamed per group for dCtr, gathered per point for dQ)
+        int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
+        if (rc) return rc;
+        rc = ec_tnet_ctr(b, n, m, s, c, fwd_Q, fwd_Ctr, G, idx, p, q, t, dCtr, st);
+        if (rc) return rc;
+        return ec_walk(b, n, m, s, c, fwd_Q, fwd_Ctr, G, p, q, t, workspace, dQ, st);
     }
     // gather formulation: feature gradient wanted, G materialised, no per-group output
     const int lpr = c <= 256 ? c / 4 : 64;
@@ -1788,6 +1813,10 @@ int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const
     if (G == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gamma);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(arg);
+    // round 5: 64-channel slices, offsets staged in LDS, XCD-contiguous clouds (edgeconv.hip); same outputs, and
+    // b m / 64 = pcops_edge_pool_stats_rows(G) rows of partial statistics
+    if (ec_fwd_supported(b, n, m, s, c) && s <= 256)
+        return ec_edge_pool_fwd(b, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot, as_stream(stream));
     const int gl = 256 / (c / 4);
     hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3(pcops_edge_pool_stats_rows(G)), dim3(256),
                        (size_t)gl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel,
@@ -1827,6 +1856,18 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
     PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
+    if (use_owner && !det && ec_bwd_supported(b, n, m, s, c)) {
+        // round 5 (edgeconv.hip): the arg-row term + dCtr as before (LDS slices, plain stores: initialises dQ), then the
+        // dense term by a leaner owner walk over a packed inverse index, clouds XCD-contiguous
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(edge_pool_bwd_sparse_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(edge_pool_bwd_sparse_kernel<false>, dim3(b * (c / kEdgeSlice)), dim3(1024), slice_lds, st, n, m, s, c,
+                           gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ);
+        int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
+        if (rc) return rc;
+        return ec_walk(b, n, m, s, c, Q, Ctr, nullptr, p, q, t, workspace, dQ, st);
+    }
     int2 *order = static_cast<int2 *>(workspace);
     int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
     const size_t blds = (2 * (size_t)n + 1024) * sizeof(int);

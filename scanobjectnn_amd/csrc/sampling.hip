@@ -1,4 +1,4 @@
-// sampling.hip -- farthest point sampling, gather_point and its gradient for gfx950.
+// sampling.hip -- farthest point sampling, gather_point and its gradient, prob_sample for gfx950.
 //
 // Replaces sampling/tf_sampling_g.cu:105-192 + the launchers at :203-211 of the
 // reference (behaviour only; the design is CDNA4-first):
@@ -203,6 +203,122 @@ __global__ __launch_bounds__(256) void gather_point_grad_kernel(long long total,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// prob_sample = row cumsum + lower-bound search (sampling/tf_sampling_g.cu:7-103, launcher :197-200).
+// The integer output is read off fp32 partial sums, so the ASSOCIATION of the reference's scan is the contract (stated
+// in oracle/pcops_oracle.c, oracle_cumsum): groups of four summed serially, the group totals scanned by an up-sweep /
+// down-sweep pair, S[g-1] added to group g, chunks of 8192 offset by a compensated running sum.  What is free is where
+// the values live: one workgroup per ROW (the reference grid-strides 32 blocks over the rows), every thread keeps its
+// eight groups' four partial sums in registers (the reference's 32 KB `buffer4` does not exist), only the 2048 group
+// totals go through LDS (bank-skewed by one slot per 32), rows are read and written as float4 where they are aligned.
+constexpr int kScanThreads = 256;
+constexpr int kScanChunk = 8192;                         // elements per chunk (fixed by the reference: BlockSize * 4)
+constexpr int kScanGroups = kScanChunk / 4;              // group totals per chunk
+constexpr int kScanPerThread = kScanGroups / kScanThreads;
+
+__device__ __forceinline__ int scan_slot(int i) { return i + (i >> 5); }
+
+__global__ __launch_bounds__(kScanThreads) void cumsum_kernel(int n, const float *__restrict__ inp,
+                                                              float *__restrict__ out) {
+    __shared__ float tot[kScanGroups + (kScanGroups >> 5)];
+    const int t = threadIdx.x;
+    const float *x = inp + (size_t)blockIdx.x * n;
+    float *y = out + (size_t)blockIdx.x * n;
+    const bool vec = ((n & 3) == 0) && (((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    float runningsum = 0.f, runningsum2 = 0.f;
+    for (int j = 0; j < n; j += kScanChunk) {
+        const int len = min(n - j, kScanChunk);
+        const int n2 = (len + 3) >> 2;
+        float v[kScanPerThread][4];
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            const int g = t + i * kScanThreads;          // group: elements j + 4g .. j + 4g + 3
+            const int k = g * 4;
+            if (k + 3 < len) {
+                float v1, v2, v3, v4;
+                if (vec) {
+                    const float4 q = *reinterpret_cast<const float4 *>(x + j + k);
+                    v1 = q.x; v2 = q.y; v3 = q.z; v4 = q.w;
+                } else {
+                    v1 = x[j + k]; v2 = x[j + k + 1]; v3 = x[j + k + 2]; v4 = x[j + k + 3];
+                }
+                v2 += v1;
+                v4 += v3;
+                v3 += v2;
+                v4 += v2;
+                v[i][0] = v1; v[i][1] = v2; v[i][2] = v3; v[i][3] = v4;
+                tot[scan_slot(g)] = v4;
+            } else if (k < len) {                        // the ragged last group: serial sum of what exists, replicated
+                float a = 0.f;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    if (k + l < len) a += x[j + k + l];
+                    v[i][l] = a;
+                }
+                tot[scan_slot(g)] = a;
+            }
+        }
+        int u = 0;
+        for (; (2 << u) <= n2; ++u) {                    // up-sweep: aligned 2^(u+1) blocks, right half += left half
+            __syncthreads();
+            for (int k = t; k < (n2 >> (u + 1)); k += kScanThreads)
+                tot[scan_slot((((k << 1) + 2) << u) - 1)] += tot[scan_slot((((k << 1) + 1) << u) - 1)];
+        }
+        for (--u; u >= 0; --u) {                         // down-sweep: S[p] = T(2^u block ending at p) + S[p - 2^u]
+            __syncthreads();
+            for (int k = t; k < ((n2 - (1 << u)) >> (u + 1)); k += kScanThreads)
+                tot[scan_slot((((k << 1) + 3) << u) - 1)] += tot[scan_slot((((k << 1) + 2) << u) - 1)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kScanPerThread; ++i) {
+            const int g = t + i * kScanThreads;
+            const int k = g * 4;
+            if (k >= len) continue;
+            float o[4];
+            const float p = g ? tot[scan_slot(g - 1)] : 0.f;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) o[l] = (g ? v[i][l] + p : v[i][l]) + runningsum;
+            if (vec) {
+                *reinterpret_cast<float4 *>(y + j + k) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+                    if (k + l < len) y[j + k + l] = o[l];
+            }
+        }
+        const float tt = tot[scan_slot(n2 - 1)] + runningsum2;     // compensated carry into the next chunk (:79-83)
+        const float r2 = runningsum + tt;
+        runningsum2 = tt - (r2 - runningsum);
+        runningsum = r2;
+        __syncthreads();
+    }
+}
+
+// q = r * cumsum[n-1]; descending power-of-two walk to the smallest index whose cumulative value is >= q (:83-103).  The
+// row of partial sums was just written by cumsum_kernel and is L2-resident; rows up to kSearchLds floats are staged in
+// LDS once per workgroup so that the log2(n) dependent probes of a lane are LDS reads.
+constexpr int kSearchLds = 16384;
+__global__ __launch_bounds__(256) void binary_search_kernel(int n, int m, int base, const float *__restrict__ dataset,
+                                                            const float *__restrict__ query, int *__restrict__ result) {
+    __shared__ float row[kSearchLds];
+    const float *d = dataset + (size_t)blockIdx.x * n;
+    const bool staged = n <= kSearchLds;
+    if (staged) {
+        for (int k = threadIdx.x; k < n; k += 256) row[k] = d[k];
+        __syncthreads();
+    }
+    const float last = staged ? row[n - 1] : d[n - 1];
+    for (int j = blockIdx.y * 256 + threadIdx.x; j < m; j += gridDim.y * 256) {
+        const float q = query[(size_t)blockIdx.x * m + j] * last;
+        int r = n - 1;
+        for (int k = base; k >= 1; k >>= 1)
+            if (r >= k && (staged ? row[r - k] : d[r - k]) >= q) r -= k;
+        result[(size_t)blockIdx.x * m + j] = r;
+    }
+}
+
 }  // namespace
 
 constexpr int kFpsRegisterMax = 16384;       // clouds up to this size keep xyz and the min-distance in registers
@@ -266,5 +382,30 @@ extern "C" int pcops_gather_point_grad(int b, int n, int m, const float *out_g, 
     const unsigned grid = cdiv(total, 256) < 4096u ? cdiv(total, 256) : 4096u;
     hipLaunchKernelGGL(gather_point_grad_kernel, dim3(grid), dim3(256), 0, st, total, n, m, out_g,
                        idx, inp_g);
+    return pcops_launch_status();
+}
+
+// probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)   sampling/tf_sampling.cpp:65, tf_sampling_g.cu:197-200.
+// inp_p (b,n) weights, inp_r (b,m) uniform numbers, temp (b,n) caller scratch that receives the row cumsum (the
+// reference's allocate_temp, tf_sampling.cpp:86) -> out (b,m) int32.
+extern "C" int pcops_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out,
+                                 pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && m >= 0);
+    if (b == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_SHAPE(n >= 1);                 // the reference reads dataset[n-1]
+    if (b > 65535 * 32) return PCOPS_ERR_UNSUPPORTED;
+    PCOPS_REQUIRE_PTR(inp_p);
+    PCOPS_REQUIRE_PTR(temp);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(cumsum_kernel, dim3(b), dim3(kScanThreads), 0, st, n, inp_p, temp);
+    int rc = pcops_launch_status();
+    if (rc != PCOPS_OK || m == 0) return rc;
+    PCOPS_REQUIRE_PTR(inp_r);
+    PCOPS_REQUIRE_PTR(out);
+    int base = 1;
+    while (base < n) base <<= 1;
+    unsigned gy = cdiv(m, 256);
+    if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(binary_search_kernel, dim3(b, gy), dim3(256), 0, st, n, m, base, temp, inp_r, out);
     return pcops_launch_status();
 }

@@ -113,7 +113,9 @@ class FusedMLPStack(torch.autograd.Function):
             if li == 0 and gather:
                 N = C1
                 Y = None if virt else _f32((R, N), dev)
-                P = lib.pcops_sa_gather_stats_rows(B * M)
+                other = wxyz is not None or bias is not None or off4 is not None
+                P = lib.pcops_sa_gather_fwd_stats_rows(B, Nsrc, M, S, N, int(a0 is not None), int(ctr is not None),
+                                                        int(other), int(rref is not None))
                 part = _f32((P, 2, N), dev) if training else None
                 _lib.call("pcops_sa_gather_fwd_rows", B, Nsrc, M, S, N, _p(a0), _p(ctr), _p(xyz), _p(new_xyz),
                           _p(wxyz), _p(bias), idx.data_ptr(), _p(Y), _p(off4), _p(part), piv, _p(mom), rref)

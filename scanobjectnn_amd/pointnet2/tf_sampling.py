@@ -3,8 +3,7 @@
 Same names, positional order (attrs first, like the Python wrappers of the reference:
 tf_sampling.py:49-57), dtypes (f32 / i32) and differentiability: gather_point has a
 gradient w.r.t. `inp` only (tf_sampling.py:44-48); farthest_point_sample is
-non-differentiable (`ops.NoGradient`, :58).  `prob_sample` is out of scope (no model in
-scope calls it).
+non-differentiable (`ops.NoGradient`, :58), and so is prob_sample (:24).
 """
 import torch
 
@@ -17,6 +16,26 @@ def _check_xyz(t, name):
         # tf_sampling.cpp:105 "FarthestPointSample expects (batch_size,num_points,3) inp shape"
         raise ValueError("%s expects (batch_size,num_points,3) shape, got %s" % (name, tuple(t.shape)))
     return t
+
+
+def prob_sample(inp, inpr, return_cumsum=False):
+    """inp (B,ncategory) f32 weights, inpr (B,npoints) f32 numbers in [0,1] -> (B,npoints) i32: the category whose
+    cumulative-weight interval holds inpr * total (tf_sampling.py:14-23; ProbSampleGpuOp tf_sampling.cpp:65-92).
+    return_cumsum also hands back the op's scratch tensor, the row cumsum in the reference's association."""
+    if not isinstance(inp, torch.Tensor) or inp.dim() != 2:
+        raise ValueError("ProbSample expects (batch_size,num_choices) inp shape")      # tf_sampling.cpp:76
+    inp = _lib.check(inp.detach(), torch.float32, "inp", 2)
+    if not isinstance(inpr, torch.Tensor) or inpr.dim() != 2 or inpr.shape[0] != inp.shape[0]:
+        raise ValueError("ProbSample expects (batch_size,num_points) inpr shape")      # tf_sampling.cpp:79
+    inpr = _lib.check(inpr.detach(), torch.float32, "inpr", 2)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    if b > 0 and n < 1:
+        raise ValueError("ProbSample expects (batch_size,num_choices) inp shape with num_choices >= 1")
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)   # the op's allocate_temp, tf_sampling.cpp:86
+    _lib.call("pcops_prob_sample", b, n, m, _lib.ptr(inp), _lib.ptr(inpr), _lib.ptr(temp), _lib.ptr(out))
+    return (out, temp) if return_cumsum else out
 
 
 def farthest_point_sample(npoint, inp):

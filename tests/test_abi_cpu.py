@@ -46,6 +46,9 @@ def test_argument_validation_without_gpu():
     assert lib.pcops_query_ball_point(1, 8, 4, ctypes.c_float(0.1), 4, None, None, None, None, None) == -1
     assert lib.pcops_farthest_point_sample(1, 8, 0, None, None, None, None) == -3
     assert lib.pcops_knn_graph(1, 8, 3, 9, None, None, None) == -3          # k > n
+    assert lib.pcops_prob_sample(2, 0, 4, None, None, None, None, None) == -2     # the reference reads cumsum[n-1]
+    assert lib.pcops_prob_sample(2, 8, 4, None, None, None, None, None) == -1
+    assert lib.pcops_prob_sample(0, 8, 4, None, None, None, None, None) == 0
     assert lib.pcops_farthest_point_sample_workspace_bytes(32, 2048) == 0
     assert lib.pcops_mlp_stats_rows(4194304) == 512 and lib.pcops_mlp_stats_rows(100) == 1
     assert lib.pcops_adam_step(ctypes.c_longlong(6), None, None, None, None, ctypes.c_float(0.9), ctypes.c_float(0.999),

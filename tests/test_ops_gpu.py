@@ -157,6 +157,41 @@ def test_gather_point_and_grad():
     np.testing.assert_allclose(N(x.grad), O.gather_point_grad(c.shape, idx, go), rtol=0, atol=1e-5)
 
 
+# ------------------------------------------------------------------ prob_sample
+@pytest.mark.parametrize("B,n,m", [(1, 1, 5), (3, 2, 9), (4, 15, 64), (5, 100, 1000), (3, 1000, 300), (2, 1021, 77),
+                                   (7, 4096, 4096), (2, 8191, 513), (2, 8192, 100), (3, 8193, 500), (2, 16389, 64),
+                                   (2, 20000, 3000), (300, 40, 2048)])
+def test_prob_sample_vs_oracle(B, n, m):
+    """cumsum (the op's scratch) == and indices bit-exact, incl. zero-probability runs, r = 0, r = 1, r -> 1, rows that
+    are not 16-byte aligned (odd n), more than one 8192-element chunk, rows beyond the LDS-staged search (n > 16384)"""
+    rng = np.random.default_rng(B * 7 + n + m)
+    p = rng.random((B, n)).astype(np.float32)
+    p[0, : n // 2] = 0
+    p[-1, rng.integers(0, n, n // 3 + 1)] = 0
+    r = rng.random((B, m)).astype(np.float32)
+    r[:, 0] = 0.0
+    r[:, -1] = 1.0
+    r[:, 1 % m] = np.nextafter(np.float32(1), np.float32(0))
+    out, temp = tf_sampling.prob_sample(T(p), T(r), return_cumsum=True)
+    oout, otemp = O.prob_sample(p, r, return_temp=True)
+    np.testing.assert_array_equal(N(temp), otemp)
+    np.testing.assert_array_equal(N(out), oout)
+    assert out.dtype == torch.int32 and tuple(out.shape) == (B, m)
+
+
+def test_prob_sample_boundaries_and_errors():
+    p = np.array([[1, 1, 2, 4, 0, 0, 8]], np.float32)
+    r = np.array([[0, 1 / 16, 1 / 8, 0.126, 1 / 4, 1 / 2, 0.51, 1.0]], np.float32)
+    np.testing.assert_array_equal(N(tf_sampling.prob_sample(T(p), T(r))), [[0, 0, 1, 2, 2, 3, 6, 6]])
+    assert tuple(tf_sampling.prob_sample(T(p), T(r[:, :0])).shape) == (1, 0)
+    with pytest.raises(ValueError):
+        tf_sampling.prob_sample(T(p)[0], T(r))                     # rank (tf_sampling.cpp:76)
+    with pytest.raises(ValueError):
+        tf_sampling.prob_sample(T(p), T(np.zeros((2, 4), np.float32)))   # batch mismatch (:79)
+    with pytest.raises(Exception):
+        tf_sampling.prob_sample(T(p).cpu(), T(r).cpu())            # no CPU fallback
+
+
 # ------------------------------------------------------------------ group_point
 @pytest.mark.parametrize("case", sorted(load_golden("group_point")))
 def test_group_point_golden(case):

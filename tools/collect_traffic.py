@@ -54,11 +54,16 @@ KEYS = [
 ]
 
 
+MODEL = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else None     # another bench workload (cfg3 / cfg5)
+MODEL_ARGS = ["--model", MODEL] if MODEL else []
+SUFFIX = "_" + MODEL if MODEL else ""
+
+
 def one_pass(counter):
-    d = os.path.join(OUT, "pmc_%s" % counter)
+    d = os.path.join(OUT, "pmc_%s%s" % (counter, SUFFIX))
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"] + MODEL_ARGS
     subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, cwd="/tmp",
                    env=dict(os.environ, TMPDIR="/tmp"))
     agg = collections.defaultdict(list)
@@ -127,8 +132,10 @@ def main():
                 table[key] = total
                 print("%-52s %7.3f GB per launch (fetch raw %.3f GiB x2, write %.3f GiB)" % (
                     key, total / 1e9, f / 2 ** 20, w / 2 ** 20), flush=True)
-    json.dump(table, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
-    json.dump(detail, open(os.path.join(OUT, "pmc_traffic_detail.json"), "w"), indent=1)
+    json.dump(table, open(os.path.join(OUT, "pmc_traffic%s.json" % SUFFIX), "w"), indent=1)
+    json.dump(detail, open(os.path.join(OUT, "pmc_traffic_detail%s.json" % SUFFIX), "w"), indent=1)
+    for d in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE"):          # the raw per-dispatch CSVs are large: keep the tables only
+        subprocess.run(["rm", "-rf", os.path.join(OUT, d + SUFFIX)])
 
 
 if __name__ == "__main__":
