@@ -464,7 +464,7 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
  * first-layer restructuring above):  y[g,s,:] = Q[idx[g,s],:] + Ctr[g,:] -> BN -> ReLU -> max over s.  Ctr is constant
  * inside a group and BN+ReLU is monotone per channel, so
  *   forward : qsel[g,c] = max_s (gamma[c] >= 0) | min_s (gamma[c] < 0) of Q[idx[g,s],c], arg = first s attaining it,
- *             SQ[g,c] = sum_s Q[idx[g,s],c];  stats_partial [pcops_edge_pool_stats_rows(b*m)][2][c] = partial
+ *             SQ[g,c] = sum_s Q[idx[g,s],c];  stats_partial [pcops_edge_pool_fwd_stats_rows(b,n,m,s,c)][2][c] = partial
  *             (sum y', sum y'^2), y' = y - stat_pivot (shifted moments, see pcops_mlp_gemm_fwd), evaluated as
  *             (SQ' + k c', SQ2' + 2 c' SQ' + k c'^2) with Q taken relative to its own first row, q' = q - Q[0,0,:], and
  *             c' = Ctr + Q[0,0,:] - pivot, so that neither a common offset of Q nor one of Ctr cancels in fp32
@@ -475,6 +475,9 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
  *             dQ[i] = cnt_i (q Q[i] + t) + q sum_{(g,s)->i} Ctr[g] + sum_{g: arg row -> i} a[g]   (inverse index of idx)
  * workspace: pcops_sa_scatter_workspace_bytes(b,n,m,s) bytes.  s <= 256. */
 int pcops_edge_pool_stats_rows(long long groups);
+/* rows of stats_partial THIS call shape writes (<= pcops_edge_pool_stats_rows(b*m)): the 64-channel-slice kernels of
+ * csrc/edgeconv.hip write one row per 64 groups, or one per cloud when the cloud's slice is LDS-resident */
+int pcops_edge_pool_fwd_stats_rows(int b, int n, int m, int s, int c);
 int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
                         const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,
                         const float *stat_pivot, pcops_stream_t stream);
@@ -584,6 +587,24 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
                               float *dbias, const float *fwd_Q, const float *fwd_Ctr, const float *fwd_Wxyz,
                               const float *fwd_bias, void *workspace, const pcops_rows_t *rows,
                               pcops_stream_t stream);
+
+/* ------------------------------------------------------------- classifier / T-Net heads (csrc/head.hip)
+ * BatchNorm (+ ReLU) of a fully connected layer's output over R rows (the batch) as one launch per direction:
+ * fully_connected(..., bn=True) of pointnet2/utils/tf_util.py:327-363 (batch_norm_for_fc :534-546) and
+ * dgcnn/utils/tf_util.py:317-354 (batch_norm_template :462-499).  x, y, dy, dx (R, C) dense.
+ *   training != 0: batch mean and BIASED variance normalise; moving_mean / moving_var are updated in place,
+ *                  m <- decay m + (1 - decay) batch, the variance fed being var R / (R - 1) when unbiased_moving_var
+ *                  (the pointnet2 flavour) and var otherwise (the DGCNN flavour);
+ *   training == 0: the moving statistics normalise and nothing is updated.
+ * save_mean / save_rstd (C) receive the statistics used (the backward's inputs).  relu != 0: y = max(., 0) and the
+ * backward masks dy with y > 0.  Backward: dgamma = sum g xhat, dbeta = sum g, dx = gamma rstd (g - dbeta / R - xhat
+ * dgamma / R), or gamma rstd g through frozen statistics (training == 0). */
+int pcops_fc_bn_fwd(int R, int C, const float *x, const float *gamma, const float *beta, float *moving_mean,
+                    float *moving_var, int training, float decay, float eps, int unbiased_moving_var, int relu,
+                    float *y, float *save_mean, float *save_rstd, pcops_stream_t stream);
+int pcops_fc_bn_bwd(int R, int C, const float *dy, const float *x, const float *y, const float *gamma,
+                    const float *save_mean, const float *save_rstd, int training, int relu, float *dx,
+                    float *dgamma, float *dbeta, pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -84,3 +84,19 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
     return ((unsigned long long)mh << 32) | ml;
 }
+
+// ---- XCD-aware numbering of workgroups (round 5).  Workgroup `bid` (linear dispatch order) of `nwg` runs on XCD bid % 8
+// (observed, MI355X_MICROARCH.md "Workgroup dispatch" -- a speed assumption only, nothing may depend on it): renumber so
+// that every XCD owns a CONTIGUOUS range of the virtual ids (bijective for any nwg).  Kernels that deal several
+// workgroups to one cloud use it to keep a cloud's rows in ONE L2 instead of fetching them into all eight.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+// a (parts-per-cloud, clouds) grid: the (part, cloud) this workgroup takes, all parts of a cloud on one XCD
+struct CloudPart { int part, cloud; };
+__device__ __forceinline__ CloudPart xcd_cloud_part() {
+    const unsigned vb = xcd_contiguous(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y);
+    const unsigned cloud = vb / gridDim.x;
+    return CloudPart{(int)(vb - cloud * gridDim.x), (int)cloud};
+}

@@ -7,7 +7,8 @@
 bool ec_enabled();
 bool ec_fwd_supported(int b, int n, int m, int s, int c);
 bool ec_bwd_supported(int b, int n, int m, int s, int c);
-int ec_stats_rows(long long G);      // partial-statistics rows the forward kernels write: one per 64 groups
+int ec_stats_rows(long long G);      // partial-statistics rows the L2-gather forward kernels write: one per 64 groups
+int ec_edge_pool_stats_rows(int b, int n, int m);     // ... and what pcops_edge_pool_fwd writes (one per cloud on LDS slices)
 // pooled EdgeConv layer (pcops_edge_pool_fwd): SQ, qsel, arg, shifted moments
 int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
                      float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st);

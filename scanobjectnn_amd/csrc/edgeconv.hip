@@ -40,12 +40,6 @@ __device__ __forceinline__ unsigned ec_load1(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
 }
 
-// workgroup `bid` of `nwg` runs on XCD bid % 8 (observed): renumber so that every XCD owns a CONTIGUOUS range of the
-// virtual ids (bijective for any nwg)
-__device__ __forceinline__ unsigned ec_xcd_contiguous(unsigned bid, unsigned nwg) {
-    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
 
 constexpr int kGB = 64;          // groups (forward) / points (walk) per workgroup
 constexpr int kSets = 16;        // 16-lane sets per 256-thread workgroup: one group / point each, four rounds
@@ -173,7 +167,7 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned ec_sm[];      // offsets [64][S] | statistics [16][2][64]
     const int S = a.S, C = a.C;
     const int H = C >> 6, P = a.m / kGB;
-    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
     const int b = (int)(vb / (unsigned)(H * P));
     const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
     const int h = rem / P, chunk = rem - h * P;
@@ -219,10 +213,19 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(FwdArgs a) {
 // order [b][m S] u32: (group << 8 | slot) of every grouped row, sorted by the source point it references (within a list
 // in the order the slots were handed out: no particular order);  start [b][n + 1]: list boundaries.
 // One workgroup per cloud; the rows are read 16 bytes per lane, the group of a row comes from ONE division per four rows.
-__global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S, const int *__restrict__ idx,
-                                                            unsigned *__restrict__ order, int *__restrict__ start) {
-    extern __shared__ int ec_si[];              // cnt / cursor [n] | scan scratch [1024]
-    int *cnt = ec_si, *sc = ec_si + n;
+// STAGE: the sorted list is assembled in LDS as 16-bit (group << sbits | slot) codes and leaves with coalesced stores --
+// scattering 4-byte entries straight to HBM cost 8.5x the list's bytes in partial-sector writes (357 MB counted for the
+// 42 MB list of the cfg3 graph) and was most of the kernel's 130 us.
+// perm [b][n]: the cloud's points in order of DESCENDING list length (ties in no particular order).  The walk deals
+// positions of this order to its lane sets, so the 16 points a wave works on at a time have lists of (almost) one length
+// -- a wave otherwise runs to the longest of 16 lists, about twice the mean on a kNN graph.
+template <bool STAGE>
+__global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S, int sbits, const int *__restrict__ idx,
+                                                            unsigned *__restrict__ order, int *__restrict__ start,
+                                                            int *__restrict__ perm, unsigned short *__restrict__ codes_out) {
+    extern __shared__ int ec_si[];              // cnt / cursor [n] | scan scratch [1024] | length bins [1024] | STAGE: codes [m S] u16
+    int *cnt = ec_si, *sc = ec_si + n, *lh = sc + 1024;
+    unsigned short *codes = reinterpret_cast<unsigned short *>(lh + 1024);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int mS = m * S;
     const int *ib = idx + (long long)b * mS;
@@ -235,6 +238,26 @@ __global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S,
     }
     for (int e = 4 * n4 + tid; e < mS; e += 1024) atomicAdd(&cnt[ib[e]], 1);
     __syncthreads();
+    {   // counting sort of the points by list length (bins 0 .. 1023, longer lists share the last bin), longest first
+        lh[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) atomicAdd(&lh[1023 - min(cnt[i], 1023)], 1);
+        __syncthreads();
+        const int mine = lh[tid];
+        sc[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = tid >= off ? sc[tid - off] : 0;
+            __syncthreads();
+            sc[tid] += v;
+            __syncthreads();
+        }
+        lh[tid] = sc[tid] - mine;                // exclusive: first position of the bin
+        __syncthreads();
+        int *pb = perm + (long long)b * n;
+        for (int i = tid; i < n; i += 1024) pb[atomicAdd(&lh[1023 - min(cnt[i], 1023)], 1)] = i;
+        __syncthreads();
+    }
     const int per = (n + 1023) / 1024;
     const int i0 = tid * per, i1 = min(n, i0 + per);
     int local = 0;
@@ -258,6 +281,11 @@ __global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S,
     if (tid == 0) sb[n] = mS;
     __syncthreads();
     unsigned *ob = order + (long long)b * mS;
+    auto put = [&](int i, int g, int s) {
+        const int pos = atomicAdd(&cnt[i], 1);
+        if (STAGE) codes[pos] = (unsigned short)((g << sbits) | s);
+        else ob[pos] = ((unsigned)g << 8) | (unsigned)s;
+    };
     for (int e4 = tid; e4 < n4; e4 += 1024) {
         const int4 v = *reinterpret_cast<const int4 *>(ib + 4 * e4);
         const int e = 4 * e4;
@@ -265,13 +293,22 @@ __global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S,
         const int vi[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            ob[atomicAdd(&cnt[vi[u]], 1)] = ((unsigned)g << 8) | (unsigned)s;
+            put(vi[u], g, s);
             if (++s == S) { s = 0; ++g; }
         }
     }
     for (int e = 4 * n4 + tid; e < mS; e += 1024) {
         const int g = e / S;
-        ob[atomicAdd(&cnt[ib[e]], 1)] = ((unsigned)g << 8) | (unsigned)(e - g * S);
+        put(ib[e], g, e - g * S);
+    }
+    if (!STAGE) return;
+    __syncthreads();
+    const unsigned smask = (1u << sbits) - 1u;
+    unsigned short *cb = codes_out + (long long)b * mS;       // the 16-bit form too: the LDS-resident walk stages it
+    for (int k = tid; k < mS; k += 1024) {
+        const unsigned c = codes[k];
+        ob[k] = ((c >> sbits) << 8) | (c & smask);
+        cb[k] = (unsigned short)c;
     }
 }
 
@@ -293,7 +330,7 @@ template <bool HAS_G>
 __global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
     const int C = a.C, S = a.S;
     const int H = C >> 6, P = (a.n + kGB - 1) / kGB;
-    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
     const int b = (int)(vb / (unsigned)(H * P));
     const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
     const int h = rem / P, chunk = rem - h * P;
@@ -370,7 +407,7 @@ __global__ __launch_bounds__(256) void ec_tnet_ctr_kernel(CtrArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned ec_sm[];      // offsets [64][S]
     const int S = a.S, C = a.C;
     const int H = C >> 6, P = a.m / kGB;
-    const unsigned vb = ec_xcd_contiguous(blockIdx.x, gridDim.x);
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
     const int b = (int)(vb / (unsigned)(H * P));
     const int rem = (int)(vb - (unsigned)b * (unsigned)(H * P));
     const int h = rem / P, chunk = rem - h * P;
@@ -425,6 +462,271 @@ __global__ __launch_bounds__(256) void ec_tnet_ctr_kernel(CtrArgs a) {
     }
 }
 
+// ---- LDS-resident slices (clouds of up to ~2500 points) --------------------------------------------------------------
+// The L2-gather kernels above top out at ~10.7 TB/s of gathered rows (measured: 2.7 GB of 256-byte row pieces in 255 us
+// at C = 64, 5.4 GB in 492 us at C = 128 -- a third of the L2's streaming rate, and traffic from HBM already at the
+// algorithmic 0.62 GB).  A cloud's rows are gathered k = 20 times each, so the table belongs in LDS: one workgroup of
+// 1024 lanes per (cloud, 16-channel slice) stages the slice once ([n][16] floats = 128 KB at n = 2048) and every gather
+// is a ds_read_b128.  Four lanes per group / point (a float4 of channels each), 256 groups in flight.
+constexpr int kSliceCh = 16;
+
+template <bool UP, int NI>         // NI int4 index registers per group: S <= 4 NI in the prefetched form
+__device__ __forceinline__ void ec_fwd_lds_groups(const FwdArgs &a, const float4 *qs, int b, int quad, int cl, int ch,
+                                                  f2 (&s1)[2], f2 (&s2)[2]) {
+    const int S = a.S, C = a.C, m = a.m;
+    const float kf = (float)S;
+    f2 sg[2] = {{1.f, 1.f}, {1.f, 1.f}};
+    f2 qz[2] = {{0.f, 0.f}, {0.f, 0.f}}, cz[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (!UP) {
+        const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + ch);
+        sg[0] = f2{ga.x < 0.f ? -1.f : 1.f, ga.y < 0.f ? -1.f : 1.f};
+        sg[1] = f2{ga.z < 0.f ? -1.f : 1.f, ga.w < 0.f ? -1.f : 1.f};
+    }
+    if (a.stats) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(a.Q + ch);
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.pivot) p4 = *reinterpret_cast<const float4 *>(a.pivot + ch);
+        qz[0] = f2{q0.x, q0.y}; qz[1] = f2{q0.z, q0.w};
+        cz[0] = f2{q0.x - p4.x, q0.y - p4.y}; cz[1] = f2{q0.z - p4.z, q0.w - p4.w};
+    }
+    // the group's indices (and its Ctr quad) are loaded ONE GROUP AHEAD: counters of the first version showed the waves
+    // parked at s_waitcnt 68 % of their cycles, a global-load latency per four neighbours (profiles/r05_ec_counters.txt)
+    const bool fast = (S & 3) == 0 && S <= 4 * NI;
+    const int ni = S >> 2;
+    int4 cur[NI];
+    float4 curc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (quad < m) {
+        const long long g = (long long)b * m + quad;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (j < ni) cur[j] = *reinterpret_cast<const int4 *>(a.idx + g * S + 4 * j);
+        }
+        curc = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+    }
+#pragma unroll 1
+    for (int gl = quad; gl < m; gl += 256) {
+        const long long g = (long long)b * m + gl;
+        int4 nxt[NI];
+        float4 nxtc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gl + 256 < m) {
+            if (fast) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if (j < ni) nxt[j] = *reinterpret_cast<const int4 *>(a.idx + (g + 256) * S + 4 * j);
+            }
+            nxtc = *reinterpret_cast<const float4 *>(a.Ctr + (g + 256) * C + ch);
+        }
+        const f2 ct[2] = {{curc.x, curc.y}, {curc.z, curc.w}};
+        f2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}}, sq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        float ex[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int ea[4] = {0, 0, 0, 0};
+        auto take = [&](const float4 &q, int s) {
+            const f2 qa = f2{q.x, q.y}, qb = f2{q.z, q.w};
+            const f2 da = qa - qz[0], db = qb - qz[1];
+            sq[0] += da; sq[1] += db;
+            sq2[0] = __builtin_elementwise_fma(da, da, sq2[0]);
+            sq2[1] = __builtin_elementwise_fma(db, db, sq2[1]);
+            const f2 va = UP ? qa : qa * sg[0], vb = UP ? qb : qb * sg[1];
+            const float v[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool better = v[e] > ex[e];                 // strict: the first extremum keeps the slot
+                ea[e] = better ? s : ea[e];
+                ex[e] = better ? v[e] : ex[e];
+            }
+        };
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (j < ni) {
+                    const float4 q0 = qs[cur[j].x * 4 + cl], q1 = qs[cur[j].y * 4 + cl], q2 = qs[cur[j].z * 4 + cl],
+                                 q3 = qs[cur[j].w * 4 + cl];
+                    take(q0, 4 * j); take(q1, 4 * j + 1); take(q2, 4 * j + 2); take(q3, 4 * j + 3);
+                }
+        } else {
+            const int *ig = a.idx + g * S;
+            for (int s = 0; s < S; ++s) take(qs[ig[s] * 4 + cl], s);
+        }
+        *reinterpret_cast<float4 *>(a.SQ + g * C + ch) =
+            make_float4(fmaf(kf, qz[0].x, sq[0].x), fmaf(kf, qz[0].y, sq[0].y), fmaf(kf, qz[1].x, sq[1].x),
+                        fmaf(kf, qz[1].y, sq[1].y));
+        *reinterpret_cast<float4 *>(a.qsel + g * C + ch) =
+            UP ? make_float4(ex[0], ex[1], ex[2], ex[3])
+               : make_float4(ex[0] * sg[0].x, ex[1] * sg[0].y, ex[2] * sg[1].x, ex[3] * sg[1].y);
+        uchar4 a4;
+        a4.x = (unsigned char)ea[0]; a4.y = (unsigned char)ea[1]; a4.z = (unsigned char)ea[2]; a4.w = (unsigned char)ea[3];
+        *reinterpret_cast<uchar4 *>(a.arg + g * C + ch) = a4;
+        if (a.stats) {
+            const f2 k2 = f2{kf, kf};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 cv = ct[h] + cz[h];
+                s1[h] += __builtin_elementwise_fma(k2, cv, sq[h]);
+                s2[h] += __builtin_elementwise_fma(cv, __builtin_elementwise_fma(k2, cv, sq[h] + sq[h]), sq2[h]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) cur[j] = nxt[j];
+        curc = nxtc;
+    }
+}
+
+// statistics: ONE partial row per cloud, stats [b][2][C]
+__global__ __launch_bounds__(1024) void ec_fwd_lds_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 ec_qs[];      // [n][4] | wave sums [16][2][16] floats
+    const int C = a.C, n = a.n, NS = C / kSliceCh;
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)NS), sl = (int)(vb - (unsigned)b * (unsigned)NS);
+    const int tid = threadIdx.x, quad = tid >> 2, cl = tid & 3;
+    const int ch = sl * kSliceCh + cl * 4;
+    {
+        const float *src = a.Q + (long long)b * n * C + ch;
+        for (int i = quad; i < n; i += 256) ec_qs[i * 4 + cl] = *reinterpret_cast<const float4 *>(src + (long long)i * C);
+    }
+    __syncthreads();
+    f2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const float4 ga = *reinterpret_cast<const float4 *>(a.gamma + ch);
+    const bool up = __all(!(ga.x < 0.f) && !(ga.y < 0.f) && !(ga.z < 0.f) && !(ga.w < 0.f)) != 0;
+    // (five index registers: k <= 20 neighbours take the prefetched form, larger groups read their indices in line;
+    //  eight registers per buffer spilled at the 128 VGPRs a 1024-lane workgroup leaves per lane)
+    if (up) ec_fwd_lds_groups<true, 5>(a, ec_qs, b, quad, cl, ch, s1, s2);
+    else ec_fwd_lds_groups<false, 5>(a, ec_qs, b, quad, cl, ch, s1, s2);
+    if (a.stats == nullptr) return;
+    float v[8] = {s1[0].x, s1[0].y, s1[1].x, s1[1].y, s2[0].x, s2[0].y, s2[1].x, s2[1].y};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int d = 4; d < 64; d <<= 1) v[e] += __shfl_xor(v[e], d, 64);     // the 16 quads of a wave, per channel lane
+    }
+    float *ws = reinterpret_cast<float *>(ec_qs + (size_t)n * 4);
+    const int wave = tid >> 6, lane = tid & 63;
+    if (lane < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ws[(wave * 2 + 0) * kSliceCh + lane * 4 + e] = v[e];
+            ws[(wave * 2 + 1) * kSliceCh + lane * 4 + e] = v[4 + e];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * kSliceCh) {
+        const int which = tid / kSliceCh, c = tid % kSliceCh;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += ws[(w * 2 + which) * kSliceCh + c];
+        a.stats[((long long)b * 2 + which) * C + sl * kSliceCh + c] = t;
+    }
+}
+
+// owner walk with the cloud's Ctr slice in LDS (+ one zero row at index m for the entries beyond a list), the list
+// boundaries and the length-sorted order of the points next to it (a wave's 64 points have lists of one length).
+// ONE LANE per source point and 8-channel slice, and EVERYTHING the inner loop touches in LDS: the cloud's Ctr slice
+// ([m + 1][8] floats, row m = zeros), the list boundaries and the inverse index itself as 16-bit (group << sbits | slot)
+// codes (m S of them: 80 KB for the cfg3 graph).  History of this kernel, all measured on the cfg3 graph at C = 64
+// (profiles/r05_ec_counters.txt): four lanes per point with the lists read from global memory four entries at a time
+// parked the waves at s_waitcnt 81 % of their cycles (a global-load latency per batch); batches of eight with the next
+// batch in flight cut the waiting but paid the entry decode once per float4 (54 k VALU per SIMD); one lane per point with
+// per-lane list loads turned the address coalescer into the bottleneck (64 distinct lines per load instruction).  With the
+// list in LDS there is no global access inside a list at all.  The two float4 of a row are taken in the rotated order
+// (j + lane) mod 2 and rows are 32 bytes apart, so the 16 lanes of an LDS conflict group spread over all 16 bank quads.
+constexpr int kWalkCh = 8;
+
+struct WalkLdsArgs {
+    WalkArgs w;
+    const int *perm;
+    const unsigned short *codes;
+    int sbits;
+};
+
+__global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
+    const WalkArgs &a = wa.w;
+    extern __shared__ __attribute__((aligned(16))) float4 ec_cs[];      // Ctr [m + 1][2] | start [n + 1] | codes [m S] u16
+    const int C = a.C, n = a.n, m = a.m, NS = C / kWalkCh;
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)NS), sl = (int)(vb - (unsigned)b * (unsigned)NS);
+    const int tid = threadIdx.x;
+    const int mS = m * a.S;
+    int *ss = reinterpret_cast<int *>(ec_cs + ((size_t)m + 1) * 2);
+    unsigned short *cs16 = reinterpret_cast<unsigned short *>((reinterpret_cast<uintptr_t>(ss + (n + 1)) + 15) & ~(uintptr_t)15);
+    {
+        const int pair = tid >> 1, cl = tid & 1;
+        const float *src = a.Ctr + (long long)b * m * C + sl * kWalkCh + cl * 4;
+        for (int j = pair; j < m; j += 512) ec_cs[j * 2 + cl] = *reinterpret_cast<const float4 *>(src + (long long)j * C);
+        if (pair == 0) ec_cs[m * 2 + cl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int *sb = a.start + (long long)b * (n + 1);
+        for (int i = tid; i <= n; i += 1024) ss[i] = sb[i];
+        const unsigned short *cg = wa.codes + (long long)b * mS;
+        if ((mS & 7) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0 && (reinterpret_cast<uintptr_t>(cs16) & 15) == 0) {
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(cg);
+            uint4 *d4 = reinterpret_cast<uint4 *>(cs16);
+            for (int k = tid; k < (mS >> 3); k += 1024) d4[k] = c4[k];
+        } else {
+            for (int k = tid; k < mS; k += 1024) cs16[k] = cg[k];
+        }
+    }
+    __syncthreads();
+    const int sbits = wa.sbits;
+    const int c0 = tid & 1, c1 = c0 ^ 1;         // this lane's float4 at read 0 / read 1
+    const float4 cq0 = *reinterpret_cast<const float4 *>(a.q + sl * kWalkCh + c0 * 4);
+    const float4 cq1 = *reinterpret_cast<const float4 *>(a.q + sl * kWalkCh + c1 * 4);
+    const float4 ct0 = *reinterpret_cast<const float4 *>(a.t + sl * kWalkCh + c0 * 4);
+    const float4 ct1 = *reinterpret_cast<const float4 *>(a.t + sl * kWalkCh + c1 * 4);
+    const float *Qb = a.Q + (long long)b * n * C + sl * kWalkCh;
+    float *dQb = a.dQ + (long long)b * n * C + sl * kWalkCh;
+    const int *pb = wa.perm + (long long)b * n;
+#pragma unroll 1
+    for (int p = tid; p < n; p += 1024) {
+        const int i = pb[p];
+        const int k0 = ss[i], k1 = ss[i + 1];
+        const float4 q0 = *reinterpret_cast<const float4 *>(Qb + (long long)i * C + c0 * 4);
+        const float4 q1 = *reinterpret_cast<const float4 *>(Qb + (long long)i * C + c1 * 4);
+        const float4 o0 = *reinterpret_cast<const float4 *>(dQb + (long long)i * C + c0 * 4);
+        const float4 o1 = *reinterpret_cast<const float4 *>(dQb + (long long)i * C + c1 * 4);
+        f2 a0[2] = {{0.f, 0.f}, {0.f, 0.f}}, a1[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            unsigned g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = (unsigned)cs16[k + u] >> sbits;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 x0 = ec_cs[g[u] * 2 + c0], x1 = ec_cs[g[u] * 2 + c1];
+                a0[0] += f2{x0.x, x0.y}; a0[1] += f2{x0.z, x0.w};
+                a1[0] += f2{x1.x, x1.y}; a1[1] += f2{x1.z, x1.w};
+            }
+        }
+        for (; k < k1; ++k) {
+            const unsigned g = (unsigned)cs16[k] >> sbits;
+            const float4 x0 = ec_cs[g * 2 + c0], x1 = ec_cs[g * 2 + c1];
+            a0[0] += f2{x0.x, x0.y}; a0[1] += f2{x0.z, x0.w};
+            a1[0] += f2{x1.x, x1.y}; a1[1] += f2{x1.z, x1.w};
+        }
+        const float kf = (float)(k1 - k0);
+        float4 d0, d1;
+        d0.x = o0.x + fmaf(cq0.x, fmaf(kf, q0.x, a0[0].x), kf * ct0.x);
+        d0.y = o0.y + fmaf(cq0.y, fmaf(kf, q0.y, a0[0].y), kf * ct0.y);
+        d0.z = o0.z + fmaf(cq0.z, fmaf(kf, q0.z, a0[1].x), kf * ct0.z);
+        d0.w = o0.w + fmaf(cq0.w, fmaf(kf, q0.w, a0[1].y), kf * ct0.w);
+        d1.x = o1.x + fmaf(cq1.x, fmaf(kf, q1.x, a1[0].x), kf * ct1.x);
+        d1.y = o1.y + fmaf(cq1.y, fmaf(kf, q1.y, a1[0].y), kf * ct1.y);
+        d1.z = o1.z + fmaf(cq1.z, fmaf(kf, q1.z, a1[1].x), kf * ct1.z);
+        d1.w = o1.w + fmaf(cq1.w, fmaf(kf, q1.w, a1[1].y), kf * ct1.w);
+        *reinterpret_cast<float4 *>(dQb + (long long)i * C + c0 * 4) = d0;
+        *reinterpret_cast<float4 *>(dQb + (long long)i * C + c1 * 4) = d1;
+    }
+}
+
+constexpr size_t kLdsMax = 160 * 1024;
+bool ec_lds_fwd_ok(int n) { return (size_t)n * 64 + 16 * 2 * kSliceCh * sizeof(float) <= kLdsMax; }
+size_t ec_lds_walk_bytes(int n, int m, int s) { return ((size_t)m + 1) * 32 + ((size_t)n + 1) * 4 + (((size_t)m * s * 2 + 15) & ~(size_t)15) + 16; }
+int ec_sbits(int s) { int sb = 0; while ((1 << sb) < s) ++sb; return sb; }
+bool ec_codes16_ok(int m, int s) { return ((long long)m << ec_sbits(s)) <= 65536; }
+bool ec_lds_walk_ok(int n, int m, int s) { return ec_codes16_ok(m, s) && ec_lds_walk_bytes(n, m, s) <= kLdsMax; }
+bool ec_lds_on() {
+    static const bool on = [] { const char *e = getenv("PCOPS_EDGECONV_LDS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 bool ec_shape_ok(int b, int n, int m, int s, int c) {
     // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q / the cloud's G rows
     return c >= 64 && c % 64 == 0 && m >= kGB && m % kGB == 0 && s >= 1 && s <= 128 && n >= 1 &&
@@ -443,9 +745,22 @@ bool ec_fwd_supported(int b, int n, int m, int s, int c) { return ec_enabled() &
 
 int ec_stats_rows(long long G) { return (int)((G + kGB - 1) / kGB); }
 
+// rows of partial statistics pcops_edge_pool_fwd writes on this path: one per cloud (LDS slices) or one per 64 groups
+int ec_edge_pool_stats_rows(int b, int n, int m) {
+    return (ec_lds_on() && ec_lds_fwd_ok(n)) ? b : ec_stats_rows((long long)b * m);
+}
+
 int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
                      float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st) {
     FwdArgs a = {b, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel, arg, nullptr, stats, pivot};
+    if (ec_lds_on() && ec_lds_fwd_ok(n)) {
+        const size_t lds = (size_t)n * 64 + 16 * 2 * kSliceCh * sizeof(float);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_fwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsMax) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(ec_fwd_lds_kernel, dim3((unsigned)b * (c / kSliceCh)), dim3(1024), lds, st, a);
+        return pcops_launch_status();
+    }
     const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
     const size_t lds = ((size_t)kGB * s + kSets * 128) * sizeof(float);
     hipLaunchKernelGGL(ec_fwd_kernel<0>, dim3(grid), dim3(256), lds, st, a);
@@ -462,18 +777,32 @@ int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float
 }
 
 bool ec_bwd_supported(int b, int n, int m, int s, int c) {
-    return ec_enabled() && ec_shape_ok(b, n, m, s, c) && n <= 16384 && s <= 256;
+    // (the inverse index keeps order | start | perm inside the caller's workspace of 4 b m s + b (n + 1) + 2 ints)
+    return ec_enabled() && ec_shape_ok(b, n, m, s, c) && n <= 16384 && s <= 256 && 2ll * m * s >= n;
 }
 
-// workspace: order (b m s u32) | start (b (n + 1) int32) -- inside what pcops_sa_scatter_workspace_bytes asks for
+// workspace: order (b m s u32) | start (b (n + 1) int32) | perm (b n int32) | codes (b m s u16) -- inside what pcops_sa_scatter_workspace_bytes asks for
 int ec_csr_build(int b, int n, int m, int s, const int *idx, void *workspace, hipStream_t st) {
     unsigned *order = static_cast<unsigned *>(workspace);
     int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
-    const size_t lds = ((size_t)n + 1024) * sizeof(int);
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-        return PCOPS_ERR_LAUNCH;
-    hipLaunchKernelGGL(ec_csr_build_kernel, dim3(b), dim3(1024), lds, st, n, m, s, idx, order, start);
+    int *perm = start + (size_t)b * (n + 1);
+    unsigned short *codes = reinterpret_cast<unsigned short *>(perm + (size_t)b * n);
+    const size_t lds = ((size_t)n + 2048) * sizeof(int);
+    const int sbits = ec_sbits(s);
+    const bool stage = ec_codes16_ok(m, s) && lds + (size_t)m * s * 2 <= 160 * 1024;
+    if (stage) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_csr_build_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(ec_csr_build_kernel<true>, dim3(b), dim3(1024), lds + (size_t)m * s * 2, st, n, m, s, sbits, idx, order,
+                           start, perm, codes);
+    } else {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_csr_build_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        hipLaunchKernelGGL(ec_csr_build_kernel<false>, dim3(b), dim3(1024), lds, st, n, m, s, sbits, idx, order, start, perm,
+                           codes);
+    }
     return pcops_launch_status();
 }
 
@@ -482,6 +811,16 @@ int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr,
     const unsigned *order = static_cast<const unsigned *>(workspace);
     const int *start = reinterpret_cast<const int *>(order + (size_t)b * m * s);
     WalkArgs a = {b, n, m, s, c, Q, Ctr, G, p, q, t, order, start, dQ};
+    if (!G && ec_lds_on() && ec_lds_walk_ok(n, m, s) && c % kWalkCh == 0) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_walk_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kLdsMax) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
+        const int *perm = start + (size_t)b * (n + 1);
+        const unsigned short *codes = reinterpret_cast<const unsigned short *>(perm + (size_t)b * n);
+        WalkLdsArgs wa = {a, perm, codes, ec_sbits(s)};
+        hipLaunchKernelGGL(ec_walk_lds_kernel, dim3((unsigned)b * (c / kWalkCh)), dim3(1024), ec_lds_walk_bytes(n, m, s), st, wa);
+        return pcops_launch_status();
+    }
     const unsigned grid = (unsigned)((long long)b * (c / 64) * ((n + kGB - 1) / kGB));
     if (G) hipLaunchKernelGGL(ec_walk_kernel<true>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(ec_walk_kernel<false>, dim3(grid), dim3(256), 0, st, a);

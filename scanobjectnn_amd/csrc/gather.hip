@@ -1803,6 +1803,10 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
 }
 
 int pcops_edge_pool_stats_rows(long long G) { return (int)((G + 63) / 64); }
+int pcops_edge_pool_fwd_stats_rows(int b, int n, int m, int s, int c) {
+    if (ec_fwd_supported(b, n, m, s, c) && s <= 256) return ec_edge_pool_stats_rows(b, n, m);
+    return pcops_edge_pool_stats_rows((long long)b * m);
+}
 
 int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
                         const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats_partial,

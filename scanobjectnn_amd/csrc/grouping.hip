@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void qbp_kernel(int n, int m, int qpw, QbpArgs
     __shared__ __attribute__((aligned(16))) float stage[64 * STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * qpw;
+    const CloudPart cp = xcd_cloud_part();      // a cloud's workgroups on ONE XCD: the cloud is fetched into one L2 (round 5;
+    const int b = cp.cloud;                     // round-robin placement had every XCD stage every cloud: 2.75x the bytes)
+    const int q0 = (cp.part * 4 + wave) * qpw;
     const int nq = q0 < m ? min(qpw, m - q0) : 0;      // a wave without queries still helps staging the cloud
     const float *p1 = xyz1 + (size_t)b * n * 3;
     const size_t qbase = (size_t)b * m + q0;

@@ -185,11 +185,12 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     float *sc = cs + CH * LD;          // [CH]   (16-byte aligned: CH * LD is a multiple of 4)
     float *qd = sc + CH;               // [QD][256] queued distances
     int *qj = reinterpret_cast<int *>(qd + QD * 256);   // [QD][256] and their indices
-    const int b = blockIdx.y;
+    const CloudPart cp = xcd_cloud_part();      // the query blocks of a cloud share its candidates: one XCD, one L2
+    const int b = cp.cloud;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
     const float *xb = x + (size_t)b * n * c;
-    const int q = blockIdx.x * 128 + wave * 32 + li;       // this lane's query row
+    const int q = cp.part * 128 + wave * 32 + li;          // this lane's query row
     const bool qin = q < n;
 
     // query fragments: bq[kk] = x[q][2 kk + half]; squared norm by the contract's fmaf chain
@@ -438,11 +439,12 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
     float *su = sc + CH;                               // [CH]       (1 - A) s_j
     int *pj = reinterpret_cast<int *>(su + CH);        // [PD][512]  pending survivors
     _Float16 *chh = reinterpret_cast<_Float16 *>(pj + PD * 512);   // [CH][LH]  fp16 candidates (the filter's A operand)
-    const int b = blockIdx.y;
+    const CloudPart cp = xcd_cloud_part();      // the query blocks of a cloud share its candidates: one XCD, one L2
+    const int b = cp.cloud;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, li = lane & 31;
     const float *xb = x + (size_t)b * n * CP;
-    const int q = blockIdx.x * 256 + wave * 32 + li;      // 8 waves = 256 queries share one candidate chunk
+    const int q = cp.part * 256 + wave * 32 + li;         // 8 waves = 256 queries share one candidate chunk
     const bool qin = q < n;
 
     // the query row: fp32 in registers (exact distances) and fp16 B fragments (channels 16 kk + 8 half .. + 7)

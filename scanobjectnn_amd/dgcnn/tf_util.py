@@ -101,6 +101,18 @@ def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, we
                                               wd=weight_decay or None, use_xavier=use_xavier)
         biases = get_variable('biases', [num_outputs], constant_initializer(0.0))
         out = _dense(inputs, weights, biases)
+        if bn and activation_fn in (relu, None) and fused_mlp.fc_batch_norm_supported(out) and not (
+                torch.is_grad_enabled() and _pn2._double_backward_requested()):
+            # BN (+ ReLU) of the head as one launch per direction (csrc/head.hip); same variables as _batch_norm creates
+            names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
+            with variable_scope('bn'):
+                beta = get_variable('beta', [num_outputs], constant_initializer(0.0))
+                gamma = get_variable('gamma', [num_outputs], constant_initializer(1.0))
+                mov_mean = get_variable(names[0], [num_outputs], constant_initializer(0.0), trainable=False)
+                mov_var = get_variable(names[1], [num_outputs], constant_initializer(1.0), trainable=False)
+            decay = float(bn_decay) if bn_decay is not None else 0.9
+            return fused_mlp.fc_batch_norm(out, gamma, beta, mov_mean, mov_var, is_training, decay, BN_EPS, False,
+                                           activation_fn is relu)
         if bn:
             out = _bn(out, is_training, bn_decay, 'bn', is_dist)
         if activation_fn is not None:

@@ -498,6 +498,58 @@ def small_linear(x, w, b):
     return _SmallLinear.apply(x.contiguous(), w.contiguous(), b)
 
 
+class _FcBatchNorm(torch.autograd.Function):
+    """BatchNorm (+ ReLU) behind a fully connected layer -- a few hundred rows -- as one launch per direction
+    (csrc/head.hip, pcops_fc_bn_fwd / _bwd) instead of F.batch_norm + relu or a dozen elementwise / reduce launches.
+    apply(x, gamma, beta, moving_mean, moving_var, training, decay, eps, unbiased_moving_var, relu) -> y"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mm, mv, training, decay, eps, unbiased, relu):
+        R, C = x.shape
+        dev = x.device
+        y = _f32((R, C), dev)
+        stat = _f32((2, C), dev)
+        _lib.call("pcops_fc_bn_fwd", R, C, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                  int(bool(training)), float(decay), float(eps), int(bool(unbiased)), int(bool(relu)), y.data_ptr(),
+                  stat[0].data_ptr(), stat[1].data_ptr())
+        ctx.save_for_backward(x, y, gamma, stat)
+        ctx.flags = (bool(training), bool(relu))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y, gamma, stat = ctx.saved_tensors
+        training, relu = ctx.flags
+        R, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = _f32((R, C), dev)
+        dgb = _f32((2, C), dev)
+        _lib.call("pcops_fc_bn_bwd", R, C, dy.data_ptr(), x.data_ptr(), y.data_ptr(), gamma.data_ptr(), stat[0].data_ptr(),
+                  stat[1].data_ptr(), int(training), int(relu), dx.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr())
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+FC_BN = os.environ.get("PCOPS_FC_BN", "1") != "0"
+FC_BN_MAX_ROWS = 8192
+
+
+def fc_batch_norm_supported(x):
+    return (FC_BN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= FC_BN_MAX_ROWS
+            and not _dist.sync_bn_active())
+
+
+def fc_batch_norm(x, gamma, beta, mm, mv, training, decay, eps, unbiased_moving_var, relu):
+    """(rows, C) -> BN (+ ReLU) with the moving statistics updated in place when training"""
+    y = _FcBatchNorm.apply(x.contiguous(), gamma, beta, mm, mv, bool(training), float(decay), float(eps),
+                           bool(unbiased_moving_var), bool(relu))
+    if TRACE is not None and relu:      # parity tests (tests/decisions.py): the ReLU decision of this layer, as torch.relu's
+        from .graph import get_default_graph
+        TRACE.append(("relu", get_default_graph().full_name("")[:-1], y.detach()))
+    return y
+
+
 class _RowsLinear(torch.autograd.Function):
     """Y = X W + b on (rows, K) through the libpcops GEMMs, backward included.  Exists for the per-source-point
     contraction of a grouped first layer (Q = points W_f + b): rows = B*N is large and the weight gradient is a
@@ -563,7 +615,7 @@ class EdgeConvPool(torch.autograd.Function):
         sync = training and _dist.sync_bn_active()
         SQ, qsel = _f32((G, C), dev), _f32((G, C), dev)
         arg = torch.empty((G, C), dtype=torch.uint8, device=dev)
-        P = lib.pcops_edge_pool_stats_rows(G)
+        P = lib.pcops_edge_pool_fwd_stats_rows(B, Nsrc, M, S, C)
         part = _f32((P, 2, C), dev) if training else None
         _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
                   gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part),

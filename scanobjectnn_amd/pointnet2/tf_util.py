@@ -231,6 +231,17 @@ def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, we
                                               wd=weight_decay, use_xavier=use_xavier)
         biases = get_variable('biases', [num_outputs], constant_initializer(0.0))
         out = _dense(inputs, weights, biases)
+        if bn and activation_fn in (relu, None) and fused_mlp.fc_batch_norm_supported(out) and not (
+                torch.is_grad_enabled() and _double_backward_requested()):
+            # BN (+ ReLU) of the head as one launch per direction (csrc/head.hip); the variables of batch_norm_template
+            with variable_scope('bn'):
+                beta = get_variable('beta', [num_outputs], constant_initializer(0.0))
+                gamma = get_variable('gamma', [num_outputs], constant_initializer(1.0))
+                moving_mean = get_variable('moving_mean', [num_outputs], constant_initializer(0.0), trainable=False)
+                moving_var = get_variable('moving_variance', [num_outputs], constant_initializer(1.0), trainable=False)
+            decay = float(bn_decay) if bn_decay is not None else 0.9
+            return fused_mlp.fc_batch_norm(out, gamma, beta, moving_mean, moving_var, is_training, decay, BN_EPS, True,
+                                           activation_fn is relu)
         if bn:
             out = batch_norm_for_fc(out, is_training, bn_decay, 'bn')
         if activation_fn is not None:
