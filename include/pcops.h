@@ -588,6 +588,41 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
                               const float *fwd_bias, void *workspace, const pcops_rows_t *rows,
                               pcops_stream_t stream);
 
+/* ---- the [Q | Ctr] forms of the five entry points above (csrc/edgeconv.hip).  EdgeConv's first conv is linear in the
+ * edge feature, concat(x_i, x_j - x_i) W = x_j W_b + x_i (W_a - W_b) (dgcnn/utils/tf_util.py:699-705 + dgcnn.py:39-44):
+ * Q = X W_b and Ctr = X (W_a - W_b) + bias are the column halves of ONE product X [W_b | W_a - W_b] with row stride 2 c,
+ * and dQ / dCtr the halves of one gradient, so the per-point GEMM, its weight gradient and its data gradient run once
+ * instead of twice (and autograd has nothing to add up).  ldq / ldc / lddq / lddc: row strides in floats (multiples of 4,
+ * >= c) of Q / Ctr / dQ / dCtr; everything else as in the dense entry points; n == m.  Only shapes
+ * pcops_edge_ld_supported() accepts have kernels (64-channel slices, whole 64-group chunks, LDS-resident clouds);
+ * PCOPS_ERR_UNSUPPORTED otherwise, and in deterministic mode.  The sa_* pair is the Q + Ctr form of
+ * pcops_sa_gather_fwd / pcops_sa_scatter_bwd (no coordinate term, G materialised, dQ and dCtr both produced). */
+int pcops_edge_ld_supported(int b, int n, int m, int s, int c);
+int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, const float *gamma, float *SQ, float *qsel, unsigned char *arg,
+                           float *stats_partial, const float *stat_pivot, pcops_stream_t stream);
+int pcops_edge_pool_out_ld(long long groups, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
+                           const float *shift, float *out, float *ysel, pcops_stream_t stream);
+int pcops_edge_pool_bwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, const float *gpool, const float *ysel, const float *SQ,
+                           const unsigned char *arg, const float *scale, const float *shift, const float *p,
+                           const float *q, const float *t, float *dQ, int lddq, float *dCtr, int lddc, void *workspace,
+                           pcops_stream_t stream);
+int pcops_sa_gather_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, float *Y, float *stats_partial, const float *stat_pivot,
+                           pcops_stream_t stream);
+int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, const float *p, const float *q,
+                            const float *t, const int *idx, const float *Q, int ldq, const float *Ctr, int ldc,
+                            float *dQ, int lddq, float *dCtr, int lddc, void *workspace, pcops_stream_t stream);
+
+/* the concatenated weight of the [Q | Ctr] form: W1 (2 c, cp) = the reference's EdgeConv kernel [W_a ; W_b] (rows 0..c-1
+ * multiply x_i, rows c..2c-1 multiply x_j - x_i), b1 (cp) or NULL -> Wcat (kp, 2 cp) = [W_b | W_a - W_b] (rows c..kp-1
+ * zero: the input zero-padded to kp channels), bcat (2 cp) = [0 | b1]; and the backward map dWcat, dbcat -> dW1, db1. */
+int pcops_edge_weights_fwd(int c, int cp, int kp, const float *W1, const float *b1, float *Wcat, float *bcat,
+                           pcops_stream_t stream);
+int pcops_edge_weights_bwd(int c, int cp, const float *dWcat, const float *dbcat, float *dW1, float *db1,
+                           pcops_stream_t stream);
+
 /* ------------------------------------------------------------- classifier / T-Net heads (csrc/head.hip)
  * BatchNorm (+ ReLU) of a fully connected layer's output over R rows (the batch) as one launch per direction:
  * fully_connected(..., bn=True) of pointnet2/utils/tf_util.py:327-363 (batch_norm_for_fc :534-546) and

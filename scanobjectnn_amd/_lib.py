@@ -85,6 +85,13 @@ SIGNATURES = {
     "pcops_knn_point_dist": ([_I, _I, _I, _I, _P, _P, _P], True),
     "pcops_scatter_rows_sorted": ([_I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P], True),
     "pcops_edge_feature_grad_central": ([_I, _I, _I, _I, _P, _P], True),
+    "pcops_edge_pool_fwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
+    "pcops_edge_pool_out_ld": ([_LL, _I, _P, _P, _I, _P, _P, _P, _P], True),
+    "pcops_edge_pool_bwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I] + [_P] * 10 + [_P, _I, _P, _I, _P], True),
+    "pcops_sa_gather_fwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P], True),
+    "pcops_sa_scatter_bwd_ld": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], True),
+    "pcops_edge_weights_fwd": ([_I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_edge_weights_bwd": ([_I, _I, _P, _P, _P, _P], True),
     "pcops_fc_bn_fwd": ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P], True),
     "pcops_fc_bn_bwd": ([_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P], True),
 }
@@ -107,6 +114,7 @@ PLAIN = {
     "pcops_sa_scatter_rows": ([_I, _I], _I),
     "pcops_edge_pool_stats_rows": ([_LL], _I),
     "pcops_edge_pool_fwd_stats_rows": ([_I] * 5, _I),
+    "pcops_edge_ld_supported": ([_I] * 5, _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),
     "pcops_mlp_gemm_fwd_pool_rows_supported": ([_I, _I, _I], _I),

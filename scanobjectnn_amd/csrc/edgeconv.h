@@ -9,15 +9,23 @@ bool ec_fwd_supported(int b, int n, int m, int s, int c);
 bool ec_bwd_supported(int b, int n, int m, int s, int c);
 int ec_stats_rows(long long G);      // partial-statistics rows the L2-gather forward kernels write: one per 64 groups
 int ec_edge_pool_stats_rows(int b, int n, int m);     // ... and what pcops_edge_pool_fwd writes (one per cloud on LDS slices)
+// ldq / ldc / lddq / lddc: row strides (floats) of Q / Ctr / dQ / dCtr: c for dense tensors, 2 c for the column halves
+// of one (b, n, 2 c) product [Q | Ctr]
 // pooled EdgeConv layer (pcops_edge_pool_fwd): SQ, qsel, arg, shifted moments
-int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
-                     float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st);
+int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const int *idx,
+                     const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot,
+                     hipStream_t st);
 // stored first layer of a gather stack, Y = Q[idx] + Ctr (pcops_sa_gather_fwd_rows in its Q + Ctr form)
-int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, float *Y,
-                  float *stats, const float *pivot, hipStream_t st);
-// inverse index of idx into `workspace` (order | start), then the owner walk over it
+int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const int *idx,
+                  float *Y, float *stats, const float *pivot, hipStream_t st);
+// inverse index of idx into `workspace` (order | start | perm | codes), then the owner walk over it
 int ec_csr_build(int b, int n, int m, int s, const int *idx, void *workspace, hipStream_t st);
-int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const float *p,
-            const float *q, const float *t, const void *workspace, float *dQ, hipStream_t st);
-int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const int *idx,
-                const float *p, const float *q, const float *t, float *dCtr, hipStream_t st);
+int ec_walk(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *G,
+            const float *p, const float *q, const float *t, const void *workspace, float *dQ, int lddq, hipStream_t st);
+int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *G,
+                const int *idx, const float *p, const float *q, const float *t, float *dCtr, int lddc, hipStream_t st);
+// arg-row term of the EdgeConv backward + dCtr (initialises dQ); LDS slice of n x 16 floats
+bool ec_sparse_ok(int n);
+int ec_sparse(int b, int n, int m, int s, int c, const float *gpool, const float *ysel, const float *SQ, const float *Ctr,
+              int ldc, const unsigned char *arg, const int *idx, const float *scale, const float *shift, const float *p,
+              const float *q, const float *t, float *dCtr, int lddc, float *dQ, int lddq, hipStream_t st);

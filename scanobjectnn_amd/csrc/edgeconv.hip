@@ -44,8 +44,11 @@ __device__ __forceinline__ unsigned ec_load1(__amdgpu_buffer_rsrc_t r, unsigned 
 constexpr int kGB = 64;          // groups (forward) / points (walk) per workgroup
 constexpr int kSets = 16;        // 16-lane sets per 256-thread workgroup: one group / point each, four rounds
 
+// ldq / ldc (and lddq / lddc below): row strides in floats of Q / Ctr (dQ / dCtr) -- C for dense tensors, 2 C when the
+// two are the column halves of ONE (b, n, 2 C) product [Q | Ctr] (the *_ld entry points: one GEMM, one gradient)
 struct FwdArgs {
     int b, n, m, S, C;
+    int ldq, ldc;
     const float *Q, *Ctr;
     const int *idx;
     const float *gamma;          // MODE 0: direction of the extremum
@@ -89,7 +92,7 @@ __device__ __forceinline__ void ec_fwd_groups(const FwdArgs &a, const unsigned *
     for (int r = 0; r < kGB / kSets; ++r) {
         const int gl = set + kSets * r;
         const long long g = g0 + gl;
-        const float4 c4 = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+        const float4 c4 = *reinterpret_cast<const float4 *>(a.Ctr + g * a.ldc + ch);
         const f2 ct[2] = {{c4.x, c4.y}, {c4.z, c4.w}};
         f2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}}, sq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
         float ex[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256) void ec_fwd_kernel(FwdArgs a) {
     const int ch = h * 64 + quad * 4;
     // byte offsets of the gathered rows, relative to Q: ((b n + idx) C + h 64) * 4 -- one LDS word per (group, slot)
     const int *ig = a.idx + g0 * S;
-    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)C + (unsigned)h * 64u) * 4u;
-    const unsigned c4 = (unsigned)C * 4u;
+    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)a.ldq + (unsigned)h * 64u) * 4u;
+    const unsigned c4 = (unsigned)a.ldq * 4u;
     for (int e = tid; e < kGB * S; e += 256) ec_sm[e] = (unsigned)ig[e] * c4 + base;
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * C * 4));
+    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * a.ldq * 4));
     const unsigned tq = (unsigned)quad * 16u;
     f2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     bool up = true;
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(1024) void ec_csr_build_kernel(int n, int m, int S,
 // sentinel (m << 8), whose rows lie outside the cloud-sized buffer resources and read as zeros.
 struct WalkArgs {
     int b, n, m, S, C;
+    int ldq, ldc, lddq;
     const float *Q, *Ctr, *G;
     const float *p, *q, *t;
     const unsigned *order;
@@ -336,9 +340,10 @@ __global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
     const int h = rem / P, chunk = rem - h * P;
     const int tid = threadIdx.x, set = tid >> 4, quad = tid & 15;
     const int ch = h * 64 + quad * 4;
-    const unsigned c4 = (unsigned)C * 4u, tq = ((unsigned)h * 64u + (unsigned)quad * 4u) * 4u;
+    const unsigned c4 = (unsigned)C * 4u, cc4 = (unsigned)a.ldc * 4u, tq = ((unsigned)h * 64u + (unsigned)quad * 4u) * 4u;
     const int mS = a.m * S;
-    const __amdgpu_buffer_rsrc_t rc = ec_rsrc(a.Ctr + (long long)b * a.m * C, (unsigned)a.m * c4);
+    // (the Ctr resource ends with the cloud's last row: a column-slice view shares its rows with Q, never with cloud b + 1)
+    const __amdgpu_buffer_rsrc_t rc = ec_rsrc(a.Ctr + (long long)b * a.m * a.ldc, (unsigned)(a.m - 1) * cc4 + c4);
     const __amdgpu_buffer_rsrc_t rg = ec_rsrc(HAS_G ? a.G + (long long)b * mS * C : a.Ctr, HAS_G ? (unsigned)mS * c4 : 0u);
     const __amdgpu_buffer_rsrc_t ro = ec_rsrc(a.order + (long long)b * mS, (unsigned)mS * 4u);
     const int *sb = a.start + (long long)b * (a.n + 1);
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const unsigned g = w[u] >> 8;
-                cc[u] = ec_load4(rc, g * c4 + tq);
+                cc[u] = ec_load4(rc, g * cc4 + tq);
                 if (HAS_G) gg[u] = ec_load4(rg, (g * (unsigned)S + (w[u] & 255u)) * c4 + tq);
             }
 #pragma unroll
@@ -374,8 +379,8 @@ __global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
         }
         const long long pt = (long long)b * a.n + i;
         const float kf = (float)(k1 - k0);
-        const float4 qi = *reinterpret_cast<const float4 *>(a.Q + pt * C + ch);
-        float4 *dst = reinterpret_cast<float4 *>(a.dQ + pt * C + ch);
+        const float4 qi = *reinterpret_cast<const float4 *>(a.Q + pt * a.ldq + ch);
+        float4 *dst = reinterpret_cast<float4 *>(a.dQ + pt * a.lddq + ch);
         float4 d;
         d.x = fmaf(cq.x, fmaf(kf, qi.x, ac[0].x), kf * ct.x);
         d.y = fmaf(cq.y, fmaf(kf, qi.y, ac[0].y), kf * ct.y);
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(256) void ec_walk_kernel(WalkArgs a) {
 // the G rows of a group are one contiguous run (streamed), the Q rows are L2 gathers exactly as in the forward.
 struct CtrArgs {
     int b, n, m, S, C;
+    int ldq, ldc, lddc;
     const float *Q, *Ctr, *G;
     const int *idx;
     const float *p, *q, *t;
@@ -415,11 +421,11 @@ __global__ __launch_bounds__(256) void ec_tnet_ctr_kernel(CtrArgs a) {
     const int tid = threadIdx.x, set = tid >> 4, quad = tid & 15;
     const int ch = h * 64 + quad * 4;
     const int *ig = a.idx + g0 * S;
-    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)C + (unsigned)h * 64u) * 4u;
-    const unsigned c4 = (unsigned)C * 4u;
+    const unsigned base = ((unsigned)b * (unsigned)a.n * (unsigned)a.ldq + (unsigned)h * 64u) * 4u;
+    const unsigned c4 = (unsigned)a.ldq * 4u;
     for (int e = tid; e < kGB * S; e += 256) ec_sm[e] = (unsigned)ig[e] * c4 + base;
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * C * 4));
+    const __amdgpu_buffer_rsrc_t rq = ec_rsrc(a.Q, (unsigned)((long long)a.b * a.n * a.ldq * 4));
     const unsigned tq = (unsigned)quad * 16u;
     const float4 cp = *reinterpret_cast<const float4 *>(a.p + ch);
     const float4 cq = *reinterpret_cast<const float4 *>(a.q + ch);
@@ -452,13 +458,13 @@ __global__ __launch_bounds__(256) void ec_tnet_ctr_kernel(CtrArgs a) {
             sq[0] += f2{qv.x, qv.y}; sq[1] += f2{qv.z, qv.w};
             sgm[0] += f2{gv.x, gv.y}; sgm[1] += f2{gv.z, gv.w};
         }
-        const float4 c4v = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+        const float4 c4v = *reinterpret_cast<const float4 *>(a.Ctr + g * a.ldc + ch);
         float4 d;
         d.x = fmaf(cp.x, sgm[0].x, fmaf(cq.x, fmaf(kf, c4v.x, sq[0].x), kf * ct.x));
         d.y = fmaf(cp.y, sgm[0].y, fmaf(cq.y, fmaf(kf, c4v.y, sq[0].y), kf * ct.y));
         d.z = fmaf(cp.z, sgm[1].x, fmaf(cq.z, fmaf(kf, c4v.z, sq[1].x), kf * ct.z));
         d.w = fmaf(cp.w, sgm[1].y, fmaf(cq.w, fmaf(kf, c4v.w, sq[1].y), kf * ct.w));
-        *reinterpret_cast<float4 *>(a.dCtr + g * C + ch) = d;
+        *reinterpret_cast<float4 *>(a.dCtr + g * a.lddc + ch) = d;
     }
 }
 
@@ -502,7 +508,7 @@ __device__ __forceinline__ void ec_fwd_lds_groups(const FwdArgs &a, const float4
             for (int j = 0; j < NI; ++j)
                 if (j < ni) cur[j] = *reinterpret_cast<const int4 *>(a.idx + g * S + 4 * j);
         }
-        curc = *reinterpret_cast<const float4 *>(a.Ctr + g * C + ch);
+        curc = *reinterpret_cast<const float4 *>(a.Ctr + g * a.ldc + ch);
     }
 #pragma unroll 1
     for (int gl = quad; gl < m; gl += 256) {
@@ -515,7 +521,7 @@ __device__ __forceinline__ void ec_fwd_lds_groups(const FwdArgs &a, const float4
                 for (int j = 0; j < NI; ++j)
                     if (j < ni) nxt[j] = *reinterpret_cast<const int4 *>(a.idx + (g + 256) * S + 4 * j);
             }
-            nxtc = *reinterpret_cast<const float4 *>(a.Ctr + (g + 256) * C + ch);
+            nxtc = *reinterpret_cast<const float4 *>(a.Ctr + (g + 256) * a.ldc + ch);
         }
         const f2 ct[2] = {{curc.x, curc.y}, {curc.z, curc.w}};
         f2 sq[2] = {{0.f, 0.f}, {0.f, 0.f}}, sq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -581,8 +587,8 @@ __global__ __launch_bounds__(1024) void ec_fwd_lds_kernel(FwdArgs a) {
     const int tid = threadIdx.x, quad = tid >> 2, cl = tid & 3;
     const int ch = sl * kSliceCh + cl * 4;
     {
-        const float *src = a.Q + (long long)b * n * C + ch;
-        for (int i = quad; i < n; i += 256) ec_qs[i * 4 + cl] = *reinterpret_cast<const float4 *>(src + (long long)i * C);
+        const float *src = a.Q + (long long)b * n * a.ldq + ch;
+        for (int i = quad; i < n; i += 256) ec_qs[i * 4 + cl] = *reinterpret_cast<const float4 *>(src + (long long)i * a.ldq);
     }
     __syncthreads();
     f2 s1[2] = {{0.f, 0.f}, {0.f, 0.f}}, s2[2] = {{0.f, 0.f}, {0.f, 0.f}};
@@ -650,8 +656,8 @@ __global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
     unsigned short *cs16 = reinterpret_cast<unsigned short *>((reinterpret_cast<uintptr_t>(ss + (n + 1)) + 15) & ~(uintptr_t)15);
     {
         const int pair = tid >> 1, cl = tid & 1;
-        const float *src = a.Ctr + (long long)b * m * C + sl * kWalkCh + cl * 4;
-        for (int j = pair; j < m; j += 512) ec_cs[j * 2 + cl] = *reinterpret_cast<const float4 *>(src + (long long)j * C);
+        const float *src = a.Ctr + (long long)b * m * a.ldc + sl * kWalkCh + cl * 4;
+        for (int j = pair; j < m; j += 512) ec_cs[j * 2 + cl] = *reinterpret_cast<const float4 *>(src + (long long)j * a.ldc);
         if (pair == 0) ec_cs[m * 2 + cl] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int *sb = a.start + (long long)b * (n + 1);
         for (int i = tid; i <= n; i += 1024) ss[i] = sb[i];
@@ -671,17 +677,18 @@ __global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
     const float4 cq1 = *reinterpret_cast<const float4 *>(a.q + sl * kWalkCh + c1 * 4);
     const float4 ct0 = *reinterpret_cast<const float4 *>(a.t + sl * kWalkCh + c0 * 4);
     const float4 ct1 = *reinterpret_cast<const float4 *>(a.t + sl * kWalkCh + c1 * 4);
-    const float *Qb = a.Q + (long long)b * n * C + sl * kWalkCh;
-    float *dQb = a.dQ + (long long)b * n * C + sl * kWalkCh;
+    const float *Qb = a.Q + (long long)b * n * a.ldq + sl * kWalkCh;
+    float *dQb = a.dQ + (long long)b * n * a.lddq + sl * kWalkCh;
+    const int ldq = a.ldq, lddq = a.lddq;
     const int *pb = wa.perm + (long long)b * n;
 #pragma unroll 1
     for (int p = tid; p < n; p += 1024) {
         const int i = pb[p];
         const int k0 = ss[i], k1 = ss[i + 1];
-        const float4 q0 = *reinterpret_cast<const float4 *>(Qb + (long long)i * C + c0 * 4);
-        const float4 q1 = *reinterpret_cast<const float4 *>(Qb + (long long)i * C + c1 * 4);
-        const float4 o0 = *reinterpret_cast<const float4 *>(dQb + (long long)i * C + c0 * 4);
-        const float4 o1 = *reinterpret_cast<const float4 *>(dQb + (long long)i * C + c1 * 4);
+        const float4 q0 = *reinterpret_cast<const float4 *>(Qb + (long long)i * ldq + c0 * 4);
+        const float4 q1 = *reinterpret_cast<const float4 *>(Qb + (long long)i * ldq + c1 * 4);
+        const float4 o0 = *reinterpret_cast<const float4 *>(dQb + (long long)i * lddq + c0 * 4);
+        const float4 o1 = *reinterpret_cast<const float4 *>(dQb + (long long)i * lddq + c1 * 4);
         f2 a0[2] = {{0.f, 0.f}, {0.f, 0.f}}, a1[2] = {{0.f, 0.f}, {0.f, 0.f}};
         int k = k0;
         for (; k + 4 <= k1; k += 4) {
@@ -711,8 +718,8 @@ __global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
         d1.y = o1.y + fmaf(cq1.y, fmaf(kf, q1.y, a1[0].y), kf * ct1.y);
         d1.z = o1.z + fmaf(cq1.z, fmaf(kf, q1.z, a1[1].x), kf * ct1.z);
         d1.w = o1.w + fmaf(cq1.w, fmaf(kf, q1.w, a1[1].y), kf * ct1.w);
-        *reinterpret_cast<float4 *>(dQb + (long long)i * C + c0 * 4) = d0;
-        *reinterpret_cast<float4 *>(dQb + (long long)i * C + c1 * 4) = d1;
+        *reinterpret_cast<float4 *>(dQb + (long long)i * lddq + c0 * 4) = d0;
+        *reinterpret_cast<float4 *>(dQb + (long long)i * lddq + c1 * 4) = d1;
     }
 }
 
@@ -727,10 +734,71 @@ bool ec_lds_on() {
     return on;
 }
 
+// ---- the arg-row term of the EdgeConv backward + dCtr (gather.hip edge_pool_bwd_sparse_kernel with row strides) -------
+//   a[g,c] = p[c] gpool[g,c] [relu(bn(ysel[g,c])) > 0]  goes to row idx[g, arg[g,c]] of dQ;  dCtr[g] = q (SQ + k Ctr) + k t + a.
+// One workgroup per (cloud, 16-channel slice): the slice of dQ (n x 16 floats) is accumulated in LDS with LDS atomics --
+// one per (group, channel), 20x fewer than the dense term -- and leaves with plain stores (this initialises dQ).
+constexpr int kSparseSlice = 16;
+struct SparseArgs {
+    int n, m, S, C, ldc, lddq, lddc;
+    const float *gpool, *ysel, *SQ, *Ctr;
+    const unsigned char *arg;
+    const int *idx;
+    const float *scale, *shift, *p, *q, *t;
+    float *dCtr, *dQ;
+};
+
+__global__ __launch_bounds__(1024) void ec_sparse_kernel(SparseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ec_acc[];          // [n][16]
+    constexpr int NT = 1024, GL = NT / kSparseSlice, U = 4;
+    const int n = a.n, m = a.m, S = a.S, C = a.C;
+    const int nsl = C / kSparseSlice;
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)nsl), c0 = (int)(vb - (unsigned)b * (unsigned)nsl) * kSparseSlice;
+    const int tid = threadIdx.x, cl = tid % kSparseSlice, gl = tid / kSparseSlice;
+    for (int e = tid; e < n * kSparseSlice; e += NT) ec_acc[e] = 0.f;
+    __syncthreads();
+    const int c = c0 + cl;
+    const float sc = a.scale[c], sh = a.shift[c], pc = a.p[c], qc = a.q[c], tc = a.t[c];
+    const float kf = (float)S;
+    for (int j0 = gl; j0 < m; j0 += GL * U) {
+        float ys[U], gp[U], ce[U], sq[U];
+        int ar[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL < m ? j0 + u * GL : j0;
+            const long long g = (long long)b * m + j;
+            const long long e = g * C + c;
+            ys[u] = a.ysel[e]; gp[u] = a.gpool[e]; ce[u] = a.Ctr[g * a.ldc + c]; sq[u] = a.SQ[e]; ar[u] = a.arg[e];
+        }
+        int di[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL < m ? j0 + u * GL : j0;
+            di[u] = a.idx[((long long)b * m + j) * S + ar[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * GL;
+            if (j >= m) continue;
+            const long long g = (long long)b * m + j;
+            const float av = fmaf(ys[u], sc, sh) > 0.f ? pc * gp[u] : 0.f;
+            a.dCtr[g * a.lddc + c] = fmaf(qc, fmaf(kf, ce[u], sq[u]), fmaf(kf, tc, av));
+            if (av != 0.f) atomicAdd(&ec_acc[di[u] * kSparseSlice + cl], av);
+        }
+    }
+    __syncthreads();
+    float *dst = a.dQ + (long long)b * n * a.lddq + c0;
+    for (int e = tid; e < n * (kSparseSlice / 4); e += NT) {
+        const int i = e / (kSparseSlice / 4), quad = (e % (kSparseSlice / 4)) * 4;
+        *reinterpret_cast<float4 *>(dst + (long long)i * a.lddq + quad) = *reinterpret_cast<const float4 *>(&ec_acc[i * kSparseSlice + quad]);
+    }
+}
+
 bool ec_shape_ok(int b, int n, int m, int s, int c) {
-    // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q / the cloud's G rows
+    // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q (row stride up to 2 c) / the cloud's G rows
     return c >= 64 && c % 64 == 0 && m >= kGB && m % kGB == 0 && s >= 1 && s <= 128 && n >= 1 &&
-           (long long)b * n * c * 4 < (1ll << 32) && ((long long)m * s + 256) * c * 4 < (1ll << 32) && m < (1 << 23) &&
+           (long long)b * n * c * 8 < (1ll << 32) && ((long long)m * s + 256) * c * 4 < (1ll << 32) && m < (1 << 23) &&
            (long long)b * (c / 64) * ((n + kGB - 1) / kGB) < (1ll << 31) && (long long)b * (c / 64) * (m / kGB) < (1ll << 31);
 }
 
@@ -750,9 +818,10 @@ int ec_edge_pool_stats_rows(int b, int n, int m) {
     return (ec_lds_on() && ec_lds_fwd_ok(n)) ? b : ec_stats_rows((long long)b * m);
 }
 
-int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, const float *gamma,
-                     float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot, hipStream_t st) {
-    FwdArgs a = {b, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel, arg, nullptr, stats, pivot};
+int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const int *idx,
+                     const float *gamma, float *SQ, float *qsel, unsigned char *arg, float *stats, const float *pivot,
+                     hipStream_t st) {
+    FwdArgs a = {b, n, m, s, c, ldq, ldc, Q, Ctr, idx, gamma, SQ, qsel, arg, nullptr, stats, pivot};
     if (ec_lds_on() && ec_lds_fwd_ok(n)) {
         const size_t lds = (size_t)n * 64 + 16 * 2 * kSliceCh * sizeof(float);
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_fwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -767,9 +836,9 @@ int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const fl
     return pcops_launch_status();
 }
 
-int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx, float *Y,
-                  float *stats, const float *pivot, hipStream_t st) {
-    FwdArgs a = {b, n, m, s, c, Q, Ctr, idx, nullptr, nullptr, nullptr, nullptr, Y, stats, pivot};
+int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const int *idx,
+                  float *Y, float *stats, const float *pivot, hipStream_t st) {
+    FwdArgs a = {b, n, m, s, c, ldq, ldc, Q, Ctr, idx, nullptr, nullptr, nullptr, nullptr, Y, stats, pivot};
     const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
     const size_t lds = ((size_t)kGB * s + kSets * 128) * sizeof(float);
     hipLaunchKernelGGL(ec_fwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
@@ -806,11 +875,11 @@ int ec_csr_build(int b, int n, int m, int s, const int *idx, void *workspace, hi
     return pcops_launch_status();
 }
 
-int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const float *p,
-            const float *q, const float *t, const void *workspace, float *dQ, hipStream_t st) {
+int ec_walk(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *G,
+            const float *p, const float *q, const float *t, const void *workspace, float *dQ, int lddq, hipStream_t st) {
     const unsigned *order = static_cast<const unsigned *>(workspace);
     const int *start = reinterpret_cast<const int *>(order + (size_t)b * m * s);
-    WalkArgs a = {b, n, m, s, c, Q, Ctr, G, p, q, t, order, start, dQ};
+    WalkArgs a = {b, n, m, s, c, ldq, ldc, lddq, Q, Ctr, G, p, q, t, order, start, dQ};
     if (!G && ec_lds_on() && ec_lds_walk_ok(n, m, s) && c % kWalkCh == 0) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_walk_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kLdsMax) != hipSuccess)
@@ -827,10 +896,82 @@ int ec_walk(int b, int n, int m, int s, int c, const float *Q, const float *Ctr,
     return pcops_launch_status();
 }
 
-int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const float *G, const int *idx,
-                const float *p, const float *q, const float *t, float *dCtr, hipStream_t st) {
-    CtrArgs a = {b, n, m, s, c, Q, Ctr, G, idx, p, q, t, dCtr};
+int ec_tnet_ctr(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *G,
+                const int *idx, const float *p, const float *q, const float *t, float *dCtr, int lddc, hipStream_t st) {
+    CtrArgs a = {b, n, m, s, c, ldq, ldc, lddc, Q, Ctr, G, idx, p, q, t, dCtr};
     const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
     hipLaunchKernelGGL(ec_tnet_ctr_kernel, dim3(grid), dim3(256), (size_t)kGB * s * sizeof(unsigned), st, a);
+    return pcops_launch_status();
+}
+
+bool ec_sparse_ok(int n) { return (size_t)n * kSparseSlice * sizeof(float) <= kLdsMax; }
+
+int ec_sparse(int b, int n, int m, int s, int c, const float *gpool, const float *ysel, const float *SQ, const float *Ctr,
+              int ldc, const unsigned char *arg, const int *idx, const float *scale, const float *shift, const float *p,
+              const float *q, const float *t, float *dCtr, int lddc, float *dQ, int lddq, hipStream_t st) {
+    SparseArgs a = {n, m, s, c, ldc, lddq, lddc, gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ};
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_sparse_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(ec_sparse_kernel, dim3((unsigned)b * (c / kSparseSlice)), dim3(1024), (size_t)n * kSparseSlice * sizeof(float),
+                       st, a);
+    return pcops_launch_status();
+}
+
+// ---- the concatenated EdgeConv weight ---------------------------------------------------------------------------------
+// W1 (2 c, cp) = [W_a ; W_b] (rows 0..c-1 multiply x_i, rows c..2c-1 multiply x_j - x_i)  ->  Wcat (kp, 2 cp) =
+// [W_b | W_a - W_b] with rows c..kp-1 zero (the input is zero-padded to kp channels), bcat (2 cp) = [0 | b1].
+// Backward: dW_a = dWcat[:, cp:], dW_b = dWcat[:, :cp] - dWcat[:, cp:], db1 = dbcat[cp:].  One launch each instead of the
+// slice / subtract / pad / concatenate chain (and, backward, the zero-fill + copy + add of every slice).
+namespace {
+__global__ __launch_bounds__(256) void edge_weights_fwd_kernel(int c, int cp, int kp, const float *__restrict__ W1,
+                                                               const float *__restrict__ b1, float *__restrict__ Wcat,
+                                                               float *__restrict__ bcat) {
+    const int total = kp * 2 * cp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total + 2 * cp; e += gridDim.x * 256) {
+        if (e >= total) {
+            const int j = e - total;
+            bcat[j] = j < cp ? 0.f : (b1 ? b1[j - cp] : 0.f);
+            continue;
+        }
+        const int r = e / (2 * cp), j = e - r * 2 * cp;
+        float v = 0.f;
+        if (r < c) v = j < cp ? W1[(c + r) * cp + j] : W1[r * cp + (j - cp)] - W1[(c + r) * cp + (j - cp)];
+        Wcat[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void edge_weights_bwd_kernel(int c, int cp, const float *__restrict__ dWcat,
+                                                               const float *__restrict__ dbcat, float *__restrict__ dW1,
+                                                               float *__restrict__ db1) {
+    const int total = 2 * c * cp;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total + cp; e += gridDim.x * 256) {
+        if (e >= total) {
+            if (db1) db1[e - total] = dbcat[cp + (e - total)];
+            continue;
+        }
+        const int r = e / cp, j = e - r * cp;
+        dW1[e] = r < c ? dWcat[r * 2 * cp + cp + j] : dWcat[(r - c) * 2 * cp + j] - dWcat[(r - c) * 2 * cp + cp + j];
+    }
+}
+}  // namespace
+
+extern "C" int pcops_edge_weights_fwd(int c, int cp, int kp, const float *W1, const float *b1, float *Wcat, float *bcat,
+                                      pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(c >= 1 && cp >= 1 && kp >= c);
+    PCOPS_REQUIRE_PTR(W1); PCOPS_REQUIRE_PTR(Wcat); PCOPS_REQUIRE_PTR(bcat);
+    const int total = kp * 2 * cp + 2 * cp;
+    hipLaunchKernelGGL(edge_weights_fwd_kernel, dim3(cdiv(total, 256) < 256u ? cdiv(total, 256) : 256u), dim3(256), 0,
+                       as_stream(stream), c, cp, kp, W1, b1, Wcat, bcat);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_edge_weights_bwd(int c, int cp, const float *dWcat, const float *dbcat, float *dW1, float *db1,
+                                      pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(c >= 1 && cp >= 1);
+    PCOPS_REQUIRE_PTR(dWcat); PCOPS_REQUIRE_PTR(dW1);
+    if (db1) PCOPS_REQUIRE_PTR(dbcat);
+    const int total = 2 * c * cp + cp;
+    hipLaunchKernelGGL(edge_weights_bwd_kernel, dim3(cdiv(total, 256) < 256u ? cdiv(total, 256) : 256u), dim3(256), 0,
+                       as_stream(stream), c, cp, dWcat, dbcat, dW1, db1);
     return pcops_launch_status();
 }

@@ -1575,7 +1575,7 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     if (gather_fwd_is_ec(b, n, m, s, c, Q != nullptr, Ctr != nullptr, Wxyz != nullptr || bias != nullptr || off4 != nullptr ||
                          moments != nullptr, rows != nullptr) && Y != nullptr)
-        return ec_gather_fwd(b, n, m, s, c, Q, Ctr, idx, Y, stats_partial, stat_pivot, as_stream(stream));
+        return ec_gather_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, Y, stats_partial, stat_pivot, as_stream(stream));
     const int rl = 256 / (c / 4);
     const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
@@ -1641,9 +1641,9 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
         // so Y is not read at all and G is read twice (streamed per group for dCtr, gathered per point for dQ)
         int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
         if (rc) return rc;
-        rc = ec_tnet_ctr(b, n, m, s, c, fwd_Q, fwd_Ctr, G, idx, p, q, t, dCtr, st);
+        rc = ec_tnet_ctr(b, n, m, s, c, fwd_Q, c, fwd_Ctr, c, G, idx, p, q, t, dCtr, c, st);
         if (rc) return rc;
-        return ec_walk(b, n, m, s, c, fwd_Q, fwd_Ctr, G, p, q, t, workspace, dQ, st);
+        return ec_walk(b, n, m, s, c, fwd_Q, c, fwd_Ctr, c, G, p, q, t, workspace, dQ, c, st);
     }
     // gather formulation: feature gradient wanted, G materialised, no per-group output
     const int lpr = c <= 256 ? c / 4 : 64;
@@ -1820,7 +1820,7 @@ int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const
     // round 5: 64-channel slices, offsets staged in LDS, XCD-contiguous clouds (edgeconv.hip); same outputs, and
     // b m / 64 = pcops_edge_pool_stats_rows(G) rows of partial statistics
     if (ec_fwd_supported(b, n, m, s, c) && s <= 256)
-        return ec_edge_pool_fwd(b, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot, as_stream(stream));
+        return ec_edge_pool_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot, as_stream(stream));
     const int gl = 256 / (c / 4);
     hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3(pcops_edge_pool_stats_rows(G)), dim3(256),
                        (size_t)gl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel,
@@ -1870,7 +1870,7 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
                            gpool, ysel, SQ, Ctr, arg, idx, scale, shift, p, q, t, dCtr, dQ);
         int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
         if (rc) return rc;
-        return ec_walk(b, n, m, s, c, Q, Ctr, nullptr, p, q, t, workspace, dQ, st);
+        return ec_walk(b, n, m, s, c, Q, c, Ctr, c, nullptr, p, q, t, workspace, dQ, c, st);
     }
     int2 *order = static_cast<int2 *>(workspace);
     int *start = reinterpret_cast<int *>(order + (size_t)b * m * s);
@@ -1927,6 +1927,100 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
         default: hipLaunchKernelGGL(edge_pool_bwd_q_kernel<64>, dim3(2 * kCsrGrid), dim3(256), 0, st, b, n, m, s, c, Q, Ctr, q, t, order, dQ); break;
     }
     return pcops_launch_status();
+}
+
+// ---- the [Q | Ctr] forms (round 5): Q and Ctr are the column halves of ONE (b, n, 2 c) product of the layer's input
+// with the concatenated weight [W_b | W_a - W_b] (dgcnn/tf_util.edge_conv_stack), so the two per-point GEMMs, their two
+// weight gradients and the sum of their two data gradients become one of each.  Only the csrc/edgeconv.hip kernels take
+// row strides: pcops_edge_ld_supported says whether a shape has them (the caller otherwise keeps two dense tensors).
+int pcops_edge_ld_supported(int b, int n, int m, int s, int c) {
+    return (n == m && s <= 256 && ec_fwd_supported(b, n, m, s, c) && ec_bwd_supported(b, n, m, s, c) && ec_sparse_ok(n) &&
+            !pcops_get_deterministic()) ? 1 : 0;
+}
+
+int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, const float *gamma, float *SQ, float *qsel, unsigned char *arg,
+                           float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && ldq % 4 == 0 && ldc % 4 == 0);
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gamma);
+    PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(arg);
+    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    return ec_edge_pool_fwd(b, n, m, s, c, Q, ldq, Ctr, ldc, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot,
+                            as_stream(stream));
+}
+
+namespace {
+__global__ __launch_bounds__(256) void edge_pool_out_ld_kernel(long long total4, int C, int ldc, const float *__restrict__ qsel,
+                                                               const float *__restrict__ Ctr, const float *__restrict__ scale,
+                                                               const float *__restrict__ shift, float *__restrict__ out,
+                                                               float *__restrict__ ysel) {
+    const int c4n = C / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const long long g = e / c4n;
+        const int c = (int)(e - g * c4n) * 4;
+        const float4 qs = *reinterpret_cast<const float4 *>(qsel + g * C + c);
+        const float4 ct = *reinterpret_cast<const float4 *>(Ctr + g * ldc + c);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 y = make_float4(qs.x + ct.x, qs.y + ct.y, qs.z + ct.z, qs.w + ct.w);
+        *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), fmaxf(fmaf(y.y, sc.y, sh.y), 0.f),
+                                                                   fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), fmaxf(fmaf(y.w, sc.w, sh.w), 0.f));
+        if (ysel) *reinterpret_cast<float4 *>(ysel + g * C + c) = y;
+    }
+}
+}  // namespace
+
+int pcops_edge_pool_out_ld(long long G, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
+                           const float *shift, float *out, float *ysel, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 0 && c >= 4 && c % 4 == 0 && ldc >= c && ldc % 4 == 0);
+    if (G == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
+    const long long total4 = G * (c / 4);
+    const unsigned grid = cdiv(total4, 256) < 16384u ? cdiv(total4, 256) : 16384u;
+    hipLaunchKernelGGL(edge_pool_out_ld_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total4, c, ldc, qsel, Ctr, scale,
+                       shift, out, ysel);
+    return pcops_launch_status();
+}
+
+int pcops_edge_pool_bwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, const float *gpool, const float *ysel, const float *SQ, const unsigned char *arg,
+                           const float *scale, const float *shift, const float *p, const float *q, const float *t,
+                           float *dQ, int lddq, float *dCtr, int lddc, void *workspace, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && lddq >= c && lddc >= c);
+    PCOPS_REQUIRE_SHAPE(ldq % 4 == 0 && ldc % 4 == 0 && lddq % 4 == 0 && lddc % 4 == 0);
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
+    PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dQ); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
+    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    int rc = ec_sparse(b, n, m, s, c, gpool, ysel, SQ, Ctr, ldc, arg, idx, scale, shift, p, q, t, dCtr, lddc, dQ, lddq, st);
+    if (rc) return rc;
+    rc = ec_csr_build(b, n, m, s, idx, workspace, st);
+    if (rc) return rc;
+    return ec_walk(b, n, m, s, c, Q, ldq, Ctr, ldc, nullptr, p, q, t, workspace, dQ, lddq, st);
+}
+
+int pcops_sa_gather_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
+                           const int *idx, float *Y, float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && ldq % 4 == 0 && ldc % 4 == 0);
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(Y);
+    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    return ec_gather_fwd(b, n, m, s, c, Q, ldq, Ctr, ldc, idx, Y, stats_partial, stat_pivot, as_stream(stream));
+}
+
+int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, const float *p, const float *q, const float *t,
+                            const int *idx, const float *Q, int ldq, const float *Ctr, int ldc, float *dQ, int lddq,
+                            float *dCtr, int lddc, void *workspace, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && lddq >= c && lddc >= c);
+    PCOPS_REQUIRE_SHAPE(ldq % 4 == 0 && ldc % 4 == 0 && lddq % 4 == 0 && lddc % 4 == 0);
+    PCOPS_REQUIRE_PTR(G); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(idx);
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(dQ); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
+    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
+    if (rc) return rc;
+    rc = ec_tnet_ctr(b, n, m, s, c, Q, ldq, Ctr, ldc, G, idx, p, q, t, dCtr, lddc, st);
+    if (rc) return rc;
+    return ec_walk(b, n, m, s, c, Q, ldq, Ctr, ldc, G, p, q, t, workspace, dQ, lddq, st);
 }
 
 int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const float *moments, int C,

@@ -238,8 +238,19 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
     names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
     layers = _pn2._stack_variables(2 * c, widths, list(scopes), 1e-3, None, True, names)
     w1, b1 = layers[0][0], layers[0][1]
-    w_a, w_b = w1[:c], w1[c:]
     x2d = x.reshape(b * n, c)
+    decay = bn_decay if bn_decay is not None else 0.9
+    k = nn_idx.shape[2]
+    if b * n >= 8192 and widths[0] % 4 == 0 and fused_mlp.edge_qc_supported(b, n, k, widths[0]):
+        # ONE per-point GEMM: X [W_b | W_a - W_b] + [0 | b1] = [Q | Ctr] (pcops.h "[Q | Ctr] forms"), one weight gradient,
+        # one data gradient -- nothing for autograd to slice, pad or add up
+        kp = c if c % 8 == 0 else (c + 7) // 8 * 8
+        xp = x2d if kp == c else F.pad(x2d, (0, kp - c))
+        wcat, bcat = fused_mlp.edge_weights(w1, b1, kp)
+        qc = fused_mlp.rows_linear(xp, wcat, bcat).view(b, n, 2 * widths[0])
+        out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, QC=qc)
+        return out.view(b, n, 1, widths[-1])
+    w_a, w_b = w1[:c], w1[c:]
     if c % 8 == 0 and b * n >= 8192 and widths[0] % 4 == 0:
         # B*N rows into a C x C' weight: the libpcops GEMMs (the library picks a few-CU kernel for these weight gradients)
         q = fused_mlp.rows_linear(x2d, w_b).view(b, n, widths[0])

@@ -71,6 +71,7 @@ class FusedMLPStack(torch.autograd.Function):
         lib = _lib.load()
         rref = rows.ref if rows is not None else None
         identity = bool(int(pool) & 2)      # gather stack whose idx is 0..n-1 per cloud (group_all): scatter = reshape
+        qc = bool(int(pool) & 4)            # a0 is the (B, N, 2 C1) product [Q | Ctr] of ONE GEMM (pcops.h "[Q | Ctr] forms")
         pool = bool(int(pool) & 1)
         gather = idx is not None
         need_grad = any(ctx.needs_input_grad)
@@ -82,6 +83,9 @@ class FusedMLPStack(torch.autograd.Function):
             Nsrc = a0.shape[1] if a0 is not None else xyz.shape[1]
             C1 = layers[0][2].shape[0]
             R, K0 = B * M * S, None
+            if qc:
+                assert ctr is None and xyz is None and wxyz is None and bias is None and rows is None and M == Nsrc
+                assert a0.shape[2] == 2 * C1 and a0.is_contiguous()
         else:
             R, K0 = a0.shape
         Ys, means, rstds, scales, shifts, Ws = [], [], [], [], [], []
@@ -110,7 +114,15 @@ class FusedMLPStack(torch.autograd.Function):
             # forward statistics are shifted moments around the layer's moving mean (pcops.h pcops_mlp_gemm_fwd): the
             # producer and pcops_mlp_bn_finalize get the same pivot; finalize reads it before it updates the buffer
             piv = mm.data_ptr() if (training and STAT_PIVOT) else None
-            if li == 0 and gather:
+            if li == 0 and gather and qc:
+                N = C1
+                Y = _f32((R, N), dev)
+                P = lib.pcops_sa_gather_fwd_stats_rows(B, Nsrc, M, S, N, 1, 1, 0, 0)
+                part = _f32((P, 2, N), dev) if training else None
+                _lib.call("pcops_sa_gather_fwd_ld", B, Nsrc, M, S, N, a0.data_ptr(), 2 * N, a0.data_ptr() + 4 * N, 2 * N,
+                          idx.data_ptr(), Y.data_ptr(), _p(part), piv)
+                W2 = None
+            elif li == 0 and gather:
                 N = C1
                 Y = None if virt else _f32((R, N), dev)
                 other = wxyz is not None or bias is not None or off4 is not None
@@ -217,6 +229,7 @@ class FusedMLPStack(torch.autograd.Function):
                          [l[2] for l in layers], argmax, ysel, off4, xyzw, mom)
             ctx.biases = [l[1] for l in layers]
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
+            ctx.qc = qc
             ctx.rows = rows
             ctx.pool_top = pool_top
             if TRACE is not None:
@@ -294,6 +307,16 @@ class FusedMLPStack(torch.autograd.Function):
                 _lib.call("pcops_xyz_first_layer_grads", xstats.shape[0], xstats.data_ptr(), mom.shape[0], mom.data_ptr(),
                           N, wxyz.data_ptr(), _p(bias), p.data_ptr(), q.data_ptr(), t.data_ptr(), dbeta.data_ptr(),
                           means[0].data_ptr(), R, dwxyz.data_ptr(), _p(dbias))
+                break
+            if l == 0 and gather and getattr(ctx, "qc", False):
+                # [Q | Ctr] form: dQ and dCtr are the column halves of ONE (B, N, 2 C1) gradient
+                B, M, _ = idx.shape
+                Nsrc = a0.shape[1]
+                d0 = _f32((B, Nsrc, 2 * N), dev)
+                wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4, dtype=torch.int32, device=dev)
+                _lib.call("pcops_sa_scatter_bwd_ld", B, Nsrc, M, S, N, Gptr, p.data_ptr(), q.data_ptr(), t.data_ptr(),
+                          idx.data_ptr(), a0.data_ptr(), 2 * N, a0.data_ptr() + 4 * N, 2 * N, d0.data_ptr(), 2 * N,
+                          d0.data_ptr() + 4 * N, 2 * N, wsp.data_ptr())
                 break
             if l == 0 and gather:
                 B, M, _ = idx.shape
@@ -550,6 +573,50 @@ def fc_batch_norm(x, gamma, beta, mm, mv, training, decay, eps, unbiased_moving_
     return y
 
 
+class _EdgeWeights(torch.autograd.Function):
+    """apply(W1 (2 c, cp), b1 (cp) or None, kp) -> Wcat (kp, 2 cp) = [W_b | W_a - W_b] (rows >= c zero), bcat (2 cp) = [0 | b1]:
+    the concatenated weight of the [Q | Ctr] form as one launch per direction (pcops_edge_weights_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, w1, b1, kp):
+        c, cp = w1.shape[0] // 2, w1.shape[1]
+        dev = w1.device
+        wcat, bcat = _f32((kp, 2 * cp), dev), _f32(2 * cp, dev)
+        _lib.call("pcops_edge_weights_fwd", c, cp, int(kp), w1.data_ptr(), _p(b1), wcat.data_ptr(), bcat.data_ptr())
+        ctx.dims = (c, cp, b1 is not None)
+        return wcat, bcat
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dwcat, dbcat):
+        c, cp, has_b = ctx.dims
+        dev = dwcat.device
+        dwcat = dwcat.contiguous()
+        dw1 = _f32((2 * c, cp), dev)
+        db1 = _f32(cp, dev) if has_b else None
+        _lib.call("pcops_edge_weights_bwd", c, cp, dwcat.data_ptr(), dbcat.contiguous().data_ptr() if has_b else None,
+                  dw1.data_ptr(), _p(db1))
+        return dw1, db1, None
+
+
+def edge_weights(w1, b1, kp):
+    return _EdgeWeights.apply(w1.contiguous(), b1, int(kp))
+
+
+_COEF = {}
+
+
+def _unit_coef(n4, dev):
+    """(p, q, t) = (1, 0, 0) for pcops_mlp_wgrad (dY = G): a constant, built once per width and device"""
+    key = (n4, str(dev))
+    v = _COEF.get(key)
+    if v is None:
+        v = torch.zeros(3 * n4, dtype=torch.float32, device=dev)
+        v[:n4] = 1.0
+        _COEF[key] = v
+    return v
+
+
 class _RowsLinear(torch.autograd.Function):
     """Y = X W + b on (rows, K) through the libpcops GEMMs, backward included.  Exists for the per-source-point
     contraction of a grouped first layer (Q = points W_f + b): rows = B*N is large and the weight gradient is a
@@ -581,8 +648,7 @@ class _RowsLinear(torch.autograd.Function):
             _lib.call("pcops_mlp_gemm_fwd", R, N, K, g.data_ptr(), N, None, None, wt.data_ptr(), None, dx.data_ptr(), None, None)
         if ctx.needs_input_grad[1] or ctx.has_bias:
             n4 = (N + 3) // 4 * 4
-            coef = torch.zeros(3 * n4, dtype=torch.float32, device=dev)     # p = 1, q = 0, t = 0: dY = G
-            coef[:n4] = 1.0
+            coef = _unit_coef(n4, dev)                                      # p = 1, q = 0, t = 0: dY = G
             scratch = _f32(lib.pcops_mlp_wgrad_splits(R, K, N) * (K * N + N), dev)
             dw, db = _f32((K, N), dev), _f32(N, dev)
             _lib.call("pcops_mlp_wgrad", R, K, N, x.data_ptr(), K, None, None, g.data_ptr(), g.data_ptr(),
@@ -608,7 +674,8 @@ class EdgeConvPool(torch.autograd.Function):
     def forward(ctx, Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased):
         lib = _lib.load()
         B, M, S = idx.shape
-        Nsrc, C = Q.shape[1], Q.shape[2]
+        qc = Ctr is None            # Q is the (B, N, 2 C) product [Q | Ctr] of ONE GEMM (pcops.h "[Q | Ctr] forms")
+        Nsrc, C = Q.shape[1], (Q.shape[2] // 2 if qc else Q.shape[2])
         dev = Q.device
         G = B * M
         need_grad = any(ctx.needs_input_grad)
@@ -617,9 +684,14 @@ class EdgeConvPool(torch.autograd.Function):
         arg = torch.empty((G, C), dtype=torch.uint8, device=dev)
         P = lib.pcops_edge_pool_fwd_stats_rows(B, Nsrc, M, S, C)
         part = _f32((P, 2, C), dev) if training else None
-        _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
-                  gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part),
-                  mm.data_ptr() if (training and STAT_PIVOT) else None)   # shifted moments around the moving mean
+        piv0 = mm.data_ptr() if (training and STAT_PIVOT) else None          # shifted moments around the moving mean
+        if qc:
+            assert Q.is_contiguous() and M == Nsrc
+            _lib.call("pcops_edge_pool_fwd_ld", B, Nsrc, M, S, C, Q.data_ptr(), 2 * C, Q.data_ptr() + 4 * C, 2 * C,
+                      idx.data_ptr(), gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part), piv0)
+        else:
+            _lib.call("pcops_edge_pool_fwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
+                      gamma.data_ptr(), SQ.data_ptr(), qsel.data_ptr(), arg.data_ptr(), _p(part), piv0)
         vecs = _VecArena([C], 4, dev)
         scale, shift = vecs.take(C), vecs.take(C)
         mean = rstd = None
@@ -641,8 +713,12 @@ class EdgeConvPool(torch.autograd.Function):
                 mean, rstd = mm.detach().clone(), torch.rsqrt(mv.detach() + float(eps))
         out = _f32((G, C), dev)
         ysel = _f32((G, C), dev) if (training or need_grad) else None
-        _lib.call("pcops_edge_pool_out", G, C, qsel.data_ptr(), Ctr.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  out.data_ptr(), _p(ysel))
+        if qc:
+            _lib.call("pcops_edge_pool_out_ld", G, C, qsel.data_ptr(), Q.data_ptr() + 4 * C, 2 * C, scale.data_ptr(),
+                      shift.data_ptr(), out.data_ptr(), _p(ysel))
+        else:
+            _lib.call("pcops_edge_pool_out", G, C, qsel.data_ptr(), Ctr.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                      out.data_ptr(), _p(ysel))
         if training or need_grad:
             ctx.saved = (Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift)
             ctx.flags = (bool(training), bool(sync))
@@ -656,7 +732,8 @@ class EdgeConvPool(torch.autograd.Function):
         Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift = ctx.saved
         training, sync = ctx.flags
         B, M, S = idx.shape
-        Nsrc, C = Q.shape[1], Q.shape[2]
+        qc = Ctr is None
+        Nsrc, C = Q.shape[1], (Q.shape[2] // 2 if qc else Q.shape[2])
         dev = Q.device
         G = B * M
         grad_out = grad_out.contiguous()
@@ -680,8 +757,15 @@ class EdgeConvPool(torch.autograd.Function):
         if not training:
             q.zero_()
             t.zero_()
-        dQ, dCtr = _f32((B, Nsrc, C), dev), _f32((B, M, C), dev)
         wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4, dtype=torch.int32, device=dev)
+        if qc:          # dQ and dCtr: the column halves of ONE gradient of the [Q | Ctr] product
+            dQC = _f32((B, Nsrc, 2 * C), dev)
+            _lib.call("pcops_edge_pool_bwd_ld", B, Nsrc, M, S, C, Q.data_ptr(), 2 * C, Q.data_ptr() + 4 * C, 2 * C,
+                      idx.data_ptr(), grad_out.data_ptr(), ysel.data_ptr(), SQ.data_ptr(), arg.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), dQC.data_ptr(), 2 * C,
+                      dQC.data_ptr() + 4 * C, 2 * C, wsp.data_ptr())
+            return dQC, None, None, dgamma, dbeta, None, None, None, None, None, None
+        dQ, dCtr = _f32((B, Nsrc, C), dev), _f32((B, M, C), dev)
         _lib.call("pcops_edge_pool_bwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
                   grad_out.data_ptr(), ysel.data_ptr(), SQ.data_ptr(), arg.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   p.data_ptr(), q.data_ptr(), t.data_ptr(), dQ.data_ptr(), dCtr.data_ptr(), wsp.data_ptr())
@@ -727,6 +811,7 @@ FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-blo
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
+EDGE_QC = os.environ.get("PCOPS_EDGE_QC", "1") != "0"        # EdgeConv's two per-point GEMMs as one [Q | Ctr] product
 
 
 def _compactable(idx, pool, L, widths, Q, Ctr, xyz, wxyz, identity_idx):
@@ -747,8 +832,14 @@ def _compactable(idx, pool, L, widths, Q, Ctr, xyz, wxyz, identity_idx):
     return bool(_lib.load().pcops_gather_stack_rows_supported(B, n, M, S, 1 if Q is not None else 0, L, arr))
 
 
+def edge_qc_supported(b, n, s, c):
+    """the [Q | Ctr] forms have kernels for this EdgeConv shape (pcops.h): one per-point GEMM instead of two"""
+    return bool(EDGE_QC and _lib.load().pcops_edge_ld_supported(int(b), int(n), int(n), int(s), int(c))
+                and not _dist.sync_bn_active())
+
+
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
-                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None):
+                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None, QC=None):
     """Grouped stack whose first conv was applied before the grouping:
          Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
     idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
@@ -757,6 +848,16 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
     Returns (B*M, C_L) if pool else (B*M*S, C_L)."""
     c = lambda t: t.contiguous() if t is not None else None   # noqa: E731
     S = idx.shape[2]
+    if QC is not None:
+        # QC (B, N, 2 C1) = [Q | Ctr], the product of the layer's input with the concatenated weight (edge_qc_supported)
+        assert Q is None and Ctr is None and xyz is None and wxyz is None and bias is None
+        if len(layer_tensors) == 1 and pool:
+            _w, _b, gamma, beta, mm, mv = layer_tensors[0]
+            return EdgeConvPool.apply(QC.contiguous(), None, idx.contiguous(), gamma, beta, mm, mv, bool(training),
+                                      float(decay), float(eps), bool(unbiased))
+        return FusedMLPStack.apply(QC.contiguous(), None, idx.contiguous(), None, None, None, None, int(S),
+                                   int(bool(pool)) | 4, bool(training), float(decay), float(eps), bool(unbiased), None,
+                                   len(layer_tensors), *_flat(layer_tensors, True))
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xyz, new_xyz)):
         # the fused path has no d(loss)/d(coordinates) (the reference has one through GroupPoint / GatherPoint and
         # the centring subtraction): the callers take the unfused path then -- never detach silently

@@ -520,3 +520,48 @@ def test_split_operand_weight_gradient_accuracy(M, K, N):
     assert err <= 5e-7 and err <= 0.2 * err_torch, (err, err_torch)
     sums = G.double().sum(0)
     assert ((db.double() - sums).abs().max() / sums.abs().max()).item() <= 2e-6
+
+
+# ---------------------------------------------------------------------------- [Q | Ctr] forms (round 5)
+@pytest.mark.parametrize("cin,widths", [(3, [64]), (64, [64]), (64, [128]), (3, [64, 128])])
+def test_edge_conv_stack_one_gemm_matches_two(cin, widths):
+    """edge_conv_stack through ONE per-point product X [W_b | W_a - W_b] (pcops.h "[Q | Ctr] forms": strided Q / Ctr / dQ /
+    dCtr in the edgeconv.hip kernels, concatenated weight by pcops_edge_weights_*) against the two-GEMM path it replaces:
+    same variables, same output, same gradients w.r.t. the input and every variable, same moving statistics"""
+    from scanobjectnn_amd.dgcnn import tf_util as D
+    from scanobjectnn_amd.graph import Model
+    B, N, k = 8, 1024, 20
+    g = torch.Generator().manual_seed(cin * 10 + len(widths))
+    x0 = torch.randn(B, N, cin, generator=g).to(DEV)
+    nn_idx = D.knn_graph(x0, k=k)
+    scopes = ['l%d' % i for i in range(len(widths))]
+
+    def net(x, is_training, bn_decay=None):
+        return D.edge_conv_stack(x, nn_idx, widths, scopes, is_training, bn_decay), {}
+
+    assert fused_mlp.edge_qc_supported(B, N, k, widths[0])
+    res = []
+    for flag in (True, False):
+        fused_mlp.EDGE_QC = flag
+        try:
+            m = Model(net, device=DEV, seed=5).build(x0)
+            x = x0.clone().requires_grad_(True)
+            y, _ = m(x, is_training=True, bn_decay=0.8)
+            torch.manual_seed(1)
+            go = torch.randn(y.shape, device=DEV)
+            y.backward(go)
+            grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+            res.append((y.detach(), x.grad.clone(), grads, {k_: v.clone() for k_, v in m.state_dict().items()}))
+        finally:
+            fused_mlp.EDGE_QC = True
+    (y1, dx1, g1, s1), (y2, dx2, g2, s2) = res
+    assert sorted(g1) == sorted(g2) and sorted(s1) == sorted(s2)
+    assert (y1 - y2).abs().max().item() <= 2e-5 * max(1.0, y2.abs().max().item())
+    assert (dx1 - dx2).abs().max().item() <= 1e-4 * max(1.0, dx2.abs().max().item())
+    for n in g1:
+        # a bias in front of BatchNorm has the exact gradient 0 (BN removes the mean): what either path returns for it is
+        # the rounding residue of a sum over all rows, 1e-4-sized and different between ANY two summation orders
+        tol = 1e-3 if n.endswith("biases") else 2e-4 * max(1.0, g2[n].abs().max().item())
+        assert (g1[n] - g2[n]).abs().max().item() <= tol, n
+    for n in s1:
+        assert torch.allclose(s1[n], s2[n], atol=1e-5, rtol=1e-4), n
