@@ -29,17 +29,28 @@ def sync_bn_active():
 
 
 _STAT_GROUP = None
+# PCOPS_STAT_GROUP=1: the SyncBN statistics travel on their OWN communicator (so that the small, latency-critical
+# all-reduces inside forward / backward do not queue behind the multi-MB gradient ranges `FlatParams.enable_overlap`
+# issues from autograd hooks).  Off by default: two RCCL communicators in flight at once are only safe if
+# every rank's GPU schedules their kernels in the same order, which nothing guarantees when the gradient ranges run
+# asynchronously -- on ONE communicator the issue order (identical on every rank: same graph, same hook order) IS the
+# execution order.  When requested, the group is created EAGERLY in init_from_env(), where every rank is known to
+# arrive (new_group() is a world collective; a lazily created group hangs the job if some rank's first step never
+# reaches a SyncBN layer), and each statistics exchange first waits for the gradient ranges already under way
+# (`pending_work`), which orders the two communicators explicitly.
+STAT_GROUP_SEPARATE = os.environ.get("PCOPS_STAT_GROUP", "0") == "1"
+pending_work = []        # async gradient all-reduces in flight on the default group (FlatParams registers / clears them)
 
 
 def stat_group():
-    """The communicator of the SyncBN statistics: its own process group, so that the small, latency-critical
-    all-reduces inside forward / backward do not queue behind the multi-MB gradient ranges that
-    `FlatParams.enable_overlap` issues on the default group from autograd hooks.  Created at the first use,
-    which every rank reaches at the same point of the same graph."""
-    global _STAT_GROUP
-    if _STAT_GROUP is None:
-        _STAT_GROUP = dist.new_group()
+    """The communicator of the SyncBN statistics: None = the default group, or the dedicated one init_from_env() made"""
     return _STAT_GROUP
+
+
+def _before_stat_exchange():
+    if _STAT_GROUP is not None:
+        for w in pending_work:
+            w.wait()
 
 
 def allreduce_stat_partials(part, rows, pivot=None):
@@ -58,6 +69,7 @@ def allreduce_stat_partials(part, rows, pivot=None):
         tot[0, 1] += 2.0 * p * tot[0, 0] + float(rows) * p * p
         tot[0, 0] += float(rows) * p
     if _multi_rank():
+        _before_stat_exchange()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=stat_group())
     hi = tot.float()
     lo = (tot - hi.double()).float()
@@ -77,6 +89,9 @@ def init_from_env(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    global _STAT_GROUP
+    if world > 1 and STAT_GROUP_SEPARATE and _STAT_GROUP is None:
+        _STAT_GROUP = dist.new_group()          # a world collective: here, where every rank arrives
     return rank, world, local
 
 
@@ -127,6 +142,7 @@ def sync_batch_stats(flat):
     n = flat.shape[0]
     s = torch.stack([flat.sum(dim=0), (flat * flat).sum(dim=0)])
     if _multi_rank():
+        _before_stat_exchange()
         s = dfn.all_reduce(s, op=dist.ReduceOp.SUM, group=stat_group())
     total = n * (dist.get_world_size() if _multi_rank() else 1)
     mean = s[0] / total

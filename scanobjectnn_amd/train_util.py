@@ -122,7 +122,10 @@ class FlatParams:
         import torch.distributed as dist
         i0, i1, s, e = self._buckets[b]
         self._pack(i0, i1, self.grad[s:e])
-        self._works.append(dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        work = dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        self._works.append(work)
+        from . import dist as D
+        D.pending_work.append(work)      # a SyncBN exchange on a separate communicator orders itself behind these
         self._pending[b] = -1            # launched
 
     def collect_mean(self, world):
@@ -138,6 +141,7 @@ class FlatParams:
         for w in self._works:
             w.wait()
         del self._works[:]
+        del D.pending_work[:]
         self.grad.mul_(1.0 / self._world)
         for p, v in zip(self.params, self._gviews):
             p.grad = v

@@ -103,11 +103,13 @@ def _pointnet_setup(batch, npts):
     return pointnet_cls, net, x, y
 
 
-def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps, overlap=0):
+def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps, overlap=0, own_stat_group=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     torch.set_num_threads(1)
+    D.STAT_GROUP_SEPARATE = own_stat_group          # PCOPS_STAT_GROUP=1: created eagerly by init_from_env on every rank
     D.init_from_env(backend="gloo")
+    assert (D.stat_group() is not None) == own_stat_group
     D.SYNC_BN = sync_bn
     mod, net, x, y = _pointnet_setup(batch, npts)
     fp = TU.FlatParams(net)
@@ -134,11 +136,11 @@ def _model_worker(rank, world, port, q, sync_bn, batch, npts, steps, overlap=0):
     dist.destroy_process_group()
 
 
-def _run_model_dp(world, sync_bn, batch=8, npts=32, steps=2, overlap=0):
+def _run_model_dp(world, sync_bn, batch=8, npts=32, steps=2, overlap=0, own_stat_group=False):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, sync_bn, batch, npts, steps, overlap))
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q, sync_bn, batch, npts, steps, overlap, own_stat_group))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -202,6 +204,18 @@ def test_overlapped_bucket_allreduce_equals_the_single_collective():
             assert torch.equal(over[r][3], plain[r][3])                      # first step's averaged gradient
             assert torch.equal(over[r][0], plain[r][0])                      # parameters after two Adam steps
         assert torch.equal(over[0][0], over[1][0])
+
+
+def test_sync_bn_on_its_own_communicator_with_overlapped_ranges():
+    """PCOPS_STAT_GROUP=1: the SyncBN statistics on a dedicated process group -- created eagerly by
+    init_from_env() on every rank (a lazily created group hangs a job whose ranks do not all reach a SyncBN layer), and
+    every exchange ordered behind the gradient ranges already in flight on the default group -- gives the same gradient
+    and parameters as the one-communicator run, with the overlapped ranges enabled"""
+    plain = _run_model_dp(2, sync_bn=True, overlap=3)
+    own = _run_model_dp(2, sync_bn=True, overlap=3, own_stat_group=True)
+    for r in range(2):
+        assert torch.equal(own[r][3], plain[r][3]) and torch.equal(own[r][0], plain[r][0])
+    assert torch.equal(own[0][0], own[1][0])
 
 
 def test_overlap_with_a_parameter_the_loss_does_not_reach():
