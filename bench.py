@@ -114,23 +114,15 @@ class ClockPoller:
 
 
 def _split_operands(d):
-    """does this launch run on the bf16 matrix pipe with split operands (csrc/mlp.hip: ws_plan's forward rule,
-    wgrad_bf3_plan)?"""
-    if d["work_unit"] != "flop":
-        return False
-    if d["kernel"] in SPLIT_OPERAND_KERNELS:
-        return os.environ.get("PCOPS_GEMM_BF3", "1") != "0" and d["shape"][0] >= 8192
-    if d["kernel"] == "pcops_mlp_wgrad":
-        m, k, n = d["shape"][:3]
-        return os.environ.get("PCOPS_WGRAD_BF3", "1") != "0" and m >= 32768 and k > 64 and n > 64
-    return False
+    """did this launch run on the bf16 matrix pipe with split operands?  The LIBRARY's own answer, read back right after
+    the launch (pcops_last_launch_pipe, KernelTimer) -- not a mirror of ws_plan / wgrad_bf3_plan's rules"""
+    return d["work_unit"] == "flop" and d.get("pipe_code") == 1
 
 
 def _half_split(d):
     """the one-pass backward: its dW half on the fp32 pipe, its dX half on the bf16 pipe with split operands
     (bwd_fused_kernel<..., DX3>)"""
-    return (d["work_unit"] == "flop" and d["kernel"] in ("pcops_mlp_bwd_fused", "pcops_mlp_bwd_fused_xyz")
-            and os.environ.get("PCOPS_BWD_FUSED_DX3", "1") != "0")
+    return d["work_unit"] == "flop" and d.get("pipe_code") == 2
 
 
 def _mfma_frac(d):
@@ -351,13 +343,13 @@ class KernelTimer:
         else:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            self.records.append((name, args, self._open, ev))
+            self.records.append((name, args, self._open, ev, int(_lib.load().pcops_last_launch_pipe())))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
         frac_cache = {}
-        for name, args, s, e in self.records:
+        for name, args, s, e, pipe in self.records:
             ms = s.elapsed_time(e)
             compacted = None
             if args and isinstance(args[-1], tuple) and args[-1][0] == "rows":
@@ -378,6 +370,7 @@ class KernelTimer:
             d = agg.setdefault(key, {"kernel": name, "shape": list(key[1:]), "launches": 0, "ms": 0.0,
                                      "bytes": 0, "work": 0, "work_unit": unit})
             d["launches"] += 1
+            d["pipe_code"] = pipe if unit == "flop" else 0     # the matrix pipe the library took for this launch
             d["ms"] += ms
             d["bytes"] += by          # per-launch averages below: compacted row counts vary from step to step
             d["work"] += work

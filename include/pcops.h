@@ -18,7 +18,9 @@
  *     3d_interpolation/tf_interpolate.cpp:258);
  *   - return PCOPS_OK (0) or a negative pcops_status; argument checks mirror the
  *     OP_REQUIRES of the reference's OpKernels;
- *   - re-entrant, no global mutable state.
+ *   - re-entrant.  The only process-wide mutable state is the pair of switches below (pcops_set_deterministic,
+ *     pcops_set_option): both are atomics read at the START of every call, so a caller that wants a per-call choice
+ *     sets the option, issues the call and may restore it; kernels already enqueued are not affected.
  */
 #ifndef PCOPS_H
 #define PCOPS_H
@@ -49,6 +51,29 @@ typedef enum pcops_status {
 
 const char *pcops_strerror(int status);
 int pcops_abi_version(void);
+
+/* Arithmetic options.  Each selects between two formulations of the SAME fp32-in / fp32-out product whose results are both
+ * within the parity bars of tests/ (the split forms carry all 24 mantissa bits of each operand in three bf16 pieces and
+ * drop products <= 2^-24 relative; the fp16 pre-filter only rejects candidates, survivors get exact distances).  Values:
+ *   PCOPS_OPT_GEMM_SPLIT_BF16          0 fp32 MFMA, 1 (default) split operands on the bf16 matrix pipe, 2 split only where
+ *                                      the weight pieces stay LDS-resident       (pcops_mlp_gemm_fwd* and the dX products)
+ *   PCOPS_OPT_WGRAD_SPLIT_BF16         0 / 1 (default): pcops_mlp_wgrad* of layers wider than 64 on both sides
+ *   PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16  0 / 1 (default): the dX half of pcops_mlp_bwd_fused*
+ *   PCOPS_OPT_KNN_F16_PREFILTER        0 / 1 (default): pcops_knn_graph* at c == 64, k <= 20, n >= 256 (seeded or not)
+ * pcops_set_option returns the PREVIOUS value (>= 0) or PCOPS_ERR_BAD_ARGUMENT.  The environment variables of rounds 3-4
+ * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16) only seed the initial values (test overrides). */
+typedef enum pcops_option {
+    PCOPS_OPT_GEMM_SPLIT_BF16 = 1,
+    PCOPS_OPT_WGRAD_SPLIT_BF16 = 2,
+    PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16 = 3,
+    PCOPS_OPT_KNN_F16_PREFILTER = 4,
+    PCOPS_OPT_COUNT = 5
+} pcops_option;
+int pcops_set_option(int option, int value);
+int pcops_get_option(int option);
+/* diagnostics: the matrix pipe the calling thread's LAST matrix-product launch took (0 fp32 pipe or not a product, 1 bf16
+ * pipe with split operands, 2 the one-pass backward's fp32 dW + split dX) -- what a roofline label should be priced on */
+int pcops_last_launch_pipe(void);
 
 /* ------------------------------------------------------------------ sampling */
 /* farthestpointsamplingLauncher(b,n,m,inp,temp,out)   sampling/tf_sampling.cpp:94,
@@ -181,11 +206,16 @@ int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *nn_idx,
  * precondition is CHECKED per query: a seed row with an entry outside [0, n) or with a repeated entry names fewer than k
  * distinct points and is ignored (that query is scanned without a bound) -- nn_idx is pcops_knn_graph's for ANY seed.
  * seed == NULL: pcops_knn_graph.
- * (c == 64, k <= 20, no seed, 16-byte aligned x: the pairs are first evaluated in fp16 on the 16-bit matrix pipe and
- * only those whose fp16 distance minus a rigorous error bound can still enter a list get the exact fp32 distance --
- * same indices, csrc/knn.hip knn_f16_kernel; PCOPS_KNN_F16=0 keeps the fp32-MFMA kernel.) */
+ * (c == 64, k <= 20, n >= 256, 16-byte aligned x, seeded or not: the pairs are first evaluated in fp16 on the 16-bit
+ * matrix pipe and only those whose fp16 distance minus a rigorous error bound can still enter a list get the exact fp32
+ * distance -- same indices, csrc/knn.hip knn_f16_kernel; PCOPS_OPT_KNN_F16_PREFILTER = 0 keeps the fp32-MFMA kernel.)
+ * pcops_knn_graph_path says which kernel a call takes and whether that kernel USES a seed: bit 0-3 the kernel
+ * (1 lane-per-query VALU, 2 fp32-MFMA distances, 3 fp16 pre-filter + exact survivors), bit 4 set when a seed is honoured
+ * (the VALU kernel ignores it) -- callers decide from this whether passing the previous graph pays, instead of mirroring
+ * the launcher's conditions. */
 int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
                            pcops_stream_t stream);
+int pcops_knn_graph_path(int b, int n, int c, int k, const float *x);
 /* get_edge_feature: x (b,n,c), nn_idx (b,n,k) -> out (b,n,k,2c) = [x_i | x_j - x_i] */
 int pcops_edge_feature(int b, int n, int c, int k, const float *x, const int *nn_idx,
                        float *out, pcops_stream_t stream);

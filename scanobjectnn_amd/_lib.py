@@ -123,6 +123,10 @@ PLAIN = {
     "pcops_scatter_rows_sorted_max_ndst": ([], _I),
     "pcops_scatter_rows_sorted_supported": ([_I, _I], _I),
     "pcops_mlp_pool_top_supported": ([_I, _I, _I, _I], _I),
+    "pcops_knn_graph_path": ([_I, _I, _I, _I, _P], _I),
+    "pcops_last_launch_pipe": ([], _I),
+    "pcops_set_option": ([_I, _I], _I),
+    "pcops_get_option": ([_I], _I),
     "pcops_set_deterministic": ([_I], None),
     "pcops_get_deterministic": ([], _I),
 }
@@ -216,6 +220,21 @@ def check(t, dtype, name, ndim=None):
     if ndim is not None and t.dim() != ndim:
         raise ValueError("%s must have rank %d, got shape %s" % (name, ndim, tuple(t.shape)))
     return t.contiguous()
+
+
+OPT_GEMM_SPLIT_BF16, OPT_WGRAD_SPLIT_BF16, OPT_BWD_FUSED_DX_SPLIT_BF16, OPT_KNN_F16_PREFILTER = 1, 2, 3, 4
+
+
+def set_option(option, value):
+    """pcops_set_option (pcops.h "Arithmetic options"); returns the previous value"""
+    prev = int(load().pcops_set_option(int(option), int(value)))
+    if prev < 0:
+        raise PcopsError("pcops_set_option(%d, %d): %s" % (option, value, strerror(prev)))
+    return prev
+
+
+def get_option(option):
+    return int(load().pcops_get_option(int(option)))
 
 
 def set_deterministic(on=True):

@@ -28,7 +28,53 @@ static std::atomic<int> g_deterministic{[] {
     return (e && e[0] == '1') ? 1 : 0;
 }()};
 extern "C" void pcops_set_deterministic(int on) { g_deterministic.store(on ? 1 : 0); }
+
+// ---- arithmetic options (pcops.h pcops_set_option).  The ONLY process-wide mutable state besides the deterministic
+// switch: which of two exact-to-fp32 formulations a product runs in.  Rounds 3-4 read these from the environment once per
+// process inside the launchers (a TF-side caller could not choose per call); now the environment
+// only provides the initial value (test override) and the launchers read the table at every call.
+namespace {
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+std::atomic<int> g_options[PCOPS_OPT_COUNT] = {};
+std::atomic<int> g_options_init{0};
+void options_init() {
+    if (g_options_init.load(std::memory_order_acquire)) return;
+    static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    while (busy.test_and_set(std::memory_order_acquire)) {}
+    if (!g_options_init.load(std::memory_order_relaxed)) {
+        g_options[PCOPS_OPT_GEMM_SPLIT_BF16].store(env_int("PCOPS_GEMM_BF3", 1));
+        g_options[PCOPS_OPT_WGRAD_SPLIT_BF16].store(env_int("PCOPS_WGRAD_BF3", 1) != 0);
+        g_options[PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16].store(env_int("PCOPS_BWD_FUSED_DX3", 1) != 0);
+        g_options[PCOPS_OPT_KNN_F16_PREFILTER].store(env_int("PCOPS_KNN_F16", 1) != 0);
+        g_options_init.store(1, std::memory_order_release);
+    }
+    busy.clear(std::memory_order_release);
+}
+}  // namespace
+
+extern "C" int pcops_get_option(int option) {
+    if (option <= 0 || option >= PCOPS_OPT_COUNT) return PCOPS_ERR_BAD_ARGUMENT;
+    options_init();
+    return g_options[option].load();
+}
+
+extern "C" int pcops_set_option(int option, int value) {
+    if (option <= 0 || option >= PCOPS_OPT_COUNT || value < 0) return PCOPS_ERR_BAD_ARGUMENT;
+    if (option == PCOPS_OPT_GEMM_SPLIT_BF16 ? value > 2 : value > 1) return PCOPS_ERR_BAD_ARGUMENT;
+    options_init();
+    return g_options[option].exchange(value);
+}
 extern "C" int pcops_get_deterministic(void) { return g_deterministic.load(); }
+
+// diagnostics (bench.py): which matrix pipe the LAST matrix-product launch of the calling thread took -- 0 the fp32 pipe
+// (or no product), 1 the bf16 pipe with split operands, 2 half and half (one-pass backward: dW fp32, dX split).  The
+// launchers note it where they decide, so a roofline label is the library's own decision, not a mirror of its rules.
+static thread_local int t_last_pipe = 0;
+void pcops_note_pipe(int pipe) { t_last_pipe = pipe; }
+extern "C" int pcops_last_launch_pipe(void) { return t_last_pipe; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The training step's parameter update as ONE launch over the flat buffers (host: train_util.TFAdam).  TensorFlow's Adam

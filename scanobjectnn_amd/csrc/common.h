@@ -29,6 +29,8 @@ static inline hipStream_t as_stream(pcops_stream_t s) { return reinterpret_cast<
 static inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
 
 extern "C" int pcops_get_deterministic(void);     // abi.hip: bit-reproducible backward passes requested
+extern "C" int pcops_get_option(int option);      // abi.hip: the arithmetic options of pcops.h (read at every call)
+void pcops_note_pipe(int pipe);                   // abi.hip: what pcops_last_launch_pipe() reports (0 fp32, 1 split bf16, 2 both)
 
 constexpr int kWave = 64;  // CDNA wavefront
 

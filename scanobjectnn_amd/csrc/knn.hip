@@ -672,10 +672,7 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
     }
 }
 
-static bool knn_f16_enabled() {
-    static const bool on = [] { const char *e = getenv("PCOPS_KNN_F16"); return !(e && e[0] == '0'); }();
-    return on;
-}
+static bool knn_f16_enabled() { return pcops_get_option(PCOPS_OPT_KNN_F16_PREFILTER) != 0; }
 
 int launch_knn_f16(int b, int n, int k, const float *x, int *nn_idx, const int *seed, hipStream_t st) {
     constexpr int CP = 64, CH = 128;
@@ -855,6 +852,20 @@ extern "C" int pcops_knn_graph(int b, int n, int c, int k, const float *x, int *
     return pcops_knn_graph_seeded(b, n, c, k, x, nullptr, nn_idx, stream);
 }
 
+static bool knn_use_mfma() {
+    static const bool on = [] { const char *e = getenv("PCOPS_KNN_MFMA"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    return on;
+}
+static bool knn_takes_f16(int n, int c, int k, const float *x) {
+    return knn_use_mfma() && knn_f16_enabled() && c == 64 && k <= 20 && n >= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+extern "C" int pcops_knn_graph_path(int b, int n, int c, int k, const float *x) {
+    (void)b;
+    if (knn_takes_f16(n, c, k, x)) return 3 | 16;
+    if (knn_use_mfma() && k <= 32 && c <= 128) return 2 | 16;
+    return c <= 128 ? 1 : 0;
+}
+
 extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x, const int *seed, int *nn_idx,
                                       pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0 && c >= 1);
@@ -864,11 +875,10 @@ extern "C" int pcops_knn_graph_seeded(int b, int n, int c, int k, const float *x
     PCOPS_REQUIRE_PTR(nn_idx);
     PCOPS_REQUIRE_SHAPE(b <= 65535);
     hipStream_t st = as_stream(stream);
-    static const bool use_mfma = [] { const char *e = getenv("PCOPS_KNN_MFMA"); return !(e && e[0] == '0'); }();
+    const bool use_mfma = knn_use_mfma();
     // 64-channel graphs (DGCNN's feature graphs): fp16 pre-filter on the 16-bit matrix pipe + exact distances of the
     // survivors (knn_f16_kernel above); rows must be 16-byte aligned
-    if (use_mfma && knn_f16_enabled() && c == 64 && k <= 20 && n >= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        return launch_knn_f16(b, n, k, x, nn_idx, seed, st);
+    if (knn_takes_f16(n, c, k, x)) return launch_knn_f16(b, n, k, x, nn_idx, seed, st);
     if (use_mfma && k <= 32 && c <= 128) {
 #define PCOPS_KNN_CASE(CP_)                                                      \
     do {                                                                         \

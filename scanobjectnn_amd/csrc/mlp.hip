@@ -1337,13 +1337,9 @@ static size_t ws_lds_bytes_bf3(int Kp, int bn, int waves, bool wst, int ncoef) {
     return (size_t)((wst ? 2 * 32 : Kp) * bn * 3 / 2 + crows * Kp + 6 * bn + waves * 32 * ldw + waves * 2 * bn) * sizeof(float);
 }
 
-static int ws_bf3_mode() {       // PCOPS_GEMM_BF3 = 0: off, 1 (default): on, 2: only where the weight pieces stay resident
-    static const int mode = [] {
-        const char *e = getenv("PCOPS_GEMM_BF3");
-        return e ? atoi(e) : 1;
-    }();
-    return mode;
-}
+// PCOPS_OPT_GEMM_SPLIT_BF16 = 0: off, 1 (default): on, 2: only where the weight pieces stay resident (pcops_set_option; the
+// environment variable PCOPS_GEMM_BF3 only seeds the table)
+static int ws_bf3_mode() { return pcops_get_option(PCOPS_OPT_GEMM_SPLIT_BF16); }
 
 static int ws_ncoef(int am) { return am == A_PLAIN ? 0 : (am == A_BNRELU ? 2 : (am == A_DY ? 3 : (am == A_XYZ ? 6 : 5))); }
 
@@ -1458,6 +1454,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
+    pcops_note_pipe(pl.bf3 ? 1 : 0);
     if constexpr (EM == E_FWD) {
     if (pl.bf3) {
 #define PCOPS_WS3_LAUNCH(NT_, EH_)                                                                    \
@@ -1511,6 +1508,7 @@ int launch_gemm(GemmArgs &a, hipStream_t st) {
         return rc;
     }
     if (a.blocks) return PCOPS_ERR_UNSUPPORTED;      // compacted rows: wave-stream kernels only
+    pcops_note_pipe(0);                              // the tiled kernel: fp32 MFMA
     return launch_gemm_rt<AM, EM>(a, st);
 }
 
@@ -3638,10 +3636,7 @@ struct Bf3WgradPlan {
 // split-operand weight gradient (wgrad_bf3_kernel): the large layers wider than 64 on both sides
 static bool wgrad_bf3_plan(long long M, int K, int N, int ldx, const void *X, const void *G, const void *Y,
                            const void *gpool, const void *argmax, Bf3WgradPlan *pl) {
-    static const bool on = [] {
-        const char *e = getenv("PCOPS_WGRAD_BF3");
-        return !(e && e[0] == '0');
-    }();
+    const bool on = pcops_get_option(PCOPS_OPT_WGRAD_SPLIT_BF16) != 0;
     if (!on || M < 32768 || K <= 64 || N <= 64) return false;
     if (K % 4 != 0 || N % 4 != 0 || ldx % 4 != 0) return false;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(G) & 15) ||
@@ -4590,8 +4585,10 @@ static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStr
     if (self && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, true)))
         return PCOPS_ERR_UNSUPPORTED;            // Gram matrix: producer/consumer kernel only
     Bf3WgradPlan b3;
+    pcops_note_pipe(0);
     if (ws_enabled() && wgrad_pc_enabled() && !self && a.amode != A_XYZ &&
         wgrad_bf3_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &b3)) {
+        pcops_note_pipe(1);
         splits = b3.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
         const dim3 grid(b3.groups, b3.kblocks, b3.nblocks);
@@ -4764,10 +4761,8 @@ static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, 
         return !(e && e[0] == '0');
     }();
     const bool nsk = nsk_on && tn == 2 && N <= 96;
-    static const bool dx3 = [] {
-        const char *e = getenv("PCOPS_BWD_FUSED_DX3");
-        return !(e && e[0] == '0');
-    }();
+    const bool dx3 = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) != 0;
+    pcops_note_pipe(dx3 ? 2 : 0);
 #define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
     do {                                                                                                   \
         auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \

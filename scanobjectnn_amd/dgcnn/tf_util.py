@@ -155,7 +155,6 @@ def knn(adj_matrix, k=20):
 KNN_SEED = os.environ.get("PCOPS_KNN_SEED", "1") != "0"
 KNN_SEED_MAX_C = int(os.environ.get("PCOPS_KNN_SEED_MAX_C", "64"))
 KNN_SEED_FORCE = False       # tests: take the hint whatever the shape (every seeded kernel variant is then exercised)
-KNN_F16 = os.environ.get("PCOPS_KNN_F16", "1") != "0"      # (mirrors the library's switch: csrc/knn.hip knn_f16_enabled)
 
 
 def knn_graph(point_cloud, k=20, seed=None):
@@ -173,7 +172,9 @@ def knn_graph(point_cloud, k=20, seed=None):
     # 64-channel distance plus an insertion and the hint WINS (1720 -> 1555 us, profiles/r04_knn_seed_ab.txt), so it is
     # taken for narrow inputs (<= 16 channels) and for exactly the shape that kernel takes (64 channels, k <= 20); anything
     # else would run the fp32-MFMA kernel, where it does not pay
-    pays = KNN_SEED_FORCE or c <= 16 or (c == 64 and k <= 20 and n >= 256 and KNN_F16)
+    # (which kernel the call takes, and whether it honours a seed at all, is the LIBRARY's answer: pcops_knn_graph_path)
+    path = int(_lib.load().pcops_knn_graph_path(b, n, c, k, _lib.ptr(x)))
+    pays = bool(path & 16) and (KNN_SEED_FORCE or c <= 16 or (path & 15) == 3)
     if (seed is not None and KNN_SEED and c <= KNN_SEED_MAX_C and pays and tuple(seed.shape) == (b, n, k)
             and seed.dtype == torch.int32):
         _lib.call("pcops_knn_graph_seeded", b, n, c, k, _lib.ptr(x), _lib.ptr(seed.contiguous()), _lib.ptr(out))

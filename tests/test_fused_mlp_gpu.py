@@ -463,11 +463,10 @@ def test_split_operand_forward_is_more_accurate_than_an_fp32_chain(M, K, N):
     h.h products alone in the tile's accumulators) -- against float64: relative RMS error at most HALF of what a K-long
     fp32 fmaf chain makes on the same operands (measured: 0.35 ... 0.4 of it), no row off, and the statistics the epilogue
     emits are the sums of what it stored."""
-    import os
-    if os.environ.get("PCOPS_GEMM_BF3", "1") == "0":
-        pytest.skip("split operands switched off")
     from scanobjectnn_amd import _lib
     lib = _lib.load()
+    if _lib.get_option(_lib.OPT_GEMM_SPLIT_BF16) == 0:
+        pytest.skip("split operands switched off")
     g = torch.Generator().manual_seed(M + K)
     X = torch.randn(M, K, generator=g).to(DEV)
     W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
@@ -565,3 +564,31 @@ def test_edge_conv_stack_one_gemm_matches_two(cin, widths):
         assert (g1[n] - g2[n]).abs().max().item() <= tol, n
     for n in s1:
         assert torch.allclose(s1[n], s2[n], atol=1e-5, rtol=1e-4), n
+
+
+def test_arithmetic_options_are_per_call_state_of_the_library():
+    """pcops_set_option: the split-operand forward product can be switched per call -- the launcher reads
+    the table at every call, reports the pipe it took, and both formulations agree to fp32 rounding"""
+    from scanobjectnn_amd import _lib
+    lib = _lib.load()
+    M, K, N = 65536, 128, 128
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    outs, pipes = [], []
+    prev = _lib.get_option(_lib.OPT_GEMM_SPLIT_BF16)
+    try:
+        for mode in (1, 0, 1):
+            assert _lib.set_option(_lib.OPT_GEMM_SPLIT_BF16, mode) in (0, 1, 2)
+            Y = torch.empty(M, N, device=DEV)
+            _lib.call("pcops_mlp_gemm_fwd", M, K, N, X.data_ptr(), K, None, None, W.data_ptr(), None, Y.data_ptr(), None, None)
+            pipes.append(int(lib.pcops_last_launch_pipe()))
+            outs.append(Y)
+    finally:
+        _lib.set_option(_lib.OPT_GEMM_SPLIT_BF16, prev)
+    assert pipes == [1, 0, 1]
+    assert torch.equal(outs[0], outs[2])
+    ref = X.double() @ W.double()
+    for Y in outs:
+        assert (Y.double() - ref).abs().max().item() < 2e-5
+    assert lib.pcops_set_option(99, 1) < 0 and lib.pcops_set_option(_lib.OPT_KNN_F16_PREFILTER, 2) < 0
