@@ -777,6 +777,36 @@ def main():
         clock = poller.summary()
     else:
         elapsed, local_elapsed, host_elapsed, dom_live = measure(step, args.steps, args.warmup, dom_key is not None, dom_key)
+    # N > 1: the SAME invocation also measures rank 0 running alone (no collective, the other ranks parked at a barrier), so a
+    # scaling curve built from the per-N lines has its own single-GPU baseline from the same box, build and clock state
+    solo = None
+    if world > 1 and not args.forward_only:
+        D.barrier()
+        if rank == 0:
+            def solo_step():
+                s_ = state["step"]
+                fp.begin_step()
+                fp._armed = False               # no gradient ranges leave: this is the one-GPU step
+                out = net(inputs["x"], is_training=True, bn_decay=TU.get_bn_decay(s_, B))
+                loss = mod.get_loss(out[0], out[1], y, mask)[0] if has_mask else mod.get_loss(out[0], y, out[1])
+                loss.backward()
+                fp.collect()
+                opt.step(TU.get_learning_rate(s_, B))
+                state["step"] = s_ + 1
+            keep_sync = D.SYNC_BN
+            D.SYNC_BN = False
+            for _ in range(min(args.warmup, 3)):
+                solo_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                solo_step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            D.SYNC_BN = keep_sync
+            solo = {"value": B * args.steps / el, "unit": "clouds/s", "ms_per_step": el / args.steps * 1e3, "n_gpus": 1,
+                    "note": "rank 0 alone in this invocation (other ranks idle): the N = 1 point of the scaling curve"}
+        D.barrier()
     ar_ms = [a.elapsed_time(b) for a, b in ar_events]
     per_rank = D.gather_floats(B * args.steps / local_elapsed, dev)      # every rank's own clouds/s
     ar_all = D.gather_floats(sum(ar_ms) / max(len(ar_ms), 1), dev)
@@ -892,6 +922,8 @@ def main():
         "kernels": [{k: d[k] for k in ("kernel", "shape", "launches", "avg_us", "gbs", "gwork_s", "work_unit",
                                         "hbm_frac", "mfma_frac", "bound_frac", "pipe", "pipe_busy_frac")} for d in kernels[:24]],
     }
+    if solo:
+        line["single_gpu_same_invocation"] = solo
     if extras:
         line["extras"] = extras
     if qbp:

@@ -44,6 +44,9 @@ def test_bench_two_ranks_control_flow():
     assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
     assert d["config"]["shared_gpu_debug"] is True
     assert d["allreduce_ms_per_step"] > 0
+    # the N = 1 point of the scaling curve from the SAME invocation (rank 0 alone, the other ranks parked)
+    solo = d["single_gpu_same_invocation"]
+    assert solo["n_gpus"] == 1 and solo["value"] > 0 and abs(solo["value"] - 16 * 3 / (solo["ms_per_step"] * 3e-3)) / solo["value"] < 1e-6
 
 
 def test_bench_refuses_a_world_size_it_was_not_asked_for():

@@ -253,3 +253,119 @@ def test_rccl_backend_initialises_and_reduces_the_flat_bucket_on_one_gpu():
     # the single-collective step's, bit for bit (round 3 allowed 1e-3 here -- the two steps then differed by their scatter
     # atomics AND by the batch-norm pivots the first step had moved, enough for a ReLU to fall the other way)
     assert res["ranges"] >= 3 and res["under_way"] >= res["ranges"] - 1 and res["overlap_err"] == 0.0, res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 5 (VERDICT r4 #5ii): the two-rank SyncBN gradient against the FLOAT64 TRUTH OF THE WHOLE BATCH evaluated WITH THE
+# DECISIONS THE RANKS TOOK.  The tests above compare two fp32 evaluations, so one ReLU / arg-max near-tie that falls
+# differently moves the gradient by 1e-2 and the bars had to allow it (5e-2 ceilings, medians).  Here every rank's discrete
+# decisions (ReLU masks, pool arg-max rows, DGCNN's neighbour graphs) are read back exactly as test_models_parity_gpu.py
+# reads a single process's (tests/decisions.py), the ranks' halves are joined in batch order, and the float64 restatement
+# (oracle/ref_models.py) of the WHOLE batch is differentiated on those decisions: what is left is arithmetic -- the SyncBN
+# exchange included -- and it is held to 1e-4, on three seeds per model, with no ceiling for flips.
+def _pack(t):
+    import numpy as np
+    a = t.cpu().numpy()
+    return (np.packbits(a.reshape(-1)), a.shape) if a.dtype == bool else (a.astype(np.int32), a.shape)
+
+
+def _unpack(p, dtype):
+    import numpy as np
+    data, shape = p
+    if dtype == "bool":
+        n = int(np.prod(shape))
+        return torch.from_numpy(np.unpackbits(data)[:n].astype(bool).reshape(shape))
+    return torch.from_numpy(data.astype(np.int64).reshape(shape))
+
+
+def _decision_worker(rank, world, port, name, q, seed):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    import decisions as DEC
+    from scanobjectnn_amd import dist as D
+    from scanobjectnn_amd.dgcnn import tf_util as td
+    D.init_from_env(backend="gloo")
+    torch.cuda.set_device(0)
+    D.SYNC_BN = True
+    F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+    mod, net, x, y = _build(name, seed)
+    graphs = []
+    real = td.knn_graph
+
+    def recording(point_cloud, k=20, seed=None):
+        nn = real(point_cloud, k=k, seed=seed)
+        graphs.append(nn.cpu().numpy())
+        return nn
+    td.knn_graph = recording
+    lo, hi = D.shard_range(B, rank, world)
+    rec = DEC.Recorder(net, "cpu")
+    net.zero_grad(set_to_none=True)
+    with rec.recording():
+        out = net(x[lo:hi].contiguous(), is_training=True, bn_decay=0.9)
+    mod.get_loss(out[0], y[lo:hi].contiguous()).backward()
+    dec = rec.decisions()
+    names = [k for k, p in sorted(net.named_parameters()) if p.grad is not None]
+    g = torch.cat([p.grad.reshape(-1) for _, p in sorted(net.named_parameters()) if p.grad is not None])
+    dist.all_reduce(g)
+    g /= world
+    q.put((rank, g.cpu().numpy(), names, {k: _pack(v) for k, v in dec.relu.items()},
+           {k: (_pack(a), _pack(b)) for k, (a, b) in dec.pool.items()}, graphs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ssg", "dgcnn"])
+def test_sync_bn_two_ranks_against_float64_on_the_ranks_decisions(name, monkeypatch):
+    import numpy as np
+    import decisions as DEC
+    from oracle import ref_models as R
+    from scanobjectnn_amd.dgcnn import dgcnn
+    from scanobjectnn_amd.pointnet2 import pointnet2_cls_ssg
+    mod, ref = {"ssg": (pointnet2_cls_ssg, R.pointnet2_cls_ssg), "dgcnn": (dgcnn, R.dgcnn)}[name]
+    TIE = 2e-4
+    worst = 0.0
+    for seed in (3, 4, 5):
+        world, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_decision_worker, args=(r, world, port, name, q, seed)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert np.array_equal(res[0][1], res[1][1])                     # the all-reduced gradient, identical on both ranks
+        got, names = torch.from_numpy(res[0][1]).double(), res[0][2]
+        # the ranks' decisions joined in batch order
+        Dj = R.Decisions()
+        for k in res[0][3]:
+            Dj.relu[k] = torch.cat([_unpack(r[3][k], "bool") for r in res]).to(DEV)
+        for k in res[0][4]:
+            Dj.pool[k] = (torch.cat([_unpack(r[4][k][0], "int") for r in res]).to(DEV),
+                          torch.cat([_unpack(r[4][k][1], "bool") for r in res]).to(DEV))
+        kw = {}
+        if name == "dgcnn":
+            assert len(res[0][5]) == 5
+            kw["nn_list"] = [np.concatenate([r[5][i] for r in res], 0) for i in range(5)]
+        _, net, x, y = _build(name, seed)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        P = {k: v.requires_grad_(v.is_floating_point())
+             for k, v in R.params_from_state_dict(sd, dtype=torch.float64, device=DEV).items()}
+        rep = {}
+        with R.imposing(Dj, None, rep):
+            want = ref(x.double(), P, True, **kw)
+        mod.get_loss(want if not isinstance(want, tuple) else want[0], y).backward()
+        ref_g = torch.cat([(P[k[len("graph."):]].grad if P[k[len("graph."):]].grad is not None
+                            else torch.zeros_like(P[k[len("graph."):]])).reshape(-1) for k in names]).cpu()
+        flips = DEC.summarise(rep, TIE)
+        assert flips["all_ties"], (seed, flips)                          # a decision that differs from float64's is a near-tie
+        err = ((got - ref_g).norm() / ref_g.norm()).item()
+        worst = max(worst, err)
+        assert err <= 1e-4, (name, seed, err, flips)
+    print("two-rank SyncBN vs float64 on the ranks' decisions, %s: worst relative gradient error %.2e" % (name, worst))
