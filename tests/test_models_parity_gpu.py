@@ -306,7 +306,7 @@ def _grad_errors(got, want):
 GRAD_MODELS = ["ssg", "bga", "msg", "dgcnn", "dgcnn_bga"]
 
 
-def _grad_case(name, seed, monkeypatch):
+def _grad_case(name, seed, monkeypatch, batch=None, num_point=None, paths=("fused", "layer")):
     """one (model, seed): gradients of the training loss through the fused kernels and through the layer-by-layer path,
     each against the float64 truth on its own decisions (`e_*`) and against the float64 truth evaluated WITH THE
     DECISIONS THAT PATH TOOK (`em_*`), and what those decisions were"""
@@ -320,7 +320,8 @@ def _grad_case(name, seed, monkeypatch):
         "msg": (pointnet2_cls_msg, R.pointnet2_cls_msg, 1024, False),
         "dgcnn": (dgcnn, R.dgcnn, 256, False),
         "dgcnn_bga": (dgcnn_bga, R.dgcnn_bga, 256, True)}[name]
-    B = 16
+    B = batch or 16
+    n_pts = num_point or n_pts
     c = synth_clouds(B, n_pts, seed=seed)
     y = torch.from_numpy(synth_labels(B, seed=seed))
     mask = torch.from_numpy(synth_masks(B, n_pts, seed=seed)) if has_mask else None
@@ -356,12 +357,14 @@ def _grad_case(name, seed, monkeypatch):
     # the layer-by-layer path (library GEMM + torch batch norm): the fp32 yardstick.  DGCNN: on the neighbour graphs of the
     # fused run (which the truth is evaluated with too -- a 20th-neighbour tie that falls the other way is a different
     # network; the graphs themselves are bit-exact against the oracle, test_dgcnn_logits / test_knn_gpu.py)
-    monkeypatch.setattr(t2, "FUSED_MLP", False)
-    if is_dg:
-        replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
-        monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
-    _, D_layer, g_layer = product_grads()
-    monkeypatch.setattr(t2, "FUSED_MLP", True)
+    D_layer = g_layer = None
+    if "layer" in paths:
+        monkeypatch.setattr(t2, "FUSED_MLP", False)
+        if is_dg:
+            replay = iter([torch.from_numpy(g).to(DEV) for g in graphs_fused])
+            monkeypatch.setattr(td, "knn_graph", lambda point_cloud, k=20, seed=None: next(replay))
+        _, D_layer, g_layer = product_grads()
+        monkeypatch.setattr(t2, "FUSED_MLP", True)
     monkeypatch.setattr(td, "knn_graph", real)
 
     kw = {"nn_list": graphs_fused} if is_dg else {}
@@ -380,7 +383,7 @@ def _grad_case(name, seed, monkeypatch):
     D64 = R.Decisions()
     loss_ref, g64 = truth(record=D64)
     assert abs(loss_fused - loss_ref) <= 1e-4
-    out = {"seed": seed}
+    out = {"seed": seed, "loss_fused": loss_fused, "loss_ref": loss_ref}
     if is_dg:
         # the third kind of discrete decision: the neighbour graphs.  The truth above is evaluated ON the product's graphs
         # (each bit-exact against the oracle given its input tensor: test_dgcnn_logits, test_knn_gpu.py); here they are
@@ -403,6 +406,8 @@ def _grad_case(name, seed, monkeypatch):
         out["graph_rows"] = int(graphs_fused[0].shape[0] * graphs_fused[0].shape[1])
         assert sum(out["graph_rows_differing"]) <= 0.01 * 5 * out["graph_rows"], out       # few, and only near-ties can differ
     for path, D, g in (("fused", D_fused, g_fused), ("layer", D_layer, g_layer)):
+        if path not in paths:
+            continue
         # the read-back covers exactly the layers of the network, each with the kind of decision it has
         assert set(D.relu) == set(D64.relu) and set(D.pool) == set(D64.pool), \
             (path, sorted(set(D.relu) ^ set(D64.relu)), sorted(set(D.pool) ^ set(D64.pool)))
@@ -410,6 +415,10 @@ def _grad_case(name, seed, monkeypatch):
         _, g64_forced = truth(D, report=rep)
         e, worst = _grad_errors(g, g64)
         em, worst_m = _grad_errors(g, g64_forced)
+        if batch:       # bench-size runs: the per-variable picture too (relative error of every variable's gradient)
+            out["per_variable_" + path] = {k: ((g[k].double() - g64_forced[k]).norm() / g64_forced[k].norm().clamp_min(1e-30)).item()
+                                           for k in g64_forced}
+            out["grad_norm_" + path] = {k: g[k].double().norm().item() for k in g64_forced}
         out.update({"e_" + path: e, "em_" + path: em, "worst_" + path: worst, "worst_masked_" + path: worst_m,
                     "flips_" + path: DEC.summarise(rep, TIE)})
     return out
@@ -453,7 +462,10 @@ def test_model_training_gradients(name, monkeypatch):
         # sums (no bar without one) and no worse than the layer-by-layer path
         assert c["em_fused"] <= GRAD_CEILING, c
         assert c["em_fused"] <= max(1.5 * c["em_layer"], GRAD_RESOLUTION), c
-        assert c["e_fused"] <= 1e-1, c                    # sanity, flips included
+        # flips included: an UNMASKED ceiling too (a defect confined to the elements classified as flips must not
+        # hide behind the mask) -- 2e-2, the bar of rounds 1-2 (measured worst 1.5e-2, dgcnn, one head-level near-tie), and
+        # every masked flip is a float64 near-tie on both paths (all_ties above)
+        assert c["e_fused"] <= 2e-2, c
     # flips included, the two paths are hit alike.  Per seed the ratio e_fused / e_layer is a coin toss between << 1 and
     # >> 1 (whichever path met the nastier tie: 0.002 ... 127 in the committed record, both directions), so the MEDIAN
     # ERRORS of the two paths are compared, not the median of that ratio (recorded as median_unmasked_ratio)
