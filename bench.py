@@ -189,7 +189,11 @@ def _algo(name, a):
         return b * (4 * m * c + 24 * n + 4 * n * c), 0, ""
     if name in ("pcops_knn_graph", "pcops_knn_graph_seeded"):      # (seeded: + the hint's k indices per query)
         b, n, c, k = a[:4]
-        return b * (4 * n * c + 4 * n * k * (2 if name.endswith("seeded") else 1)), 2 * b * n * n * c, "flop"
+        # counted in PAIR TESTS, like the other search kernels: the distances of the 64-channel graphs run as fp16 MFMAs that
+        # keep the matrix pipe busy 3.5 % of the launch, and what binds is instruction issue in the selection (574 k
+        # wave-instructions per SIMD and launch, profiles/r04_pmc_insts_dgcnn.txt) -- pricing 2 n^2 c flops against the fp32
+        # matrix peak (rounds 2-4) named a bound the kernel does not have
+        return b * (4 * n * c + 4 * n * k * (2 if name.endswith("seeded") else 1)), b * n * n, "pairs"
     if name in ("pcops_edge_feature", "pcops_edge_feature_grad"):
         b, n, c, k = a[:4]
         return b * (4 * n * c + 4 * n * k + 8 * n * k * c), 0, ""
@@ -402,8 +406,12 @@ def _measured_traffic(dom):
             continue
         key = "%s%s" % (dom["kernel"], tuple(dom["shape"]))
         if key in table:
+            _measured_traffic.source = os.path.relpath(f, ROOT)
             return table[key]
     return None
+
+
+_measured_traffic.source = None
 
 
 def _ball_query_fractions(x, kernels):
@@ -597,6 +605,8 @@ def side_model(name, dev, steps=10, warmup=3):
         res["dominant"] = {"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / 3.0,
                            "bound": "mfma" if mf > hbm else "hbm", "frac": max(mf, hbm), "hbm_frac": hbm, "mfma_frac": mf,
                            "share_of_step": d["ms"] / 3.0 / (el / steps * 1e3)}
+        if d["work_unit"] == "pairs":       # a search kernel: neither roofline binds, instruction issue does
+            res["dominant"].update({"bound": "valu_issue", "frac": None, "pair_tests_per_s": d["gwork_s"] * 1e9})
         res["kernels"] = [{"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / 3.0,
                            "bound_frac": max(d["gbs"] / HBM_PEAK_GBS, _mfma_frac(d))}
                           for d in ks[:6]]
@@ -866,7 +876,7 @@ def main():
         # the binding roofline of the dominant kernel = the one it sits closer to: HBM for the streaming
         # kernels; for the MFMA GEMMs whichever of (algorithmic bytes / 8 TB/s, flops / 157.3 TF/s) is larger
         hbm_frac, mfma_frac = dom["hbm_frac"], dom["mfma_frac"]
-        traffic = _measured_traffic(dom)
+        traffic = _measured_traffic(dom)     # PMC bytes of this kernel from the committed profile of the same command (below)
         split = _split_operands(dom)
         if mfma_frac > hbm_frac and split:       # six bf16 products per algorithmic fp32 product, on the bf16 pipe
             roofline = {"bound": "mfma", "achieved": 6.0 * dom["gwork_s"] / 1e3, "peak": BF16_PEAK_TFLOPS,
@@ -881,6 +891,10 @@ def main():
                          "launches": dom["launches"], "algorithmic_bytes_per_launch": dom["bytes"],
                          "algorithmic_flops_per_launch": dom["work"] if dom["work_unit"] == "flop" else None,
                          "hbm_frac": hbm_frac, "mfma_frac": mfma_frac,
+                         # `traffic` is NOT measured by this process (PMC counters need their own rocprofv3 passes): it is this
+                         # kernel's FETCH x 2 + WRITE bytes from the committed passes of the same command, named here
+                         "traffic_source": ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` (tools/collect_traffic.py), "
+                                            "not collected in this run" % _measured_traffic.source) if traffic is not None else None,
                          # which pipe(s) the launch's products run on, and the share of the launch the matrix pipe is busy
                          # at its nominal rate (`frac` prices the ALGORITHMIC fp32 flops against the fp32-input peak)
                          "pipe": ("f32 mfma (dW) + bf16 x 6 (dX)" if _half_split(dom) else

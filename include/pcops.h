@@ -633,6 +633,11 @@ int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, in
                            float *stats_partial, const float *stat_pivot, pcops_stream_t stream);
 int pcops_edge_pool_out_ld(long long groups, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
                            const float *shift, float *out, float *ysel, pcops_stream_t stream);
+/* ... and a SECOND copy of `out` into a column block of a wider row-major tensor (out2 + g * ld2): DGCNN concatenates the
+ * four EdgeConv outputs (dgcnn/models/dgcnn.py:83), so each layer stores its block of the (b, n, 320) tensor on the way
+ * out and no concatenation pass (671 MB read + written) runs.  out2 may be NULL (= pcops_edge_pool_out_ld). */
+int pcops_edge_pool_out_ld2(long long groups, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
+                            const float *shift, float *out, float *ysel, float *out2, int ld2, pcops_stream_t stream);
 int pcops_edge_pool_bwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
                            const int *idx, const float *gpool, const float *ysel, const float *SQ,
                            const unsigned char *arg, const float *scale, const float *shift, const float *p,

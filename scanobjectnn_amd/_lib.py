@@ -87,6 +87,7 @@ SIGNATURES = {
     "pcops_edge_feature_grad_central": ([_I, _I, _I, _I, _P, _P], True),
     "pcops_edge_pool_fwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_pool_out_ld": ([_LL, _I, _P, _P, _I, _P, _P, _P, _P], True),
+    "pcops_edge_pool_out_ld2": ([_LL, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I], True),
     "pcops_edge_pool_bwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I] + [_P] * 10 + [_P, _I, _P, _I, _P], True),
     "pcops_sa_gather_fwd_ld": ([_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P], True),
     "pcops_sa_scatter_bwd_ld": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], True),

@@ -1953,7 +1953,7 @@ namespace {
 __global__ __launch_bounds__(256) void edge_pool_out_ld_kernel(long long total4, int C, int ldc, const float *__restrict__ qsel,
                                                                const float *__restrict__ Ctr, const float *__restrict__ scale,
                                                                const float *__restrict__ shift, float *__restrict__ out,
-                                                               float *__restrict__ ysel) {
+                                                               float *__restrict__ ysel, float *__restrict__ out2, int ld2) {
     const int c4n = C / 4;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
         const long long g = e / c4n;
@@ -1962,8 +1962,10 @@ __global__ __launch_bounds__(256) void edge_pool_out_ld_kernel(long long total4,
         const float4 ct = *reinterpret_cast<const float4 *>(Ctr + g * ldc + c);
         const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
         const float4 y = make_float4(qs.x + ct.x, qs.y + ct.y, qs.z + ct.z, qs.w + ct.w);
-        *reinterpret_cast<float4 *>(out + g * C + c) = make_float4(fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), fmaxf(fmaf(y.y, sc.y, sh.y), 0.f),
-                                                                   fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), fmaxf(fmaf(y.w, sc.w, sh.w), 0.f));
+        const float4 o = make_float4(fmaxf(fmaf(y.x, sc.x, sh.x), 0.f), fmaxf(fmaf(y.y, sc.y, sh.y), 0.f),
+                                     fmaxf(fmaf(y.z, sc.z, sh.z), 0.f), fmaxf(fmaf(y.w, sc.w, sh.w), 0.f));
+        *reinterpret_cast<float4 *>(out + g * C + c) = o;
+        if (out2) *reinterpret_cast<float4 *>(out2 + g * ld2 + c) = o;       // the layer's column block of the concatenation
         if (ysel) *reinterpret_cast<float4 *>(ysel + g * C + c) = y;
     }
 }
@@ -1971,13 +1973,19 @@ __global__ __launch_bounds__(256) void edge_pool_out_ld_kernel(long long total4,
 
 int pcops_edge_pool_out_ld(long long G, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
                            const float *shift, float *out, float *ysel, pcops_stream_t stream) {
+    return pcops_edge_pool_out_ld2(G, c, qsel, Ctr, ldc, scale, shift, out, ysel, nullptr, 0, stream);
+}
+
+int pcops_edge_pool_out_ld2(long long G, int c, const float *qsel, const float *Ctr, int ldc, const float *scale,
+                            const float *shift, float *out, float *ysel, float *out2, int ld2, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(G >= 0 && c >= 4 && c % 4 == 0 && ldc >= c && ldc % 4 == 0);
+    if (out2) PCOPS_REQUIRE_SHAPE(ld2 >= c && ld2 % 4 == 0 && (reinterpret_cast<uintptr_t>(out2) & 15) == 0);
     if (G == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(out);
     const long long total4 = G * (c / 4);
     const unsigned grid = cdiv(total4, 256) < 16384u ? cdiv(total4, 256) : 16384u;
     hipLaunchKernelGGL(edge_pool_out_ld_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total4, c, ldc, qsel, Ctr, scale,
-                       shift, out, ysel);
+                       shift, out, ysel, out2, ld2);
     return pcops_launch_status();
 }
 

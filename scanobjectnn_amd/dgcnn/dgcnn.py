@@ -17,17 +17,22 @@ def placeholder_inputs(batch_size, num_point, device=None):
     return pointclouds_pl, labels_pl
 
 
-def _edge_conv(x, width, scope, k, is_training, bn_decay, seed=None):
-    """-> (features (B,N,1,width), this layer's neighbour graph).  seed: the previous layer's graph -- the reference
+def _edge_conv(x, width, scope, k, is_training, bn_decay, seed=None, cat_slot=None):
+    """-> (features (B,N,1,width), this layer's neighbour graph[, the alias of the layer's block in cat_slot's buffer]).  seed: the previous layer's graph -- the reference
     rebuilds the kNN graph on every layer's features (dgcnn.py:31-71); consecutive graphs of the same points mostly
     agree, which the kernel uses as a starting threshold (same result, tf_util.knn_graph)."""
     nn_idx = tf_util.knn_graph(x, k=k, seed=seed)
     if tf_util.fused_ok(x, [width]):
         # EdgeConv without the (B,N,k,2C) edge tensor: first conv per point, gather + add, fused BN/ReLU/max
+        if cat_slot is not None:
+            net, block = tf_util.edge_conv_stack(x, nn_idx, [width], [scope], is_training, bn_decay, cat_slot=cat_slot)
+            return net, nn_idx, block
         return tf_util.edge_conv_stack(x, nn_idx, [width], [scope], is_training, bn_decay), nn_idx
     edge_feature = tf_util.get_edge_feature(x, nn_idx=nn_idx, k=k)
     net = tf_util.conv2d(edge_feature, width, [1, 1], padding='VALID', stride=[1, 1], bn=True,
                          is_training=is_training, scope=scope, bn_decay=bn_decay)
+    if cat_slot is not None:
+        return net.amax(dim=-2, keepdim=True), nn_idx, None
     return net.amax(dim=-2, keepdim=True), nn_idx               # (B,N,1,width)
 
 
@@ -42,11 +47,26 @@ def backbone(point_cloud, is_training, bn_decay, k=20):
             edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
             transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
     point_cloud_transformed = torch.matmul(point_cloud, transform)
-    net1, g1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay, seed=nn_idx)
-    net2, g2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay, seed=g1)
-    net3, g3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay, seed=g2)
-    net4, _ = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay, seed=g3)
-    cat = torch.cat([net1, net2, net3, net4], dim=-1)
+    cat = None
+    if point_cloud.is_cuda and tf_util.fused_ok(point_cloud_transformed, [64]):
+        # the four EdgeConv layers store their outputs straight into their column blocks of the (B, N, 1, 320) tensor the
+        # reference builds with tf.concat (dgcnn.py:83): no concatenation pass (round 5)
+        from .. import fused_mlp
+        b, n = point_cloud.shape[0], point_cloud.shape[1]
+        buf = fused_mlp.CatBuffer((b, n, 1, 320), point_cloud.device)
+        net1, g1, s1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay, seed=nn_idx, cat_slot=(buf, 0))
+        net2, g2, s2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay, seed=g1, cat_slot=(buf, 64))
+        net3, g3, s3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay, seed=g2, cat_slot=(buf, 128))
+        net4, _, s4 = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay, seed=g3, cat_slot=(buf, 192))
+        if all(s is not None for s in (s1, s2, s3, s4)):
+            cat = fused_mlp.cat_assemble(buf, [s1, s2, s3, s4])
+    else:
+        net1, g1 = _edge_conv(point_cloud_transformed, 64, 'dgcnn1', k, is_training, bn_decay, seed=nn_idx)
+        net2, g2 = _edge_conv(net1, 64, 'dgcnn2', k, is_training, bn_decay, seed=g1)
+        net3, g3 = _edge_conv(net2, 64, 'dgcnn3', k, is_training, bn_decay, seed=g2)
+        net4, _ = _edge_conv(net3, 128, 'dgcnn4', k, is_training, bn_decay, seed=g3)
+    if cat is None:
+        cat = torch.cat([net1, net2, net3, net4], dim=-1)
     if tf_util.fused_ok(cat, [1024]):
         out_max = tf_util.conv2d_stack_global_max(cat, [1024], ['agg'], is_training, bn_decay)
     else:

@@ -226,14 +226,17 @@ def fused_ok(x, widths):
             and 256 % (widths[0] // 4) == 0 and (widths[0] >= 256 or 256 % widths[0] == 0) and widths[0] <= 1024)
 
 
-def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, is_dist=False):
+def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, is_dist=False, cat_slot=None):
     """get_edge_feature + len(widths) x conv2d([1,1], bn, relu) + max over the k neighbours, without ever
     building the (B,N,k,2C) edge tensor.  The first conv is linear in the edge feature [x_i | x_j - x_i]:
         [x_i | x_j - x_i] W + b = x_i (W_a - W_b) + x_j W_b + b        (W = [W_a ; W_b], rows 0..C-1 / C..2C-1)
     so it is evaluated once per POINT (two small library GEMMs) and the (B,N,k,C') activation is the gather + add
     of csrc/gather.hip (`Q[b, nn_idx] + Ctr[b, i]`); the rest is the fused MLP stack.  Variables are exactly the
     ones `conv2d(..., scope=scopes[i], bn=True)` creates (dgcnn/models/dgcnn.py:39-48, transform_nets.py:18-27).
-    point_cloud (B,N,C)|(B,N,1,C), nn_idx (B,N,k) -> (B,N,1,widths[-1])"""
+    point_cloud (B,N,C)|(B,N,1,C), nn_idx (B,N,k) -> (B,N,1,widths[-1])
+    cat_slot = (fused_mlp.CatBuffer over (B,N,C_total), column): a single-layer stack on the one-GEMM path ALSO stores its
+    output as that column block of the buffer and returns (out, block alias) -- the caller assembles the concatenation of
+    several layers' outputs with fused_mlp.cat_assemble instead of torch.cat (no copy pass)."""
     x = _squeeze_cloud(point_cloud)
     b, n, c = x.shape
     names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
@@ -249,8 +252,12 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
         xp = x2d if kp == c else F.pad(x2d, (0, kp - c))
         wcat, bcat = fused_mlp.edge_weights(w1, b1, kp)
         qc = fused_mlp.rows_linear(xp, wcat, bcat).view(b, n, 2 * widths[0])
+        if cat_slot is not None and len(widths) == 1:
+            out, block = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, QC=qc,
+                                                    cat_slot=cat_slot)
+            return out.view(b, n, 1, widths[-1]), block
         out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, QC=qc)
-        return out.view(b, n, 1, widths[-1])
+        return (out.view(b, n, 1, widths[-1]), None) if cat_slot is not None else out.view(b, n, 1, widths[-1])
     w_a, w_b = w1[:c], w1[c:]
     if c % 8 == 0 and b * n >= 8192 and widths[0] % 4 == 0:
         # B*N rows into a C x C' weight: the libpcops GEMMs (the library picks a few-CU kernel for these weight gradients)
@@ -268,7 +275,7 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
         ctr = torch.addmm(b1, x2d, w_a - w_b).view(b, n, widths[0])  # centre term + bias
     decay = bn_decay if bn_decay is not None else 0.9
     out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, Q=q, Ctr=ctr)
-    return out.view(b, n, 1, widths[-1])
+    return (out.view(b, n, 1, widths[-1]), None) if cat_slot is not None else out.view(b, n, 1, widths[-1])
 
 
 def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False, pool_max=False):

@@ -664,15 +664,55 @@ def rows_linear(x2d, w, b=None):
     return _RowsLinear.apply(x2d.contiguous(), w.contiguous(), b)
 
 
+def _alias(buf, col, width):
+    """an UNTRACKED alias of buf[..., col:col + width]: same storage, no autograd view relation (the kernels write through
+    raw pointers; a tracked view of a buffer other nodes also write into would trip the version counter)"""
+    t = torch.empty(0, dtype=buf.dtype, device=buf.device)
+    return t.set_(buf.untyped_storage(), buf.storage_offset() + col, tuple(buf.shape[:-1]) + (width,), buf.stride())
+
+
+class CatBuffer:
+    """the (..., C_total) tensor several layers store their column blocks into on their way out (DGCNN's concatenation of
+    the four EdgeConv outputs, dgcnn.py:83) -- see pcops_edge_pool_out_ld2"""
+
+    def __init__(self, shape, device):
+        self.buf = torch.empty(shape, dtype=torch.float32, device=device)
+
+
+class _CatAssemble(torch.autograd.Function):
+    """apply(cat, *slices) -> the assembled tensor.  Forward: nothing to do (the blocks were stored by their producers);
+    backward: the column blocks of the gradient, as strided views"""
+
+    @staticmethod
+    def forward(ctx, cat, *slices):
+        base = cat.buf.storage_offset()
+        ctx.spans = [(s.storage_offset() - base, s.shape[-1], tuple(s.shape)) for s in slices]
+        assert sum(w for _, w, _ in ctx.spans) == cat.buf.shape[-1]
+        return _alias(cat.buf, 0, cat.buf.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.reshape(-1, g.shape[-1])                  # (rows, C_total): a view of a contiguous gradient
+        return (None,) + tuple(g2[:, c:c + w].reshape(shape[:-1] + (w,)) if g2[:, c:c + w].shape != shape else g2[:, c:c + w]
+                               for c, w, shape in ctx.spans)
+
+
+def cat_assemble(cat, slices):
+    return _CatAssemble.apply(cat, *slices)
+
+
 class EdgeConvPool(torch.autograd.Function):
-    """apply(Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased) -> (B*M, C)
+    """apply(Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased[, cat, col]) -> (B*M, C)
+    [cat (a CatBuffer over (B, M, C_total)) and col: the output is ALSO stored as columns col..col+C of cat.buf, and a second
+    output aliases that block -- for fused_mlp.cat_assemble]
     One pooled layer  y = Q[idx] + Ctr -> BN -> ReLU -> max over the neighbours  without the (B,M,S,C) tensor in either
     direction (csrc/gather.hip, edge_pool_*): the statistics, the pooled value and both gradients are functions of
     per-group sums / extrema of the gathered Q rows."""
 
     @staticmethod
-    def forward(ctx, Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased):
+    def forward(ctx, Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased, cat=None, col=0):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)
         B, M, S = idx.shape
         qc = Ctr is None            # Q is the (B, N, 2 C) product [Q | Ctr] of ONE GEMM (pcops.h "[Q | Ctr] forms")
         Nsrc, C = Q.shape[1], (Q.shape[2] // 2 if qc else Q.shape[2])
@@ -713,7 +753,12 @@ class EdgeConvPool(torch.autograd.Function):
                 mean, rstd = mm.detach().clone(), torch.rsqrt(mv.detach() + float(eps))
         out = _f32((G, C), dev)
         ysel = _f32((G, C), dev) if (training or need_grad) else None
-        if qc:
+        sl = None
+        if qc and cat is not None:
+            sl = _alias(cat.buf.view(G, -1), int(col), C)
+            _lib.call("pcops_edge_pool_out_ld2", G, C, qsel.data_ptr(), Q.data_ptr() + 4 * C, 2 * C, scale.data_ptr(),
+                      shift.data_ptr(), out.data_ptr(), _p(ysel), sl.data_ptr(), cat.buf.shape[-1])
+        elif qc:
             _lib.call("pcops_edge_pool_out_ld", G, C, qsel.data_ptr(), Q.data_ptr() + 4 * C, 2 * C, scale.data_ptr(),
                       shift.data_ptr(), out.data_ptr(), _p(ysel))
         else:
@@ -724,11 +769,16 @@ class EdgeConvPool(torch.autograd.Function):
             ctx.flags = (bool(training), bool(sync))
             if TRACE is not None:
                 TRACE.append(ctx)
-        return out
+        ctx.nout = 2 if sl is not None else 1
+        return (out, sl) if sl is not None else out
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, *grads):
         lib = _lib.load()
+        # the gradient of the dense output and (cat form) of the block stored into the concatenation
+        given = [g for g in grads if g is not None]
+        assert given, "EdgeConvPool.backward without any gradient"
+        grad_out = given[0] if len(given) == 1 else given[0] + given[1]
         Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift = ctx.saved
         training, sync = ctx.flags
         B, M, S = idx.shape
@@ -764,12 +814,12 @@ class EdgeConvPool(torch.autograd.Function):
                       idx.data_ptr(), grad_out.data_ptr(), ysel.data_ptr(), SQ.data_ptr(), arg.data_ptr(), scale.data_ptr(),
                       shift.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), dQC.data_ptr(), 2 * C,
                       dQC.data_ptr() + 4 * C, 2 * C, wsp.data_ptr())
-            return dQC, None, None, dgamma, dbeta, None, None, None, None, None, None
+            return dQC, None, None, dgamma, dbeta, None, None, None, None, None, None, None, None
         dQ, dCtr = _f32((B, Nsrc, C), dev), _f32((B, M, C), dev)
         _lib.call("pcops_edge_pool_bwd", B, Nsrc, M, S, C, Q.data_ptr(), Ctr.data_ptr(), idx.data_ptr(),
                   grad_out.data_ptr(), ysel.data_ptr(), SQ.data_ptr(), arg.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   p.data_ptr(), q.data_ptr(), t.data_ptr(), dQ.data_ptr(), dCtr.data_ptr(), wsp.data_ptr())
-        return dQ, dCtr, None, dgamma, dbeta, None, None, None, None, None, None
+        return dQ, dCtr, None, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def edge_conv_pool_supported(C, S):
@@ -839,7 +889,7 @@ def edge_qc_supported(b, n, s, c):
 
 
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
-                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None, QC=None):
+                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None, QC=None, cat_slot=None):
     """Grouped stack whose first conv was applied before the grouping:
          Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
     idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
@@ -853,6 +903,9 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
         assert Q is None and Ctr is None and xyz is None and wxyz is None and bias is None
         if len(layer_tensors) == 1 and pool:
             _w, _b, gamma, beta, mm, mv = layer_tensors[0]
+            if cat_slot is not None:         # -> (out, the alias of its block in cat_slot[0].buf)
+                return EdgeConvPool.apply(QC.contiguous(), None, idx.contiguous(), gamma, beta, mm, mv, bool(training),
+                                          float(decay), float(eps), bool(unbiased), cat_slot[0], int(cat_slot[1]))
             return EdgeConvPool.apply(QC.contiguous(), None, idx.contiguous(), gamma, beta, mm, mv, bool(training),
                                       float(decay), float(eps), bool(unbiased))
         return FusedMLPStack.apply(QC.contiguous(), None, idx.contiguous(), None, None, None, None, int(S),

@@ -32,5 +32,11 @@ PY
 find $R -name "*kernel_trace.csv" -delete; find $R -name "*agent_info.csv" -delete
 python tools/collect_traffic.py > $R/traffic.log 2>&1
 python tools/collect_traffic.py --mfma > $R/mfma.log 2>&1
-cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_detail.json gpurun_out/pmc_mfma.json $R/ 2>/dev/null
+# round 5: FETCH / WRITE bytes of the cfg3 and cfg5 steps too (VERDICT r4 missing #3)
+python tools/collect_traffic.py --model dgcnn > $R/traffic_dgcnn.log 2>&1
+python tools/collect_traffic.py --model pointnet2_cls_msg > $R/traffic_msg.log 2>&1
+cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_detail.json gpurun_out/pmc_mfma.json gpurun_out/pmc_traffic_detail_dgcnn.json gpurun_out/pmc_traffic_detail_pointnet2_cls_msg.json $R/ 2>/dev/null
+bash tools/pmc_insts.sh > /dev/null 2>&1; cp gpurun_out/pmc_insts.txt $R/pmc_insts_ssg.txt 2>/dev/null
+bash tools/pmc_insts.sh --model dgcnn > /dev/null 2>&1; cp gpurun_out/pmc_insts.txt $R/pmc_insts_dgcnn.txt 2>/dev/null
+bash tools/r5_ec.sh round > $R/ec_micro.log 2>&1; cp gpurun_out/ec_round/*.txt $R/ 2>/dev/null
 ls -la $R
