@@ -18,7 +18,11 @@ __global__ __launch_bounds__(512) void k(int iters, const int *__restrict__ rows
             const int r = rows[(it * 16 + u) & 1023];          // wave-uniform row
             if (MODE == 0) atomicAdd(&t[r * 68 + lane], v);
             else if (MODE == 1) t[r * 68 + lane] += v;
-            else if (MODE == 2) {                                 // 16 lanes x 4 components per row, 4 rows per instruction
+            else if (MODE == 3) {                                 // integer atomics, same address pattern as MODE 0 (round 5)
+                atomicAdd(reinterpret_cast<unsigned *>(&t[r * 68 + lane]), (unsigned)lane + 1u);
+            } else if (MODE == 4) {                               // 64-bit integer atomics: 32 lanes' worth of 8-byte slots per row
+                atomicAdd(reinterpret_cast<unsigned long long *>(&t[(r & 15) * 136]) + lane, (unsigned long long)lane + 1ull);
+            } else if (MODE == 2) {                                 // 16 lanes x 4 components per row, 4 rows per instruction
                 const int rr = rows[((it * 16 + u) * 4 + (lane >> 4)) & 1023];
                 float *q = &t[rr * 68 + (lane & 15) * 4];
                 atomicAdd(q, v); atomicAdd(q + 1, v); atomicAdd(q + 2, v); atomicAdd(q + 3, v);
@@ -53,5 +57,7 @@ int main() {
     run(k<0>, "ds_add_f32 row-uniform ", 64);
     run(k<1>, "read+add+write         ", 64);
     run(k<2>, "ds_add_f32 x4, 4 rows  ", 256);
+    run(k<3>, "ds_add_u32 row-uniform ", 64);
+    run(k<4>, "ds_add_u64 row-uniform ", 64);
     return 0;
 }
