@@ -158,6 +158,90 @@ struct TopK {
     }
 };
 
+// Round 5: the sorted list as ONE 64-bit key per slot, ordered as an IEEE double, so that a sorted insertion is
+// v_max_f64 + v_min_f64 per slot (2 instructions, fp64 min / max run at the fp32 rate on this chip) instead of
+// compare + med3 + two selects (4), and the (distance, index) tie rule is part of the order itself:
+//   key = bits((double)d)  [exact; the low 29 mantissa bits of a converted float are zero]
+//         | index in those 29 bits  (complemented when d < 0: a negative double grows DOWNWARDS with its magnitude)
+//         + 512 in the exponent field  (a monotone shift that keeps d = +0 -- every query's distance to itself -- and
+//           fp32 denormals away from fp64 denormals: nothing depends on how min / max treat those).
+// Keys of distinct candidates are distinct, so  L[s] <- min(L[s], max(L[s-1], x))  is an exact sorted insertion whatever
+// order the candidates arrive in.  Non-finite distances never enter (the old lists' strict '<' against +inf): they and
+// the idle lanes of a flush round insert the sentinel, which is above every key; an unfilled slot reads back as
+// (+inf, index 0) like TopK's.
+__device__ __forceinline__ double key_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // (fmin() would canonicalise both operands first: 2 more)
+    return r;
+}
+__device__ __forceinline__ double key_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int KL>
+struct TopKey {
+    static constexpr int kSentHi = 0x7FE00000, kBias = 0x20000000, kIdxMask = 0x1FFFFFFF;
+    double key[KL];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int s = 0; s < KL; ++s) key[s] = __hiloint2double(kSentHi, 0);
+    }
+    // accept: the lane has a candidate and its distance is finite (d < +inf)
+    static __device__ __forceinline__ double make(float d, int j, bool accept) {
+        const double kd = (double)d;
+        int hi = __double2hiint(kd);
+        const int t = hi >> 31;
+        const int lo = __double2loint(kd) | ((j ^ t) & kIdxMask);
+        hi = accept ? hi + kBias : kSentHi;
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ void insert(double x) {
+#pragma unroll
+        for (int s = KL - 1; s >= 1; --s) key[s] = key_min(key[s], key_max(key[s - 1], x));
+        key[0] = key_min(key[0], x);
+    }
+    __device__ __forceinline__ float value(int s) const {
+        const int hi = __double2hiint(key[s]);
+        const float v = (float)__hiloint2double(hi - kBias, __double2loint(key[s]) & ~kIdxMask);
+        return hi == kSentHi ? INFINITY : v;
+    }
+    __device__ __forceinline__ int index(int s) const {
+        const int hi = __double2hiint(key[s]);
+        return hi == kSentHi ? 0 : ((__double2loint(key[s]) ^ (hi >> 31)) & kIdxMask);
+    }
+};
+
+#ifdef PCOPS_KNN_LIST32
+// A/B build (tools/build_variant.sh list32 "-DPCOPS_KNN_LIST32=1"): the (value, index) register lists of rounds 2-4 behind
+// TopKey's interface
+template <int KL>
+struct TopList {
+    struct Entry { float d; int j; };
+    TopK<KL> t;
+    __device__ __forceinline__ void init() { t.init(); }
+    static __device__ __forceinline__ Entry make(float d, int j, bool accept) { return Entry{accept ? d : INFINITY, j}; }
+    __device__ __forceinline__ void insert(Entry e) { t.insert_ascending(e.d, e.j); }
+    __device__ __forceinline__ void merge(Entry e) { t.insert_lex(e.d, e.j); }
+    __device__ __forceinline__ Entry get(int s) const { return Entry{t.v[s], t.ix[s]}; }
+    static __device__ __forceinline__ Entry from_lane(Entry e, int src) {
+        return Entry{__shfl(e.d, src, 64), __shfl(e.j, src, 64)};
+    }
+    __device__ __forceinline__ float value(int s) const { return t.v[s]; }
+    __device__ __forceinline__ int index(int s) const { return t.ix[s]; }
+};
+#else
+template <int KL>
+struct TopList : TopKey<KL> {
+    typedef double Entry;
+    __device__ __forceinline__ void merge(double x) { this->insert(x); }
+    __device__ __forceinline__ double get(int s) const { return this->key[s]; }
+    static __device__ __forceinline__ double from_lane(double e, int src) {
+        return __hiloint2double(__shfl(__double2hiint(e), src, 64), __shfl(__double2loint(e), src, 64));
+    }
+};
+#endif
+
 // (Round 2 also tried pipelining the tiles INSIDE a wave -- the MFMA chain of tile t+1 issued two at a time between
 // the selection instructions of tile t, fragments preloaded a group ahead, branch-free pushes: 2482 vs 2505 us on 64
 // channels, 1090 vs 937 us on 3.  Per SIMD the time is close to (VALU + SALU + LDS instructions) x ~4.5 cycles PLUS the
@@ -267,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
         // direct form above (c <= 128: 6e-5); the margin is an order of magnitude wider
         if (qin && seed_ok) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
     }
-    TopK<KL> top;
+    TopList<KL> top;
     top.init();
     int nq = 0;                        // entries in this lane's queue
     // SHARED threshold of the two half-waves (round 3): lanes l and l ^ 32 scan the two halves of the SAME query's
@@ -280,15 +364,12 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     float thr = tau;                   // d < kth && d <= tau2 && d < tau as ONE compare (the list only changes in flush)
     auto flush = [&]() {
         const int mx = (int)wave_max_u32((unsigned)nq);
-        for (int u = 0; u < mx; ++u) {
-            const float d = u < nq ? qd[u * 256 + tid] : INFINITY;
-            const int j = qj[u * 256 + tid];
-            top.insert_ascending(d, j);
-        }
+        for (int u = 0; u < mx; ++u)
+            top.insert(TopList<KL>::make(qd[u * 256 + tid], qj[u * 256 + tid], u < nq));   // (queued distances are finite)
         nq = 0;
-        const float hv = top.v[(KL + 1) / 2 - 1];
+        const float hv = top.value((KL + 1) / 2 - 1);
         tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
-        thr = fminf(fminf(top.v[KL - 1], nextafterf(tau2, INFINITY)), tau);
+        thr = fminf(fminf(top.value(KL - 1), nextafterf(tau2, INFINITY)), tau);
     };
 
     // the candidate chunks are software pipelined: chunk i+1 travels global -> registers (16-byte loads when the rows
@@ -369,17 +450,19 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(int n, int c, int k, c
     if (__any(nq > 0)) flush();
 
     // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
+    {
+        typename TopList<KL>::Entry theirs[KL];
 #pragma unroll
-    for (int s = 0; s < KL; ++s) {
-        const float pv = __shfl(top.v[s], li + 32, 64);
-        const int pi = __shfl(top.ix[s], li + 32, 64);
-        if (half == 0) top.insert_lex(pv, pi);
+        for (int s = 0; s < KL; ++s) theirs[s] = TopList<KL>::from_lane(top.get(s), li + 32);
+#pragma unroll
+        for (int s = 0; s < KL; ++s)
+            if (half == 0) top.merge(theirs[s]);
     }
     if (half == 0 && qin) {
         int *o = nn_idx + ((size_t)b * n + q) * k;
 #pragma unroll
         for (int s = 0; s < KL; ++s)
-            if (s < k) o[s] = top.ix[s];
+            if (s < k) o[s] = top.index(s);
     }
 }
 
@@ -526,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
         // is an order of magnitude wider (as in knn_mfma_kernel)
         if (qin && seed_ok) tau = worst + 1e-3f * (sq + smax) + 1e-30f;
     }
-    TopK<KL> top;
+    TopList<KL> top;
     top.init();
     int nq = 0;
     float tau2 = INFINITY, thr = tau, tp = (tau - sqa) + kKnnB;
@@ -631,20 +714,19 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
                         }
                         __builtin_amdgcn_sched_barrier(0);             // (all sixteen reads hoisted to the top cost 21 spilled registers)
                     }
-                    float d = (sq + (-2.f * inner)) + sc[rr];
-                    d = live ? d : INFINITY;
+                    const float d = (sq + (-2.f * inner)) + sc[rr];
 #ifdef PCOPS_KNN_STATS
                     st_acc += (live && d < thr) ? 1u : 0u;
 #endif
-                    top.insert_ascending(d, j);
+                    top.insert(TopList<KL>::make(d, j, live && d < INFINITY));
                 }
 #ifdef PCOPS_KNN_STATS
                 st_rounds += (lane == 0) ? (unsigned)mx : 0u;
 #endif
                 nq = 0;
-                const float hv = top.v[(KL + 1) / 2 - 1];
+                const float hv = top.value((KL + 1) / 2 - 1);
                 tau2 = fmaxf(hv, __shfl_xor(hv, 32, 64));
-                thr = fminf(fminf(top.v[KL - 1], nextafterf(tau2, INFINITY)), tau);
+                thr = fminf(fminf(top.value(KL - 1), nextafterf(tau2, INFINITY)), tau);
                 tp = filter_off ? INFINITY : (thr - sqa) + kKnnB;   // reject iff  fma(-2, acc, su_j) > tp
                 }
             }
@@ -658,17 +740,19 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
 #endif
 
     // merge the half-wave lists of each query: lanes 0..31 absorb their partner's (already sorted) entries
+    {
+        typename TopList<KL>::Entry theirs[KL];
 #pragma unroll
-    for (int s = 0; s < KL; ++s) {
-        const float pv = __shfl(top.v[s], li + 32, 64);
-        const int pi = __shfl(top.ix[s], li + 32, 64);
-        if (half == 0) top.insert_lex(pv, pi);
+        for (int s = 0; s < KL; ++s) theirs[s] = TopList<KL>::from_lane(top.get(s), li + 32);
+#pragma unroll
+        for (int s = 0; s < KL; ++s)
+            if (half == 0) top.merge(theirs[s]);
     }
     if (half == 0 && qin) {
         int *o = nn_idx + ((size_t)b * n + q) * k;
 #pragma unroll
         for (int s = 0; s < KL; ++s)
-            if (s < k) o[s] = top.ix[s];
+            if (s < k) o[s] = top.index(s);
     }
 }
 

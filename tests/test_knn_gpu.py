@@ -63,7 +63,7 @@ def test_seeded_knn_graph_is_the_same_graph(b, n, c, k, kind, monkeypatch):
     assert torch.equal(nn, dg.knn_graph(T(x), k=k))
 
 
-@pytest.mark.parametrize("case", ["huge", "nan_free_mixed", "tiny", "ties"])
+@pytest.mark.parametrize("case", ["huge", "nan_free_mixed", "tiny", "ties", "subnormal_mix"])
 def test_knn_graph_fp16_filter_edge_inputs(case):
     """the 64-channel graph kernel pre-filters in fp16 (csrc/knn.hip knn_f16_kernel): features beyond the fp16 range, far
     below its normal range, wildly mixed magnitudes and exact ties must all give the oracle's indices -- the filter only
@@ -78,10 +78,42 @@ def test_knn_graph_fp16_filter_edge_inputs(case):
         x[:, 1::7] *= 1.0e-6
     elif case == "tiny":
         x *= 1.0e-6                                              # fp16 subnormals / flush to zero
+    elif case == "subnormal_mix":
+        # the filter's error bound assumes GRADUAL underflow in the float -> half conversion and in the fp16 MFMA.
+        # Channels are either fp16-subnormal (3e-5 .. 6e-5) or small (2e-3 .. 1e-2), all positive: were subnormals flushed,
+        # a subnormal channel of one point against a small channel of another would move a distance by ~3e-7 per channel
+        # with one sign -- ~1e-5 over the row, five times the bound A (s_i + s_j) + B -- and the graph would lose neighbours
+        n = 2048
+        tiny = rng.uniform(3.0e-5, 6.0e-5, (b, n, c))
+        small = rng.uniform(2.0e-3, 1.0e-2, (b, n, c))
+        x = np.where(rng.random((b, n, c)) < 0.5, tiny, small).astype(np.float32)
     else:
         x = (rng.integers(0, 2, (b, n, c)) * 0.5).astype(np.float32)   # many exactly equal distances
     nn = dg.knn_graph(T(x), k=k)
     np.testing.assert_array_equal(N(nn), O.knn_graph(x, k))
+
+
+@pytest.mark.parametrize("c", [3, 64, 16])
+def test_knn_graph_zero_and_negative_distances(c):
+    """round 5: the sorted lists are 64-bit keys ordered as doubles (csrc/knn.hip TopKey).  Exercised here: distance exactly
+    +0 (every point to itself, and exact duplicates -> the index decides), distances that come out NEGATIVE from
+    (s_i - 2 <x_i, x_j>) + s_j (near-duplicates at a large offset: the index order reverses inside a negative double unless it
+    is complemented), fp32-denormal distances, and a cloud with fewer distinct points than k"""
+    rng = np.random.default_rng(c)
+    b, n, k = 2, 640, 20
+    base = rng.standard_normal((b, n // 4, c)).astype(np.float32) + np.float32(50.0)
+    x = np.concatenate([base, base,                                                  # exact duplicates
+                        np.nextafter(base, np.float32(np.inf)),                      # one ulp away: rounding decides the sign
+                        np.nextafter(base, np.float32(-np.inf))], axis=1).astype(np.float32)
+    x = x[:, rng.permutation(n)]
+    ref = O.knn_graph(x, k)
+    d = O.pairwise_distance(x[:1])[0]
+    assert (d < 0).any() and (d == 0).any()                                          # the case is what it claims to be
+    np.testing.assert_array_equal(N(dg.knn_graph(T(x), k=k)), ref)
+    tiny = (rng.standard_normal((b, 512, c)) * 1e-21).astype(np.float32)             # squared distances ~1e-42: fp32 denormals
+    np.testing.assert_array_equal(N(dg.knn_graph(T(tiny), k=k)), O.knn_graph(tiny, k))
+    few = np.repeat(rng.standard_normal((b, 4, c)).astype(np.float32), 64, axis=1)   # 4 distinct points, 64 copies each
+    np.testing.assert_array_equal(N(dg.knn_graph(T(few), k=k)), O.knn_graph(few, k))
 
 
 def test_knn_graph_4d_input_and_lattice_ties():

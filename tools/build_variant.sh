@@ -13,7 +13,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-
 pids=()
 echo "$EXTRA" > $OBJ/flags.new
 if ! cmp -s $OBJ/flags.new $OBJ/flags 2>/dev/null; then rm -f $OBJ/*.o; cp $OBJ/flags.new $OBJ/flags; fi
-for f in abi sampling grouping interpolate knn mlp gather; do
+for f in abi sampling grouping interpolate knn mlp gather edgeconv head; do
   if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ $SRC/common.h -nt $OBJ/$f.o ]; then
     /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o &
     pids+=($!)
