@@ -260,8 +260,10 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
  * gamma >= 0, decreasing for gamma < 0 (scale = gamma * rstd) -- so per group of S consecutive rows
  *   ysel[g,c] = max_s y (gamma[c] >= 0) | min_s y (gamma[c] < 0),  argsel[g,c] = first row attaining it (8 bit)
  * and, once scale/shift are known, pcops_mlp_pool_select gives out = relu(scale*ysel + shift) without re-reading
- * Y.  S % 32 == 0, S <= 256, M % S == 0, ldx == K; PCOPS_ERR_UNSUPPORTED when the shape is outside what
- * pcops_mlp_gemm_fwd_pool_supported(M,K,N,S) accepts.
+ * Y.  S % 32 == 0, S <= 256, M % S == 0, ldx == K -- or (round 5) groups that are NOT whole 32-row tiles: S % 4 == 0,
+ * 8 <= S < 256, lcm(S, 32) <= 256 and M a multiple of it (DGCNN's T-Net: S = 20, MSG: S = 16; a wave walks lcm(S, 32)
+ * rows = whole groups, a lane's four consecutive rows always lie inside one group; split-operand kernels only);
+ * PCOPS_ERR_UNSUPPORTED when the shape is outside what pcops_mlp_gemm_fwd_pool_supported(M,K,N,S) accepts.
  * pro_scale == pro_shift == NULL: X is the stack's raw input.  Y == NULL: the activation is not stored at all (it then
  * only exists as statistics and group extrema) -- enough for a forward without backward and for the algebraic backward
  * of a pooled top layer below. */

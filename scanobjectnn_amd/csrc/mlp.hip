@@ -163,6 +163,10 @@ struct GemmArgs {
     // 32*pool_sub rows the pooled activation is relu(scale * ysel + shift) with ysel the max (gamma >= 0) or min
     // (gamma < 0) of y over the group; psel gets the first row attaining it
     int pool_sub;
+    // round 5: groups of pool_s4 rows with pool_s4 % 4 == 0 and NOT a multiple of 32 (DGCNN's T-Net: 20 neighbours): a wave
+    // walks 32 pool_sub = lcm(pool_s4, 32) rows = 32 pool_sub / pool_s4 WHOLE groups; pool_inv = 65536 / pool_s4 + 1
+    // (row / pool_s4 as a multiplication, exact for the rows of one walk: checked by the launcher).  0: one group per walk
+    int pool_s4, pool_inv;
     const float *pgamma;                // [N]
     float *ysel;                        // [M / (32 pool_sub)][N]
     unsigned char *psel;                // [M / (32 pool_sub)][N]
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     //      operand stripe stays fp32 and is split in registers on the way to the matrix pipe (every element is read by
     //      exactly one lane, so the split costs the same there as at staging time and needs no second stripe).
     constexpr bool BF3 = (VAR & 4) != 0;
+    constexpr bool S4 = (VAR & 8) != 0;       // pooled forward over groups that are not whole tiles (GemmArgs::pool_s4)
     constexpr bool POOL = (VAR & 3) == 1 || (VAR & 3) == 3, WST = (VAR & 3) == 2 || (VAR & 3) == 3;   // 3: pooled AND streamed
     constexpr int BN = NT * 32;
     constexpr int NTH = NT / EH;                   // accumulator tiles per epilogue pass
@@ -876,8 +881,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // pooled epilogue then cost a wave 18 500 cycles per tile against 7 000 without pooling, tools/phase_prof.py.)
     float gmx[POOL ? NT : 1];                         // uncompacted groups: running max over the group's tiles, its row
     int grw[POOL ? NT : 1];
+    float gmy[S4 ? NT : 1];                           // pool_s4: the running pair of the ODD groups (gmx / grw: the even ones)
+    int gry[S4 ? NT : 1];
 #pragma unroll
     for (int i = 0; i < (POOL ? NT : 1); ++i) { gmx[i] = -INFINITY; grw[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < (S4 ? NT : 1); ++i) { gmy[i] = -INFINITY; gry[i] = 0; }
     const int peer32 = (lane ^ 32) << 2;
     // value + row of the better of (this half-wave, the other): larger value, then lower row
     auto meet = [&](float &m, int &r) {
@@ -916,6 +925,58 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
                         a.ysel[blk * N + n] = fmaf(m, sg, pv);               // the raw y at that row, as it is stored
                         a.psel[blk * N + n] = (unsigned char)(s0 + r);
+                    }
+                }
+            }
+        } else if constexpr (S4) {
+            // Groups of S rows, S % 4 == 0: the four rows a lane holds in registers 4 seg .. 4 seg + 3 (rows 8 seg + hrow .. + 3 of
+            // the tile) lie inside ONE group, so the lane takes their (max, first row) on registers and merges it into the
+            // running pair of the group's parity -- the two half-waves may be in neighbouring groups.  Rows 8 seg .. 8 seg + 7
+            // are done in both half-waves after segment seg: a group that ends there is met across the half-waves and
+            // stored at once, which frees its pair before the next group of the same parity begins (S >= 8).
+            const int S_ = a.pool_s4;
+            const int gps = 32 * SUB / S_;                                   // groups per walk
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg) {
+                const int rs = 32 * sub + 8 * seg + hrow;                    // first row of the lane's segment, in the walk
+                const int g = (rs * a.pool_inv) >> 16;                       // rs / S_
+                const int rg0 = rs - g * S_;
+                const bool odd = (g & 1) != 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float m = acc[nt][4 * seg];
+                    int r = 0;
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        const float x = acc[nt][4 * seg + i];
+                        const bool gt = x > m;                               // strict: the first maximum stays
+                        m = gt ? x : m;
+                        r = gt ? i : r;
+                    }
+                    r += rg0;
+                    const bool te = !odd && m > gmx[nt], to = odd && m > gmy[nt];
+                    gmx[nt] = te ? m : gmx[nt]; grw[nt] = te ? r : grw[nt];
+                    gmy[nt] = to ? m : gmy[nt]; gry[nt] = to ? r : gry[nt];
+                }
+                const int pe = 32 * sub + 8 * seg + 8;                       // rows of the walk done so far (wave-uniform)
+                const int ge = (pe * a.pool_inv) >> 16;                      // groups that end at or before row pe
+                if (ge >= 1 && ge * S_ > pe - 8) {                           // group ge - 1 ended inside this segment pair
+                    const int gd = ge - 1;
+                    const long long gg = st * gps + gd;
+                    const bool dodd = (gd & 1) != 0;                         // wave-uniform
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float m = dodd ? gmy[nt] : gmx[nt];
+                        int r = dodd ? gry[nt] : grw[nt];
+                        meet(m, r);
+                        const int n = n0 + 32 * nt + (lane & 31);
+                        if (low && n < N) {
+                            const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
+                            a.ysel[gg * N + n] = fmaf(m, sg, pv);
+                            a.psel[gg * N + n] = (unsigned char)r;
+                        }
+                        if (dodd) { gmy[nt] = -INFINITY; gry[nt] = 0; }
+                        else { gmx[nt] = -INFINITY; grw[nt] = 0; }
                     }
                 }
             }
@@ -1471,6 +1532,25 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
+        if constexpr (AM == A_BNRELU || AM == A_PLAIN) {
+            if (a.pool_s4 > 0) {     // groups that are not whole tiles: their own instantiations (VAR | 8), split operands only
+#define PCOPS_WS3S4_LAUNCH(NT_, EH_)                                                                  \
+    do {                                                                                              \
+        auto kern = pl.wst ? gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, 15> : gemm_ws_kernel<NT_, AM, EM, 32, 8, EH_, 13>; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+            return PCOPS_ERR_LAUNCH;                                                                  \
+        a.nrowgrp = pl.gy;                                                                            \
+        const int P_ = a.stats ? pcops_mlp_stats_rows(a.M) : 0;                                       \
+        hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
+    } while (0)
+                if (pl.bn == 128) PCOPS_WS3S4_LAUNCH(4, 4);
+                else if (pl.bn == 96) PCOPS_WS3S4_LAUNCH(3, 3);
+                else PCOPS_WS3S4_LAUNCH(2, 2);
+#undef PCOPS_WS3S4_LAUNCH
+                return pcops_launch_status();
+            }
+        }
         if (pl.bn == 128) PCOPS_WS3_LAUNCH(4, 4);
         else if (pl.bn == 96) PCOPS_WS3_LAUNCH(3, 3);
         else PCOPS_WS3_LAUNCH(2, 2);
@@ -1478,6 +1558,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         return pcops_launch_status();
     }
     }
+    if (a.pool_s4 > 0) return PCOPS_ERR_UNSUPPORTED;      // (only the split-operand kernels carry that epilogue)
     if (pl.bn == 128) PCOPS_WS_LAUNCH(4, 2);
     else if (pl.bn == 96) PCOPS_WS_LAUNCH(3, 3);
     else PCOPS_WS_LAUNCH(2, 1);
@@ -4176,12 +4257,40 @@ int pcops_mlp_gemm_fwd(int M, int K, int N, const float *X, int ldx, const float
                                    stream);
 }
 
+// groups of S rows that are not whole 32-row tiles (round 5): S % 4 == 0, 8 <= S < 256, a walk of lcm(S, 32) <= 256 rows
+static int pool_s4_sub(int S) {
+    if (S % 32 == 0 || S % 4 != 0 || S < 8 || S > 255) return 0;
+    int l = S;
+    while (l % 32 != 0) l += S;
+    if (l > 256) return 0;
+    const int inv = 65536 / S + 1;
+    for (int r = 0; r <= l; ++r)
+        if (((r * inv) >> 16) != r / S) return 0;
+    return l / 32;
+}
+static bool pool_s4_enabled() {
+    static const bool on = [] { const char *e = getenv("PCOPS_POOL_S4"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    return on;
+}
+static void set_pool_group(GemmArgs &a, int S) {
+    const int sub4 = pool_s4_sub(S);
+    a.pool_sub = sub4 ? sub4 : S / 32;
+    a.pool_s4 = sub4 ? S : 0;
+    a.pool_inv = sub4 ? 65536 / S + 1 : 0;
+}
 static bool fwd_pool_shape_ok(int M, int K, int N, int S) {
-    if (S < 32 || S > 256 || S % 32 != 0 || M % S != 0) return false;
+    const int sub4 = pool_s4_enabled() ? pool_s4_sub(S) : 0;
+    if (sub4) {
+        if (M % (32 * sub4) != 0) return false;
+    } else if (S < 32 || S > 256 || S % 32 != 0 || M % S != 0) {
+        return false;
+    }
     GemmArgs a = {};
-    a.M = M; a.K = K; a.N = N; a.ldx = K; a.ldy = N; a.pool_sub = S / 32;
+    a.M = M; a.K = K; a.N = N; a.ldx = K; a.ldy = N;
+    set_pool_group(a, S);
     WsPlan pl;
-    return ws_enabled() && ws_plan(a, A_BNRELU, &pl);
+    if (!(ws_enabled() && ws_plan(a, A_BNRELU, &pl, true))) return false;
+    return !sub4 || pl.bf3;                                 // groups that are not whole tiles: split-operand kernels only
 }
 
 int pcops_mlp_gemm_fwd_pool_supported(int M, int K, int N, int S) { return fwd_pool_shape_ok(M, K, N, S) ? 1 : 0; }
@@ -4200,7 +4309,8 @@ int pcops_mlp_gemm_fwd_pool(int M, int K, int N, int S, const float *X, int ldx,
     GemmArgs a = {};
     a.M = M; a.K = K; a.N = N; a.X = X; a.ldx = ldx; a.v0 = pro_scale; a.v1 = pro_shift;
     a.W = W; a.bias = bias; a.Y = Y; a.ldy = N; a.stats = stats_partial; a.pivot = stats_partial ? stat_pivot : nullptr;
-    a.pool_sub = S / 32; a.pgamma = gamma; a.ysel = ysel; a.psel = argsel;
+    set_pool_group(a, S);
+    a.pgamma = gamma; a.ysel = ysel; a.psel = argsel;
     WsPlan pl;
     if (!ws_plan(a, A_BNRELU, &pl)) return PCOPS_ERR_UNSUPPORTED;   // pointer alignment
     if (!pro_scale) return launch_gemm<A_PLAIN, E_FWD>(a, as_stream(stream));      // the stack's raw input
