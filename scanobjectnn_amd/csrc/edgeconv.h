@@ -29,3 +29,9 @@ bool ec_sparse_ok(int n);
 int ec_sparse(int b, int n, int m, int s, int c, const float *gpool, const float *ysel, const float *SQ, const float *Ctr,
               int ldc, const unsigned char *arg, const int *idx, const float *scale, const float *shift, const float *p,
               const float *q, const float *t, float *dCtr, int lddc, float *dQ, int lddq, hipStream_t st);
+// both terms of the EdgeConv backward + dCtr in one owner walk (after ec_csr_build): no LDS atomics, dQ written once
+bool ec_bwd_fused_ok(int n, int m, int s, int c);
+int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *gpool,
+                 const float *ysel, const float *SQ, const unsigned char *arg, const float *scale, const float *shift,
+                 const float *p, const float *q, const float *t, const void *workspace, float *dQ, int lddq, float *dCtr,
+                 int lddc, hipStream_t st);

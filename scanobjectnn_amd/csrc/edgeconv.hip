@@ -795,6 +795,202 @@ __global__ __launch_bounds__(1024) void ec_sparse_kernel(SparseArgs a) {
     }
 }
 
+// ---- both terms of the EdgeConv backward in ONE owner walk (round 5, second half) -----------------------------------
+//   dQ[i,c] = q (cnt Q[i] + sum_{(g,s) -> i} Ctr[g]) + cnt t  +  sum_{(g,s) -> i, arg[g,c] == s} a[g,c],
+//   a[g,c] = p gpool[g,c] [relu(bn(ysel[g,c])) > 0],     dCtr[g] = q (SQ + k Ctr) + k t + a.
+// The arg-row term used to be its own kernel that added a[g,c] into an LDS copy of dQ with ds_add_f32 -- 0.33 lane-ops per
+// clock and CU (tools/ubench/lds_atomic.hip): 165 of its 195 us were that one instruction -- and the dense term a second
+// walk that read dQ back.  Here a point's list is walked ONCE: next to the Ctr rows the LDS holds a[g] and the four arg
+// bytes of the slice, and an entry adds a[g,c] where its slot IS the arg -- a compare and a select, no atomic; dQ leaves
+// with plain stores and is never read, dCtr comes out of the staging phase.
+// One workgroup per (cloud, 8-channel slice): the slice is loaded 32 contiguous bytes per group row (two lanes), parked in
+// registers, and walked in two passes of 4 channels -- LDS: Ctr | a [m][8] floats, arg [m] u32, codes [m S] u16 (154 KB at
+// m = 2048, S = 20), the list boundaries come from L2.  A lane owns TWO points per pass: position p and position n - 1 - p
+// of the descending-length order (perm), so every wave gets long lists and short ones.
+constexpr int kBwdCh = 8, kBwdGP = 4;        // channels per workgroup; groups a lane pair stages (m <= 512 kBwdGP)
+
+struct BwdLdsArgs {
+    int n, m, S, C, sbits;
+    int ldq, ldc, lddq, lddc;
+    const float *Q, *Ctr, *gpool, *ysel, *SQ;
+    const unsigned char *arg;
+    const float *scale, *shift, *p, *q, *t;
+    const int *start, *perm;
+    const unsigned short *codes;
+    float *dQ, *dCtr;
+};
+
+#ifdef PCOPS_EC_PROF
+__device__ unsigned long long g_ec_prof[8];
+#define EC_T(i_) do { if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_ec_prof[i_], n_ - ec_t); ec_t = n_; } } while (0)
+#else
+#define EC_T(i_) do {} while (0)
+#endif
+__global__ __launch_bounds__(1024) void ec_bwd_lds_kernel(BwdLdsArgs a) {
+#ifdef PCOPS_EC_PROF
+    unsigned long long ec_t = __builtin_readcyclecounter();
+#endif
+    extern __shared__ __attribute__((aligned(16))) float4 ec_ca[];      // Ctr rows [m + 1] | a rows [m + 1]
+    const int n = a.n, m = a.m, C = a.C, NS = C / kBwdCh, mS = m * a.S;
+    const unsigned vb = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = (int)(vb / (unsigned)NS), sl = (int)(vb - (unsigned)b * (unsigned)NS);
+    const int tid = threadIdx.x;
+    unsigned *ar = reinterpret_cast<unsigned *>(ec_ca + ((size_t)m + 1) * 2);                   // [m + 1]
+    // (offsets on the LDS pointer itself: a round trip through uintptr_t makes it a generic pointer and the reads flat loads)
+    unsigned short *cs16 = reinterpret_cast<unsigned short *>(ec_ca + ((size_t)m + 1) * 2 + ((size_t)m + 1 + 3) / 4);
+    // ---- staging: this lane's half (4 channels) of up to kBwdGP group rows, dCtr on the way
+    const int h = tid & 1, cbase = sl * kBwdCh + 4 * h;
+    const float4 cq = *reinterpret_cast<const float4 *>(a.q + cbase);
+    const float4 ct = *reinterpret_cast<const float4 *>(a.t + cbase);
+    float4 sctr[kBwdGP], sa[kBwdGP];
+    unsigned sarg[kBwdGP];
+    {
+        const float4 cs = *reinterpret_cast<const float4 *>(a.scale + cbase);
+        const float4 ch = *reinterpret_cast<const float4 *>(a.shift + cbase);
+        const float4 cp = *reinterpret_cast<const float4 *>(a.p + cbase);
+        const float kf = (float)a.S;
+        float4 ys[kBwdGP], gp[kBwdGP], sq[kBwdGP];
+#pragma unroll
+        for (int r = 0; r < kBwdGP; ++r) {
+            const int j = (tid >> 1) + 512 * r;
+            const long long g = (long long)b * m + (j < m ? j : 0);
+            sctr[r] = *reinterpret_cast<const float4 *>(a.Ctr + g * a.ldc + cbase);
+            ys[r] = *reinterpret_cast<const float4 *>(a.ysel + g * C + cbase);
+            gp[r] = *reinterpret_cast<const float4 *>(a.gpool + g * C + cbase);
+            sq[r] = *reinterpret_cast<const float4 *>(a.SQ + g * C + cbase);
+            sarg[r] = *reinterpret_cast<const unsigned *>(a.arg + g * C + cbase);
+        }
+#pragma unroll
+        for (int r = 0; r < kBwdGP; ++r) {
+            const int j = (tid >> 1) + 512 * r;
+            float4 av;
+            av.x = fmaf(ys[r].x, cs.x, ch.x) > 0.f ? cp.x * gp[r].x : 0.f;
+            av.y = fmaf(ys[r].y, cs.y, ch.y) > 0.f ? cp.y * gp[r].y : 0.f;
+            av.z = fmaf(ys[r].z, cs.z, ch.z) > 0.f ? cp.z * gp[r].z : 0.f;
+            av.w = fmaf(ys[r].w, cs.w, ch.w) > 0.f ? cp.w * gp[r].w : 0.f;
+            sa[r] = av;
+            if (j < m) {
+                float4 d;
+                d.x = fmaf(cq.x, fmaf(kf, sctr[r].x, sq[r].x), fmaf(kf, ct.x, av.x));
+                d.y = fmaf(cq.y, fmaf(kf, sctr[r].y, sq[r].y), fmaf(kf, ct.y, av.y));
+                d.z = fmaf(cq.z, fmaf(kf, sctr[r].z, sq[r].z), fmaf(kf, ct.z, av.z));
+                d.w = fmaf(cq.w, fmaf(kf, sctr[r].w, sq[r].w), fmaf(kf, ct.w, av.w));
+                *reinterpret_cast<float4 *>(a.dCtr + ((long long)b * m + j) * a.lddc + cbase) = d;
+            }
+        }
+        const unsigned short *cg = a.codes + (long long)b * mS;
+        if ((mS & 7) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
+            const uint4 *c4 = reinterpret_cast<const uint4 *>(cg);
+            uint4 *d4 = reinterpret_cast<uint4 *>(cs16);
+            for (int k = tid; k < (mS >> 3); k += 1024) d4[k] = c4[k];
+        } else {
+            for (int k = tid; k < mS; k += 1024) cs16[k] = cg[k];
+        }
+    }
+    EC_T(0);                                                             // staging loads consumed, dCtr and codes issued
+    const int sbits = a.sbits;
+    const unsigned smask = (1u << sbits) - 1u;
+    const int *sb = a.start + (long long)b * (n + 1);
+    const int *pb = a.perm + (long long)b * n;
+    // this lane's two points (positions tid and n - 1 - tid ... of the descending-length order: a long list and a short
+    // one) and their list boundaries: loaded ONCE, next to the staging loads -- a chain of three dependent L2 round trips
+    // (perm -> start -> Q row) at the top of every point was most of the walk's time
+    int pi[2], pk0[2], pk1[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int base = u * 1024, len = min(1024, n - base);
+        const bool in = tid < len;
+        const int pos = in ? (u ? base + len - 1 - tid : base + tid) : 0;
+        pi[u] = in ? pb[pos] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        pk0[u] = pi[u] >= 0 ? sb[pi[u]] : 0;
+        pk1[u] = pi[u] >= 0 ? sb[pi[u] + 1] : 0;
+    }
+    const float *Qb = a.Q + (long long)b * n * a.ldq + sl * kBwdCh;
+    float *dQb = a.dQ + (long long)b * n * a.lddq + sl * kBwdCh;
+    float4 qn[2];                                                        // Q rows of the pass to come
+#pragma unroll
+    for (int u = 0; u < 2; ++u) qn[u] = *reinterpret_cast<const float4 *>(Qb + (long long)(pi[u] >= 0 ? pi[u] : 0) * a.ldq);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();                                                 // the previous pass has left the LDS slice
+        if (h == pass) {
+#pragma unroll
+            for (int r = 0; r < kBwdGP; ++r) {
+                const int j = (tid >> 1) + 512 * r;
+                if (j < m) {
+                    ec_ca[j] = sctr[r];
+                    ec_ca[m + 1 + j] = sa[r];
+                    ar[j] = sarg[r];
+                }
+            }
+        }
+        const float4 qc[2] = {qn[0], qn[1]};
+        if (pass == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                qn[u] = *reinterpret_cast<const float4 *>(Qb + (long long)(pi[u] >= 0 ? pi[u] : 0) * a.ldq + 4);
+        }
+        __syncthreads();
+        EC_T(1 + 2 * pass);                                              // barriers + LDS fill
+        const int c0 = sl * kBwdCh + 4 * pass;
+        const float4 wq = *reinterpret_cast<const float4 *>(a.q + c0);
+        const float4 wt = *reinterpret_cast<const float4 *>(a.t + c0);
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            const int i = u ? pi[1] : pi[0];
+            if (i < 0) continue;
+            const int k0 = u ? pk0[1] : pk0[0], k1 = u ? pk1[1] : pk1[0];
+            const float4 qi = u ? qc[1] : qc[0];
+            f2 sc0 = {0.f, 0.f}, sc1 = {0.f, 0.f};                       // sums of Ctr, channels (0 1) (2 3)
+            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);                  // arg-row sums
+            // an entry reads its group's Ctr row and arg word; the a row ONLY when one of the four arg bytes is its slot
+            // (18 % of the lanes: the LDS moves bytes for active lanes only, and random-row reads are what bounds the walk)
+            auto entry = [&](unsigned code) {
+                const unsigned g = code >> sbits, s = code & smask;
+                const float4 x = ec_ca[g];
+                const unsigned z = ar[g] ^ (s * 0x01010101u);             // a zero byte where arg == slot
+                sc0 += f2{x.x, x.y};
+                sc1 += f2{x.z, x.w};
+                if ((z - 0x01010101u) & ~z & 0x80808080u) {
+                    const float4 av = ec_ca[m + 1 + g];
+                    sv.x += (z & 0x000000ffu) == 0u ? av.x : 0.f;
+                    sv.y += (z & 0x0000ff00u) == 0u ? av.y : 0.f;
+                    sv.z += (z & 0x00ff0000u) == 0u ? av.z : 0.f;
+                    sv.w += (z & 0xff000000u) == 0u ? av.w : 0.f;
+                }
+            };
+            int k = k0;
+            for (; k + 4 <= k1; k += 4) {
+                unsigned cd[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cd[v] = cs16[k + v];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) entry(cd[v]);
+            }
+            for (; k < k1; ++k) entry(cs16[k]);
+            const float kf = (float)(k1 - k0);
+            float4 d;
+            d.x = fmaf(wq.x, fmaf(kf, qi.x, sc0.x), fmaf(kf, wt.x, sv.x));
+            d.y = fmaf(wq.y, fmaf(kf, qi.y, sc0.y), fmaf(kf, wt.y, sv.y));
+            d.z = fmaf(wq.z, fmaf(kf, qi.z, sc1.x), fmaf(kf, wt.z, sv.z));
+            d.w = fmaf(wq.w, fmaf(kf, qi.w, sc1.y), fmaf(kf, wt.w, sv.w));
+            *reinterpret_cast<float4 *>(dQb + (long long)i * a.lddq + 4 * pass) = d;
+        }
+        EC_T(2 + 2 * pass);                                              // wave 0's walk of the pass
+    }
+#ifdef PCOPS_EC_PROF
+    __syncthreads();
+    EC_T(5);                                                             // the other waves' tail
+    if (threadIdx.x == 0) atomicAdd(&g_ec_prof[7], 1ull);
+#endif
+}
+
+size_t ec_bwd_lds_bytes(int m, int s) {
+    return ((size_t)m + 1) * 32 + (((size_t)m + 1) * 4 + 15) / 16 * 16 + (((size_t)m * s * 2 + 15) & ~(size_t)15) + 16;
+}
 bool ec_shape_ok(int b, int n, int m, int s, int c) {
     // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q (row stride up to 2 c) / the cloud's G rows
     return c >= 64 && c % 64 == 0 && m >= kGB && m % kGB == 0 && s >= 1 && s <= 128 && n >= 1 &&
@@ -803,6 +999,46 @@ bool ec_shape_ok(int b, int n, int m, int s, int c) {
 }
 
 }  // namespace
+
+bool ec_bwd_fused_ok(int n, int m, int s, int c) {
+    // OFF by default: measured 523 us against 478 us for the two kernels at (256, 2048, k = 20, C = 64).  The phase split
+    // (tools/r5_ecprof.py, profiles/r05_ec_bwd_fused_phases.txt): 75 000 of a workgroup's 138 000 cycles are the STAGING of its
+    // 8-channel slice -- 32 bytes out of every 256-byte row of four matrices, ~10 000 L1 misses per workgroup at ~0.13 lines
+    // per cycle and CU -- and two 4-channel walks take 27 000 each (VALU issue: 27 instructions per entry).  The walk itself
+    // is what was hoped for (no atomics: 183 us per layer for both terms); row-major operands sliced this thin are not.
+    static const bool on = [] { const char *e = getenv("PCOPS_EDGECONV_BWD_FUSED"); return e && e[0] == '1'; }();
+    return on && c % kBwdCh == 0 && m <= 512 * kBwdGP && s <= 255 && ec_codes16_ok(m, s) && ec_bwd_lds_bytes(m, s) <= kLdsMax &&
+           n >= 1 && n <= 2048;
+}
+
+int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const float *gpool,
+                 const float *ysel, const float *SQ, const unsigned char *arg, const float *scale, const float *shift,
+                 const float *p, const float *q, const float *t, const void *workspace, float *dQ, int lddq, float *dCtr,
+                 int lddc, hipStream_t st) {
+    const unsigned *order = static_cast<const unsigned *>(workspace);
+    const int *start = reinterpret_cast<const int *>(order + (size_t)b * m * s);
+    const int *perm = start + (size_t)b * (n + 1);
+    const unsigned short *codes = reinterpret_cast<const unsigned short *>(perm + (size_t)b * n);
+    BwdLdsArgs a = {n, m, s, c, ec_sbits(s), ldq, ldc, lddq, lddc, Q, Ctr, gpool, ysel, SQ, arg, scale, shift, p, q, t,
+                    start, perm, codes, dQ, dCtr};
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(ec_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kLdsMax) != hipSuccess)
+        return PCOPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(ec_bwd_lds_kernel, dim3((unsigned)b * (c / kBwdCh)), dim3(1024), ec_bwd_lds_bytes(m, s), st, a);
+    return pcops_launch_status();
+}
+
+
+#ifdef PCOPS_EC_PROF
+// diagnostics build (tools/build_variant.sh ecprof "-DPCOPS_EC_PROF=1"): phase cycle sums of ec_bwd_lds_kernel's lane 0
+extern "C" int pcops_ec_debug_prof(unsigned long long *out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return PCOPS_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_ec_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ec_prof), z, sizeof(z)) != hipSuccess) return PCOPS_ERR_LAUNCH;
+    return PCOPS_OK;
+}
+#endif
 
 bool ec_enabled() {
     static const bool on = [] { const char *e = getenv("PCOPS_EDGECONV_R5"); return !(e && e[0] == '0'); }();

@@ -1860,6 +1860,12 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
     PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
+    if (use_owner && !det && ec_bwd_supported(b, n, m, s, c) && ec_bwd_fused_ok(n, m, s, c)) {
+        // round 5, second half: both terms and dCtr in ONE owner walk (edgeconv.hip ec_bwd_lds_kernel)
+        int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
+        if (rc) return rc;
+        return ec_bwd_fused(b, n, m, s, c, Q, c, Ctr, c, gpool, ysel, SQ, arg, scale, shift, p, q, t, workspace, dQ, c, dCtr, c, st);
+    }
     if (use_owner && !det && ec_bwd_supported(b, n, m, s, c)) {
         // round 5 (edgeconv.hip): the arg-row term + dCtr as before (LDS slices, plain stores: initialises dQ), then the
         // dense term by a leaner owner walk over a packed inverse index, clouds XCD-contiguous
@@ -2000,6 +2006,12 @@ int pcops_edge_pool_bwd_ld(int b, int n, int m, int s, int c, const float *Q, in
     PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dQ); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
     if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
+    if (ec_bwd_fused_ok(n, m, s, c)) {
+        int rc0 = ec_csr_build(b, n, m, s, idx, workspace, st);
+        if (rc0) return rc0;
+        return ec_bwd_fused(b, n, m, s, c, Q, ldq, Ctr, ldc, gpool, ysel, SQ, arg, scale, shift, p, q, t, workspace, dQ, lddq,
+                            dCtr, lddc, st);
+    }
     int rc = ec_sparse(b, n, m, s, c, gpool, ysel, SQ, Ctr, ldc, arg, idx, scale, shift, p, q, t, dCtr, lddc, dQ, lddq, st);
     if (rc) return rc;
     rc = ec_csr_build(b, n, m, s, idx, workspace, st);

@@ -399,3 +399,50 @@ def test_adam_step_is_the_reference_update():
         assert torch.allclose(oa.m, ob.m, rtol=1e-6, atol=1e-12) and torch.allclose(oa.v, ob.v, rtol=1e-6, atol=1e-20)
         # lr-sized updates computed a few ulp apart, added to parameters of magnitude <= 0.2: one ulp of those is 1.5e-8
         assert (fa.flat - fb.flat).abs().max().item() <= 3.1e-8
+
+
+# ------------------------------------------------------------------ EdgeConv backward, both terms in one owner walk (round 5)
+@pytest.mark.parametrize("b,n,k,C,ld", [(3, 2048, 20, 64, False), (2, 2048, 20, 128, True), (2, 1024, 20, 64, True),
+                                        (2, 1088, 16, 64, False), (1, 1984, 20, 256, False)])
+def test_edge_pool_bwd_against_float64(b, n, k, C, ld):
+    """pcops_edge_pool_bwd / _ld (csrc/edgeconv.hip ec_bwd_lds_kernel: inverse index, then ONE walk that adds the Ctr rows
+    AND the arg-row values of every list entry) against the definition in float64:
+      a[g,c] = p gpool [scale ysel + shift > 0],  dCtr[g] = q (SQ + k Ctr) + k t + a,
+      dQ[i] = q (cnt_i Q[i] + sum_{(g,s) -> i} Ctr[g]) + cnt_i t + sum_{(g,s) -> i, arg[g,c] == s} a[g,c]"""
+    from scanobjectnn_amd.dgcnn import tf_util
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(n + C)
+    x = torch.from_numpy(synth_clouds(b, n, seed=C)).to(DEV)
+    idx = tf_util.knn_graph(x, k=k)                                   # a real graph: list lengths 0 .. ~100
+    m, G = n, b * n
+    QC = torch.randn(b, n, 2 * C, device=DEV, generator=gen)
+    Q, Ctr = (QC[..., :C], QC[..., C:]) if ld else (QC[..., :C].contiguous(), QC[..., C:].contiguous())
+    gpool, ysel, SQ = (torch.randn(G, C, device=DEV, generator=gen) for _ in range(3))
+    arg = torch.randint(0, k, (G, C), device=DEV, generator=gen, dtype=torch.int32).to(torch.uint8)
+    sc, sh, p, q, t = (torch.randn(C, device=DEV, generator=gen) for _ in range(5))
+    wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(b, n, m, k)) // 4, dtype=torch.int32, device=DEV)
+    P = lambda v: v.data_ptr()
+    if ld:
+        dQC = torch.full((b, n, 2 * C), float("nan"), device=DEV)
+        _lib.call("pcops_edge_pool_bwd_ld", b, n, m, k, C, P(QC), 2 * C, P(QC) + 4 * C, 2 * C, P(idx), P(gpool), P(ysel), P(SQ),
+                  P(arg), P(sc), P(sh), P(p), P(q), P(t), P(dQC), 2 * C, P(dQC) + 4 * C, 2 * C, P(wsp))
+        dQ, dCtr = dQC[..., :C], dQC[..., C:]
+    else:
+        dQ, dCtr = torch.full((b, n, C), float("nan"), device=DEV), torch.full((b, m, C), float("nan"), device=DEV)
+        _lib.call("pcops_edge_pool_bwd", b, n, m, k, C, P(Q), P(Ctr), P(idx), P(gpool), P(ysel), P(SQ), P(arg), P(sc), P(sh),
+                  P(p), P(q), P(t), P(dQ), P(dCtr), P(wsp))
+    torch.cuda.synchronize()
+    d = torch.float64
+    a = torch.where(ysel * sc + sh > 0, (p * gpool).to(d), torch.zeros((), dtype=d, device=DEV)).view(b, m, C)
+    Ctr64 = Ctr.to(d)
+    want_ctr = q.to(d) * (SQ.to(d).view(b, m, C) + k * Ctr64) + k * t.to(d) + a
+    ii = idx.long()                                                    # (b, m, k)
+    cnt = torch.zeros(b, n, dtype=d, device=DEV).scatter_add_(1, ii.view(b, -1), torch.ones(b, m * k, dtype=d, device=DEV))
+    sumc = torch.zeros(b, n, C, dtype=d, device=DEV).index_put_(
+        (torch.arange(b, device=DEV).view(b, 1, 1).expand(b, m, k), ii), Ctr64.unsqueeze(2).expand(b, m, k, C), accumulate=True)
+    hit = arg.view(b, m, 1, C).long() == torch.arange(k, device=DEV).view(1, 1, k, 1)          # (b, m, k, C)
+    suma = torch.zeros(b, n, C, dtype=d, device=DEV).index_put_(
+        (torch.arange(b, device=DEV).view(b, 1, 1).expand(b, m, k), ii), a.unsqueeze(2) * hit.to(d), accumulate=True)
+    want_q = q.to(d) * (cnt.unsqueeze(-1) * Q.to(d) + sumc) + cnt.unsqueeze(-1) * t.to(d) + suma
+    assert (dCtr.to(d) - want_ctr).abs().max().item() <= 2e-5 * want_ctr.abs().max().item()
+    assert (dQ.to(d) - want_q).abs().max().item() <= 2e-5 * want_q.abs().max().item()
