@@ -39,4 +39,10 @@ cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_detail.json gpurun_out/pmc
 bash tools/pmc_insts.sh > /dev/null 2>&1; cp gpurun_out/pmc_insts.txt $R/pmc_insts_ssg.txt 2>/dev/null
 bash tools/pmc_insts.sh --model dgcnn > /dev/null 2>&1; cp gpurun_out/pmc_insts.txt $R/pmc_insts_dgcnn.txt 2>/dev/null
 bash tools/r5_ec.sh round > $R/ec_micro.log 2>&1; cp gpurun_out/ec_round/*.txt $R/ 2>/dev/null
+# launches per step and the share of generic (torch / runtime) kernels
+for m in pointnet2_cls_ssg dgcnn; do
+  bash tools/r5_launches.sh $m round > /dev/null 2>&1; cp gpurun_out/launch_${m}_round/summary.txt $R/launches_$m.txt 2>/dev/null
+  rm -rf gpurun_out/launch_${m}_round
+done
+python tools/bench_knn.py > $R/knn_bench.txt 2>&1
 ls -la $R
