@@ -881,12 +881,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     // pooled epilogue then cost a wave 18 500 cycles per tile against 7 000 without pooling, tools/phase_prof.py.)
     float gmx[POOL ? NT : 1];                         // uncompacted groups: running max over the group's tiles, its row
     int grw[POOL ? NT : 1];
-    float gmy[S4 ? NT : 1];                           // pool_s4: the running pair of the ODD groups (gmx / grw: the even ones)
-    int gry[S4 ? NT : 1];
+    float gmy[S4 ? NT : 1];                           // pool_s4: the running maxima of the group AFTER the oldest open one (gmx)
+    unsigned prw = 0u, pry = 0u;                      // ... and the rows of both, one byte per column block
+    int pgo = 0;                                      // pool_s4: the oldest open group of the walk
+    static_assert(!S4 || NT <= 4, "pool_s4: four row bytes per register");
 #pragma unroll
     for (int i = 0; i < (POOL ? NT : 1); ++i) { gmx[i] = -INFINITY; grw[i] = 0; }
 #pragma unroll
-    for (int i = 0; i < (S4 ? NT : 1); ++i) { gmy[i] = -INFINITY; gry[i] = 0; }
+    for (int i = 0; i < (S4 ? NT : 1); ++i) gmy[i] = -INFINITY;
     const int peer32 = (lane ^ 32) << 2;
     // value + row of the better of (this half-wave, the other): larger value, then lower row
     auto meet = [&](float &m, int &r) {
@@ -931,17 +933,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         } else if constexpr (S4) {
             // Groups of S rows, S % 4 == 0: the four rows a lane holds in registers 4 seg .. 4 seg + 3 (rows 8 seg + hrow .. + 3 of
             // the tile) lie inside ONE group, so the lane takes their (max, first row) on registers and merges it into the
-            // running pair of the group's parity -- the two half-waves may be in neighbouring groups.  Rows 8 seg .. 8 seg + 7
-            // are done in both half-waves after segment seg: a group that ends there is met across the half-waves and
-            // stored at once, which frees its pair before the next group of the same parity begins (S >= 8).
+            // running pair of the OLDEST OPEN group (gmx / grw) or of the one after it (gmy / gry) -- the two half-waves may be
+            // in neighbouring groups, never further apart (S >= 8).  Rows 8 seg .. 8 seg + 7 are done in both half-waves after
+            // segment seg: a group that ends there is met across the half-waves and stored at once, and the next group's
+            // pair moves up.
             const int S_ = a.pool_s4;
             const int gps = 32 * SUB / S_;                                   // groups per walk
+            if (sub == 0) pgo = 0;
 #pragma unroll
             for (int seg = 0; seg < 4; ++seg) {
                 const int rs = 32 * sub + 8 * seg + hrow;                    // first row of the lane's segment, in the walk
                 const int g = (rs * a.pool_inv) >> 16;                       // rs / S_
                 const int rg0 = rs - g * S_;
-                const bool odd = (g & 1) != 0;
+                const bool nxt = g != pgo;                                   // the group after the oldest open one
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     float m = acc[nt][4 * seg];
@@ -954,20 +958,21 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         r = gt ? i : r;
                     }
                     r += rg0;
-                    const bool te = !odd && m > gmx[nt], to = odd && m > gmy[nt];
-                    gmx[nt] = te ? m : gmx[nt]; grw[nt] = te ? r : grw[nt];
-                    gmy[nt] = to ? m : gmy[nt]; gry[nt] = to ? r : gry[nt];
+                    // (the rows of the NT column blocks share ONE register per pair, a byte each: the walk is at most 256 rows)
+                    const bool t0 = !nxt && m > gmx[nt], t1 = nxt && m > gmy[nt];
+                    gmx[nt] = t0 ? m : gmx[nt];
+                    gmy[nt] = t1 ? m : gmy[nt];
+                    const unsigned bm = 0xffu << (8 * nt), rb = (unsigned)r << (8 * nt);
+                    prw = t0 ? ((prw & ~bm) | rb) : prw;
+                    pry = t1 ? ((pry & ~bm) | rb) : pry;
                 }
                 const int pe = 32 * sub + 8 * seg + 8;                       // rows of the walk done so far (wave-uniform)
-                const int ge = (pe * a.pool_inv) >> 16;                      // groups that end at or before row pe
-                if (ge >= 1 && ge * S_ > pe - 8) {                           // group ge - 1 ended inside this segment pair
-                    const int gd = ge - 1;
-                    const long long gg = st * gps + gd;
-                    const bool dodd = (gd & 1) != 0;                         // wave-uniform
+                if ((pgo + 1) * S_ <= pe) {                                  // the oldest open group is complete in both half-waves
+                    const long long gg = st * gps + pgo;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        float m = dodd ? gmy[nt] : gmx[nt];
-                        int r = dodd ? gry[nt] : grw[nt];
+                        float m = gmx[nt];
+                        int r = (int)((prw >> (8 * nt)) & 0xffu);
                         meet(m, r);
                         const int n = n0 + 32 * nt + (lane & 31);
                         if (low && n < N) {
@@ -975,9 +980,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                             a.ysel[gg * N + n] = fmaf(m, sg, pv);
                             a.psel[gg * N + n] = (unsigned char)r;
                         }
-                        if (dodd) { gmy[nt] = -INFINITY; gry[nt] = 0; }
-                        else { gmx[nt] = -INFINITY; grw[nt] = 0; }
+                        gmx[nt] = gmy[nt];
+                        gmy[nt] = -INFINITY;
                     }
+                    prw = pry;
+                    pry = 0u;
+                    ++pgo;
                 }
             }
         } else {
