@@ -653,7 +653,9 @@ __global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
     const int tid = threadIdx.x;
     const int mS = m * a.S;
     int *ss = reinterpret_cast<int *>(ec_cs + ((size_t)m + 1) * 2);
-    unsigned short *cs16 = reinterpret_cast<unsigned short *>((reinterpret_cast<uintptr_t>(ss + (n + 1)) + 15) & ~(uintptr_t)15);
+    // (the offset is taken on the LDS pointer: rounding it up through uintptr_t made it a GENERIC pointer and every read of
+    // the codes a flat load through the LDS aperture)
+    unsigned short *cs16 = reinterpret_cast<unsigned short *>(ec_cs + ((size_t)m + 1) * 2 + ((size_t)n + 1 + 3) / 4);
     {
         const int pair = tid >> 1, cl = tid & 1;
         const float *src = a.Ctr + (long long)b * m * a.ldc + sl * kWalkCh + cl * 4;
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(1024) void ec_walk_lds_kernel(WalkLdsArgs wa) {
         const int *sb = a.start + (long long)b * (n + 1);
         for (int i = tid; i <= n; i += 1024) ss[i] = sb[i];
         const unsigned short *cg = wa.codes + (long long)b * mS;
-        if ((mS & 7) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0 && (reinterpret_cast<uintptr_t>(cs16) & 15) == 0) {
+        if ((mS & 7) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
             const uint4 *c4 = reinterpret_cast<const uint4 *>(cg);
             uint4 *d4 = reinterpret_cast<uint4 *>(cs16);
             for (int k = tid; k < (mS >> 3); k += 1024) d4[k] = c4[k];
