@@ -57,6 +57,7 @@ struct FwdArgs {
     float *Y;                    // MODE 1
     float *stats;                // [b * m / 64][2][C] or NULL
     const float *pivot;          // shifted moments around this vector (or NULL: 0)
+    int nt;                      // MODE 1: Y leaves with non-temporal stores (256 MB and more)
 };
 
 // ---- forward ------------------------------------------------------------------------------------------------------
@@ -98,6 +99,7 @@ __device__ __forceinline__ void ec_fwd_groups(const FwdArgs &a, const unsigned *
         float ex[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int ea[4] = {0, 0, 0, 0};
         float *yrow = MODE == 1 ? a.Y + g * S * (long long)C + ch : nullptr;
+        const bool ynt = MODE == 1 && a.nt != 0;
         const unsigned *og = offs + gl * S;
         auto take = [&](const float4 &q, int s) {
             const f2 qa = f2{q.x, q.y}, qb = f2{q.z, q.w};
@@ -116,7 +118,11 @@ __device__ __forceinline__ void ec_fwd_groups(const FwdArgs &a, const unsigned *
                 }
             } else {
                 const f2 ya = ct[0] + qa, yb = ct[1] + qb;
-                *reinterpret_cast<float4 *>(yrow + (long long)s * C) = make_float4(ya.x, ya.y, yb.x, yb.y);
+                // (non-temporal for the big streams -- the T-Net's 2.7 GB: 748 -> 695 us; nothing reads Y back before it
+                // has left every cache anyway)
+                typedef float ec_f4 __attribute__((ext_vector_type(4)));
+                if (ynt) __builtin_nontemporal_store(ec_f4{ya.x, ya.y, yb.x, yb.y}, reinterpret_cast<ec_f4 *>(yrow + (long long)s * C));
+                else *reinterpret_cast<float4 *>(yrow + (long long)s * C) = make_float4(ya.x, ya.y, yb.x, yb.y);
                 const f2 da = ya - pv[0], db = yb - pv[1];
                 s1[0] += da; s1[1] += db;
                 s2[0] = __builtin_elementwise_fma(da, da, s2[0]);
@@ -1076,7 +1082,9 @@ int ec_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq,
 
 int ec_gather_fwd(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc, const int *idx,
                   float *Y, float *stats, const float *pivot, hipStream_t st) {
-    FwdArgs a = {b, n, m, s, c, ldq, ldc, Q, Ctr, idx, nullptr, nullptr, nullptr, nullptr, Y, stats, pivot};
+    static const bool nt_on = [] { const char *e = getenv("PCOPS_NT_STORE"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    FwdArgs a = {b, n, m, s, c, ldq, ldc, Q, Ctr, idx, nullptr, nullptr, nullptr, nullptr, Y, stats, pivot,
+                 (nt_on && (long long)b * m * s * c * 4 >= (256ll << 20)) ? 1 : 0};
     const unsigned grid = (unsigned)((long long)b * (c / 64) * (m / kGB));
     const size_t lds = ((size_t)kGB * s + kSets * 128) * sizeof(float);
     hipLaunchKernelGGL(ec_fwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);

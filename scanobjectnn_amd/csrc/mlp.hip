@@ -91,10 +91,13 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned v
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 x) {
+// nt: non-temporal (aux bit 1 on gfx94x / gfx950): the output is a stream far larger than the L2 and the memory-side cache
+// that nothing reads back soon -- not allocating its lines measured 7 % on a pure 2.7 GB write stream (edgeconv.hip MODE 1)
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float4 x, bool nt = false) {
     u32x4 v;
     v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y); v.z = __float_as_uint(x.z); v.w = __float_as_uint(x.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+    if (nt) __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 2);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
     // gfx950 store-data hazard hipcc does not pad: a VALU write to the data registers of a 16-byte buffer store in the
     // very next issue slot still reaches the store (observed: the .w word of the last four lanes of every 16-lane group
     // took the NEXT row's value whenever a v_pk_add_f32 rewrote v[n+2:n+3] right behind the store).  LLVM's recogniser
@@ -167,6 +170,7 @@ struct GemmArgs {
     // walks 32 pool_sub = lcm(pool_s4, 32) rows = 32 pool_sub / pool_s4 WHOLE groups; pool_inv = 65536 / pool_s4 + 1
     // (row / pool_s4 as a multiplication, exact for the rows of one walk: checked by the launcher).  0: one group per walk
     int pool_s4, pool_inv;
+    int nt_out;                         // Y leaves with non-temporal stores (set by the launchers: outputs of 256 MB and more)
     const float *pgamma;                // [N]
     float *ysel;                        // [M / (32 pool_sub)][N]
     unsigned char *psel;                // [M / (32 pool_sub)][N]
@@ -1177,6 +1181,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const long long row0 = tile * 32;
         const int erem = (int)((long long)M - row0 < 32 ? (long long)M - row0 : 32);   // rows of this tile (scalar, 32 bit)
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Y + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
+        const bool ynt = a.nt_out != 0;
         const __amdgpu_buffer_rsrc_t rprev =
             make_rsrc(((EM == E_MASK || EM == E_MASKA) ? a.Yprev : a.Y) + row0 * a.ldy, ((long long)M - row0) * a.ldy * 4);
         auto epilogue = [&](auto full_) {
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 // (a pooled forward whose backward is algebraic, or that has no backward, passes Y == NULL: the
                 // activation only exists as statistics and group extrema)
                 if ((EM != E_MASKX && !(EM == E_FWD && POOL)) || a.Y)
-                    buf_store4(rout, yvoff, (unsigned)j * yrowstep, o);  // rows >= M / columns >= N: dropped by the bounds check
+                    buf_store4(rout, yvoff, (unsigned)j * yrowstep, o, ynt);  // rows >= M / columns >= N: dropped by the bounds check
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
@@ -1507,8 +1512,15 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
     return true;
 }
 
+static bool nt_stores_enabled() {
+    static const bool on = [] { const char *e = getenv("PCOPS_NT_STORE"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    return on;
+}
+static int nt_for_bytes(long long bytes) { return (nt_stores_enabled() && bytes >= (256ll << 20)) ? 1 : 0; }
+
 template <int AM, int EM>
 int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
+    a.nt_out = a.Y ? nt_for_bytes((long long)a.M * a.ldy * 4) : 0;
 #define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
         const bool pool_ = EM == E_FWD && a.pool_sub > 0;                                             \
@@ -1970,6 +1982,7 @@ struct WgradArgs {
     const int *Mdev;
     // bwd_fused_kernel only: the layer's weights, the masked data gradient it also writes, its column statistics
     const float *W; float *Gprev; float *gstats; float *xstats;
+    int nt_out;              // Gprev leaves with non-temporal stores
 };
 
 template <int VK, int VN>
@@ -3397,6 +3410,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             // them to the next stripe's loop so that they issue under its first MFMAs was measured: no difference.)
             if (!(dbg & 2)) {
                 const __amdgpu_buffer_rsrc_t rgp = make_rsrc(XYZ ? nullptr : a.Gprev + row0 * K, XYZ ? 0 : (M - row0) * K * 4);
+                const bool gnt = a.nt_out != 0;
                 float4 ofs[XYZ ? 4 : 1];
                 if (XYZ) {
 #pragma unroll
@@ -3416,7 +3430,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                             sx[b][1] = fmaf(ofs[v].y, gv, sx[b][1]);
                             sx[b][2] = fmaf(ofs[v].z, gv, sx[b][2]);
                         } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
+                            if (gnt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 2);
+                            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
                         }
                         accd[b][v] = 0.f;
                     }
@@ -4936,6 +4951,7 @@ int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, cons
     a.dmode = gpool ? A_DYPOOL : A_DY; a.G = G; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
     a.gpool = gpool; a.argmax = argmax; a.S = S > 0 ? S : 1;
     a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
+    a.nt_out = nt_for_bytes((long long)M * K * 4);
     PCOPS_ROWS(a, rows);
 #ifdef PCOPS_BF_DEBUG
     { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
