@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                                                             const float *__restrict__ pivot,
                                                             float *__restrict__ moments, int groups_per_block,
                                                             const RowBlock *__restrict__ blocks,
-                                                            const int *__restrict__ bstart) {
+                                                            const int *__restrict__ bstart, int nt) {
+    // nt: Y leaves with non-temporal stores (a stream of 256 MB and more that nothing reads back soon, mlp.hip buf_store4)
     // blocks != NULL: compacted rows -- group g writes its first 16 (bstart[g+1] - bstart[g]) rows to rows
     // 16 bstart[g] ..., and its row 0 enters the statistics / moments with the weight of the copies left out
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [RL][2][C] statistics scratch | staged rows
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(256) void sa_gather_fwd_kernel(long long G, int n, 
                     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (Q) q = *reinterpret_cast<const float4 *>(Q + (b * n + __float_as_int(e.w)) * (long long)C + cq);
                     const float4 y = first_layer_quad(ctr, Q != nullptr, q, Wxyz != nullptr, e.x, e.y, e.z, w0, w1, w2);
-                    if (Y) *reinterpret_cast<float4 *>(Y + r * C + cq) = y;      // NULL: statistics only
+                    if (Y) {                                                      // NULL: statistics only
+                        typedef float g_f4 __attribute__((ext_vector_type(4)));
+                        if (nt) __builtin_nontemporal_store(g_f4{y.x, y.y, y.z, y.w}, reinterpret_cast<g_f4 *>(Y + r * C + cq));
+                        else *reinterpret_cast<float4 *>(Y + r * C + cq) = y;
+                    }
                     const float wt = s == 0 ? w0row : 1.f;
                     const float4 d = make_float4(y.x - pv.x, y.y - pv.y, y.z - pv.z, y.w - pv.w);
                     const float4 wy = make_float4(wt * d.x, wt * d.y, wt * d.z, wt * d.w);
@@ -1577,12 +1582,14 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
                          moments != nullptr, rows != nullptr) && Y != nullptr)
         return ec_gather_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, Y, stats_partial, stat_pivot, as_stream(stream));
     const int rl = 256 / (c / 4);
+    static const bool nt_on = [] { const char *e = getenv("PCOPS_NT_STORE"); return !(e && e[0] == '0'); }();   // kernel A/B only
     const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
     if (((size_t)rl * 2 * c + staged) * sizeof(float) > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(sa_gather_fwd_kernel, dim3(pcops_sa_gather_stats_rows(G)), dim3(256),
                        ((size_t)rl * 2 * c + staged) * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, xyz, new_xyz,
                        Wxyz, bias, idx, Y, off4, stats_partial, stat_pivot, moments, gather_groups_per_block(G),
-                       rows ? static_cast<const RowBlock *>(rows->blocks) : nullptr, rows ? rows->block_start : nullptr);
+                       rows ? static_cast<const RowBlock *>(rows->blocks) : nullptr, rows ? rows->block_start : nullptr,
+                       (nt_on && Y && G * s * c * 4 >= (256ll << 20)) ? 1 : 0);
     return pcops_launch_status();
 }
 

@@ -88,6 +88,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, lo
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000);
 }
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    // (aux 2 = non-temporal on the streamed operand reads: SSG 23.05 vs 23.05 k, DGCNN 9.85 vs 9.85 k -- nothing; stores: see buf_store4)
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
