@@ -693,10 +693,19 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
                 st_surv += (unsigned)nq;
 #endif
                 {
-                const int mx = (int)wave_max_u32((unsigned)nq);
+                // the two half-waves of a query POOL their survivors (round 5): both lanes hold the query row and either list may
+                // take any candidate now that the lists are keys (the merge takes the best of the union, tau2's argument holds for
+                // any split), so the lane with fewer survivors takes the partner's LAST ones -- a round costs 133 instructions for
+                // the whole wave, and the rounds of a flush are the fullest lane's count: max over 32 pairs of half the pair's
+                // sum instead of max over 64 lanes
+                const int nb = __shfl_xor(nq, 32, 64);                 // the partner's count
+                const int mine = (nq + nb + (half == 0 ? 1 : 0)) >> 1; // survivors this lane processes
+                const int mx = (int)wave_max_u32((unsigned)mine);
                 for (int u = 0; u < mx; ++u) {
-                    const bool live = u < nq;
-                    const int j = live ? pj[u * 512 + tid] : j0;
+                    const bool live = u < mine;
+                    const bool own = u < nq;                           // (nq >= mine: all of them its own)
+                    const int slot = own ? u * 512 + tid : (nb - 1 - (u - nq)) * 512 + (tid ^ 32);
+                    const int j = live ? pj[slot] : j0;
                     const int rr = j - j0;
                     const float *row = cs + rr * LD;
                     float inner = 0.f;
