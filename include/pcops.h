@@ -519,6 +519,27 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
                         const float *gpool, const float *ysel, const float *SQ, const unsigned char *arg,
                         const float *scale, const float *shift, const float *p, const float *q, const float *t,
                         float *dQ, float *dCtr, void *workspace, pcops_stream_t stream);
+/* First EdgeConv layer of a grouped stack whose INPUT needs no gradient (round 5; reference: the T-Net's tconv1 on the edge
+ * features of the raw cloud, dgcnn/models/transform_nets.py:18-27 over tf_util.get_edge_feature, tf_util.py:660-706).  The
+ * layer is linear in the six edge channels e = [x_g | x_j - x_g], j = idx[g, s]:  Y1 = e W + b, and with the BN backward
+ * dY1 = p Gm + q Y1 + t of the layer
+ *   dW (6, c) = p (E^T Gm) + q (E^T E W + E^T 1 b) + t E^T 1,     db = p sum Gm + q sum Y1 + t rows
+ * -- one streaming pass over the masked gradient Gm (b m s, c) instead of the scatter to per-point gradients
+ * (pcops_sa_scatter_bwd_ld: two passes over Gm, one a gather through an inverse index) and the GEMM backward behind it.
+ *   pcops_edge_first_moments: moments_partial [pcops_edge_first_rows()][27] -- 21 second moments of e (upper triangle,
+ *     row-major) then its 6 sums; forward time (xyz (b, n, 3), idx (b, m, s), m == n for an EdgeConv graph);
+ *   pcops_edge_first_wgrad:   wpartial [pcops_edge_first_rows()][6][c] = partial sums of E^T Gm (c = 64 | 128);
+ *   pcops_edge_first_layer_grads: dW (6, c), dbias (c, may be NULL) from both, p / q / t and sumG (= dbeta) from
+ *     pcops_mlp_bn_bwd_coeffs, mean from pcops_mlp_bn_finalize, rows = b m s; sums in double, fixed order. */
+int pcops_edge_first_rows(void);
+int pcops_edge_first_supported(int b, int n, int m, int s, int c);
+int pcops_edge_first_moments(int b, int n, int m, int s, const float *xyz, const int *idx, float *moments_partial,
+                             pcops_stream_t stream);
+int pcops_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *xyz, const int *idx,
+                           float *wpartial, pcops_stream_t stream);
+int pcops_edge_first_layer_grads(int P1, const float *wpartial, int P2, const float *moments_partial, int c, const float *W,
+                                 const float *bias, const float *p, const float *q, const float *t, const float *sumG,
+                                 const float *mean, long long rows, float *dW, float *dbias, pcops_stream_t stream);
 /* dWxyz (3,c) and dbias (c, may be NULL) of an arithmetic first layer from the sums described at
  * pcops_mlp_gemm_dgrad_xyz: xyz_stats [P1][3][c], moments [P2][9] (pcops_sa_gather_fwd), p/q/t and sumG (= dbeta) from
  * pcops_mlp_bn_bwd_coeffs, mean from pcops_mlp_bn_finalize, rows = b*m*s. */

@@ -35,3 +35,12 @@ int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, con
                  const float *ysel, const float *SQ, const unsigned char *arg, const float *scale, const float *shift,
                  const float *p, const float *q, const float *t, const void *workspace, float *dQ, int lddq, float *dCtr,
                  int lddc, hipStream_t st);
+// first EdgeConv layer of a stack whose input needs no gradient: dW (6, c) / db from E^T Gm and the edge moments
+int ec_edge_first_rows();
+bool ec_edge_first_supported(int b, int n, int m, int s, int c);
+int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, hipStream_t st);
+int ec_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *x, const int *idx, float *part,
+                        hipStream_t st);
+int ec_edge_first_grads(int P1, const float *wpart, int P2, const float *mpart, int c, const float *W, const float *bias,
+                        const float *p, const float *q, const float *t, const float *sumG, const float *mean, long long rows,
+                        float *dW, float *dbias, hipStream_t st);

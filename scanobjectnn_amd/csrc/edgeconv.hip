@@ -999,6 +999,155 @@ __global__ __launch_bounds__(1024) void ec_bwd_lds_kernel(BwdLdsArgs a) {
 size_t ec_bwd_lds_bytes(int m, int s) {
     return ((size_t)m + 1) * 32 + (((size_t)m + 1) * 4 + 15) / 16 * 16 + (((size_t)m * s * 2 + 15) & ~(size_t)15) + 16;
 }
+// ---- first EdgeConv layer of a stack whose INPUT needs no gradient (DGCNN's T-Net: the raw cloud) -------------------
+// The layer is linear in the six edge-feature channels e = [x_g | x_j - x_g] (j = idx[g, s]):  Y1 = e W + b, so its weight
+// gradient is  dW = p (E^T Gm) + q (E^T E W + E^T 1 b) + t E^T 1  with dY1 = p Gm + q Y1 + t  (gather.hip
+// xyz_first_layer_grads_kernel states the 3-input form): ONE streaming pass over the masked gradient Gm for E^T Gm and a
+// tiny pass over the edges for the 27 moments, instead of the scatter to per-point dQ / dCtr (two passes over Gm, one of
+// them a gather through an inverse index) and the GEMM backward behind it.
+constexpr int kEdgeMom = 27;        // 21 second moments (upper triangle, row-major) + 6 first moments
+
+__global__ __launch_bounds__(256) void edge_moments_kernel(int n, int m, int S, long long rows, const float *__restrict__ x,
+                                                           const int *__restrict__ idx, float *__restrict__ part) {
+    __shared__ float red[4][kEdgeMom];
+    float a[kEdgeMom];
+#pragma unroll
+    for (int i = 0; i < kEdgeMom; ++i) a[i] = 0.f;
+    const long long mS = (long long)m * S;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
+        const long long b = r / mS;
+        const int g = (int)((r - b * mS) / S);
+        const float *xg = x + ((long long)b * n + g) * 3, *xj = x + ((long long)b * n + idx[r]) * 3;
+        float e[6];
+        e[0] = xg[0]; e[1] = xg[1]; e[2] = xg[2];
+        e[3] = xj[0] - e[0]; e[4] = xj[1] - e[1]; e[5] = xj[2] - e[2];
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = i; j < 6; ++j) { a[k] = fmaf(e[i], e[j], a[k]); ++k; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[21 + i] += e[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kEdgeMom; ++i) {
+        float v = a[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kEdgeMom)
+        part[(long long)blockIdx.x * kEdgeMom + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// E^T Gm, partial per workgroup: [gridDim][6][C].  A lane set of C / 4 lanes per row (float4 of Gm each), 256 / (C / 4) rows
+// per step, four steps in flight; the six edge values of a row are computed by every lane of its set (broadcast loads).
+template <int LPR>     // lanes per row = C / 4 (16 or 32)
+__global__ __launch_bounds__(256) void edge_first_wgrad_kernel(int n, int m, int S, long long rows, const float *__restrict__ G,
+                                                               const float *__restrict__ x, const int *__restrict__ idx,
+                                                               float *__restrict__ part) {
+    constexpr int RW = 256 / LPR, C = 4 * LPR, U = 4;
+    extern __shared__ float ew_red[];                   // [RW][6][C]
+    const int tid = threadIdx.x, rl = tid / LPR, cq = (tid % LPR) * 4;
+    float acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    const long long mS = (long long)m * S;
+    const long long step = (long long)gridDim.x * RW * U;
+    for (long long r0 = (long long)blockIdx.x * RW * U + rl; r0 < rows; r0 += step) {
+        float4 gv[U];
+        int jj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = r0 + (long long)u * RW;
+            const bool in = r < rows;
+            gv[u] = in ? *reinterpret_cast<const float4 *>(G + r * C + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            jj[u] = in ? idx[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long r = r0 + (long long)u * RW;
+            if (r >= rows) continue;
+            const long long b = r / mS;
+            const int g = (int)((r - b * mS) / S);
+            const float *xg = x + ((long long)b * n + g) * 3, *xj = x + ((long long)b * n + jj[u]) * 3;
+            float e[6];
+            e[0] = xg[0]; e[1] = xg[1]; e[2] = xg[2];
+            e[3] = xj[0] - e[0]; e[4] = xj[1] - e[1]; e[5] = xj[2] - e[2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                acc[i][0] = fmaf(e[i], gv[u].x, acc[i][0]); acc[i][1] = fmaf(e[i], gv[u].y, acc[i][1]);
+                acc[i][2] = fmaf(e[i], gv[u].z, acc[i][2]); acc[i][3] = fmaf(e[i], gv[u].w, acc[i][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        *reinterpret_cast<float4 *>(&ew_red[(rl * 6 + i) * C + cq]) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    __syncthreads();
+    for (int e = tid; e < 6 * C; e += 256) {
+        float v = 0.f;
+        for (int r = 0; r < RW; ++r) v += ew_red[r * 6 * C + e];
+        part[(long long)blockIdx.x * 6 * C + e] = v;
+    }
+}
+
+//   dW[i][c] = p A[i][c] + q B[i][c] + t S[i],  B = M W + S b,  db[c] = p sumG + q mean rows + t rows      (all sums in double)
+__global__ __launch_bounds__(1024) void edge_first_grads_kernel(int P1, const float *__restrict__ wpart, int P2,
+                                                                const float *__restrict__ mpart, int C,
+                                                                const float *__restrict__ W, const float *__restrict__ bias,
+                                                                const float *__restrict__ p, const float *__restrict__ q,
+                                                                const float *__restrict__ t, const float *__restrict__ sumG,
+                                                                const float *__restrict__ mean, double rows,
+                                                                float *__restrict__ dW, float *__restrict__ dbias) {
+    __shared__ double smA[6][32][32];
+    __shared__ double smM[kEdgeMom][32];
+    __shared__ double mom[kEdgeMom];
+    const int tid = threadIdx.x, cl = tid & 31, g = tid >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    if (tid < kEdgeMom * 32) {
+        const int l = tid / kEdgeMom, k = tid % kEdgeMom;
+        double a = 0.0;
+        for (int r = l; r < P2; r += 32) a += (double)mpart[(long long)r * kEdgeMom + k];
+        smM[k][l] = a;
+    }
+    double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (c < C)
+        for (int r = g; r < P1; r += 32)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) a[i] += (double)wpart[((long long)r * 6 + i) * C + c];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) smA[i][g][cl] = a[i];
+    __syncthreads();
+    if (tid < kEdgeMom) {
+        double v = 0.0;
+        for (int l = 0; l < 32; ++l) v += smM[tid][l];
+        mom[tid] = v;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    double A[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int l = 0; l < 32; ++l)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i] += smA[i][l][cl];
+    const double b = bias ? (double)bias[c] : 0.0;
+    const double pc = p[c], qc = q[c], tc = t[c];
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        double B = mom[21 + i] * b;
+#pragma unroll 1
+        for (int j = 0; j < 6; ++j) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            B += mom[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)] * (double)W[j * C + c];     // upper triangle, row-major
+        }
+        dW[i * C + c] = (float)(pc * A[i] + qc * B + tc * mom[21 + i]);
+    }
+    if (dbias) dbias[c] = (float)(pc * (double)sumG[c] + qc * ((double)mean[c] * rows) + tc * rows);
+}
+
 bool ec_shape_ok(int b, int n, int m, int s, int c) {
     // 64-channel slices, whole 64-group chunks, 8-bit slots, 32-bit byte offsets into Q (row stride up to 2 c) / the cloud's G rows
     return c >= 64 && c % 64 == 0 && m >= kGB && m % kGB == 0 && s >= 1 && s <= 128 && n >= 1 &&
@@ -1036,6 +1185,37 @@ int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, con
     return pcops_launch_status();
 }
 
+
+constexpr int kEdgeFirstGrid = 2048;     // partial rows of the two passes below
+int ec_edge_first_rows() { return kEdgeFirstGrid; }
+bool ec_edge_first_supported(int b, int n, int m, int s, int c) {
+    return b >= 1 && n >= 1 && m >= 1 && s >= 1 && (c == 64 || c == 128);
+}
+int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, hipStream_t st) {
+    const long long rows = (long long)b * m * s;
+    hipLaunchKernelGGL(edge_moments_kernel, dim3(kEdgeFirstGrid), dim3(256), 0, st, n, m, s, rows, x, idx, part);
+    return pcops_launch_status();
+}
+int ec_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *x, const int *idx, float *part,
+                        hipStream_t st) {
+    const long long rows = (long long)b * m * s;
+    if (c == 64)
+        hipLaunchKernelGGL(edge_first_wgrad_kernel<16>, dim3(kEdgeFirstGrid), dim3(256), (size_t)16 * 6 * 64 * 4, st, n, m, s, rows, G, x,
+                           idx, part);
+    else if (c == 128)
+        hipLaunchKernelGGL(edge_first_wgrad_kernel<32>, dim3(kEdgeFirstGrid), dim3(256), (size_t)8 * 6 * 128 * 4, st, n, m, s, rows, G, x,
+                           idx, part);
+    else
+        return PCOPS_ERR_UNSUPPORTED;
+    return pcops_launch_status();
+}
+int ec_edge_first_grads(int P1, const float *wpart, int P2, const float *mpart, int c, const float *W, const float *bias,
+                        const float *p, const float *q, const float *t, const float *sumG, const float *mean, long long rows,
+                        float *dW, float *dbias, hipStream_t st) {
+    hipLaunchKernelGGL(edge_first_grads_kernel, dim3((c + 31) / 32), dim3(1024), 0, st, P1, wpart, P2, mpart, c, W, bias, p, q, t,
+                       sumG, mean, (double)rows, dW, dbias);
+    return pcops_launch_status();
+}
 
 #ifdef PCOPS_EC_PROF
 // diagnostics build (tools/build_variant.sh ecprof "-DPCOPS_EC_PROF=1"): phase cycle sums of ec_bwd_lds_kernel's lane 0

@@ -2050,6 +2050,32 @@ int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, c
     return ec_walk(b, n, m, s, c, Q, ldq, Ctr, ldc, G, p, q, t, workspace, dQ, lddq, st);
 }
 
+// ---- first EdgeConv layer of a stack whose input needs no gradient (edgeconv.hip): weight gradient without a scatter
+int pcops_edge_first_rows(void) { return ec_edge_first_rows(); }
+int pcops_edge_first_supported(int b, int n, int m, int s, int c) { return ec_edge_first_supported(b, n, m, s, c) ? 1 : 0; }
+int pcops_edge_first_moments(int b, int n, int m, int s, const float *xyz, const int *idx, float *moments_partial,
+                             pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1);
+    PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(moments_partial);
+    return ec_edge_first_moments(b, n, m, s, xyz, idx, moments_partial, as_stream(stream));
+}
+int pcops_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *xyz, const int *idx,
+                           float *wpartial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4);
+    PCOPS_REQUIRE_PTR(G); PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(wpartial);
+    if (!ec_edge_first_supported(b, n, m, s, c) || (reinterpret_cast<uintptr_t>(G) & 15)) return PCOPS_ERR_UNSUPPORTED;
+    return ec_edge_first_wgrad(b, n, m, s, c, G, xyz, idx, wpartial, as_stream(stream));
+}
+int pcops_edge_first_layer_grads(int P1, const float *wpartial, int P2, const float *moments_partial, int c, const float *W,
+                                 const float *bias, const float *p, const float *q, const float *t, const float *sumG,
+                                 const float *mean, long long rows, float *dW, float *dbias, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(P1 >= 1 && P2 >= 1 && c >= 1 && rows >= 1);
+    PCOPS_REQUIRE_PTR(wpartial); PCOPS_REQUIRE_PTR(moments_partial); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(p);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(sumG); PCOPS_REQUIRE_PTR(mean); PCOPS_REQUIRE_PTR(dW);
+    return ec_edge_first_grads(P1, wpartial, P2, moments_partial, c, W, bias, p, q, t, sumG, mean, rows, dW, dbias,
+                               as_stream(stream));
+}
+
 int pcops_xyz_first_layer_grads(int P1, const float *xyz_stats, int P2, const float *moments, int C,
                                 const float *Wxyz, const float *bias, const float *p, const float *q, const float *t,
                                 const float *sumG, const float *mean, long long rows, float *dWxyz, float *dbias,

@@ -250,6 +250,15 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
         # one data gradient -- nothing for autograd to slice, pad or add up
         kp = c if c % 8 == 0 else (c + 7) // 8 * 8
         xp = x2d if kp == c else F.pad(x2d, (0, kp - c))
+        if fused_mlp.edge_direct_supported(b, n, k, c, widths[0], len(widths), x):
+            # the input needs no gradient (the T-Net on the raw cloud): [Q | Ctr] outside autograd, the layer's weight
+            # gradient straight from the masked gradient of its output (no scatter to per-point gradients, no GEMM backward)
+            with torch.no_grad():
+                wcat, bcat = fused_mlp.edge_weights(w1, b1, kp)
+                qc = fused_mlp.rows_linear(xp, wcat, bcat).view(b, n, 2 * widths[0])
+            out = fused_mlp.gather_mlp_stack(nn_idx, True, is_training, decay, BN_EPS, False, layers, QC=qc,
+                                             direct=(x.detach(), w1, b1))
+            return (out.view(b, n, 1, widths[-1]), None) if cat_slot is not None else out.view(b, n, 1, widths[-1])
         wcat, bcat = fused_mlp.edge_weights(w1, b1, kp)
         qc = fused_mlp.rows_linear(xp, wcat, bcat).view(b, n, 2 * widths[0])
         if cat_slot is not None and len(widths) == 1:

@@ -72,6 +72,10 @@ class FusedMLPStack(torch.autograd.Function):
         rref = rows.ref if rows is not None else None
         identity = bool(int(pool) & 2)      # gather stack whose idx is 0..n-1 per cloud (group_all): scatter = reshape
         qc = bool(int(pool) & 4)            # a0 is the (B, N, 2 C1) product [Q | Ctr] of ONE GEMM (pcops.h "[Q | Ctr] forms")
+        # qc with an input that needs no gradient (DGCNN's T-Net on the raw cloud): xyz = the (B, N, 3) input, wxyz = the
+        # layer's (6, C1) weight, bias = its bias -- their gradients come from ONE streaming pass over the masked gradient
+        # (pcops.h pcops_edge_first_*), a0 gets none and no scatter runs
+        direct = bool(int(pool) & 8)
         pool = bool(int(pool) & 1)
         gather = idx is not None
         need_grad = any(ctx.needs_input_grad)
@@ -84,7 +88,10 @@ class FusedMLPStack(torch.autograd.Function):
             C1 = layers[0][2].shape[0]
             R, K0 = B * M * S, None
             if qc:
-                assert ctr is None and xyz is None and wxyz is None and bias is None and rows is None and M == Nsrc
+                assert ctr is None and rows is None and M == Nsrc and new_xyz is None
+                assert direct or (xyz is None and wxyz is None and bias is None)
+                assert not direct or (xyz is not None and wxyz is not None and tuple(wxyz.shape) == (6, C1) and L >= 2
+                                      and not ctx.needs_input_grad[0])
                 assert a0.shape[2] == 2 * C1 and a0.is_contiguous()
         else:
             R, K0 = a0.shape
@@ -121,6 +128,9 @@ class FusedMLPStack(torch.autograd.Function):
                 part = _f32((P, 2, N), dev) if training else None
                 _lib.call("pcops_sa_gather_fwd_ld", B, Nsrc, M, S, N, a0.data_ptr(), 2 * N, a0.data_ptr() + 4 * N, 2 * N,
                           idx.data_ptr(), Y.data_ptr(), _p(part), piv)
+                if direct and need_grad:      # the 27 moments of the edge features, for E^T Y1 in the backward
+                    mom = _f32((lib.pcops_edge_first_rows(), 27), dev)
+                    _lib.call("pcops_edge_first_moments", B, Nsrc, M, S, xyz.data_ptr(), idx.data_ptr(), mom.data_ptr())
                 W2 = None
             elif li == 0 and gather:
                 N = C1
@@ -230,6 +240,7 @@ class FusedMLPStack(torch.autograd.Function):
             ctx.biases = [l[1] for l in layers]
             ctx.meta = (S, pool, L, R, K0, gather, identity, bool(training), bool(sync))
             ctx.qc = qc
+            ctx.direct = gather and qc and direct
             ctx.rows = rows
             ctx.pool_top = pool_top
             if TRACE is not None:
@@ -306,6 +317,19 @@ class FusedMLPStack(torch.autograd.Function):
                 dbias = _f32(N, dev) if bias is not None else None
                 _lib.call("pcops_xyz_first_layer_grads", xstats.shape[0], xstats.data_ptr(), mom.shape[0], mom.data_ptr(),
                           N, wxyz.data_ptr(), _p(bias), p.data_ptr(), q.data_ptr(), t.data_ptr(), dbeta.data_ptr(),
+                          means[0].data_ptr(), R, dwxyz.data_ptr(), _p(dbias))
+                break
+            if l == 0 and gather and getattr(ctx, "direct", False):
+                # the input needs no gradient: dW (6, C1) / db straight from E^T Gm and the edge moments -- no scatter
+                B, M, _ = idx.shape
+                P1 = lib.pcops_edge_first_rows()
+                wpart = _f32((P1, 6, N), dev)
+                _lib.call("pcops_edge_first_wgrad", B, a0.shape[1], M, S, N, Gptr, xyz.data_ptr(), idx.data_ptr(),
+                          wpart.data_ptr())
+                dwxyz = _f32((6, N), dev)
+                dbias = _f32(N, dev) if bias is not None else None
+                _lib.call("pcops_edge_first_layer_grads", P1, wpart.data_ptr(), mom.shape[0], mom.data_ptr(), N,
+                          wxyz.data_ptr(), _p(bias), p.data_ptr(), q.data_ptr(), t.data_ptr(), dbeta.data_ptr(),
                           means[0].data_ptr(), R, dwxyz.data_ptr(), _p(dbias))
                 break
             if l == 0 and gather and getattr(ctx, "qc", False):
@@ -859,6 +883,7 @@ TRACE = None
 STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
+EDGE_DIRECT = os.environ.get("PCOPS_EDGE_DIRECT", "1") != "0"   # first EdgeConv layer of a stack on an input without gradient
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 EDGE_QC = os.environ.get("PCOPS_EDGE_QC", "1") != "0"        # EdgeConv's two per-point GEMMs as one [Q | Ctr] product
@@ -888,8 +913,17 @@ def edge_qc_supported(b, n, s, c):
                 and not _dist.sync_bn_active())
 
 
+def edge_direct_supported(b, n, k, c_in, c1, n_layers, x):
+    """the first EdgeConv layer's weight gradient without a scatter (pcops.h pcops_edge_first_*): 3-channel input that
+    needs no gradient, a stack of at least two layers on the one-GEMM path"""
+    if not (EDGE_DIRECT and c_in == 3 and n_layers >= 2) or (torch.is_grad_enabled() and x.requires_grad):
+        return False
+    return bool(_lib.load().pcops_edge_first_supported(b, n, n, k, c1))
+
+
 def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q=None, Ctr=None, xyz=None,
-                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None, QC=None, cat_slot=None):
+                     new_xyz=None, wxyz=None, bias=None, identity_idx=False, pts_cnt=None, QC=None, cat_slot=None,
+                     direct=None):
     """Grouped stack whose first conv was applied before the grouping:
          Y1[b,j,s,:] = Q[b,idx] + Ctr[b,j] + (xyz[b,idx] - new_xyz[b,j]) wxyz + bias     (terms optional)
     idx (B,M,S) int32, Q (B,N,C1), Ctr (B,M,C1), xyz (B,N,3), new_xyz (B,M,3), wxyz (3,C1), bias (C1);
@@ -908,6 +942,14 @@ def gather_mlp_stack(idx, pool, training, decay, eps, unbiased, layer_tensors, Q
                                           float(decay), float(eps), bool(unbiased), cat_slot[0], int(cat_slot[1]))
             return EdgeConvPool.apply(QC.contiguous(), None, idx.contiguous(), gamma, beta, mm, mv, bool(training),
                                       float(decay), float(eps), bool(unbiased))
+        if direct is not None:
+            # direct = (x (B, N, 3) without gradient, w1 (6, C1), b1): QC was computed from them OUTSIDE autograd; the layer's
+            # weight gradient goes straight to w1 / b1 (edge_direct_supported)
+            x3, w1, b1 = direct
+            assert not QC.requires_grad and not x3.requires_grad and len(layer_tensors) >= 2
+            return FusedMLPStack.apply(QC.contiguous(), None, idx.contiguous(), x3.contiguous(), None, w1.contiguous(), b1,
+                                       int(S), int(bool(pool)) | 4 | 8, bool(training), float(decay), float(eps),
+                                       bool(unbiased), None, len(layer_tensors), *_flat(layer_tensors, True))
         return FusedMLPStack.apply(QC.contiguous(), None, idx.contiguous(), None, None, None, None, int(S),
                                    int(bool(pool)) | 4, bool(training), float(decay), float(eps), bool(unbiased), None,
                                    len(layer_tensors), *_flat(layer_tensors, True))

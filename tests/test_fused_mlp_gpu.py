@@ -566,6 +566,51 @@ def test_edge_conv_stack_one_gemm_matches_two(cin, widths):
         assert torch.allclose(s1[n], s2[n], atol=1e-5, rtol=1e-4), n
 
 
+@pytest.mark.parametrize("B,N,k,widths", [(8, 1024, 20, [64, 128]), (4, 2048, 20, [64, 128]), (8, 1024, 16, [128, 64, 64])])
+def test_edge_conv_first_layer_gradient_without_a_scatter(B, N, k, widths):
+    """an EdgeConv stack on an input that needs NO gradient (DGCNN's T-Net on the raw cloud): the first layer's weight / bias
+    gradient comes from ONE pass over the masked gradient of its output and the 27 edge moments (pcops.h pcops_edge_first_*)
+    instead of the scatter to per-point gradients and the GEMM backward -- same output, same gradients of every variable,
+    same moving statistics as the scatter path"""
+    from scanobjectnn_amd.dgcnn import tf_util as D
+    from scanobjectnn_amd.graph import Model
+    g = torch.Generator().manual_seed(N + k)
+    x0 = torch.randn(B, N, 3, generator=g).to(DEV)
+    nn_idx = D.knn_graph(x0, k=k)
+    scopes = ['l%d' % i for i in range(len(widths))]
+
+    def net(x, is_training, bn_decay=None):
+        return D.edge_conv_stack(x, nn_idx, widths, scopes, is_training, bn_decay), {}
+
+    assert fused_mlp.edge_direct_supported(B, N, k, 3, widths[0], len(widths), x0)
+    res = []
+    for flag in (True, False):
+        fused_mlp.EDGE_DIRECT = flag
+        try:
+            fused_mlp.TRACE = []
+            m = Model(net, device=DEV, seed=5).build(x0)
+            y, _ = m(x0, is_training=True, bn_decay=0.8)
+            took = [bool(getattr(e, "direct", False)) for e in fused_mlp.TRACE if hasattr(e, "saved")]
+            torch.manual_seed(1)
+            go = torch.randn(y.shape, device=DEV)
+            y.backward(go)
+            res.append((y.detach(), {n: p.grad.clone() for n, p in m.named_parameters()},
+                        {k_: v.clone() for k_, v in m.state_dict().items()}, took))
+        finally:
+            fused_mlp.EDGE_DIRECT = True
+            fused_mlp.TRACE = None
+    (y1, g1, s1, t1), (y2, g2, s2, t2) = res
+    assert any(t1) and not any(t2)                                   # the two runs really took the two paths
+    assert sorted(g1) == sorted(g2)
+    assert torch.equal(y1, y2)                                       # the forward is the same computation
+    for n in g1:
+        # (a bias in front of BatchNorm has the exact gradient 0: both paths return rounding residue for it)
+        tol = 1e-3 if n.endswith("biases") else 2e-4 * max(1.0, g2[n].abs().max().item())
+        assert (g1[n] - g2[n]).abs().max().item() <= tol, (n, (g1[n] - g2[n]).abs().max().item(), g2[n].abs().max().item())
+    for n in s1:
+        assert torch.allclose(s1[n], s2[n], atol=1e-6, rtol=1e-5), n
+
+
 def test_arithmetic_options_are_per_call_state_of_the_library():
     """pcops_set_option: the split-operand forward product can be switched per call -- the launcher reads
     the table at every call, reports the pipe it took, and both formulations agree to fp32 rounding"""
