@@ -226,6 +226,15 @@ def _algo(name, a):
     if name == "pcops_mlp_bwd_fused":         # data + weight gradient in one pass: reads Yprev (K), G?, Y (N); writes Gprev (K)
         M, K, N = a[:3]
         return 4 * (2 * M * K + (1 if a[6] is None else 2) * M * N), 4 * M * K * N, "flop"
+    if name == "pcops_mlp_bwd_fused_edge":    # ... above a first EdgeConv layer without input gradient: Yprev, Y and 32 B of
+        M, K, N = a[:3]                       # edge channels per row in, NO Gprev (its E^T Gprev is reduced in the kernel)
+        return 4 * (M * K + M * N + 8 * M), 4 * M * K * N, "flop"
+    if name == "pcops_edge_first_wgrad":      # E^T Gm: one pass over the masked gradient (b m s rows of c)
+        b, n, m, s_, c = a[:5]
+        return 4 * b * m * s_ * (c + 1), 12 * b * m * s_ * c, "flop(VALU)"
+    if name == "pcops_edge_first_moments":    # idx + the gathered cloud in; (optionally) the 32-byte edge rows out
+        b, n, m, s_ = a[:4]
+        return b * m * s_ * (4 + (32 if a[7] is not None else 0)), 0, ""
     if name == "pcops_mlp_bwd_fused_xyz":     # ... over the xyz form: 16 bytes per row instead of Yprev, no Gprev
         M, K, N = a[:3]
         return 4 * (4 * M + (1 if a[7] is None else 2) * M * N), 4 * M * K * N, "flop"

@@ -527,16 +527,24 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
  * -- one streaming pass over the masked gradient Gm (b m s, c) instead of the scatter to per-point gradients
  * (pcops_sa_scatter_bwd_ld: two passes over Gm, one a gather through an inverse index) and the GEMM backward behind it.
  *   pcops_edge_first_moments: moments_partial [pcops_edge_first_rows()][27] -- 21 second moments of e (upper triangle,
- *     row-major) then its 6 sums; forward time (xyz (b, n, 3), idx (b, m, s), m == n for an EdgeConv graph);
+ *     row-major) then its 6 sums; forward time (xyz (b, n, 3), idx (b, m, s), m == n for an EdgeConv graph); edge_rows
+ *     (may be NULL): the rows e themselves, (b m s, 8) with two pad floats, for pcops_mlp_bwd_fused_edge;
  *   pcops_edge_first_wgrad:   wpartial [pcops_edge_first_rows()][6][c] = partial sums of E^T Gm (c = 64 | 128);
  *   pcops_edge_first_layer_grads: dW (6, c), dbias (c, may be NULL) from both, p / q / t and sumG (= dbeta) from
  *     pcops_mlp_bn_bwd_coeffs, mean from pcops_mlp_bn_finalize, rows = b m s; sums in double, fixed order. */
 int pcops_edge_first_rows(void);
 int pcops_edge_first_supported(int b, int n, int m, int s, int c);
 int pcops_edge_first_moments(int b, int n, int m, int s, const float *xyz, const int *idx, float *moments_partial,
-                             pcops_stream_t stream);
+                             float *edge_rows, pcops_stream_t stream);
 int pcops_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *xyz, const int *idx,
                            float *wpartial, pcops_stream_t stream);
+/* the one-pass backward (pcops_mlp_bwd_fused_rows) of the POOLED layer above such a first layer: the masked gradient of
+ * the first layer is not written -- E^T Gm leaves as edge_stats [pcops_mlp_bwd_fused_groups(M, K, N, S, 1)][6][K], in the
+ * place of pcops_edge_first_wgrad's wpartial.  Groups of S rows that are not whole 32-row tiles (the k neighbours). */
+int pcops_mlp_bwd_fused_edge(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                                  const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                                  const unsigned char *argmax, int S, const float *W, float *partial, float *dW, float *db,
+                                  float *stats_partial, const float *edge_rows, float *edge_stats, pcops_stream_t stream);
 int pcops_edge_first_layer_grads(int P1, const float *wpartial, int P2, const float *moments_partial, int c, const float *W,
                                  const float *bias, const float *p, const float *q, const float *t, const float *sumG,
                                  const float *mean, long long rows, float *dW, float *dbias, pcops_stream_t stream);

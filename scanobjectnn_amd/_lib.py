@@ -63,7 +63,8 @@ SIGNATURES = {
     "pcops_edge_pool_out": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_pool_bwd": ([_I, _I, _I, _I, _I] + [_P] * 15, True),
     "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
-    "pcops_edge_first_moments": ([_I, _I, _I, _I, _P, _P, _P], True),
+    "pcops_edge_first_moments": ([_I, _I, _I, _I, _P, _P, _P, _P], True),
+    "pcops_mlp_bwd_fused_edge": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_first_wgrad": ([_I, _I, _I, _I, _I, _P, _P, _P, _P], True),
     "pcops_edge_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
     "pcops_sa_scatter_bwd": ([_I, _I, _I, _I, _I] + [_P] * 22, True),

@@ -38,7 +38,7 @@ int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, con
 // first EdgeConv layer of a stack whose input needs no gradient: dW (6, c) / db from E^T Gm and the edge moments
 int ec_edge_first_rows();
 bool ec_edge_first_supported(int b, int n, int m, int s, int c);
-int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, hipStream_t st);
+int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, float *e8, hipStream_t st);
 int ec_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *x, const int *idx, float *part,
                         hipStream_t st);
 int ec_edge_first_grads(int P1, const float *wpart, int P2, const float *mpart, int c, const float *W, const float *bias,

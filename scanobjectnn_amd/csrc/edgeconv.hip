@@ -1008,7 +1008,8 @@ size_t ec_bwd_lds_bytes(int m, int s) {
 constexpr int kEdgeMom = 27;        // 21 second moments (upper triangle, row-major) + 6 first moments
 
 __global__ __launch_bounds__(256) void edge_moments_kernel(int n, int m, int S, long long rows, const float *__restrict__ x,
-                                                           const int *__restrict__ idx, float *__restrict__ part) {
+                                                           const int *__restrict__ idx, float *__restrict__ part,
+                                                           float *__restrict__ e8) {
     __shared__ float red[4][kEdgeMom];
     float a[kEdgeMom];
 #pragma unroll
@@ -1021,6 +1022,10 @@ __global__ __launch_bounds__(256) void edge_moments_kernel(int n, int m, int S, 
         float e[6];
         e[0] = xg[0]; e[1] = xg[1]; e[2] = xg[2];
         e[3] = xj[0] - e[0]; e[4] = xj[1] - e[1]; e[5] = xj[2] - e[2];
+        if (e8) {        // the rows themselves, 32 bytes each, for the one-pass backward of the layer above (mlp.hip SIDE)
+            *reinterpret_cast<float4 *>(e8 + r * 8) = make_float4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<float4 *>(e8 + r * 8 + 4) = make_float4(e[4], e[5], 0.f, 0.f);
+        }
         int k = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
@@ -1191,9 +1196,9 @@ int ec_edge_first_rows() { return kEdgeFirstGrid; }
 bool ec_edge_first_supported(int b, int n, int m, int s, int c) {
     return b >= 1 && n >= 1 && m >= 1 && s >= 1 && (c == 64 || c == 128);
 }
-int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, hipStream_t st) {
+int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, float *e8, hipStream_t st) {
     const long long rows = (long long)b * m * s;
-    hipLaunchKernelGGL(edge_moments_kernel, dim3(kEdgeFirstGrid), dim3(256), 0, st, n, m, s, rows, x, idx, part);
+    hipLaunchKernelGGL(edge_moments_kernel, dim3(kEdgeFirstGrid), dim3(256), 0, st, n, m, s, rows, x, idx, part, e8);
     return pcops_launch_status();
 }
 int ec_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *x, const int *idx, float *part,

@@ -2054,10 +2054,11 @@ int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, c
 int pcops_edge_first_rows(void) { return ec_edge_first_rows(); }
 int pcops_edge_first_supported(int b, int n, int m, int s, int c) { return ec_edge_first_supported(b, n, m, s, c) ? 1 : 0; }
 int pcops_edge_first_moments(int b, int n, int m, int s, const float *xyz, const int *idx, float *moments_partial,
-                             pcops_stream_t stream) {
+                             float *edge_rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1);
     PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(moments_partial);
-    return ec_edge_first_moments(b, n, m, s, xyz, idx, moments_partial, as_stream(stream));
+    if (reinterpret_cast<uintptr_t>(edge_rows) & 15) return PCOPS_ERR_UNSUPPORTED;
+    return ec_edge_first_moments(b, n, m, s, xyz, idx, moments_partial, edge_rows, as_stream(stream));
 }
 int pcops_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *xyz, const int *idx,
                            float *wpartial, pcops_stream_t stream) {

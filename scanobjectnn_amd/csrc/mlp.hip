@@ -1984,6 +1984,7 @@ struct WgradArgs {
     // bwd_fused_kernel only: the layer's weights, the masked data gradient it also writes, its column statistics
     const float *W; float *Gprev; float *gstats; float *xstats;
     int nt_out;              // Gprev leaves with non-temporal stores
+    const float *side;       // SIDE: [M][8] per-row inputs (six used) of the reduced first layer below
 };
 
 template <int VK, int VN>
@@ -2995,12 +2996,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
 // length (768 instead of 2 048 matrix cycles per stripe and wave, ~700 cycles of split arithmetic in exchange), the h.h
 // products in the block's accumulator, the small ones in a second one.  The dW half stays on the fp32 pipe (its operands
 // would have to be staged transposed).
-template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false>
+// SIDE (round 5): the layer below is the first EdgeConv layer of a stack whose input needs no gradient (pcops.h
+// pcops_edge_first_*): its masked gradient is not written either -- its weight gradient is linear in E^T Gprev, E the six edge
+// channels of a row, which ride along as 32 bytes per row (a.side) and are reduced exactly like the xyz form's offsets.
+template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false, bool SIDE = false>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
     // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
     constexpr int KB = 64, NB = 64 * TN, RS = 32;
-    constexpr int LD = 2 * KB + NB + 4;                       // X | raw | dY | pad (row stride = 4 banks mod 32)
+    static_assert(!(XYZ && SIDE), "one reduced first layer below");
+    constexpr int NX = XYZ ? 3 : (SIDE ? 6 : 0);              // per-row inputs the masked gradient is reduced against
+    constexpr int LD = 2 * KB + NB + (SIDE ? 12 : 4);         // X | raw | dY | pad (row stride = 4 banks mod 32; SIDE: 12 mod 32)
     constexpr int A4 = KB / 4, D4 = NB / 4;
     constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -3074,6 +3080,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         static_assert(QD <= kBlk && kBlk % QD == 0, "block of row pt / D4 + j QD is (j QD) / 16");
         struct Regs {
             float4 px[NA], pg[ND], py[ND];
+            float4 pe;                                         // SIDE: one float4 of the stripe's 32 x 8 side rows (lanes 0..63)
             unsigned pm[(is_pool(DMODE)) ? ND : 1];
             float bw[compact ? NBLK : 1];                      // weight of the first row of each block of the stripe
             int bs0[B_ ? NBLK : 1];
@@ -3096,6 +3103,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const float *ixp = XYZ ? a.off4 + (long long)irow * 4 : a.X + (long long)irow * a.ldx;
         const float *iyp = a.Y + (long long)irow * a.ldy;
         const float *igp = (is_pool(DMODE) ? a.Y : a.G) + (long long)irow * a.ldy;
+        const float *iep = SIDE ? a.side + (long long)irow * 8 : nullptr;
         const long long xadv = (long long)rstep * (XYZ ? 4 : a.ldx), yadv = (long long)rstep * a.ldy;
         const int Sg = is_pool(DMODE) ? a.S : 1;
         const int dq = rstep / Sg, dr = rstep % Sg;            // (once per kernel)
@@ -3129,6 +3137,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             } else {
 #pragma unroll
                 for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
+            }
+            if (SIDE) {
+                const __amdgpu_buffer_rsrc_t re = make_rsrc_u32(iep, rows_here * 32u);   // rows beyond M read as zeros
+                rg_.pe = buf_load4(re, pt < 64 ? (unsigned)pt * 16u : kOOB, 0u);
+                iep += (long long)rstep * 8;
             }
             const PoolRows pr((long long)ig0, is0, Sg);
             rg_.s0 = is0;
@@ -3170,6 +3183,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             if (dbg & 8) return;
             const int row0 = srow;
             const PoolRows prs((long long)sg0, ss0, Sg);
+            if (SIDE && pt < 64) *reinterpret_cast<float4 *>(&dst[(pt >> 1) * LD + 2 * KB + NB + 4 * (pt & 1)]) = rg_.pe;
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int r = pt / A4 + j * (256 / A4);
@@ -3329,9 +3343,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             msc[b] = coefA[32 * cbp + 16 * b + c16];
             msh[b] = coefA[KB + 32 * cbp + 16 * b + c16];
         }
-        float sx[XYZ ? 2 : 1][3];                              // xyz form: sums of offset (x) masked gradient
+        float sx[NX ? 2 : 1][NX ? NX : 1];                     // xyz / side form: sums of row input (x) masked gradient
 #pragma unroll
-        for (int b = 0; b < (XYZ ? 2 : 1); ++b) sx[b][0] = sx[b][1] = sx[b][2] = 0.f;
+        for (int b = 0; b < (NX ? 2 : 1); ++b)
+#pragma unroll
+            for (int i = 0; i < (NX ? NX : 1); ++i) sx[b][i] = 0.f;
         __syncthreads();
         for (long long i = 0; i < cnt; ++i) {
             const float *sb = buf + (i & 1) * RS * LD;
@@ -3410,13 +3426,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             // ---- Gprev rows of this stripe: mask, column sums, store (before the stripe buffer is handed back).  (Handing
             // them to the next stripe's loop so that they issue under its first MFMAs was measured: no difference.)
             if (!(dbg & 2)) {
-                const __amdgpu_buffer_rsrc_t rgp = make_rsrc(XYZ ? nullptr : a.Gprev + row0 * K, XYZ ? 0 : (M - row0) * K * 4);
+                const __amdgpu_buffer_rsrc_t rgp = make_rsrc(NX ? nullptr : a.Gprev + row0 * K, NX ? 0 : (M - row0) * K * 4);
                 const bool gnt = a.nt_out != 0;
-                float4 ofs[XYZ ? 4 : 1];
-                if (XYZ) {
+                float4 ofs[NX ? 4 : 1], of2[SIDE ? 4 : 1];
+                if (NX) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < 4; ++v) {
                         ofs[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + 2 * KB + NB]);
+                        if (SIDE) of2[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + 2 * KB + NB + 4]);
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
@@ -3426,10 +3444,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                         if (DX3) smd[b][v] = 0.f;
                         s1[b] += gv;
                         s2[b] = fmaf(gv, yr[b][v], s2[b]);
-                        if (XYZ) {
+                        if (NX) {
                             sx[b][0] = fmaf(ofs[v].x, gv, sx[b][0]);
                             sx[b][1] = fmaf(ofs[v].y, gv, sx[b][1]);
                             sx[b][2] = fmaf(ofs[v].z, gv, sx[b][2]);
+                            if (SIDE) {
+                                sx[b][3] = fmaf(ofs[v].w, gv, sx[b][3]);
+                                sx[b][4] = fmaf(of2[v].x, gv, sx[b][4]);
+                                sx[b][5] = fmaf(of2[v].y, gv, sx[b][5]);
+                            }
                         } else {
                             if (gnt) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 2);
                             else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), rgp, goff[b][v], 0, 0);
@@ -3458,22 +3481,23 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             s2[b] += __shfl_xor(s2[b], 16, 64); s2[b] += __shfl_xor(s2[b], 32, 64);
         }
 #pragma unroll
-        for (int b = 0; b < (XYZ ? 2 : 1); ++b)
+        for (int b = 0; b < (NX ? 2 : 1); ++b)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < NX; ++i) {
                 sx[b][i] += __shfl_xor(sx[b][i], 16, 64);
                 sx[b][i] += __shfl_xor(sx[b][i], 32, 64);
             }
         __syncthreads();                                       // matches the producers' db hand-over
-        float *sst = buf + 256 * 4;                            // [2 row halves][5][KB], behind the db scratch
+        constexpr int NSR = 2 + (NX > 3 ? NX : 3);             // statistics rows per row half: s1, s2, the NX input sums
+        float *sst = buf + 256 * 4;                            // [2 row halves][NSR][KB], behind the db scratch
         if (lane < 16) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                sst[(rh * 5 + 0) * KB + 32 * cbp + 16 * b + c16] = s1[b];
-                sst[(rh * 5 + 1) * KB + 32 * cbp + 16 * b + c16] = s2[b];
-                if (XYZ) {
+                sst[(rh * NSR + 0) * KB + 32 * cbp + 16 * b + c16] = s1[b];
+                sst[(rh * NSR + 1) * KB + 32 * cbp + 16 * b + c16] = s2[b];
+                if (NX) {
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) sst[(rh * 5 + 2 + i) * KB + 32 * cbp + 16 * b + c16] = sx[b][i];
+                    for (int i = 0; i < NX; ++i) sst[(rh * NSR + 2 + i) * KB + 32 * cbp + 16 * b + c16] = sx[b][i];
                 }
             }
         }
@@ -3487,12 +3511,12 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < (XYZ ? 5 : 2) * KB; i += 256) {
+        for (int i = tid; i < (2 + NX) * KB; i += 256) {
             const int which = i / KB, c = i % KB;
-            const float v = sst[which * KB + c] + sst[(5 + which) * KB + c];
+            const float v = sst[which * KB + c] + sst[(NSR + which) * KB + c];
             if (c < K) {
                 if (which < 2) a.gstats[((long long)grp * 2 + which) * K + c] = v;
-                else a.xstats[((long long)grp * 3 + which - 2) * K + c] = v;
+                else a.xstats[((long long)grp * NX + which - 2) * K + c] = v;
             }
         }
     }
@@ -4883,12 +4907,13 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
                                     Gprev, stats_partial, nullptr, stream);
 }
 
-static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st) {
+static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
+                            bool side = false) {
     const int K = a.K, N = a.N;
     a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
     const int tn = N <= 64 ? 1 : 2;
     const int NB = 64 * tn;
-    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + 4)) * sizeof(float);
+    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
     const bool pooled = a.gpool != nullptr;
     static const bool nsk_on = [] {
         const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
@@ -4915,6 +4940,21 @@ static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, 
         else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU, X_);                                       \
         else PCOPS_BF_LAUNCH(TN_, A_DYPOOL, X_);                                                           \
     } while (0)
+    if (side) {
+        // (the first EdgeConv layer below: pooled groups of k neighbours, plain rows -- pcops_mlp_bwd_fused_edge checks)
+#define PCOPS_BF_SIDE(TN_)                                                                                 \
+    do {                                                                                                   \
+        auto kern = dx3 ? bwd_fused_kernel<TN_, A_DYPOOL, false, false, true, true>                        \
+                        : bwd_fused_kernel<TN_, A_DYPOOL, false, false, false, true>;                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+        if (tn == 1) PCOPS_BF_SIDE(1);
+        else PCOPS_BF_SIDE(2);
+#undef PCOPS_BF_SIDE
+    } else
     if (tn == 1 && xyz) PCOPS_BF_MODES(1, true);
     else if (tn == 1) PCOPS_BF_MODES(1, false);
     else if (xyz) PCOPS_BF_MODES(2, true);
@@ -4958,6 +4998,30 @@ int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, cons
     { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
 #endif
     return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream));
+}
+
+int pcops_mlp_bwd_fused_edge(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                                  const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                                  const unsigned char *argmax, int S, const float *W, float *partial, float *dW, float *db,
+                                  float *stats_partial, const float *edge_rows, float *edge_stats, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && S >= 1);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(gpool);
+    PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(stats_partial);
+    PCOPS_REQUIRE_PTR(edge_rows); PCOPS_REQUIRE_PTR(edge_stats);
+    const int groups = bwd_fused_groups(M, K, N, S, true);
+    if (groups == 0 || S % 32 == 0) return PCOPS_ERR_UNSUPPORTED;       // (whole-tile groups take another operand form)
+    if ((reinterpret_cast<uintptr_t>(Yprev) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+        (reinterpret_cast<uintptr_t>(gpool) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3) || (reinterpret_cast<uintptr_t>(edge_rows) & 15))
+        return PCOPS_ERR_UNSUPPORTED;
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_BNRELU; a.X = Yprev; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = A_DYPOOL; a.G = nullptr; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.gpool = gpool; a.argmax = argmax; a.S = S;
+    a.W = W; a.Gprev = nullptr; a.gstats = stats_partial; a.xstats = edge_stats; a.side = edge_rows;
+    return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream), true);
 }
 
 int pcops_mlp_bwd_fused_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,

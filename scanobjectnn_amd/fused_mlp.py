@@ -130,7 +130,14 @@ class FusedMLPStack(torch.autograd.Function):
                           idx.data_ptr(), Y.data_ptr(), _p(part), piv)
                 if direct and need_grad:      # the 27 moments of the edge features, for E^T Y1 in the backward
                     mom = _f32((lib.pcops_edge_first_rows(), 27), dev)
-                    _lib.call("pcops_edge_first_moments", B, Nsrc, M, S, xyz.data_ptr(), idx.data_ptr(), mom.data_ptr())
+                    # ... and, where the layer above takes the one-pass backward, the edge rows themselves (32 bytes each):
+                    # E^T Gm is then reduced inside that kernel and the masked gradient is never written
+                    N1 = layers[1][0].shape[-1]
+                    if (EDGE_DIRECT_FUSED and BWD_FUSED and L == 2 and pool and S % 32 != 0
+                            and lib.pcops_mlp_bwd_fused_groups(R, N, N1, S, 1)):
+                        ctx.edge_rows = _f32((R, 8), dev)
+                    _lib.call("pcops_edge_first_moments", B, Nsrc, M, S, xyz.data_ptr(), idx.data_ptr(), mom.data_ptr(),
+                              _p(getattr(ctx, "edge_rows", None)))
                 W2 = None
             elif li == 0 and gather:
                 N = C1
@@ -322,10 +329,13 @@ class FusedMLPStack(torch.autograd.Function):
             if l == 0 and gather and getattr(ctx, "direct", False):
                 # the input needs no gradient: dW (6, C1) / db straight from E^T Gm and the edge moments -- no scatter
                 B, M, _ = idx.shape
-                P1 = lib.pcops_edge_first_rows()
-                wpart = _f32((P1, 6, N), dev)
-                _lib.call("pcops_edge_first_wgrad", B, a0.shape[1], M, S, N, Gptr, xyz.data_ptr(), idx.data_ptr(),
-                          wpart.data_ptr())
+                if xstats is not None:        # reduced by the one-pass backward of the layer above
+                    wpart, P1 = xstats, xstats.shape[0]
+                else:
+                    P1 = lib.pcops_edge_first_rows()
+                    wpart = _f32((P1, 6, N), dev)
+                    _lib.call("pcops_edge_first_wgrad", B, a0.shape[1], M, S, N, Gptr, xyz.data_ptr(), idx.data_ptr(),
+                              wpart.data_ptr())
                 dwxyz = _f32((6, N), dev)
                 dbias = _f32(N, dev) if bias is not None else None
                 _lib.call("pcops_edge_first_layer_grads", P1, wpart.data_ptr(), mom.shape[0], mom.data_ptr(), N,
@@ -388,6 +398,17 @@ class FusedMLPStack(torch.autograd.Function):
                 dW, db = _f32((K, N), dev), _f32(N, dev)
                 P = fused_groups
                 part = _f32((P, 2, K), dev)
+                edge_rows = getattr(ctx, "edge_rows", None) if (l == 1 and pooled and getattr(ctx, "direct", False)) else None
+                if edge_rows is not None:   # the first EdgeConv layer below, input without gradient: E^T Gm reduced in the kernel
+                    xstats = _f32((P, 6, K), dev)
+                    _lib.call("pcops_mlp_bwd_fused_edge", R, K, N, Ys[0].data_ptr(), scales[0].data_ptr(),
+                              shifts[0].data_ptr(), Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S,
+                              Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(),
+                              edge_rows.data_ptr(), xstats.data_ptr())
+                    grads[6 * l + 0] = dW
+                    grads[6 * l + 1] = db
+                    Gm = None
+                    continue
                 if xyz_prev:     # the arithmetic first layer below: its masked gradient is reduced, never written
                     xstats = _f32((P, 3, K), dev)
                     _lib.call("pcops_mlp_bwd_fused_xyz_rows", R, K, N, off4.data_ptr(), xyzw.data_ptr(),
@@ -884,6 +905,7 @@ STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
 EDGE_DIRECT = os.environ.get("PCOPS_EDGE_DIRECT", "1") != "0"   # first EdgeConv layer of a stack on an input without gradient
+EDGE_DIRECT_FUSED = os.environ.get("PCOPS_EDGE_DIRECT_FUSED", "1") != "0"   # ... its E^T Gm inside the one-pass backward above
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 EDGE_QC = os.environ.get("PCOPS_EDGE_QC", "1") != "0"        # EdgeConv's two per-point GEMMs as one [Q | Ctr] product
