@@ -504,6 +504,9 @@ int launch_knn_mfma(int b, int n, int c, int k, const float *x, int *nn_idx, con
 // graphs), k <= 20; everything else takes knn_mfma_kernel.
 typedef _Float16 f16x8k __attribute__((ext_vector_type(8)));
 constexpr int kKnnPD = 32;             // pending survivors per lane; checked once per 32-row tile (<= 16 new entries each)
+// (A, B assume GRADUAL underflow in v_cvt_f16_f32 and in the fp16 MFMA -- a channel below 6.1e-5 keeps its subnormal value.  It
+// holds on gfx950: tests/test_knn_gpu.py "subnormal_mix" builds clouds whose graphs would lose neighbours by five times the
+// bound if subnormals were flushed, and they are bit-exact.)
 constexpr float kKnnA = 1.1e-3f, kKnnB = 1e-6f;
 
 #ifdef PCOPS_KNN_STATS
