@@ -27,9 +27,12 @@ def dgcnn_rows():
         ("ec_fwd_kernel<1>", None, "T-Net first layer Y = Q[idx] + Ctr stored (10.5 M x 64)", F * R * 64 + 2 * ec(64) + idx),
         ("ec_tnet_ctr_kernel", None, "T-Net scatter, per-group output: G streamed, Q gathered", F * R * 64 + 3 * ec(64) + idx),
         ("ec_walk_kernel<true>", None, "T-Net scatter, owner walk: G rows gathered once", F * R * 64 + 3 * ec(64) + R * 4),
-        ("bwd_fused_kernel<2, 3", None, "T-Net one-pass backward 64 -> 128 (10.5 M rows): Yprev, Y in; Gprev out", F * R * (64 + 128 + 64)),
-        ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 4>", 163840, "T-Net forward 64 -> 128 (10.5 M rows)", F * R * (64 + 128)),
-        ("bn_relu_maxpool_kernel", 8388608, "T-Net max over k of the 128-wide layer", F * R * 128 + 2 * ec(128) + G * 128),
+        ("bwd_fused_kernel<2, 3, false, false, true, true>", None, "T-Net one-pass backward 64 -> 128 (10.5 M rows), E^T Gprev reduced inside: Yprev, Y, 32 B of edge channels per row in; no Gprev", F * R * (64 + 128 + 8)),
+        ("bwd_fused_kernel<2, 3, false, false, true>", None, "T-Net one-pass backward 64 -> 128 (10.5 M rows): Yprev, Y in; Gprev out (first half of the round)", F * R * (64 + 128 + 64)),
+        ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 13>", 163840, "T-Net forward 64 -> 128 (10.5 M rows) with the k = 20 max-pool in its epilogue: Y1 in; Y2, extrema + arg out", F * R * (64 + 128) + 5 * G * 128),
+        ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 4>", 163840, "T-Net forward 64 -> 128 (10.5 M rows), separate max-pool pass (first half of the round)", F * R * (64 + 128)),
+        ("bn_relu_maxpool_kernel", 8388608, "T-Net max over k of the 128-wide layer (first half of the round; gone)", F * R * 128 + 2 * ec(128) + G * 128),
+        ("edge_moments_kernel", None, "T-Net edge rows (32 B each) + their 27 moments: idx in, rows out", idx + 32 * R),
         ("gemm_ws_kernel<4, 0, 0, 32, 8, 4, 7>", None, "aggregation forward 320 -> 1024 with the pooled epilogue (Y not stored)", F * G * 320),
         ("gemm_ws_kernel<4, 0, 5, 64, 8, 2, 2>", None, "aggregation data gradient (algebraic form): X in, G out", 2 * F * G * 320),
         ("gram_full_kernel<10", None, "Gram matrix of the 320-wide input", F * G * 320),
