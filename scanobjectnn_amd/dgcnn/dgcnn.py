@@ -37,7 +37,7 @@ def _edge_conv(x, width, scope, k, is_training, bn_decay, seed=None, cat_slot=No
 
 
 def backbone(point_cloud, is_training, bn_decay, k=20):
-    """shared by dgcnn / dgcnn_bga: returns (net1..net4, out_max) with out_max (B,1,1,1024) = the max over the points
+    """shared by dgcnn / dgcnn_bga: returns (net1..net4, their concatenation, out_max) with out_max (B,1,1,1024) = the max over the points
     of the 1024-wide `agg` layer (both models only ever use that max, dgcnn.py:79-84 / dgcnn_bga.py)"""
     nn_idx = tf_util.knn_graph(point_cloud, k=k)
     with variable_scope('transform_net1'):
@@ -73,7 +73,7 @@ def backbone(point_cloud, is_training, bn_decay, k=20):
         agg = tf_util.conv2d(cat, 1024, [1, 1], padding='VALID', stride=[1, 1], bn=True, is_training=is_training,
                              scope='agg', bn_decay=bn_decay)
         out_max = tf_util.max_pool2d(agg, [agg.shape[1], 1], padding='VALID', scope='maxpool')
-    return net1, net2, net3, net4, out_max
+    return net1, net2, net3, net4, cat, out_max    # cat: the (B,N,1,320) concatenation (dgcnn_bga's segmentation head reuses it)
 
 
 def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):

@@ -20,7 +20,7 @@ def placeholder_inputs(batch_size, num_point, device=None):
 def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
     """point_cloud (B,N,3) -> class_pred (B,num_class), seg_pred (B,N,2)"""
     batch_size, num_point = point_cloud.shape[0], point_cloud.shape[1]
-    net1, net2, net3, net4, out_max = backbone(point_cloud, is_training, bn_decay)        # out_max (B,1,1,1024)
+    net1, net2, net3, net4, local, out_max = backbone(point_cloud, is_training, bn_decay)  # out_max (B,1,1,1024)
     expand = out_max.expand(batch_size, num_point, 1, 1024)
 
     net = out_max.reshape(batch_size, -1)
@@ -31,6 +31,16 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
     net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp2')
     class_pred = tf_util.fully_connected(net, num_class, activation_fn=None, scope='fc3')
 
+    per_cloud = torch.cat([class_vector.view(batch_size, 256), out_max.view(batch_size, 1024)], dim=-1)
+    if tf_util.cloud_point_ok(per_cloud, local, [512, 256]):
+        # the first 1280 of the reference's 1600 concatenated channels are per-cloud constants: their part of seg/conv1 is
+        # ONE (B, 1280) product, not 2048 of them per cloud (tf_util.conv2d_stack_cloud_point); decay as below
+        net = tf_util.conv2d_stack_cloud_point(per_cloud, local, [512, 256], ['seg/conv1', 'seg/conv2'], is_training, None,
+                                               is_dist=True)
+        net = tf_util.dropout(net, keep_prob=0.7, is_training=is_training, scope='dp1')
+        net = tf_util.conv2d(net, 2, [1, 1], padding='VALID', stride=[1, 1], activation_fn=None,
+                             scope='seg/conv3', is_dist=True)
+        return class_pred, net.squeeze(2)
     concat = torch.cat([class_vector.expand(batch_size, num_point, 1, 256), expand, net1, net2, net3, net4],
                        dim=-1)                                                             # 1600 ch
     if tf_util.fused_ok(concat, [512, 256]):

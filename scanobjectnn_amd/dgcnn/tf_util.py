@@ -287,6 +287,33 @@ def edge_conv_stack(point_cloud, nn_idx, widths, scopes, is_training, bn_decay, 
     return (out.view(b, n, 1, widths[-1]), None) if cat_slot is not None else out.view(b, n, 1, widths[-1])
 
 
+def cloud_point_ok(per_cloud, per_point, widths):
+    b, n = per_point.shape[0], per_point.shape[1]
+    return (fused_ok(per_point, widths) and b * n >= 8192 and n <= 16384 and per_point.shape[-1] % 4 == 0
+            and fused_mlp.CLOUD_POINT)
+
+
+def conv2d_stack_cloud_point(per_cloud, per_point, widths, scopes, is_training, bn_decay, is_dist=False):
+    """len(widths) x conv2d([1,1], bn, relu) on concat([per_cloud broadcast over the points | per_point], -1) WITHOUT the
+    concatenation.  The first conv is linear:  [c_b | x_bn] W + bias = x_bn W_x + (c_b W_c + bias)  -- a (B N, Cx) product per
+    point and a (B, Cc) product per cloud, and Y1 = Q + Ctr is the gather form of csrc/gather.hip with the identity index (one
+    group per cloud).  The reference builds the (B, N, 1, 1600) tensor of dgcnn_bga's segmentation head, 1280 of whose channels
+    are per-cloud constants (dgcnn_bga.py:118-128): four fifths of its first conv's work, forward and backward, multiplied the
+    same two vectors 2048 times.  Variables are the ones conv2d(..., scope=scopes[i]) creates on the concatenated width.
+    per_cloud (B, Cc), per_point (B, N, 1, Cx) | (B, N, Cx) -> (B, N, 1, widths[-1])"""
+    b, n = per_point.shape[0], per_point.shape[1]
+    cc, cx = per_cloud.shape[-1], per_point.shape[-1]
+    names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
+    layers = _pn2._stack_variables(cc + cx, widths, list(scopes), 1e-3, None, True, names)
+    w1, b1 = layers[0][0], layers[0][1]
+    q = fused_mlp.rows_linear(per_point.reshape(b * n, cx), w1[cc:]).view(b, n, widths[0])
+    ctr = torch.addmm(b1, per_cloud.reshape(b, cc), w1[:cc]).view(b, 1, widths[0])
+    idx = torch.arange(n, dtype=torch.int32, device=q.device).view(1, 1, n).expand(b, 1, n).contiguous()
+    decay = bn_decay if bn_decay is not None else 0.9
+    out = fused_mlp.gather_mlp_stack(idx, False, is_training, decay, BN_EPS, False, layers, Q=q, Ctr=ctr, identity_idx=True)
+    return out.view(b, n, 1, widths[-1])
+
+
 def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False, pool_max=False):
     """len(widths) x conv2d([1,1], bn, relu) on a channel-last (B,H,W,C) tensor through the fused MLP stack
     (this module's BN flavour: biased variance in the moving statistics); pool_max: + max over axis 2."""

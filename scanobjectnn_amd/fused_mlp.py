@@ -904,6 +904,7 @@ TRACE = None
 STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
+CLOUD_POINT = os.environ.get("PCOPS_CLOUD_POINT", "1") != "0"   # dgcnn_bga's head: per-cloud + per-point first conv without the concat
 EDGE_DIRECT = os.environ.get("PCOPS_EDGE_DIRECT", "1") != "0"   # first EdgeConv layer of a stack on an input without gradient
 EDGE_DIRECT_FUSED = os.environ.get("PCOPS_EDGE_DIRECT_FUSED", "1") != "0"   # ... its E^T Gm inside the one-pass backward above
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
