@@ -229,6 +229,12 @@ def _algo(name, a):
     if name == "pcops_mlp_bwd_fused_edge":    # ... above a first EdgeConv layer without input gradient: Yprev, Y and 32 B of
         M, K, N = a[:3]                       # edge channels per row in, NO Gprev (its E^T Gprev is reduced in the kernel)
         return 4 * (M * K + M * N + 8 * M), 4 * M * K * N, "flop"
+    if name == "pcops_cloud_bias_fwd":        # Y = Q + Ctr[cloud]: Q in, Y out
+        rows, rpg, c = a[:3]
+        return 8 * rows * c, 0, ""
+    if name == "pcops_cloud_bias_bwd":        # G, Y in; dQ out
+        rows, rpg, c = a[:3]
+        return 4 * rows * c * (3 if a[8] is not None else 2), 0, ""
     if name == "pcops_edge_first_wgrad":      # E^T Gm: one pass over the masked gradient (b m s rows of c)
         b, n, m, s_, c = a[:5]
         return 4 * b * m * s_ * (c + 1), 12 * b * m * s_ * c, "flop(VALU)"

@@ -519,6 +519,18 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
                         const float *gpool, const float *ysel, const float *SQ, const unsigned char *arg,
                         const float *scale, const float *shift, const float *p, const float *q, const float *t,
                         float *dQ, float *dCtr, void *workspace, pcops_stream_t stream);
+/* First layer of a stack whose groups are WHOLE CLOUDS in their own row order (round 5; reference: dgcnn_bga.py:118-128, the
+ * segmentation head's concat of 1280 per-cloud channels with 320 per-point ones -- see DESIGN.md section 4.15):
+ *   Y[r, :] = Q[r, :] + Ctr[r / rows_per_group, :]  with shifted-moment partials [pcops_cloud_bias_rows(rows)][2][c], and
+ *   backward  dQ = p G + q Y + t  (may be NULL),  dCtr[g] = sum over the group's rows of it; partial: [..rows(rows)][c] scratch.
+ * rows_per_group a multiple of 256, c % 4 == 0, c <= 1024, 256 % (c / 4) == 0.  The general form of the same layer is
+ * pcops_sa_gather_fwd / pcops_sa_scatter_bwd with the identity index. */
+int pcops_cloud_bias_supported(long long rows, int rows_per_group, int c);
+int pcops_cloud_bias_rows(long long rows);
+int pcops_cloud_bias_fwd(long long rows, int rows_per_group, int c, const float *Q, const float *Ctr, float *Y,
+                         float *stats_partial, const float *stat_pivot, pcops_stream_t stream);
+int pcops_cloud_bias_bwd(long long rows, int rows_per_group, int c, const float *G, const float *Y, const float *p, const float *q,
+                         const float *t, float *dQ, float *dCtr, float *partial, pcops_stream_t stream);
 /* First EdgeConv layer of a grouped stack whose INPUT needs no gradient (round 5; reference: the T-Net's tconv1 on the edge
  * features of the raw cloud, dgcnn/models/transform_nets.py:18-27 over tf_util.get_edge_feature, tf_util.py:660-706).  The
  * layer is linear in the six edge channels e = [x_g | x_j - x_g], j = idx[g, s]:  Y1 = e W + b, and with the BN backward

@@ -63,6 +63,8 @@ SIGNATURES = {
     "pcops_edge_pool_out": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_pool_bwd": ([_I, _I, _I, _I, _I] + [_P] * 15, True),
     "pcops_xyz_first_layer_grads": ([_I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P], True),
+    "pcops_cloud_bias_fwd": ([_LL, _I, _I, _P, _P, _P, _P, _P], True),
+    "pcops_cloud_bias_bwd": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_first_moments": ([_I, _I, _I, _I, _P, _P, _P, _P], True),
     "pcops_mlp_bwd_fused_edge": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_edge_first_wgrad": ([_I, _I, _I, _I, _I, _P, _P, _P, _P], True),
@@ -121,6 +123,8 @@ PLAIN = {
     "pcops_edge_pool_fwd_stats_rows": ([_I] * 5, _I),
     "pcops_edge_ld_supported": ([_I] * 5, _I),
     "pcops_edge_first_rows": ([], _I),
+    "pcops_cloud_bias_supported": ([_LL, _I, _I], _I),
+    "pcops_cloud_bias_rows": ([_LL], _I),
     "pcops_edge_first_supported": ([_I] * 5, _I),
     "pcops_sa_scatter_workspace_bytes": ([_I, _I, _I, _I], _U64),
     "pcops_rows_max_blocks": ([_I, _I, _I], _U64),

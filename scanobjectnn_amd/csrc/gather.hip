@@ -927,6 +927,106 @@ __global__ __launch_bounds__(256) void sa_scatter_owner_kernel(CsrArgs a) {
     }
 }
 
+// ---- first layer of a stack whose groups are whole clouds in their own order (identity index, round 5) ---------------------
+//   Y[r, :] = Q[r, :] + Ctr[r / rpg, :]   (+ shifted moments),      backward:  dQ = p G + q Y + t,  dCtr[g] = sum_{r in g} dQ[r]
+// The general gather kernels deal ONE workgroup per group -- 128 workgroups for dgcnn_bga's segmentation head (2048 x 512 per
+// cloud), 659 us for a 1 GB stream; its backward was two elementwise torch launches plus a column-sum pass over the same rows.
+constexpr int kCloudRows = 256;         // rows per workgroup (a whole number of them per group)
+__global__ __launch_bounds__(256) void cloud_bias_fwd_kernel(long long rows, int rpg, int C, const float *__restrict__ Q,
+                                                             const float *__restrict__ Ctr, float *__restrict__ Y,
+                                                             float *__restrict__ stats, const float *__restrict__ pivot, int nt) {
+    extern __shared__ float cb_red[];               // [RL][2][C]
+    const int c4n = C / 4, RL = 256 / c4n;
+    const int cq = (threadIdx.x % c4n) * 4, rl = threadIdx.x / c4n;
+    const long long r0 = (long long)blockIdx.x * kCloudRows;
+    const long long g = r0 / rpg;
+    const float4 ct = *reinterpret_cast<const float4 *>(Ctr + g * C + cq);
+    const float4 pv = pivot ? *reinterpret_cast<const float4 *>(pivot + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    typedef float cb_f4 __attribute__((ext_vector_type(4)));
+    for (int i = rl; i < kCloudRows; i += 4 * RL) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + i + u * RL;
+            q[u] = (i + u * RL < kCloudRows && r < rows) ? *reinterpret_cast<const float4 *>(Q + r * C + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + i + u * RL;
+            if (!(i + u * RL < kCloudRows && r < rows)) continue;
+            const float4 y = make_float4(q[u].x + ct.x, q[u].y + ct.y, q[u].z + ct.z, q[u].w + ct.w);
+            if (nt) __builtin_nontemporal_store(cb_f4{y.x, y.y, y.z, y.w}, reinterpret_cast<cb_f4 *>(Y + r * C + cq));
+            else *reinterpret_cast<float4 *>(Y + r * C + cq) = y;
+            const float d[4] = {y.x - pv.x, y.y - pv.y, y.z - pv.z, y.w - pv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += d[e]; s2[e] = fmaf(d[e], d[e], s2[e]); }
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cb_red[(rl * 2 + 0) * C + cq + e] = s1[e];
+        cb_red[(rl * 2 + 1) * C + cq + e] = s2[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        float v = 0.f;
+        for (int r = 0; r < RL; ++r) v += cb_red[r * 2 * C + e];
+        stats[(long long)blockIdx.x * 2 * C + e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void cloud_bias_bwd_kernel(long long rows, int C, const float *__restrict__ G,
+                                                             const float *__restrict__ Y, const float *__restrict__ p,
+                                                             const float *__restrict__ q, const float *__restrict__ t,
+                                                             float *__restrict__ dQ, float *__restrict__ part) {
+    extern __shared__ float cb_red[];               // [RL][C]
+    const int c4n = C / 4, RL = 256 / c4n;
+    const int cq = (threadIdx.x % c4n) * 4, rl = threadIdx.x / c4n;
+    const long long r0 = (long long)blockIdx.x * kCloudRows;
+    const float4 cp = *reinterpret_cast<const float4 *>(p + cq), cqv = *reinterpret_cast<const float4 *>(q + cq),
+                 ctv = *reinterpret_cast<const float4 *>(t + cq);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = rl; i < kCloudRows; i += 4 * RL) {
+        float4 g[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + i + u * RL;
+            const bool in = i + u * RL < kCloudRows && r < rows;
+            g[u] = in ? *reinterpret_cast<const float4 *>(G + r * C + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[u] = in ? *reinterpret_cast<const float4 *>(Y + r * C + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long r = r0 + i + u * RL;
+            if (!(i + u * RL < kCloudRows && r < rows)) continue;
+            const float4 d = make_float4(fmaf(cp.x, g[u].x, fmaf(cqv.x, y[u].x, ctv.x)), fmaf(cp.y, g[u].y, fmaf(cqv.y, y[u].y, ctv.y)),
+                                         fmaf(cp.z, g[u].z, fmaf(cqv.z, y[u].z, ctv.z)), fmaf(cp.w, g[u].w, fmaf(cqv.w, y[u].w, ctv.w)));
+            if (dQ) *reinterpret_cast<float4 *>(dQ + r * C + cq) = d;
+            s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cb_red[rl * C + cq + e] = s[e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += 256) {
+        float v = 0.f;
+        for (int r = 0; r < RL; ++r) v += cb_red[r * C + e];
+        part[(long long)blockIdx.x * C + e] = v;
+    }
+}
+
+// dCtr[g][c] = sum of the group's partial rows (fixed order)
+__global__ __launch_bounds__(256) void cloud_bias_reduce_kernel(int ppg, int C, const float *__restrict__ part, float *__restrict__ dCtr) {
+    const int g = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = 0.f;
+        for (int r = 0; r < ppg; ++r) v += part[((long long)g * ppg + r) * C + c];
+        dCtr[(long long)g * C + c] = v;
+    }
+}
+
 constexpr int kCsrGrid = 1024;      // persistent workgroups of the gather pass (= rows of its wpart)
 
 // gradients of an ARITHMETIC first layer from a handful of sums (see pcops_mlp_gemm_dgrad_xyz in pcops.h):
@@ -2048,6 +2148,38 @@ int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, c
     rc = ec_tnet_ctr(b, n, m, s, c, Q, ldq, Ctr, ldc, G, idx, p, q, t, dCtr, lddc, st);
     if (rc) return rc;
     return ec_walk(b, n, m, s, c, Q, ldq, Ctr, ldc, G, p, q, t, workspace, dQ, lddq, st);
+}
+
+// ---- first layer of a stack over whole clouds in their own order: Y = Q + Ctr[cloud]  (cloud_bias_*_kernel above)
+int pcops_cloud_bias_supported(long long rows, int rows_per_group, int c) {
+    return (rows >= 1 && rows_per_group >= kCloudRows && rows_per_group % kCloudRows == 0 && rows % rows_per_group == 0 && c >= 4 &&
+            c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0 && rows / kCloudRows < (1ll << 31)) ? 1 : 0;
+}
+int pcops_cloud_bias_rows(long long rows) { return (int)((rows + kCloudRows - 1) / kCloudRows); }
+int pcops_cloud_bias_fwd(long long rows, int rows_per_group, int c, const float *Q, const float *Ctr, float *Y,
+                         float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
+    PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(Y);
+    if (!pcops_cloud_bias_supported(rows, rows_per_group, c)) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(Ctr) | reinterpret_cast<uintptr_t>(Y)) & 15) return PCOPS_ERR_UNSUPPORTED;
+    static const bool nt_on = [] { const char *e = getenv("PCOPS_NT_STORE"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    const int rl = 256 / (c / 4);
+    hipLaunchKernelGGL(cloud_bias_fwd_kernel, dim3(pcops_cloud_bias_rows(rows)), dim3(256), (size_t)rl * 2 * c * sizeof(float),
+                       as_stream(stream), rows, rows_per_group, c, Q, Ctr, Y, stats_partial, stats_partial ? stat_pivot : nullptr,
+                       (nt_on && rows * c * 4 >= (256ll << 20)) ? 1 : 0);
+    return pcops_launch_status();
+}
+int pcops_cloud_bias_bwd(long long rows, int rows_per_group, int c, const float *G, const float *Y, const float *p, const float *q,
+                         const float *t, float *dQ, float *dCtr, float *partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_PTR(G); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(partial);
+    if (!pcops_cloud_bias_supported(rows, rows_per_group, c)) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dQ)) & 15) return PCOPS_ERR_UNSUPPORTED;
+    const int rl = 256 / (c / 4);
+    hipLaunchKernelGGL(cloud_bias_bwd_kernel, dim3(pcops_cloud_bias_rows(rows)), dim3(256), (size_t)rl * c * sizeof(float),
+                       as_stream(stream), rows, c, G, Y, p, q, t, dQ, partial);
+    hipLaunchKernelGGL(cloud_bias_reduce_kernel, dim3((unsigned)(rows / rows_per_group)), dim3(256), 0, as_stream(stream),
+                       rows_per_group / kCloudRows, c, partial, dCtr);
+    return pcops_launch_status();
 }
 
 // ---- first EdgeConv layer of a stack whose input needs no gradient (edgeconv.hip): weight gradient without a scatter

@@ -139,6 +139,17 @@ class FusedMLPStack(torch.autograd.Function):
                     _lib.call("pcops_edge_first_moments", B, Nsrc, M, S, xyz.data_ptr(), idx.data_ptr(), mom.data_ptr(),
                               _p(getattr(ctx, "edge_rows", None)))
                 W2 = None
+            elif (li == 0 and gather and identity and CLOUD_BIAS and a0 is not None and ctr is not None and xyz is None
+                    and wxyz is None and bias is None and rows is None and M == 1 and Nsrc == S and a0.is_contiguous()
+                    and lib.pcops_cloud_bias_supported(R, S, C1)):
+                # whole clouds in their own order: Y = Q + Ctr[cloud] as one streaming pass (pcops.h pcops_cloud_bias_*)
+                N = C1
+                Y = _f32((R, N), dev)
+                P = lib.pcops_cloud_bias_rows(R)
+                part = _f32((P, 2, N), dev) if training else None
+                _lib.call("pcops_cloud_bias_fwd", R, S, N, a0.data_ptr(), ctr.data_ptr(), Y.data_ptr(), _p(part), piv)
+                W2 = None
+                ctx.cloud_bias = True
             elif li == 0 and gather:
                 N = C1
                 Y = None if virt else _f32((R, N), dev)
@@ -351,6 +362,14 @@ class FusedMLPStack(torch.autograd.Function):
                 _lib.call("pcops_sa_scatter_bwd_ld", B, Nsrc, M, S, N, Gptr, p.data_ptr(), q.data_ptr(), t.data_ptr(),
                           idx.data_ptr(), a0.data_ptr(), 2 * N, a0.data_ptr() + 4 * N, 2 * N, d0.data_ptr(), 2 * N,
                           d0.data_ptr() + 4 * N, 2 * N, wsp.data_ptr())
+                break
+            if l == 0 and gather and getattr(ctx, "cloud_bias", False) and Gptr is not None:
+                B, M, _ = idx.shape
+                d0 = _f32((B, a0.shape[1], N), dev) if ctx.needs_input_grad[0] else None
+                d1 = _f32((B, M, N), dev)
+                scratch = _f32((lib.pcops_cloud_bias_rows(R), N), dev)
+                _lib.call("pcops_cloud_bias_bwd", R, S, N, Gptr, Ys[0].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(),
+                          _p(d0), d1.data_ptr(), scratch.data_ptr())
                 break
             if l == 0 and gather:
                 B, M, _ = idx.shape
@@ -904,6 +923,7 @@ TRACE = None
 STAT_PIVOT = os.environ.get("PCOPS_STAT_PIVOT", "1") != "0"   # BN statistics as shifted moments around the moving mean
 FUSE_POOL_ROWS = os.environ.get("PCOPS_FUSE_POOL_ROWS", "1") != "0"    # per-block pooled epilogue on compacted rows
 BWD_FUSED = os.environ.get("PCOPS_BWD_FUSED", "1") != "0"   # one-pass data + weight gradient of narrow layers (pcops_mlp_bwd_fused)
+CLOUD_BIAS = os.environ.get("PCOPS_CLOUD_BIAS", "1") != "0"     # ... its Y = Q + Ctr[cloud] and the backward as streaming passes
 CLOUD_POINT = os.environ.get("PCOPS_CLOUD_POINT", "1") != "0"   # dgcnn_bga's head: per-cloud + per-point first conv without the concat
 EDGE_DIRECT = os.environ.get("PCOPS_EDGE_DIRECT", "1") != "0"   # first EdgeConv layer of a stack on an input without gradient
 EDGE_DIRECT_FUSED = os.environ.get("PCOPS_EDGE_DIRECT_FUSED", "1") != "0"   # ... its E^T Gm inside the one-pass backward above
