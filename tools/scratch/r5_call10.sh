@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r5c10; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_fused_mlp_gpu.py -x -q -k "one_gemm or gather or edge" > $O/pytest_a.log 2>&1; echo "rc=$?" >> $O/pytest_a.log

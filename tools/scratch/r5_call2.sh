@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, GPU call 2: parity of the new edgeconv kernels + DGCNN bench A/B
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r5c2; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_fused_mlp_gpu.py tests/test_knn_gpu.py tests/test_bn_shifted_moments_gpu.py -x -q > $O/pytest_a.log 2>&1; echo "rc=$?" >> $O/pytest_a.log

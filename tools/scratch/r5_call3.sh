@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r5c3; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests/test_head_gpu.py tests/test_knn_gpu.py tests/test_ops_gpu.py -x -q > $O/pytest_a.log 2>&1; echo "rc=$?" >> $O/pytest_a.log

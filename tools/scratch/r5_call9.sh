@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r5c9; rm -rf $O; mkdir -p $O
 timeout 1200 python -m pytest tests/test_models_gpu.py tests/test_models_parity_gpu.py tests/test_deterministic_gpu.py tests/test_checkpoint_eval_gpu.py -x -q -k "dgcnn" > $O/pytest_b.log 2>&1; echo "rc=$?" >> $O/pytest_b.log

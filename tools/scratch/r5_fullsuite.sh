@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 O=gpurun_out/r5full; rm -rf $O; mkdir -p $O
 timeout 3000 python -m pytest tests -q -m gpu -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
