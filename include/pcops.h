@@ -60,14 +60,17 @@ int pcops_abi_version(void);
  *   PCOPS_OPT_WGRAD_SPLIT_BF16         0 / 1 (default): pcops_mlp_wgrad* of layers wider than 64 on both sides
  *   PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16  0 / 1 (default): the dX half of pcops_mlp_bwd_fused*
  *   PCOPS_OPT_KNN_F16_PREFILTER        0 / 1 (default): pcops_knn_graph* at c == 64, k <= 20, n >= 256 (seeded or not)
+ *   PCOPS_OPT_DGRAD_SPLIT_BF16         0 fp32 MFMA, 1 (default): pcops_mlp_gemm_dgrad* with 128..256 dY columns on the bf16 pipe in
+ *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit
  * pcops_set_option returns the PREVIOUS value (>= 0) or PCOPS_ERR_BAD_ARGUMENT.  The environment variables of rounds 3-4
- * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16) only seed the initial values (test overrides). */
+ * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16; round 6: PCOPS_DGRAD_BF3) only seed the initial values (test overrides). */
 typedef enum pcops_option {
     PCOPS_OPT_GEMM_SPLIT_BF16 = 1,
     PCOPS_OPT_WGRAD_SPLIT_BF16 = 2,
     PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16 = 3,
     PCOPS_OPT_KNN_F16_PREFILTER = 4,
-    PCOPS_OPT_COUNT = 5
+    PCOPS_OPT_DGRAD_SPLIT_BF16 = 5,
+    PCOPS_OPT_COUNT = 6
 } pcops_option;
 int pcops_set_option(int option, int value);
 int pcops_get_option(int option);

@@ -49,6 +49,7 @@ void options_init() {
         g_options[PCOPS_OPT_WGRAD_SPLIT_BF16].store(env_int("PCOPS_WGRAD_BF3", 1) != 0);
         g_options[PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16].store(env_int("PCOPS_BWD_FUSED_DX3", 1) != 0);
         g_options[PCOPS_OPT_KNN_F16_PREFILTER].store(env_int("PCOPS_KNN_F16", 1) != 0);
+        g_options[PCOPS_OPT_DGRAD_SPLIT_BF16].store(env_int("PCOPS_DGRAD_BF3", 1));
         g_options_init.store(1, std::memory_order_release);
     }
     busy.clear(std::memory_order_release);
@@ -63,7 +64,8 @@ extern "C" int pcops_get_option(int option) {
 
 extern "C" int pcops_set_option(int option, int value) {
     if (option <= 0 || option >= PCOPS_OPT_COUNT || value < 0) return PCOPS_ERR_BAD_ARGUMENT;
-    if (option == PCOPS_OPT_GEMM_SPLIT_BF16 ? value > 2 : value > 1) return PCOPS_ERR_BAD_ARGUMENT;
+    if ((option == PCOPS_OPT_GEMM_SPLIT_BF16 || option == PCOPS_OPT_DGRAD_SPLIT_BF16) ? value > 2 : value > 1)
+        return PCOPS_ERR_BAD_ARGUMENT;
     options_init();
     return g_options[option].exchange(value);
 }

@@ -30,7 +30,18 @@
 #include "common.h"
 #include <type_traits>
 
-namespace {
+// ---- build parts.  This file is compiled SEVEN times (Makefile: -DPCOPS_MLP_PART=0..6, in parallel): every part parses the
+// whole file, but only emits its share of the kernel instantiations -- part 0 the C ABI and the small kernels, parts
+// 1, 2, 3, 6 the wave-stream / tiled GEMM launchers by (operand, epilogue) mode, part 4 the weight-gradient kernels,
+// part 5 the one-pass backward and the Gram kernel.  The launchers are the only symbols that cross parts (hidden
+// visibility: none of them is part of the C ABI).  Without the macro (tools/ builds) everything is one translation unit.
+#ifndef PCOPS_MLP_PART
+#define PCOPS_MLP_PART (-1)
+#endif
+#define PCOPS_PART(p_) (PCOPS_MLP_PART < 0 || PCOPS_MLP_PART == (p_))
+#define PCOPS_HIDDEN __attribute__((visibility("hidden")))
+
+namespace pcops_mlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_rt_kernel(GemmArgs a) {
 }
 
 template <int AM, int EM>
-int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
+PCOPS_HIDDEN int launch_gemm_rt(GemmArgs &a, hipStream_t st) {
     const int tiles = (a.M + kBM - 1) / kBM;
     // enough row-tile groups to fill the chip a few times over, few enough that the partial-statistics
     // buffer stays small
@@ -1416,6 +1427,14 @@ static size_t ws_lds_bytes_bf3(int Kp, int bn, int waves, bool wst, int ncoef) {
 // environment variable PCOPS_GEMM_BF3 only seeds the table)
 static int ws_bf3_mode() { return pcops_get_option(PCOPS_OPT_GEMM_SPLIT_BF16); }
 
+// PCOPS_OPT_DGRAD_SPLIT_BF16 = 0: the data gradients stay on the fp32 pipe, 1 (default): split operands in 64-column passes
+// for K >= 128 dY columns, 2: 128-column passes where the weight pieces fit (kernel A/B)
+static int dgrad_bf3_mode() { return pcops_get_option(PCOPS_OPT_DGRAD_SPLIT_BF16); }
+static int dgrad_bf3_kmin() {
+    static const int v = [] { const char *e = getenv("PCOPS_DGRAD_BF3_KMIN"); return e ? atoi(e) : 128; }();
+    return v;
+}
+
 static int ws_ncoef(int am) { return am == A_PLAIN ? 0 : (am == A_BNRELU ? 2 : (am == A_DY ? 3 : (am == A_XYZ ? 6 : 5))); }
 
 static size_t ws_lds_bytes_streamed(int Kp, int kc, int bn, int waves, int eh, int ncoef) {
@@ -1446,10 +1465,14 @@ static bool ws_n96_enabled() {
     return on;
 }
 
-// fwd: the launch is a forward product (E_FWD epilogue) -- the only one the split-operand form is built for: the data
-// gradients of the same shapes are bandwidth bound (measured: 557 vs 556 us for SA2's 128 -> 128) and their variants
-// need more registers than a wave has at two waves per SIMD
-static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
+// kind 1: the launch is a forward product (E_FWD epilogue); kind 2: a masked data gradient (E_MASK epilogue, dY operand).
+// Round 4 built the split-operand form for the forward products only: the data gradients' 128-column variants need a
+// second accumulator set beside two prefetched operands (they spilled) and streamed weights at K = 256.  Round 6: the data
+// gradients of the layers that are matrix-pipe bound (K >= 128 dY columns) take the split form in 64-column passes --
+// 32 + 32 accumulator registers, and the weight pieces of 64 columns stay RESIDENT up to K = 256 (96 KB): no streaming, no
+// workgroup barrier; the two column blocks of a row group run on one XCD, so the second reader of a dY stripe hits its L2
+static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, int kind = 0) {
+    const bool fwd = kind == 1;
     if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
     if (a.K % 8 != 0 || a.K > 4096 || a.ldx % 4 != 0 || a.N % 4 != 0 || a.ldy % 4 != 0) return false;
     if (a.K > 256 && (am == A_XYZ || (reinterpret_cast<uintptr_t>(a.W) & 15))) return false;
@@ -1501,6 +1524,15 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, bool fwd = false) {
             pl->bf3 = false;
         }
     }
+    if (kind == 2 && is_dy(am) && dgrad_bf3_mode() && !(reinterpret_cast<uintptr_t>(a.W) & 3) && a.K >= dgrad_bf3_kmin() &&
+        a.K <= 256 && a.K % 32 == 0) {
+        const int nc = ws_ncoef(am);
+        const int bn3 = (a.N > 64 && dgrad_bf3_mode() == 2) ? 128 : 64;
+        if (ws_lds_bytes_bf3(a.K, bn3, 8, false, nc) <= 160 * 1024) {
+            pl->bf3 = true; pl->kc = 32; pl->bn = bn3; pl->eh = bn3 / 32; pl->wst = false;
+            pl->lds = ws_lds_bytes_bf3(a.K, bn3, 8, false, nc);
+        }
+    }
     if (pl->lds > 160 * 1024) return false;
     pl->ncb = (a.N + pl->bn - 1) / pl->bn;
     const long long ntiles = (((long long)a.M + 31) / 32 + (a.pool_sub > 1 ? a.pool_sub - 1 : 0)) /
@@ -1520,7 +1552,7 @@ static bool nt_stores_enabled() {
 static int nt_for_bytes(long long bytes) { return (nt_stores_enabled() && bytes >= (256ll << 20)) ? 1 : 0; }
 
 template <int AM, int EM>
-int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
+PCOPS_HIDDEN int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
     a.nt_out = a.Y ? nt_for_bytes((long long)a.M * a.ldy * 4) : 0;
 #define PCOPS_WS_LAUNCH(NT_, EH_)                                                                     \
     do {                                                                                              \
@@ -1537,7 +1569,7 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
     pcops_note_pipe(pl.bf3 ? 1 : 0);
-    if constexpr (EM == E_FWD) {
+    if constexpr (EM == E_FWD || (EM == E_MASK && is_dy(AM))) {
     if (pl.bf3) {
 #define PCOPS_WS3_LAUNCH(NT_, EH_)                                                                    \
     do {                                                                                              \
@@ -1587,6 +1619,58 @@ int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
     return pcops_launch_status();
 }
 
+// ---- which build part emits which launcher (see PCOPS_MLP_PART at the top): explicit instantiation in the owning part,
+// `extern template` (no implicit instantiation, hence no kernels) in the others
+#if PCOPS_MLP_PART >= 0
+#if PCOPS_MLP_PART == 1
+#define PCOPS_X_ template
+#else
+#define PCOPS_X_ extern template
+#endif
+PCOPS_X_ int launch_gemm_ws<A_BNRELU, E_FWD>(GemmArgs &, const WsPlan &, hipStream_t);
+#undef PCOPS_X_
+#if PCOPS_MLP_PART == 2
+#define PCOPS_X_ template
+#else
+#define PCOPS_X_ extern template
+#endif
+PCOPS_X_ int launch_gemm_ws<A_DY, E_MASK>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DY, E_PLAIN>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOL, E_MASK>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOL, E_PLAIN>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLB, E_MASK>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLB, E_PLAIN>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLU, E_MASK>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLU, E_PLAIN>(GemmArgs &, const WsPlan &, hipStream_t);
+#undef PCOPS_X_
+#if PCOPS_MLP_PART == 3
+#define PCOPS_X_ template
+#else
+#define PCOPS_X_ extern template
+#endif
+PCOPS_X_ int launch_gemm_ws<A_DY, E_MASKX>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOL, E_MASKX>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLB, E_MASKX>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_DYPOOLU, E_MASKX>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_PLAIN, E_PLAINA>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_BNRELU, E_MASKA>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_BNRELU, E_FWD>(GemmArgs &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_PLAIN, E_FWD>(GemmArgs &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_DYPOOL, E_MASK>(GemmArgs &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_DYPOOL, E_PLAIN>(GemmArgs &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_DY, E_MASK>(GemmArgs &, hipStream_t);
+PCOPS_X_ int launch_gemm_rt<A_DY, E_PLAIN>(GemmArgs &, hipStream_t);
+#undef PCOPS_X_
+#if PCOPS_MLP_PART == 6
+#define PCOPS_X_ template
+#else
+#define PCOPS_X_ extern template
+#endif
+PCOPS_X_ int launch_gemm_ws<A_PLAIN, E_FWD>(GemmArgs &, const WsPlan &, hipStream_t);
+PCOPS_X_ int launch_gemm_ws<A_XYZ, E_FWD>(GemmArgs &, const WsPlan &, hipStream_t);
+#undef PCOPS_X_
+#endif
+
 extern "C" int pcops_mlp_stats_rows(int M);
 
 static bool ws_enabled() {
@@ -1600,9 +1684,9 @@ static bool ws_enabled() {
 // one entry for both variants: the wave-stream kernel when the shape suits it, the tiled kernel otherwise.
 // The partial-statistics buffer always has pcops_mlp_stats_rows(M) rows; rows a kernel does not emit are zeroed.
 template <int AM, int EM>
-int launch_gemm(GemmArgs &a, hipStream_t st) {
+static int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD)) {
+    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : 0))) {
         int rc;
         if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
         else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
@@ -1617,6 +1701,7 @@ int launch_gemm(GemmArgs &a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // column reduction of partial statistics [P][2][N] -> double [2][N], two stages, deterministic
 constexpr int kRedSlices = 32;
+namespace {   // (non-template kernels: internal linkage, every build part carries its own copy)
 
 __global__ __launch_bounds__(256) void colreduce_stage1(int P, int N, const float *__restrict__ part,
                                                         double *__restrict__ ws) {
@@ -1962,6 +2047,7 @@ __global__ __launch_bounds__(256) void relu_mask_stats_kernel(long long R, int C
     }
 }
 
+}  // namespace
 // ---------------------------------------------------------------------------------------------
 // wgrad: dW[K][N] (+)= A^T dY over a slice of rows; both operands rebuilt from raw tensors and loaded
 // fragment-shaped straight from HBM (lane = (row parity, channel group); VK/VN consecutive channels per
@@ -3702,7 +3788,7 @@ __global__ __launch_bounds__(512, 1) void gram_full_kernel(GramArgs a) {
 }
 
 // lower triangle of a symmetric K x K result from its upper one
-__global__ __launch_bounds__(256) void mirror_lower_kernel(int K, float *__restrict__ g) {
+static __global__ __launch_bounds__(256) void mirror_lower_kernel(int K, float *__restrict__ g) {
     const int i = blockIdx.x, tid = threadIdx.x;
     for (int j = tid; j < i; j += 256) g[(long long)i * K + j] = g[(long long)j * K + i];
 }
@@ -3821,6 +3907,7 @@ static bool wgrad_ws_plan(long long M, int K, int N, int ldx, const void *X, con
     return pl->lds <= 160 * 1024;
 }
 
+namespace {
 // sum partials [P][L] -> out[L] (deterministic): 64 consecutive elements x 4 partial lanes per workgroup
 __global__ __launch_bounds__(256) void sum_partials_kernel(int P, long long L, const float *__restrict__ part,
                                                            float *__restrict__ out) {
@@ -3876,7 +3963,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
 
 // few partial rows (P <= kFusedRows): column reduction and the per-channel finalisation in ONE launch.
 // block = 32 columns x 32 row lanes; the row-lane totals meet in LDS in a fixed order (deterministic)
-constexpr int kFusedRows = 1024;
+[[maybe_unused]] constexpr int kFusedRows = 1024;
 
 __device__ __forceinline__ bool fused_col_sums(int P, int N, const float *__restrict__ part, double &s1, double &s2,
                                                int &c) {
@@ -3959,6 +4046,10 @@ int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
 }
 
 }  // namespace
+}  // namespace pcops_mlp
+using namespace pcops_mlp;
+
+#if PCOPS_PART(0)
 
 // ---------------------------------------------------------------------------------------------
 // Algebraic backward of a POOLED top layer  Y = X W + b,  X = relu(bn(Yprev)),  out = max_group relu(bn(Y)).
@@ -4234,12 +4325,14 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
     }
 }
 
+#endif  // PCOPS_PART(0)
+
 // ============================================================================ C ABI
 // wave-stream kernel or nothing (the xyz-form modes have no tiled fallback)
 template <int AM, int EM>
 static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD))) return PCOPS_ERR_UNSUPPORTED;
+    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : 0)))) return PCOPS_ERR_UNSUPPORTED;
     int rc;
     if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
     else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
@@ -4247,6 +4340,244 @@ static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     return rc;
 }
 
+// ---- launchers of the weight-gradient, one-pass-backward and Gram kernels: build parts 4 and 5 (PCOPS_MLP_PART)
+PCOPS_HIDDEN int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t st);
+PCOPS_HIDDEN int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
+                                  bool side = false);
+PCOPS_HIDDEN int gram_full_launch(GramArgs &g, int nbk, bool bnrelu, int gg, size_t lds, hipStream_t st);
+
+static int wgrad_legacy_splits(long long M, int K, int N) {
+    const int kb = (K + 63) / 64, nb = (N + 127) / 128;
+    long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    long long rows = (M + want - 1) / want;
+    rows = ((rows + 7) / 8) * 8;
+    if (rows < 8) rows = 8;
+    return (int)((M + rows - 1) / rows);
+}
+
+#if PCOPS_PART(4)
+/* dW[K][N] = A^T dY, db[N] = 1^T dY;  A = X (a_scale==NULL) or relu(X*a_scale + a_shift);
+ * dY as in pcops_mlp_gemm_dgrad.  partial: float [splits][K][N] + [splits][N] scratch (caller). */
+int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t st) {
+    const long long M = a.M;
+    const int K = a.K, N = a.N, ldx = a.ldx;
+    const float *X = a.X, *G = a.G, *Y = a.Y, *gpool = a.gpool;
+    const unsigned char *argmax = a.argmax;
+    int splits;
+    WsWgradPlan pl;
+    PcWgradPlan pc;
+    // producer/consumer kernel for the pooled forms and the widest tile; the single-role kernel (256 accumulator
+    // registers per wave) is ahead on the narrow materialised-G shapes
+    if (a.blocks && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc)))
+        return PCOPS_ERR_UNSUPPORTED;            // compacted rows: producer/consumer kernel only
+    const bool self = a.dmode == A_SELFD;
+    if (self && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, true)))
+        return PCOPS_ERR_UNSUPPORTED;            // Gram matrix: producer/consumer kernel only
+    Bf3WgradPlan b3;
+    pcops_note_pipe(0);
+    if (ws_enabled() && wgrad_pc_enabled() && !self && a.amode != A_XYZ &&
+        wgrad_bf3_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &b3)) {
+        pcops_note_pipe(1);
+        splits = b3.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(b3.groups, b3.kblocks, b3.nblocks);
+#define PCOPS_B3_LAUNCH(AM_, DM_)                                                                          \
+    do {                                                                                                   \
+        auto kern = wgrad_bf3_kernel<AM_, DM_>;                                                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(512), b3.lds, st, a);                                          \
+    } while (0)
+        if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYW);
+        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYW);
+        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLB);
+        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLB);
+        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_B3_LAUNCH(A_BNRELU, A_DY);
+        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLU);
+        else if (a.amode == A_BNRELU) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOL);
+        else if (a.dmode == A_DY) PCOPS_B3_LAUNCH(A_PLAIN, A_DY);
+        else if (a.S % 32 == 0) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLU);
+        else PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOL);
+#undef PCOPS_B3_LAUNCH
+    } else if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, self) &&
+        (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks || self ||
+         !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
+        splits = pc.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
+#define PCOPS_PC_LAUNCH(TK_, TN_, AM_, DM_)                                                                \
+    do {                                                                                                   \
+        auto kern = wgrad_pc_kernel<TK_, TN_, AM_, DM_, K96_>;                                                \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(512), pc.lds, st, a);                                          \
+    } while (0)
+#define PCOPS_PC_MODES(TK_, TN_, K96V_)                                                                    \
+    do {                                                                                                   \
+        constexpr bool K96_ = K96V_;                                                                       \
+        if (a.dmode == A_SELFD && a.amode == A_PLAIN) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_SELFD);         \
+        else if (a.dmode == A_SELFD) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_SELFD);                         \
+        else if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW); \
+        else if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYW); \
+        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYW);   \
+        else if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);              \
+        else if (a.amode == A_XYZ && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLB);                \
+        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLB); \
+        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLB);   \
+        else if (a.amode == A_XYZ && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLU);           \
+        else if (a.amode == A_XYZ) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOL);                             \
+        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);        \
+        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLU);     \
+        else if (a.amode == A_BNRELU) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOL);                       \
+        else if (a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DY);                                \
+        else if (a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLU);                             \
+        else PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOL);                                                 \
+    } while (0)
+        if (pc.tk == 1 && pc.tn == 1) PCOPS_PC_MODES(1, 1, false);
+        else if (pc.tk == 1 && pc.tn == 2) PCOPS_PC_MODES(1, 2, false);
+        else if (pc.tk == 1) PCOPS_PC_MODES(1, 4, false);
+        else if (pc.tn == 1) PCOPS_PC_MODES(2, 1, false);
+        else if (pc.tn == 2 && pc.k96) PCOPS_PC_MODES(2, 2, true);
+        else if (pc.tn == 2) PCOPS_PC_MODES(2, 2, false);
+        else PCOPS_PC_MODES(2, 4, false);
+#undef PCOPS_PC_MODES
+#undef PCOPS_PC_LAUNCH
+    } else if (a.amode == A_XYZ) {
+        return PCOPS_ERR_UNSUPPORTED;
+    } else if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
+        splits = pl.groups;
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        const dim3 grid(pl.groups, pl.kblocks, pl.nblocks);
+#define PCOPS_WG_LAUNCH(TK_, TN_, RS_, AM_, DM_)                                                           \
+    do {                                                                                                   \
+        auto kern = wgrad_ws_kernel<TK_, TN_, RS_, AM_, DM_>;                                              \
+        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                 \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)once;                                                                                        \
+        hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, a);                                          \
+    } while (0)
+#define PCOPS_WG_MODES(TK_, TN_, RS_)                                                                      \
+    do {                                                                                                   \
+        if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DY);        \
+        else if (a.amode == A_BNRELU) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DYPOOL);                  \
+        else if (a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DY);                           \
+        else PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DYPOOL);                                            \
+    } while (0)
+        if (pl.tk == 2 && pl.tn == 2) PCOPS_WG_MODES(2, 2, 32);
+        else if (pl.tk == 2) PCOPS_WG_MODES(2, 4, 32);
+        else PCOPS_WG_MODES(4, 4, 16);
+#undef PCOPS_WG_MODES
+#undef PCOPS_WG_LAUNCH
+    } else {
+        splits = wgrad_legacy_splits(M, K, N);
+        a.rows_per_block = (int)((((M + splits - 1) / splits) + 7) / 8 * 8);
+        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
+        hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3((K + 63) / 64, (N + 127) / 128, splits), dim3(256), 0, st, a);
+    }
+    int rc = pcops_launch_status();
+    if (rc) return rc;
+    // dW and db partials are adjacent ([splits][K*N] then [splits][N]): one launch sums both
+    const long long L = (long long)K * N;
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, splits, L,
+                       partial, dW, (long long)N, a.dbpart, db);
+    return pcops_launch_status();
+}
+#endif
+
+#if PCOPS_PART(5)
+int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
+                     bool side) {
+    const int K = a.K, N = a.N;
+    a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
+    const int tn = N <= 64 ? 1 : 2;
+    const int NB = 64 * tn;
+    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
+    const bool pooled = a.gpool != nullptr;
+    static const bool nsk_on = [] {
+        const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
+        return !(e && e[0] == '0');
+    }();
+    const bool nsk = nsk_on && tn == 2 && N <= 96;
+    const bool dx3 = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) != 0;
+    pcops_note_pipe(dx3 ? 2 : 0);
+#define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
+    do {                                                                                                   \
+        auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
+                                              : bwd_fused_kernel<TN_, DM_, X_, false, true>)                    \
+                        : ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>);                                                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+#define PCOPS_BF_MODES(TN_, X_)                                                                            \
+    do {                                                                                                   \
+        if (!pooled && a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYW, X_);                                          \
+        else if (a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYPOOLB, X_);                                            \
+        else if (!pooled) PCOPS_BF_LAUNCH(TN_, A_DY, X_);                                                  \
+        else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU, X_);                                       \
+        else PCOPS_BF_LAUNCH(TN_, A_DYPOOL, X_);                                                           \
+    } while (0)
+    if (side) {
+        // (the first EdgeConv layer below: pooled groups of k neighbours, plain rows -- pcops_mlp_bwd_fused_edge checks)
+#define PCOPS_BF_SIDE(TN_)                                                                                 \
+    do {                                                                                                   \
+        auto kern = dx3 ? bwd_fused_kernel<TN_, A_DYPOOL, false, false, true, true>                        \
+                        : bwd_fused_kernel<TN_, A_DYPOOL, false, false, false, true>;                      \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+        if (tn == 1) PCOPS_BF_SIDE(1);
+        else PCOPS_BF_SIDE(2);
+#undef PCOPS_BF_SIDE
+    } else
+    if (tn == 1 && xyz) PCOPS_BF_MODES(1, true);
+    else if (tn == 1) PCOPS_BF_MODES(1, false);
+    else if (xyz) PCOPS_BF_MODES(2, true);
+    else PCOPS_BF_MODES(2, false);
+#undef PCOPS_BF_MODES
+#undef PCOPS_BF_LAUNCH
+    int rc = pcops_launch_status();
+    if (rc) return rc;
+    const long long L = (long long)K * N;
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, groups, L,
+                       partial, dW, (long long)N, a.dbpart, db);
+    return pcops_launch_status();
+}
+
+int gram_full_launch(GramArgs &g, int nbk, bool bnrelu, int gg, size_t lds, hipStream_t st) {
+#define PCOPS_GRAM_LAUNCH(NBK_)                                                                            \
+    do {                                                                                                   \
+        auto kern = bnrelu ? gram_full_kernel<NBK_, true> : gram_full_kernel<NBK_, false>;               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(gg), dim3(512), lds, st, g);                                         \
+    } while (0)
+        switch (nbk) {
+            case 1: PCOPS_GRAM_LAUNCH(1); break;
+            case 2: PCOPS_GRAM_LAUNCH(2); break;
+            case 3: PCOPS_GRAM_LAUNCH(3); break;
+            case 4: PCOPS_GRAM_LAUNCH(4); break;
+            case 5: PCOPS_GRAM_LAUNCH(5); break;
+            case 6: PCOPS_GRAM_LAUNCH(6); break;
+            case 7: PCOPS_GRAM_LAUNCH(7); break;
+            case 8: PCOPS_GRAM_LAUNCH(8); break;
+            case 9: PCOPS_GRAM_LAUNCH(9); break;
+            default: PCOPS_GRAM_LAUNCH(10); break;
+        }
+#undef PCOPS_GRAM_LAUNCH
+    return PCOPS_OK;
+}
+#endif
+
+#if PCOPS_PART(0)
 extern "C" {
 
 int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
@@ -4337,7 +4668,7 @@ static bool fwd_pool_shape_ok(int M, int K, int N, int S) {
     a.M = M; a.K = K; a.N = N; a.ldx = K; a.ldy = N;
     set_pool_group(a, S);
     WsPlan pl;
-    if (!(ws_enabled() && ws_plan(a, A_BNRELU, &pl, true))) return false;
+    if (!(ws_enabled() && ws_plan(a, A_BNRELU, &pl, 1))) return false;
     return !sub4 || pl.bf3;                                 // groups that are not whole tiles: split-operand kernels only
 }
 
@@ -4672,7 +5003,6 @@ int pcops_mlp_gemm_dgrad_xyz_rows(int M, int K, int Nout, const float *G, const 
     return launch_gemm_ws_only<A_DY, E_MASKX>(a, st);
 }
 
-static int wgrad_legacy_splits(long long M, int K, int N);
 
 // workgroups (= partial copies) of the single-pass Gram kernel, 0 when it does not take the shape
 static int gram_full_groups(long long M, int K, int ldx, const void *X) {
@@ -4714,145 +5044,7 @@ int pcops_mlp_wgrad_splits(long long M, int K, int N) {
     return best;
 }
 
-static int wgrad_legacy_splits(long long M, int K, int N) {
-    const int kb = (K + 63) / 64, nb = (N + 127) / 128;
-    long long want = (1024 + (long long)kb * nb - 1) / ((long long)kb * nb);
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    long long rows = (M + want - 1) / want;
-    rows = ((rows + 7) / 8) * 8;
-    if (rows < 8) rows = 8;
-    return (int)((M + rows - 1) / rows);
-}
 
-/* dW[K][N] = A^T dY, db[N] = 1^T dY;  A = X (a_scale==NULL) or relu(X*a_scale + a_shift);
- * dY as in pcops_mlp_gemm_dgrad.  partial: float [splits][K][N] + [splits][N] scratch (caller). */
-static int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t st) {
-    const long long M = a.M;
-    const int K = a.K, N = a.N, ldx = a.ldx;
-    const float *X = a.X, *G = a.G, *Y = a.Y, *gpool = a.gpool;
-    const unsigned char *argmax = a.argmax;
-    int splits;
-    WsWgradPlan pl;
-    PcWgradPlan pc;
-    // producer/consumer kernel for the pooled forms and the widest tile; the single-role kernel (256 accumulator
-    // registers per wave) is ahead on the narrow materialised-G shapes
-    if (a.blocks && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc)))
-        return PCOPS_ERR_UNSUPPORTED;            // compacted rows: producer/consumer kernel only
-    const bool self = a.dmode == A_SELFD;
-    if (self && !(ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, true)))
-        return PCOPS_ERR_UNSUPPORTED;            // Gram matrix: producer/consumer kernel only
-    Bf3WgradPlan b3;
-    pcops_note_pipe(0);
-    if (ws_enabled() && wgrad_pc_enabled() && !self && a.amode != A_XYZ &&
-        wgrad_bf3_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &b3)) {
-        pcops_note_pipe(1);
-        splits = b3.groups;
-        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-        const dim3 grid(b3.groups, b3.kblocks, b3.nblocks);
-#define PCOPS_B3_LAUNCH(AM_, DM_)                                                                          \
-    do {                                                                                                   \
-        auto kern = wgrad_bf3_kernel<AM_, DM_>;                                                            \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(512), b3.lds, st, a);                                          \
-    } while (0)
-        if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYW);
-        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYW);
-        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLB);
-        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLB);
-        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_B3_LAUNCH(A_BNRELU, A_DY);
-        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOLU);
-        else if (a.amode == A_BNRELU) PCOPS_B3_LAUNCH(A_BNRELU, A_DYPOOL);
-        else if (a.dmode == A_DY) PCOPS_B3_LAUNCH(A_PLAIN, A_DY);
-        else if (a.S % 32 == 0) PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOLU);
-        else PCOPS_B3_LAUNCH(A_PLAIN, A_DYPOOL);
-#undef PCOPS_B3_LAUNCH
-    } else if (ws_enabled() && wgrad_pc_enabled() && wgrad_pc_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pc, self) &&
-        (gpool || pc.tn == 4 || a.amode == A_XYZ || a.blocks || self ||
-         !wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl))) {
-        splits = pc.groups;
-        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-        const dim3 grid(pc.groups, pc.kblocks, pc.nblocks);
-#define PCOPS_PC_LAUNCH(TK_, TN_, AM_, DM_)                                                                \
-    do {                                                                                                   \
-        auto kern = wgrad_pc_kernel<TK_, TN_, AM_, DM_, K96_>;                                                \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(512), pc.lds, st, a);                                          \
-    } while (0)
-#define PCOPS_PC_MODES(TK_, TN_, K96V_)                                                                    \
-    do {                                                                                                   \
-        constexpr bool K96_ = K96V_;                                                                       \
-        if (a.dmode == A_SELFD && a.amode == A_PLAIN) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_SELFD);         \
-        else if (a.dmode == A_SELFD) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_SELFD);                         \
-        else if (a.amode == A_XYZ && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYW); \
-        else if (a.amode == A_BNRELU && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYW); \
-        else if (a.amode == A_PLAIN && a.dmode == A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYW);   \
-        else if (a.amode == A_XYZ && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DY);              \
-        else if (a.amode == A_XYZ && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLB);                \
-        else if (a.amode == A_BNRELU && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLB); \
-        else if (a.amode == A_PLAIN && a.dmode != A_DY && a.blocks) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLB);   \
-        else if (a.amode == A_XYZ && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOLU);           \
-        else if (a.amode == A_XYZ) PCOPS_PC_LAUNCH(TK_, TN_, A_XYZ, A_DYPOOL);                             \
-        else if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DY);        \
-        else if (a.amode == A_BNRELU && a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOLU);     \
-        else if (a.amode == A_BNRELU) PCOPS_PC_LAUNCH(TK_, TN_, A_BNRELU, A_DYPOOL);                       \
-        else if (a.dmode == A_DY) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DY);                                \
-        else if (a.S % 32 == 0) PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOLU);                             \
-        else PCOPS_PC_LAUNCH(TK_, TN_, A_PLAIN, A_DYPOOL);                                                 \
-    } while (0)
-        if (pc.tk == 1 && pc.tn == 1) PCOPS_PC_MODES(1, 1, false);
-        else if (pc.tk == 1 && pc.tn == 2) PCOPS_PC_MODES(1, 2, false);
-        else if (pc.tk == 1) PCOPS_PC_MODES(1, 4, false);
-        else if (pc.tn == 1) PCOPS_PC_MODES(2, 1, false);
-        else if (pc.tn == 2 && pc.k96) PCOPS_PC_MODES(2, 2, true);
-        else if (pc.tn == 2) PCOPS_PC_MODES(2, 2, false);
-        else PCOPS_PC_MODES(2, 4, false);
-#undef PCOPS_PC_MODES
-#undef PCOPS_PC_LAUNCH
-    } else if (a.amode == A_XYZ) {
-        return PCOPS_ERR_UNSUPPORTED;
-    } else if (ws_enabled() && wgrad_ws_plan(M, K, N, ldx, X, G, Y, gpool, argmax, &pl)) {
-        splits = pl.groups;
-        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-        const dim3 grid(pl.groups, pl.kblocks, pl.nblocks);
-#define PCOPS_WG_LAUNCH(TK_, TN_, RS_, AM_, DM_)                                                           \
-    do {                                                                                                   \
-        auto kern = wgrad_ws_kernel<TK_, TN_, RS_, AM_, DM_>;                                              \
-        static hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                 \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)once;                                                                                        \
-        hipLaunchKernelGGL(kern, grid, dim3(256), pl.lds, st, a);                                          \
-    } while (0)
-#define PCOPS_WG_MODES(TK_, TN_, RS_)                                                                      \
-    do {                                                                                                   \
-        if (a.amode == A_BNRELU && a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DY);        \
-        else if (a.amode == A_BNRELU) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_BNRELU, A_DYPOOL);                  \
-        else if (a.dmode == A_DY) PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DY);                           \
-        else PCOPS_WG_LAUNCH(TK_, TN_, RS_, A_PLAIN, A_DYPOOL);                                            \
-    } while (0)
-        if (pl.tk == 2 && pl.tn == 2) PCOPS_WG_MODES(2, 2, 32);
-        else if (pl.tk == 2) PCOPS_WG_MODES(2, 4, 32);
-        else PCOPS_WG_MODES(4, 4, 16);
-#undef PCOPS_WG_MODES
-#undef PCOPS_WG_LAUNCH
-    } else {
-        splits = wgrad_legacy_splits(M, K, N);
-        a.rows_per_block = (int)((((M + splits - 1) / splits) + 7) / 8 * 8);
-        a.part = partial; a.dbpart = partial + (long long)splits * K * N;
-        hipLaunchKernelGGL((wgrad_kernel<2, 4>), dim3((K + 63) / 64, (N + 127) / 128, splits), dim3(256), 0, st, a);
-    }
-    int rc = pcops_launch_status();
-    if (rc) return rc;
-    // dW and db partials are adjacent ([splits][K*N] then [splits][N]): one launch sums both
-    const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, splits, L,
-                       partial, dW, (long long)N, a.dbpart, db);
-    return pcops_launch_status();
-}
 
 /* 1 when EVERY launch of a grouped stack on compacted rows has a kernel for its shape -- the *_rows entry points have no
  * tiled fallback, so a caller decides with this (and nothing else) whether to compact: group size a multiple of the
@@ -4907,67 +5099,6 @@ int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const flo
                                     Gprev, stats_partial, nullptr, stream);
 }
 
-static int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
-                            bool side = false) {
-    const int K = a.K, N = a.N;
-    a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
-    const int tn = N <= 64 ? 1 : 2;
-    const int NB = 64 * tn;
-    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
-    const bool pooled = a.gpool != nullptr;
-    static const bool nsk_on = [] {
-        const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
-        return !(e && e[0] == '0');
-    }();
-    const bool nsk = nsk_on && tn == 2 && N <= 96;
-    const bool dx3 = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) != 0;
-    pcops_note_pipe(dx3 ? 2 : 0);
-#define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
-    do {                                                                                                   \
-        auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
-                                              : bwd_fused_kernel<TN_, DM_, X_, false, true>)                    \
-                        : ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>);                                                      \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
-    } while (0)
-#define PCOPS_BF_MODES(TN_, X_)                                                                            \
-    do {                                                                                                   \
-        if (!pooled && a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYW, X_);                                          \
-        else if (a.blocks) PCOPS_BF_LAUNCH(TN_, A_DYPOOLB, X_);                                            \
-        else if (!pooled) PCOPS_BF_LAUNCH(TN_, A_DY, X_);                                                  \
-        else if (a.S % 32 == 0) PCOPS_BF_LAUNCH(TN_, A_DYPOOLU, X_);                                       \
-        else PCOPS_BF_LAUNCH(TN_, A_DYPOOL, X_);                                                           \
-    } while (0)
-    if (side) {
-        // (the first EdgeConv layer below: pooled groups of k neighbours, plain rows -- pcops_mlp_bwd_fused_edge checks)
-#define PCOPS_BF_SIDE(TN_)                                                                                 \
-    do {                                                                                                   \
-        auto kern = dx3 ? bwd_fused_kernel<TN_, A_DYPOOL, false, false, true, true>                        \
-                        : bwd_fused_kernel<TN_, A_DYPOOL, false, false, false, true>;                      \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
-    } while (0)
-        if (tn == 1) PCOPS_BF_SIDE(1);
-        else PCOPS_BF_SIDE(2);
-#undef PCOPS_BF_SIDE
-    } else
-    if (tn == 1 && xyz) PCOPS_BF_MODES(1, true);
-    else if (tn == 1) PCOPS_BF_MODES(1, false);
-    else if (xyz) PCOPS_BF_MODES(2, true);
-    else PCOPS_BF_MODES(2, false);
-#undef PCOPS_BF_MODES
-#undef PCOPS_BF_LAUNCH
-    int rc = pcops_launch_status();
-    if (rc) return rc;
-    const long long L = (long long)K * N;
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3(cdiv(L, 64) + (db ? cdiv(N, 64) : 0)), dim3(1024), 0, st, groups, L,
-                       partial, dW, (long long)N, a.dbpart, db);
-    return pcops_launch_status();
-}
 
 int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
                              const float *G, const float *Y, const float *p, const float *q, const float *t,
@@ -5183,27 +5314,10 @@ int pcops_mlp_gram(long long M, int Kp, const float *Yprev, int ldx, const float
         GramArgs g = {M, Kp, ldx, Yprev, a_scale, a_shift, partial, partial + (long long)gg * Kp * Kp};
         const int nbk = (Kp + 31) / 32;
         const size_t lds = (size_t)(2 * 32 * nbk + 2 * 32 * (32 * nbk + 4)) * sizeof(float);
-#define PCOPS_GRAM_LAUNCH(NBK_)                                                                            \
-    do {                                                                                                   \
-        auto kern = a_scale ? gram_full_kernel<NBK_, true> : gram_full_kernel<NBK_, false>;               \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
-            return PCOPS_ERR_LAUNCH;                                                                       \
-        hipLaunchKernelGGL(kern, dim3(gg), dim3(512), lds, st, g);                                         \
-    } while (0)
-        switch (nbk) {
-            case 1: PCOPS_GRAM_LAUNCH(1); break;
-            case 2: PCOPS_GRAM_LAUNCH(2); break;
-            case 3: PCOPS_GRAM_LAUNCH(3); break;
-            case 4: PCOPS_GRAM_LAUNCH(4); break;
-            case 5: PCOPS_GRAM_LAUNCH(5); break;
-            case 6: PCOPS_GRAM_LAUNCH(6); break;
-            case 7: PCOPS_GRAM_LAUNCH(7); break;
-            case 8: PCOPS_GRAM_LAUNCH(8); break;
-            case 9: PCOPS_GRAM_LAUNCH(9); break;
-            default: PCOPS_GRAM_LAUNCH(10); break;
+        {
+            const int rcl = gram_full_launch(g, nbk, a_scale != nullptr, gg, lds, st);
+            if (rcl) return rcl;
         }
-#undef PCOPS_GRAM_LAUNCH
         int rc = pcops_launch_status();
         if (rc) return rc;
         const long long L = (long long)Kp * Kp;
@@ -5268,3 +5382,4 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
 }
 
 }  // extern "C"
+#endif  // PCOPS_PART(0)
