@@ -226,8 +226,13 @@ def _algo(name, a):
     if name == "pcops_mlp_bwd_fused":         # data + weight gradient in one pass: reads Yprev (K), G?, Y (N); writes Gprev (K)
         M, K, N = a[:3]
         return 4 * (2 * M * K + (1 if a[6] is None else 2) * M * N), 4 * M * K * N, "flop"
-    if name == "pcops_mlp_bwd_fused_edge":    # ... above a first EdgeConv layer without input gradient: Yprev, Y and 32 B of
-        M, K, N = a[:3]                       # edge channels per row in, NO Gprev (its E^T Gprev is reduced in the kernel)
+    if name == "pcops_mlp_bwd_fused_gw":      # pooled form with the weight gradient as a Gram matrix: same bytes; the flops
+        M, K, N = a[:3]                       # EXECUTED are 2 M K (N + K) (+ 2 K N per arg row) -- the algorithmic ones priced
+        return 4 * (2 * M * K + M * N), 4 * M * K * N, "flop"
+    if name in ("pcops_mlp_bwd_fused_edge", "pcops_mlp_bwd_fused_edge_gw"):
+        # ... above a first EdgeConv layer without input gradient: Yprev, Y and 32 B of edge channels per row in, NO Gprev
+        # (its E^T Gprev is reduced in the kernel)
+        M, K, N = a[:3]
         return 4 * (M * K + M * N + 8 * M), 4 * M * K * N, "flop"
     if name == "pcops_cloud_bias_fwd":        # Y = Q + Ctr[cloud]: Q in, Y out
         rows, rpg, c = a[:3]
@@ -278,12 +283,28 @@ def _algo(name, a):
     if name == "pcops_mlp_pool_bwd_stats":
         G, C = a[:2]
         return 8 * G * C, 0, ""
-    if name == "pcops_edge_pool_fwd":         # Q, Ctr, idx read once (algorithmically); SQ, qsel, arg written
+    if name in ("pcops_edge_pool_fwd", "pcops_edge_pool_fwd_ld"):     # Q, Ctr, idx read once (algorithmically); SQ, qsel, arg written
         b, n, m, s_, c = a[:5]
         return 4 * (b * n * c + b * m * c + b * m * s_) + 9 * b * m * c, 0, ""
-    if name == "pcops_edge_pool_bwd":         # + gpool, ysel, SQ, arg read; dQ, dCtr written
+    if name in ("pcops_edge_pool_bwd", "pcops_edge_pool_bwd_ld"):     # + gpool, ysel, SQ, arg read; dQ, dCtr written
         b, n, m, s_, c = a[:5]
         return 4 * (2 * b * n * c + 2 * b * m * c + b * m * s_) + 13 * b * m * c, 0, ""
+    if name in ("pcops_edge_pool_out", "pcops_edge_pool_out_ld", "pcops_edge_pool_out_ld2"):
+        # qsel, Ctr in; out + ysel out (+ the second copy into the concatenation's column block)
+        groups, c = a[:2]
+        return 4 * groups * c * (5 if (name.endswith("ld2") and a[9] is not None) else 4), 0, ""
+    if name == "pcops_sa_gather_fwd_ld":      # Y = Q[idx] + Ctr stored (b m s c); Q, Ctr (b n c) and idx read once
+        b, n, m, s_, c = a[:5]
+        return 4 * (b * m * s_ * c + 2 * b * n * c + b * m * s_), 0, ""
+    if name == "pcops_sa_scatter_bwd_ld":     # G read for dCtr (streamed) and for dQ (gathered): 2 x (b m s c); dQ, dCtr out
+        b, n, m, s_, c = a[:5]
+        return 4 * (2 * b * m * s_ * c + b * m * s_ + 4 * b * n * c), 0, ""
+    if name == "pcops_scatter_rows_sorted":   # src rows gathered once, idx (+ w), out written (ordered owner walk)
+        b, rows, ndst, c, div = a[:5]
+        return 4 * (b * (rows // max(div, 1)) * c + b * rows * (2 if a[7] is not None else 1) + b * ndst * c), 0, ""
+    if name in ("pcops_fc_bn_fwd", "pcops_fc_bn_bwd"):
+        R, C = a[:2]
+        return 4 * R * C * (2 if name.endswith("fwd") else 4), 0, ""
     if name == "pcops_sa_gather_fwd":         # Y (b,m,s,c) written once; Q read once (algorithmically), idx
         b, n, m, s, c = a[:5]
         wr = (b * m * s * c if a[12] is not None else 0) + (4 * b * m * s if a[13] is not None else 0)
@@ -305,7 +326,9 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_edge_pool_fwd": 5, "pcops_edge_pool_bwd": 5, "pcops_edge_pool_out": 2,
            "pcops_mlp_bn_relu_maxpool_rows": 2, "pcops_mlp_pool_combine_rows": 2,
            "pcops_mlp_gemm_dgrad_top": 2, "pcops_mlp_gram": 2, "pcops_mlp_pool_top_addend": 4,
-           "pcops_mlp_pool_top_wsparse": 4, "pcops_scatter_rows_sorted": 5, "pcops_edge_feature_grad_central": 4}
+           "pcops_mlp_pool_top_wsparse": 4, "pcops_scatter_rows_sorted": 5, "pcops_edge_feature_grad_central": 4,
+           "pcops_edge_pool_fwd_ld": 5, "pcops_edge_pool_bwd_ld": 5, "pcops_edge_pool_out_ld": 2, "pcops_edge_pool_out_ld2": 2,
+           "pcops_sa_gather_fwd_ld": 5, "pcops_sa_scatter_bwd_ld": 5, "pcops_fc_bn_fwd": 2, "pcops_fc_bn_bwd": 2}
 
 
 class KernelTimer:
@@ -622,13 +645,36 @@ def side_model(name, dev, steps=10, warmup=3):
                            "share_of_step": d["ms"] / 3.0 / (el / steps * 1e3)}
         if d["work_unit"] == "pairs":       # a search kernel: neither roofline binds, instruction issue does
             res["dominant"].update({"bound": "valu_issue", "frac": None, "pair_tests_per_s": d["gwork_s"] * 1e9})
-        res["kernels"] = [{"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / 3.0,
-                           "bound_frac": max(d["gbs"] / HBM_PEAK_GBS, _mfma_frac(d))}
-                          for d in ks[:6]]
+        res["kernels"] = [_kernel_row(d, 3.0, el / steps * 1e3) for d in ks[:10]]
     del net, fp, opt, x
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+F16_PEAK_TFLOPS = 2500.0            # dense fp16 matrix peak (MI355X_MICROARCH.md), the pipe knn_f16_kernel's filter runs on
+
+
+def _kernel_row(d, steps, ms_per_step, traffic=None):
+    """one row of a per-kernel table: time, share of the step, and the fraction of the roofline that binds the kernel --
+    HBM or the matrix pipe it runs on for the streaming / MFMA kernels; for the search kernels (pair tests: instruction
+    issue binds) the pair rate, the fp32-VALU fraction of a 9-lane-op pair test and, for the 64-channel
+    kNN graph, its distance flops against the fp16 matrix pipe its filter runs on"""
+    hbm, mf = d["gbs"] / HBM_PEAK_GBS, _mfma_frac(d)
+    row = {"kernel": d["kernel"], "shape": d["shape"], "avg_us": d["avg_us"], "launches_per_step": d["launches"] / steps,
+           "ms_per_step": d["ms"] / steps, "share_of_step": d["ms"] / steps / ms_per_step,
+           "hbm_frac": hbm, "mfma_frac": mf, "bound": "mfma" if mf > hbm else "hbm", "bound_frac": max(hbm, mf),
+           "pipe": ("bf16 x 6 (split operands)" if _split_operands(d) else
+                    "f32 mfma (dW) + bf16 x 6 (dX)" if _half_split(d) else ("f32 mfma" if d["work_unit"] == "flop" else None))}
+    if d["work_unit"] == "pairs":
+        t = d["avg_us"] * 1e-6
+        row.update({"bound": "valu_issue", "pair_tests_per_s": d["gwork_s"] * 1e9,
+                    "bound_frac": d["work"] * QBP_VALU_OPS_PER_PAIR / t / VALU_LANE_OPS_PER_S})
+        if d["kernel"].startswith("pcops_knn_graph") and len(d["shape"]) >= 3 and d["shape"][2] >= 64:
+            row["f16_mfma_frac"] = 2.0 * d["work"] * d["shape"][2] / t / 1e12 / F16_PEAK_TFLOPS
+    if traffic is not None:
+        row["traffic"] = traffic
+    return row
 
 
 def _shared_gpu_debug():
@@ -928,6 +974,13 @@ def main():
                          "frac_of_measured_peak": (mfma_frac if (mfma_frac > hbm_frac and split) else
                                                    dom["gwork_s"] / 1e3 / MEASURED_F32_MFMA_TFLOPS
                                                    if mfma_frac > hbm_frac else dom["gbs"] / MEASURED_HBM_GBS)})
+    if roofline is not None:
+        # the object above names ONE kernel by a fixed rule -- the largest time per step in pass 1 among the kernels an HBM /
+        # MFMA roofline binds; two kernels within a few per cent of each other may swap places from box to box (r04: the
+        # one-pass backward at 0.67, r05: the 256 -> 128 data gradient at 0.47 -- same tree), so the three largest are listed
+        roofline["rule"] = "largest time per step (pass 1) among the kernels a roofline binds; top3 lists the first three"
+        roofline["top3"] = [_kernel_row(d, float(profile_steps), elapsed / args.steps * 1e3, _measured_traffic(d))
+                            for d in roofed[:3]]
     line = {
         "metric": "point-clouds/sec fwd+bwd at B×2048×3, 15-cls" if not args.forward_only
                   else "point-clouds/sec forward (eval) at B×2048×3, 15-cls",

@@ -62,15 +62,18 @@ int pcops_abi_version(void);
  *   PCOPS_OPT_KNN_F16_PREFILTER        0 / 1 (default): pcops_knn_graph* at c == 64, k <= 20, n >= 256 (seeded or not)
  *   PCOPS_OPT_DGRAD_SPLIT_BF16         0 fp32 MFMA, 1 (default): pcops_mlp_gemm_dgrad* with 128..256 dY columns on the bf16 pipe in
  *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit
+ *   PCOPS_OPT_BWD_FUSED_GRAM_WGRAD     0 (default) / 1: pcops_mlp_bwd_fused_gw* take shapes (pcops_mlp_bwd_fused_gw_groups > 0);
+ *                                      measured 15 % fewer shader cycles and -4 % .. +1 % time: the step runs at its power cap
  * pcops_set_option returns the PREVIOUS value (>= 0) or PCOPS_ERR_BAD_ARGUMENT.  The environment variables of rounds 3-4
- * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16; round 6: PCOPS_DGRAD_BF3) only seed the initial values (test overrides). */
+ * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16; round 6: PCOPS_DGRAD_BF3, PCOPS_BWD_FUSED_GW) only seed the initial values (test overrides). */
 typedef enum pcops_option {
     PCOPS_OPT_GEMM_SPLIT_BF16 = 1,
     PCOPS_OPT_WGRAD_SPLIT_BF16 = 2,
     PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16 = 3,
     PCOPS_OPT_KNN_F16_PREFILTER = 4,
     PCOPS_OPT_DGRAD_SPLIT_BF16 = 5,
-    PCOPS_OPT_COUNT = 6
+    PCOPS_OPT_BWD_FUSED_GRAM_WGRAD = 6,
+    PCOPS_OPT_COUNT = 7
 } pcops_option;
 int pcops_set_option(int option, int value);
 int pcops_get_option(int option);
@@ -560,6 +563,27 @@ int pcops_mlp_bwd_fused_edge(long long M, int K, int N, const float *Yprev, cons
                                   const float *Y, const float *p, const float *q, const float *t, const float *gpool,
                                   const unsigned char *argmax, int S, const float *W, float *partial, float *dW, float *db,
                                   float *stats_partial, const float *edge_rows, float *edge_stats, pcops_stream_t stream);
+
+/* Round 6: pcops_mlp_bwd_fused / pcops_mlp_bwd_fused_edge of a POOLED layer with the weight gradient in its GRAM FORM.  With
+ * dY = p.G + q.Y + t, one non-zero row of G per (group, channel), and Y = X W + bias:
+ *     dW = X^T (p.G) + (X^T X) W diag(q) + (X^T 1)(q.bias + t)^T
+ * -- a 64 x 64 Gram matrix on the matrix pipe instead of the K x N product (half the weight gradient's matrix time at
+ * N = 128), the arg rows as vector work, the K x N product once on the summed partials.  Same reference op as
+ * pcops_mlp_bwd_fused (tf.gradients of conv2d + batch_norm + reduce_max, pointnet2/utils/pointnet_util.py:117-127,
+ * dgcnn/models/transform_nets.py:19-27); results equal to it to fp32 rounding.  Uncompacted rows, S % 32 == 0 or
+ * 11 <= S <= 255, PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16 on; bias [N] may be NULL (a layer without bias).
+ *   pcops_mlp_bwd_fused_gw_groups  workgroups = partial copies, 0 when the shape is not taken
+ *   partial: groups (K N + N + K K + K) floats of scratch */
+int pcops_mlp_bwd_fused_gw_groups(long long M, int K, int N, int S);
+int pcops_mlp_bwd_fused_gw(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                           const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                           const unsigned char *argmax, int S, const float *W, const float *bias, float *partial, float *dW,
+                           float *db, float *Gprev, float *stats_partial, pcops_stream_t stream);
+int pcops_mlp_bwd_fused_edge_gw(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                                const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                                const unsigned char *argmax, int S, const float *W, const float *bias, float *partial,
+                                float *dW, float *db, float *stats_partial, const float *edge_rows, float *edge_stats,
+                                pcops_stream_t stream);
 int pcops_edge_first_layer_grads(int P1, const float *wpartial, int P2, const float *moments_partial, int c, const float *W,
                                  const float *bias, const float *p, const float *q, const float *t, const float *sumG,
                                  const float *mean, long long rows, float *dW, float *dbias, pcops_stream_t stream);

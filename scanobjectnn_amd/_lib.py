@@ -79,6 +79,9 @@ SIGNATURES = {
     "pcops_mlp_bwd_fused": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bwd_fused_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_adam_step": ([_LL, _P, _P, _P, _P, _F, _F, _F, _F], True),
+    # round 6: the one-pass backward of a pooled layer with the weight gradient in its Gram form (+ bias)
+    "pcops_mlp_bwd_fused_gw": ([_LL, _I, _I] + [_P] * 9 + [_I] + [_P] * 7, True),
+    "pcops_mlp_bwd_fused_edge_gw": ([_LL, _I, _I] + [_P] * 9 + [_I] + [_P] * 8, True),
     "pcops_mlp_bwd_fused_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_rows": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad_xyz_rows": ([_LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P], True),
@@ -114,6 +117,7 @@ PLAIN = {
     "pcops_mlp_bwd_pool_stats_rows": ([_LL], _I),
     "pcops_mlp_wgrad_splits": ([_LL, _I, _I], _I),
     "pcops_mlp_bwd_fused_groups": ([_LL, _I, _I, _I, _I], _I),
+    "pcops_mlp_bwd_fused_gw_groups": ([_LL, _I, _I, _I], _I),
     "pcops_gather_stack_rows_supported": ([_I, _I, _I, _I, _I, _I, _P], _I),
     "pcops_sa_scatter_rows_supported": ([_I, _I, _I, _I], _I),
     "pcops_sa_gather_stats_rows": ([_LL], _I),
@@ -234,6 +238,7 @@ def check(t, dtype, name, ndim=None):
 
 
 OPT_GEMM_SPLIT_BF16, OPT_WGRAD_SPLIT_BF16, OPT_BWD_FUSED_DX_SPLIT_BF16, OPT_KNN_F16_PREFILTER = 1, 2, 3, 4
+OPT_DGRAD_SPLIT_BF16, OPT_BWD_FUSED_GRAM_WGRAD = 5, 6            # round 6
 
 
 def set_option(option, value):

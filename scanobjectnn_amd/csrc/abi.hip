@@ -50,6 +50,7 @@ void options_init() {
         g_options[PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16].store(env_int("PCOPS_BWD_FUSED_DX3", 1) != 0);
         g_options[PCOPS_OPT_KNN_F16_PREFILTER].store(env_int("PCOPS_KNN_F16", 1) != 0);
         g_options[PCOPS_OPT_DGRAD_SPLIT_BF16].store(env_int("PCOPS_DGRAD_BF3", 1));
+        g_options[PCOPS_OPT_BWD_FUSED_GRAM_WGRAD].store(env_int("PCOPS_BWD_FUSED_GW", 0) != 0);
         g_options_init.store(1, std::memory_order_release);
     }
     busy.clear(std::memory_order_release);

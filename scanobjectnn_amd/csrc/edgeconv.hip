@@ -1194,7 +1194,8 @@ int ec_bwd_fused(int b, int n, int m, int s, int c, const float *Q, int ldq, con
 constexpr int kEdgeFirstGrid = 2048;     // partial rows of the two passes below
 int ec_edge_first_rows() { return kEdgeFirstGrid; }
 bool ec_edge_first_supported(int b, int n, int m, int s, int c) {
-    return b >= 1 && n >= 1 && m >= 1 && s >= 1 && (c == 64 || c == 128);
+    // the kernels take the centre of group g as x[cloud][g]: an EdgeConv graph, one group per source point (m == n)
+    return b >= 1 && n >= 1 && m == n && s >= 1 && (c == 64 || c == 128);
 }
 int ec_edge_first_moments(int b, int n, int m, int s, const float *x, const int *idx, float *part, float *e8, hipStream_t st) {
     const long long rows = (long long)b * m * s;

@@ -1679,8 +1679,15 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
     if (off4 || moments) PCOPS_REQUIRE_PTR(Wxyz);
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     if (gather_fwd_is_ec(b, n, m, s, c, Q != nullptr, Ctr != nullptr, Wxyz != nullptr || bias != nullptr || off4 != nullptr ||
-                         moments != nullptr, rows != nullptr) && Y != nullptr)
+                         moments != nullptr, rows != nullptr) && Y != nullptr) {
+        // the edgeconv.hip kernel writes ec_stats_rows(G) rows of partial statistics; a caller that sized and finalises the
+        // buffer with the shape-less query of round 4 (pcops_sa_gather_stats_rows) must not meet uninitialised rows
+        const int wr = ec_stats_rows(G), old = pcops_sa_gather_stats_rows(G);
+        if (stats_partial && wr < old &&
+            hipMemsetAsync(stats_partial + (long long)wr * 2 * c, 0, (size_t)(old - wr) * 2 * c * sizeof(float), as_stream(stream)) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
         return ec_gather_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, Y, stats_partial, stat_pivot, as_stream(stream));
+    }
     const int rl = 256 / (c / 4);
     static const bool nt_on = [] { const char *e = getenv("PCOPS_NT_STORE"); return !(e && e[0] == '0'); }();   // kernel A/B only
     const size_t staged = (size_t)(s >= 1024 ? s : 1024) * 4;      // floats: (dx, dy, dz, index) per staged row
@@ -1926,8 +1933,15 @@ int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(arg);
     // round 5: 64-channel slices, offsets staged in LDS, XCD-contiguous clouds (edgeconv.hip); same outputs, and
     // b m / 64 = pcops_edge_pool_stats_rows(G) rows of partial statistics
-    if (ec_fwd_supported(b, n, m, s, c) && s <= 256)
+    if (ec_fwd_supported(b, n, m, s, c) && s <= 256) {
+        // (rows beyond what this shape's kernel writes are zeroed: the shape-less query pcops_edge_pool_stats_rows is still
+        // a valid size for the buffer and a valid row count for pcops_mlp_bn_finalize)
+        const int wr = ec_edge_pool_stats_rows(b, n, m), old = pcops_edge_pool_stats_rows(G);
+        if (stats_partial && wr < old &&
+            hipMemsetAsync(stats_partial + (long long)wr * 2 * c, 0, (size_t)(old - wr) * 2 * c * sizeof(float), as_stream(stream)) != hipSuccess)
+            return PCOPS_ERR_LAUNCH;
         return ec_edge_pool_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot, as_stream(stream));
+    }
     const int gl = 256 / (c / 4);
     hipLaunchKernelGGL(edge_pool_fwd_kernel, dim3(pcops_edge_pool_stats_rows(G)), dim3(256),
                        (size_t)gl * 2 * c * sizeof(float), as_stream(stream), G, n, m, s, c, Q, Ctr, idx, gamma, SQ, qsel,
@@ -2189,7 +2203,7 @@ int pcops_edge_first_moments(int b, int n, int m, int s, const float *xyz, const
                              float *edge_rows, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1);
     PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(moments_partial);
-    if (reinterpret_cast<uintptr_t>(edge_rows) & 15) return PCOPS_ERR_UNSUPPORTED;
+    if (m != n || (reinterpret_cast<uintptr_t>(edge_rows) & 15)) return PCOPS_ERR_UNSUPPORTED;   // EdgeConv graphs: group g is point g
     return ec_edge_first_moments(b, n, m, s, xyz, idx, moments_partial, edge_rows, as_stream(stream));
 }
 int pcops_edge_first_wgrad(int b, int n, int m, int s, int c, const float *G, const float *xyz, const int *idx,

@@ -701,6 +701,11 @@ __global__ __launch_bounds__(512, 2) void knn_f16_kernel(int n, int k, const flo
                 // any split), so the lane with fewer survivors takes the partner's LAST ones -- a round costs 133 instructions for
                 // the whole wave, and the rounds of a flush are the fullest lane's count: max over 32 pairs of half the pair's
                 // sum instead of max over 64 lanes
+                // (the partner's pending entries were written by another lane of this wave: order the LDS writes before the
+                // pooled reads below -- the hardware executes a wave's LDS instructions in order, the memory model does not say so)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int nb = __shfl_xor(nq, 32, 64);                 // the partner's count
                 const int mine = (nq + nb + (half == 0 ? 1 : 0)) >> 1; // survivors this lane processes
                 const int mx = (int)wave_max_u32((unsigned)mine);

@@ -1527,7 +1527,9 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, int kind = 0) {
     if (kind == 2 && is_dy(am) && dgrad_bf3_mode() && !(reinterpret_cast<uintptr_t>(a.W) & 3) && a.K >= dgrad_bf3_kmin() &&
         a.K <= 256 && a.K % 32 == 0) {
         const int nc = ws_ncoef(am);
-        const int bn3 = (a.N > 64 && dgrad_bf3_mode() == 2) ? 128 : 64;
+        // 64-column passes (two accumulator sets of two blocks); 65..96 output columns as ONE pass of three blocks (MSG's
+        // 128 -> 96: 241..256 registers, no spill) instead of a second pass over half-empty columns
+        const int bn3 = (a.N > 64 && a.N <= 96 && ws_n96_enabled()) ? 96 : ((a.N > 64 && dgrad_bf3_mode() == 2) ? 128 : 64);
         if (ws_lds_bytes_bf3(a.K, bn3, 8, false, nc) <= 160 * 1024) {
             pl->bf3 = true; pl->kc = 32; pl->bn = bn3; pl->eh = bn3 / 32; pl->wst = false;
             pl->lds = ws_lds_bytes_bf3(a.K, bn3, 8, false, nc);
@@ -2071,6 +2073,9 @@ struct WgradArgs {
     const float *W; float *Gprev; float *gstats; float *xstats;
     int nt_out;              // Gprev leaves with non-temporal stores
     const float *side;       // SIDE: [M][8] per-row inputs (six used) of the reduced first layer below
+    // GW (bwd_fused_kernel, pooled layers): the weight gradient in its Gram form -- part receives X^T (p.G) (the arg rows
+    // only), gram_part [groups][K][K] the workgroup's X^T X, xsum_part [groups][K] its X^T 1
+    float *gram_part; float *xsum_part;
 };
 
 template <int VK, int VN>
@@ -3085,8 +3090,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
 // SIDE (round 5): the layer below is the first EdgeConv layer of a stack whose input needs no gradient (pcops.h
 // pcops_edge_first_*): its masked gradient is not written either -- its weight gradient is linear in E^T Gprev, E the six edge
 // channels of a row, which ride along as 32 bytes per row (a.side) and are reduced exactly like the xyz form's offsets.
-template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false, bool SIDE = false>
+// GW (round 6): the weight gradient of a POOLED layer in its Gram form.  dY = p.G + q.Y + t has ONE non-zero row of G per
+// (group, channel) and Y = X W + b, so  dW = X^T (p.G) + (X^T X) W diag(q) + (X^T 1)(q.b + t)^T:  the consumers multiply a
+// 64 x 64 Gram matrix (16 matrix instructions per stripe and wave instead of 16 NB / 32 -- half the dW matrix time at
+// NB = 128) and add the arg rows as vector work: lane (channel c, k slice) reads its group's (gpool, arg row) pair and adds
+// p g X[arg row][slice] -- NB / 4 fused multiply-adds per group and lane.  The K x N product with W diag(q) happens once,
+// on the summed partials (bwd_fused_gw_finish_kernel).  Kernel time is issue time on this chip (matrix and vector
+// instructions of the two waves of a SIMD add up), so half the dW matrix cycles is ~16 % of the pass.
+template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false, bool SIDE = false, bool GW = false>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
+    static_assert(!GW || (is_pool(DMODE) && DMODE != A_DYPOOLB && !XYZ), "Gram form: pooled, uncompacted rows");
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
     // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
     constexpr int KB = 64, NB = 64 * TN, RS = 32;
@@ -3157,9 +3170,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const float4 cq = *reinterpret_cast<const float4 *>(&coefD[NB + dcq]);
         const float4 ct = *reinterpret_cast<const float4 *>(&coefD[2 * NB + dcq]);
         float dbs[4] = {0.f, 0.f, 0.f, 0.f};
-        // TWO register sets: the loads of stripe i + 2 are in flight while stripe i + 1 is staged (57 KB per CU in flight
-        // instead of 29; measured within noise of one stripe ahead -- the kernel is matrix-pipe / issue bound -- and kept:
-        // the producers have the registers)
+        float xs[4] = {0.f, 0.f, 0.f, 0.f};                    // GW: column sums of X (this lane's quad)
+        // NSET register sets: the loads of stripes i + 2 .. i + NSET are in flight while stripe i + 1 is staged (29 KB per CU
+        // and set).  Round 3 measured two sets within noise of one; round 6 measured three and four (-DPCOPS_BF_NSET=3 / 4,
+        // no spills at three): SA1's layer 1 430 -> 1 515 -> 1 605 us -- more requests in flight make the pass SLOWER, so it
+        // is not bound by latency x bytes in flight either (profiles/r06_bwd_fused_gw.txt)
         constexpr bool B_ = DMODE == A_DYPOOLB;                // compacted rows: one pooling group per 16-row block
         constexpr int NBLK = RS / kBlk;                        // blocks per stripe
         constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
@@ -3171,7 +3186,12 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             float bw[compact ? NBLK : 1];                      // weight of the first row of each block of the stripe
             int bs0[B_ ? NBLK : 1];
             int s0;                                            // U_: row-in-group of the stripe's first row
-        } rs0, rs1;
+        };
+#ifndef PCOPS_BF_NSET
+#define PCOPS_BF_NSET 2
+#endif
+        constexpr int NSET = PCOPS_BF_NSET;                   // stripes in flight per producer wave (register sets)
+        Regs rs0, rs1, rs2, rs3;                               // (named objects: an array of sets went to scratch)
         const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acq) * 4u : kOOB;
         const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcq) * 4u : kOOB;
         const unsigned xstep = (unsigned)(256 / A4) * (unsigned)a.ldx * 4u;
@@ -3287,6 +3307,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 x.z = fmaxf(fmaf(y.z, casc.z, cash.z), 0.f);
                 x.w = fmaxf(fmaf(y.w, casc.w, cash.w), 0.f);
                 if (!FULL && !(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (GW) { xs[0] += x.x; xs[1] += x.y; xs[2] += x.z; xs[3] += x.w; }
                 *reinterpret_cast<float4 *>(&dst[r * LD + acq]) = x;
                 *reinterpret_cast<float4 *>(&dst[r * LD + KB + acq]) = y;
             }
@@ -3337,31 +3358,41 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 if (ss0 >= Sg) { ss0 -= Sg; ++sg0; }
             }
         };
+        static_assert(NSET >= 2 && NSET <= 4, "register sets of the producers");
         if (cnt > 0) issue(rs0);
         if (cnt > 1) issue(rs1);
+        if (NSET > 2 && cnt > 2) issue(rs2);
+        if (NSET > 3 && cnt > 3) issue(rs3);
         if (cnt > 0) {
             stage(buf, rs0);
-            if (cnt > 2) issue(rs0);
+            if (cnt > NSET) issue(rs0);
         }
         __syncthreads();                                       // stripe 0 is in buf[0]
-        // stripe i + 1 lives in set (i + 1) & 1; two stripes per loop body so that the sets are named statically
-        for (long long i = 0; i < cnt; i += 2) {
-            if (i + 1 < cnt) {
-                stage(buf + RS * LD, rs1);
-                if (i + 3 < cnt) issue(rs1);
+        // stripe j lives in register set j % NSET and goes to stripe buffer j & 1; it is staged while the consumers work on
+        // stripe j - 1, and its set is handed to stripe j + NSET at once
+        int si = 1;
+        for (long long j = 1; j <= cnt; ++j) {
+            if (j < cnt) {
+                // (a set is named by a wave-uniform index: one copy of the code per set, so that the sets stay in registers)
+                auto body = [&](Regs &rg_) {
+                    stage(buf + (j & 1) * RS * LD, rg_);
+                    if (j + NSET < cnt) issue(rg_);
+                };
+                if (si == 0) body(rs0);
+                else if (si == 1) body(rs1);
+                else if (NSET > 2 && si == 2) body(rs2);
+                else if (NSET > 3) body(rs3);
             }
             __syncthreads();
-            if (i + 1 < cnt) {
-                if (i + 2 < cnt) {
-                    stage(buf, rs0);
-                    if (i + 4 < cnt) issue(rs0);
-                }
-                __syncthreads();
-            }
+            si = si + 1 == NSET ? 0 : si + 1;
         }
         float *sdb = buf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) sdb[pt * 4 + e] = dbs[e];
+        if (GW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sdb[2048 + pt * 4 + e] = xs[e];      // behind the db scratch and the statistics
+        }
         __syncthreads();
         __syncthreads();                                       // (the consumers' statistics hand-over)
     } else {
@@ -3370,18 +3401,30 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const int half = lane >> 5, li = lane & 31;
         const int rh = wave >> 1, cbp = wave & 1;              // dX blocks: rows 16 rh .., columns 32 cbp + {0, 16} ..
         const int c16 = lane & 15, g4 = lane >> 4;
-        f32x16 accw[TN];
+        f32x16 accw[GW ? 1 : TN];                              // GW: the wave's 32 x 32 block (ck, cn) of X^T X
         f32x4 accd[2];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < (GW ? 1 : TN); ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) accw[j][v] = 0.f;
+        // GW: the arg-row term X^T (p.G): lane (channel sc, k slice skq) of the 256 consumer lanes holds KPL sums
+        constexpr int KPL = NB / 4;
+        const int sc = tid & (NB - 1), skq = tid / NB;
+        float ssp[GW ? KPL : 1];
+#pragma unroll
+        for (int j = 0; j < (GW ? KPL : 1); ++j) ssp[j] = 0.f;
+        const float spc = (GW && sc < N) ? coefD[sc] : 0.f;    // p of the lane's channel
+        constexpr int NGS = DMODE == A_DYPOOLU ? 1 : 4;        // groups a 32-row stripe can meet (S >= 11: launcher)
+        const int Sgc = is_pool(DMODE) ? a.S : 1;
+        const long long glastc = is_pool(DMODE) ? (M - 1) / Sgc : 0;
+        const int crstep = ngrp * RS, cdq = crstep / Sgc, cdr = crstep % Sgc;
+        int cg0 = (grp * RS) / Sgc, cs0 = (grp * RS) % Sgc;    // group / row-in-group of the stripe's first row (running)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v) accd[b][v] = 0.f;
         const int aoff = half * LD + ck * 32 + li;
-        const int doff = half * LD + 2 * KB + cn * TN * 32 + li;
+        const int doff = GW ? half * LD + cn * 32 + li : half * LD + 2 * KB + cn * TN * 32 + li;   // GW: the X column block cn
         const int daoff = (16 * rh + c16) * LD + 2 * KB + (DX3 ? 8 : 4) * g4;   // + 16 J (split operands: + 32 J, and + 4)
         const int nyw = NSK ? (N - cn * TN * 32 + 31) / 32 : TN;            // dW blocks of this wave with real columns
         const int jreal = NSK ? (DX3 ? (N + 31) / 32 : (N + 15) / 16) : (DX3 ? NB / 32 : NB / 16);   // steps with real columns
@@ -3438,9 +3481,24 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         for (long long i = 0; i < cnt; ++i) {
             const float *sb = buf + (i & 1) * RS * LD;
             const long long row0 = (grp + i * ngrp) * RS;
-            float av_n = sb[aoff], dv_n[TN];
+            constexpr int TW = GW ? 1 : TN;                    // B blocks of the weight-gradient product per wave
+            float av_n = sb[aoff], dv_n[TW];
 #pragma unroll
-            for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 32 * y];
+            for (int y = 0; y < TW; ++y) dv_n[y] = sb[doff + 32 * y];
+            // GW: this stripe's groups' (masked pooled gradient, arg row) of the lane's channel, requested here and used
+            // behind the matrix loop
+            float sgv[GW ? NGS : 1];
+            unsigned sam[GW ? NGS : 1];
+            if constexpr (GW) {
+#pragma unroll
+                for (int gi = 0; gi < NGS; ++gi) {
+                    long long g = (long long)cg0 + gi;
+                    g = g < glastc ? g : glastc;
+                    const int cc = sc < N ? sc : 0;
+                    sgv[gi] = a.gpool[g * N + cc];
+                    sam[gi] = a.argmax[g * N + cc];
+                }
+            }
             constexpr int JP = (RS / 2) / JN;                  // data-gradient steps spread over the RS / 2 row pairs
             // every LDS fragment is requested one use AHEAD (the scheduler would otherwise sink the reads to just in
             // front of their first use and expose the LDS latency)
@@ -3450,13 +3508,13 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
 #pragma unroll
             for (int it = 0; it < RS / 2; ++it) {
                 const float av = av_n;
-                float dv[TN];
+                float dv[TW];
 #pragma unroll
-                for (int y = 0; y < TN; ++y) dv[y] = dv_n[y];
+                for (int y = 0; y < TW; ++y) dv[y] = dv_n[y];
                 if (it + 1 < RS / 2) {
                     av_n = sb[aoff + 2 * (it + 1) * LD];
 #pragma unroll
-                    for (int y = 0; y < TN; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
+                    for (int y = 0; y < TW; ++y) dv_n[y] = sb[doff + 2 * (it + 1) * LD + 32 * y];
                 }
                 const bool dostep = it % JP == 0;
                 const int J = it / JP;
@@ -3475,8 +3533,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(dbg & 4)) {
 #pragma unroll
-                for (int y = 0; y < TN; ++y)
-                    if (!NSK || y < nyw) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
+                for (int y = 0; y < TW; ++y)
+                    if (GW || !NSK || y < nyw) accw[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, dv[y], accw[y], 0, 0, 0);
                 }
                 if (dostep && (!NSK || J < jreal) && !(dbg & 1)) {
                     if constexpr (DX3) {
@@ -3508,6 +3566,27 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (GW) {
+                // ---- the arg rows of this stripe's groups: row (gi S - cs0 + arg) of the stripe, if it lies inside
+                const int rows_here = (int)(M - row0 < RS ? M - row0 : RS);
+#pragma unroll
+                for (int gi = 0; gi < NGS; ++gi) {
+                    const int r = gi * Sgc - cs0 + (int)sam[gi];
+                    const bool ok = sc < N && (long long)cg0 + gi <= glastc && (unsigned)r < (unsigned)rows_here && sgv[gi] != 0.f;
+                    if (ok) {
+                        const float cf = spc * sgv[gi];
+                        const float *xr = &sb[r * LD + KPL * skq];
+#pragma unroll
+                        for (int j = 0; j < KPL; j += 4) {
+                            const float4 x4 = *reinterpret_cast<const float4 *>(xr + j);
+                            ssp[j] = fmaf(cf, x4.x, ssp[j]); ssp[j + 1] = fmaf(cf, x4.y, ssp[j + 1]);
+                            ssp[j + 2] = fmaf(cf, x4.z, ssp[j + 2]); ssp[j + 3] = fmaf(cf, x4.w, ssp[j + 3]);
+                        }
+                    }
+                }
+                cg0 += cdq; cs0 += cdr;
+                if (cs0 >= Sgc) { cs0 -= Sgc; ++cg0; }
             }
             // ---- Gprev rows of this stripe: mask, column sums, store (before the stripe buffer is handed back).  (Handing
             // them to the next stripe's loop so that they issue under its first MFMAs was measured: no difference.)
@@ -3550,6 +3629,21 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         }
         // dW partial of this workgroup: accw[y][v] = (k = 32 ck + (v&3) + 8 (v>>2) + 4 half, n = (NB/2) cn + 32 y + li)
         float *out = a.part + (long long)grp * K * N;
+        if constexpr (GW) {
+            // the arg-row term [K][N] from the lanes' sums, the Gram block (ck, cn) [K][K] from the accumulators
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                const int kk = KPL * skq + j;
+                if (kk < K && sc < N) out[(long long)kk * N + sc] = ssp[j];
+            }
+            float *gout = a.gram_part + (long long)grp * K * K;
+            const int jj = cn * 32 + li;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int kk = ck * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+                if (kk < K && jj < K) gout[(long long)kk * K + jj] = accw[0][v];
+            }
+        } else {
 #pragma unroll
         for (int y = 0; y < TN; ++y) {
             const int nn = (cn * TN + y) * 32 + li;
@@ -3558,6 +3652,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 const int kk = ck * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
                 if (kk < K && nn < N) out[(long long)kk * N + nn] = accw[y][v];
             }
+        }
         }
         // column statistics of Gprev: the four 16-lane sets of a wave own the same columns, the two row halves (waves
         // w, w ^ 2) meet in LDS
@@ -3594,6 +3689,15 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 float sum = 0.f;
                 for (int r = quad; r < 256; r += D4) sum += sdb[r * 4 + e];
                 if (c < N) a.dbpart[(long long)grp * N + c] = sum;
+            }
+        }
+        if constexpr (GW) {
+            const float *sxs = buf + 2048;
+            for (int c = tid; c < KB; c += 256) {
+                const int quad = c >> 2, e = c & 3;
+                float sum = 0.f;
+                for (int r = quad; r < 256; r += A4) sum += sxs[r * 4 + e];
+                if (c < K) a.xsum_part[(long long)grp * K + c] = sum;
             }
         }
         __syncthreads();
@@ -4040,6 +4144,53 @@ __global__ __launch_bounds__(1024) void bn_bwd_coeffs_fused_kernel(int P, int N,
     t_o[c] = (float)t;
 }
 
+// Gram form of the one-pass backward's weight gradient (bwd_fused_kernel<..., GW>): the P workgroups' partials of
+// S = X^T (p.G) [K][N], Gr = X^T X [K][K], xs = X^T 1 [K] and db [N] are summed in a fixed order (in double) and combined,
+//   dW[k][n] = S[k][n] + q[n] sum_j Gr[k][j] W[j][n] + xs[k] (q[n] b[n] + t[n]),
+// one workgroup per (row k, 128 columns): K <= 64.
+__global__ __launch_bounds__(128) void bwd_fused_gw_finish_kernel(int P, int K, int N, const float *__restrict__ spart,
+                                                                  const float *__restrict__ dbpart,
+                                                                  const float *__restrict__ gpart,
+                                                                  const float *__restrict__ xpart, const float *__restrict__ W,
+                                                                  const float *__restrict__ bias, const float *__restrict__ q,
+                                                                  const float *__restrict__ t, float *__restrict__ dW,
+                                                                  float *__restrict__ db) {
+    __shared__ double red[2][64];
+    __shared__ double gr[64];
+    __shared__ double xsr[128];
+    const int tid = threadIdx.x, k = blockIdx.x, n = blockIdx.y * 128 + tid;
+    {
+        const int j = tid & 63, h = tid >> 6;
+        double s = 0.0;
+        if (j < K)
+            for (int p = h; p < P; p += 2) s += (double)gpart[((long long)p * K + k) * K + j];
+        red[h][j] = s;
+        double x = 0.0;
+        for (int p = tid; p < P; p += 128) x += (double)xpart[(long long)p * K + k];
+        xsr[tid] = x;
+    }
+    __syncthreads();
+    if (tid < 64) gr[tid] = red[0][tid] + red[1][tid];
+    for (int off = 64; off >= 1; off >>= 1) {
+        if (tid < off) xsr[tid] += xsr[tid + off];
+        __syncthreads();
+    }
+    const double xs = xsr[0];
+    if (n < N) {
+        double sS = 0.0;
+        for (int p = 0; p < P; ++p) sS += (double)spart[((long long)p * K + k) * N + n];
+        double dot = 0.0;
+        for (int j = 0; j < K; ++j) dot += gr[j] * (double)W[(long long)j * N + n];
+        const double qn = (double)q[n], bn = bias ? (double)bias[n] : 0.0;
+        dW[(long long)k * N + n] = (float)(sS + qn * dot + xs * (qn * bn + (double)t[n]));
+        if (k == 0 && db) {
+            double d = 0.0;
+            for (int p = 0; p < P; ++p) d += (double)dbpart[(long long)p * N + n];
+            db[n] = (float)d;
+        }
+    }
+}
+
 int reduce_stats(int P, int N, const float *part, double *ws, hipStream_t st) {
     hipLaunchKernelGGL(colreduce_stage1, dim3((N + 31) / 32, 2, kRedSlices), dim3(256), 0, st, P, N, part, ws);
     return pcops_launch_status();
@@ -4343,7 +4494,7 @@ static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
 // ---- launchers of the weight-gradient, one-pass-backward and Gram kernels: build parts 4 and 5 (PCOPS_MLP_PART)
 PCOPS_HIDDEN int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t st);
 PCOPS_HIDDEN int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
-                                  bool side = false);
+                                  bool side = false, const float *gw_bias = nullptr);
 PCOPS_HIDDEN int gram_full_launch(GramArgs &g, int nbk, bool bnrelu, int gg, size_t lds, hipStream_t st);
 
 static int wgrad_legacy_splits(long long M, int K, int N) {
@@ -4490,9 +4641,11 @@ int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t s
 
 #if PCOPS_PART(5)
 int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
-                     bool side) {
+                     bool side, const float *gw_bias) {
     const int K = a.K, N = a.N;
     a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
+    const bool gw = a.gram_part != nullptr;     // Gram form of the weight gradient (pcops_mlp_bwd_fused_gw*): partial also
+                                                // holds [groups][K][K] + [groups][K] behind the dW / db partials
     const int tn = N <= 64 ? 1 : 2;
     const int NB = 64 * tn;
     const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
@@ -4504,6 +4657,37 @@ int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *
     const bool nsk = nsk_on && tn == 2 && N <= 96;
     const bool dx3 = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) != 0;
     pcops_note_pipe(dx3 ? 2 : 0);
+    if (gw) {
+        if (!dx3 || xyz || a.blocks || !a.gpool) return PCOPS_ERR_UNSUPPORTED;
+#define PCOPS_BFG_LAUNCH(TN_, DM_, NSK_, SIDE_)                                                            \
+    do {                                                                                                   \
+        auto kern = bwd_fused_kernel<TN_, DM_, false, NSK_, true, SIDE_, true>;                            \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
+            return PCOPS_ERR_LAUNCH;                                                                       \
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, st, a);                                     \
+    } while (0)
+        const bool u = a.S % 32 == 0;
+        if (side) {
+            if (tn == 1) PCOPS_BFG_LAUNCH(1, A_DYPOOL, false, true);
+            else PCOPS_BFG_LAUNCH(2, A_DYPOOL, false, true);
+        } else if (tn == 1) {
+            if (u) PCOPS_BFG_LAUNCH(1, A_DYPOOLU, false, false);
+            else PCOPS_BFG_LAUNCH(1, A_DYPOOL, false, false);
+        } else if (nsk) {
+            if (u) PCOPS_BFG_LAUNCH(2, A_DYPOOLU, true, false);
+            else PCOPS_BFG_LAUNCH(2, A_DYPOOL, true, false);
+        } else {
+            if (u) PCOPS_BFG_LAUNCH(2, A_DYPOOLU, false, false);
+            else PCOPS_BFG_LAUNCH(2, A_DYPOOL, false, false);
+        }
+#undef PCOPS_BFG_LAUNCH
+        int rcg = pcops_launch_status();
+        if (rcg) return rcg;
+        hipLaunchKernelGGL(bwd_fused_gw_finish_kernel, dim3(K, cdiv(N, 128)), dim3(128), 0, st, groups, K, N, a.part,
+                           a.dbpart, a.gram_part, a.xsum_part, a.W, gw_bias, a.q, a.t, dW, db);
+        return pcops_launch_status();
+    }
 #define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
     do {                                                                                                   \
         auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
@@ -5155,6 +5339,74 @@ int pcops_mlp_bwd_fused_edge(long long M, int K, int N, const float *Yprev, cons
     return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream), true);
 }
 
+/* ---- the one-pass backward of a POOLED layer with its weight gradient in the Gram form (round 6; bwd_fused_kernel<.., GW>):
+ * uncompacted rows, groups of S % 32 == 0 or 11 <= S <= 255 rows, split-operand dX half.  bias [N] (may be NULL) is the
+ * layer's own bias -- Y = X W + bias is what the form substitutes.  partial: groups (K N + N + K K + K) floats. */
+static int bwd_fused_gw_groups(long long M, int K, int N, int S) {
+    if (pcops_get_option(PCOPS_OPT_BWD_FUSED_GRAM_WGRAD) == 0 || S < 11 || S > 255) return 0;
+    if (pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) == 0) return 0;
+    return bwd_fused_groups(M, K, N, S, 1);
+}
+
+int pcops_mlp_bwd_fused_gw_groups(long long M, int K, int N, int S) { return bwd_fused_gw_groups(M, K, N, S); }
+
+static void gw_carve(WgradArgs &a, float *partial, int groups, int K, int N) {
+    a.gram_part = partial + (long long)groups * ((long long)K * N + N);
+    a.xsum_part = a.gram_part + (long long)groups * K * K;
+}
+
+int pcops_mlp_bwd_fused_gw(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                           const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                           const unsigned char *argmax, int S, const float *W, const float *bias, float *partial, float *dW,
+                           float *db, float *Gprev, float *stats_partial, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && S >= 1);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(gpool);
+    PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(db);
+    PCOPS_REQUIRE_PTR(Gprev); PCOPS_REQUIRE_PTR(stats_partial);
+    const int groups = bwd_fused_gw_groups(M, K, N, S);
+    if (groups == 0) return PCOPS_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Yprev) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+        (reinterpret_cast<uintptr_t>(gpool) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3))
+        return PCOPS_ERR_UNSUPPORTED;
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_BNRELU; a.X = Yprev; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = A_DYPOOL; a.G = nullptr; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.gpool = gpool; a.argmax = argmax; a.S = S;
+    a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
+    a.nt_out = nt_for_bytes((long long)M * K * 4);
+    gw_carve(a, partial, groups, K, N);
+    return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream), false, bias);
+}
+
+int pcops_mlp_bwd_fused_edge_gw(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
+                                const float *Y, const float *p, const float *q, const float *t, const float *gpool,
+                                const unsigned char *argmax, int S, const float *W, const float *bias, float *partial,
+                                float *dW, float *db, float *stats_partial, const float *edge_rows, float *edge_stats,
+                                pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && S >= 1);
+    PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(a_scale); PCOPS_REQUIRE_PTR(a_shift); PCOPS_REQUIRE_PTR(Y);
+    PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(gpool);
+    PCOPS_REQUIRE_PTR(argmax); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(db);
+    PCOPS_REQUIRE_PTR(stats_partial); PCOPS_REQUIRE_PTR(edge_rows); PCOPS_REQUIRE_PTR(edge_stats);
+    const int groups = bwd_fused_gw_groups(M, K, N, S);
+    if (groups == 0 || S % 32 == 0) return PCOPS_ERR_UNSUPPORTED;       // (whole-tile groups take another operand form)
+    if ((reinterpret_cast<uintptr_t>(Yprev) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+        (reinterpret_cast<uintptr_t>(gpool) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3) || (reinterpret_cast<uintptr_t>(edge_rows) & 15))
+        return PCOPS_ERR_UNSUPPORTED;
+    WgradArgs a = {};
+    a.M = M; a.K = K; a.N = N;
+    a.amode = A_BNRELU; a.X = Yprev; a.ldx = K; a.asc = a_scale; a.ash = a_shift;
+    a.dmode = A_DYPOOL; a.G = nullptr; a.Y = Y; a.ldy = N; a.p = p; a.q = q; a.t = t;
+    a.gpool = gpool; a.argmax = argmax; a.S = S;
+    a.W = W; a.Gprev = nullptr; a.gstats = stats_partial; a.xstats = edge_stats; a.side = edge_rows;
+    gw_carve(a, partial, groups, K, N);
+    return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream), true, bias);
+}
+
 int pcops_mlp_bwd_fused_xyz_rows(long long M, int K, int N, const float *off4, const float *xyzw, const float *a_scale,
                                  const float *a_shift, const float *G, const float *Y, const float *p, const float *q,
                                  const float *t, const float *gpool, const unsigned char *argmax, int S, const float *W,
@@ -5308,6 +5560,7 @@ int pcops_mlp_gram(long long M, int Kp, const float *Yprev, int ldx, const float
     PCOPS_REQUIRE_PTR(Yprev); PCOPS_REQUIRE_PTR(partial); PCOPS_REQUIRE_PTR(gram);
     PCOPS_REQUIRE_ARG((a_scale == nullptr) == (a_shift == nullptr));
     const int gg = gram_full_groups(M, Kp, ldx, Yprev);
+    pcops_note_pipe(0);
     if (gg > 0) {
         // one pass over X: whole rows staged, every upper 32 x 32 block in accumulators (gram_full_kernel)
         hipStream_t st = as_stream(stream);
@@ -5357,6 +5610,7 @@ int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA
                         const float *bias, float *C, int ldc, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     PCOPS_REQUIRE_PTR(A); PCOPS_REQUIRE_PTR(B); PCOPS_REQUIRE_PTR(C);
+    pcops_note_pipe(0);                                     // fp32 MFMA (bench labels read pcops_last_launch_pipe per launch)
     hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), M, K, N, A,
                        lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias);
     return pcops_launch_status();

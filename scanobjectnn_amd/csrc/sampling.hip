@@ -205,117 +205,177 @@ __global__ __launch_bounds__(256) void gather_point_grad_kernel(long long total,
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// prob_sample = row cumsum + lower-bound search (sampling/tf_sampling_g.cu:7-103, launcher :197-200).
-// The integer output is read off fp32 partial sums, so the ASSOCIATION of the reference's scan is the contract (stated
-// in oracle/pcops_oracle.c, oracle_cumsum): groups of four summed serially, the group totals scanned by an up-sweep /
-// down-sweep pair, S[g-1] added to group g, chunks of 8192 offset by a compensated running sum.  What is free is where
-// the values live: one workgroup per ROW (the reference grid-strides 32 blocks over the rows), every thread keeps its
-// eight groups' four partial sums in registers (the reference's 32 KB `buffer4` does not exist), only the 2048 group
-// totals go through LDS (bank-skewed by one slot per 32), rows are read and written as float4 where they are aligned.
+// prob_sample = row cumsum + lower-bound search (reference: sampling/tf_sampling_g.cu:7-103, launcher :197-200).
+// The integer output is read off fp32 partial sums, so the ASSOCIATION of the reference's scan is the contract; it is
+// stated independently in tests/test_prob_sample_cpu.py and in oracle/pcops_oracle.c.  In this file's own words:
+//   * a chunk is 8 192 elements = 2 048 QUADS; inside a quad  c0 = x0, c1 = x1 + x0, c2 = x2 + c1, c3 = (x3 + x2) + c1;
+//   * the quad totals t[0 .. nq) form a FENWICK TREE: node(e) = sum of the aligned block of lowbit(e + 1) totals ending at e,
+//     built bottom-up as  node = (its upper half's node) + (its lower half's node)  -- only blocks that lie inside nq exist;
+//   * the inclusive prefix of the totals is the tree's query, taken from the LARGEST block down:
+//         pre(e) = node(e) + pre(e - lowbit(e + 1)),   pre(-1) absent (no addition);
+//   * quad g > 0 adds pre(g - 1) to its four partial sums, then every element adds the carry of the chunks before;
+//   * the carry is kept as a (sum, compensation) pair across chunks.
+// Where the values live is this kernel's own: one workgroup per row, a lane owns EIGHT CONSECUTIVE quads, so the three
+// lowest tree levels are register arithmetic, the next six are wave shuffles of the lanes' top nodes, the last two combine
+// the four waves' tops; the query reads at most eight nodes of other lanes from a 256-entry LDS table.  No 32 KB element
+// buffer, no workgroup barrier per tree level.
 constexpr int kScanThreads = 256;
-constexpr int kScanChunk = 8192;                         // elements per chunk (fixed by the reference: BlockSize * 4)
-constexpr int kScanGroups = kScanChunk / 4;              // group totals per chunk
-constexpr int kScanPerThread = kScanGroups / kScanThreads;
+constexpr int kQuadsPerLane = 8;
+constexpr int kScanChunk = kScanThreads * kQuadsPerLane * 4;      // 8 192 elements (fixed by the contract)
 
-__device__ __forceinline__ int scan_slot(int i) { return i + (i >> 5); }
+// prefix of the lanes' top nodes in front of lane `lane_ix` (1 .. 256): Fenwick query over node[0 .. 255], largest block first
+__device__ __forceinline__ float tops_before(const float *node, int lane_ix, bool &any) {
+    float acc = 0.f;
+    any = false;
+    for (int bit = 8; bit >= 0; --bit) {
+        if (!((lane_ix >> bit) & 1)) continue;
+        const int at = (lane_ix & ~((1 << bit) - 1)) - 1;          // the node that closes this block
+        acc = any ? node[at] + acc : node[at];
+        any = true;
+    }
+    return acc;
+}
 
 __global__ __launch_bounds__(kScanThreads) void cumsum_kernel(int n, const float *__restrict__ inp,
                                                               float *__restrict__ out) {
-    __shared__ float tot[kScanGroups + (kScanGroups >> 5)];
-    const int t = threadIdx.x;
-    const float *x = inp + (size_t)blockIdx.x * n;
-    float *y = out + (size_t)blockIdx.x * n;
+    __shared__ float lane_node[kScanThreads];            // Fenwick nodes over the lanes' top nodes
+    __shared__ float wave_top[kScanThreads / 64];
+    __shared__ float chunk_total;
+    const int lane_ix = threadIdx.x, wlane = lane_ix & 63, wv = lane_ix >> 6;
+    const float *src = inp + (size_t)blockIdx.x * n;
+    float *dst = out + (size_t)blockIdx.x * n;
     const bool vec = ((n & 3) == 0) && (((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
-    float runningsum = 0.f, runningsum2 = 0.f;
-    for (int j = 0; j < n; j += kScanChunk) {
-        const int len = min(n - j, kScanChunk);
-        const int n2 = (len + 3) >> 2;
-        float v[kScanPerThread][4];
+    float carry = 0.f, carry_lost = 0.f;                 // running sum of the chunks so far and what its rounding dropped
+    for (int c0 = 0; c0 < n; c0 += kScanChunk) {
+        const int len = min(n - c0, kScanChunk);
+        const int nq = (len + 3) >> 2;                   // quads of this chunk
+        const int q0 = lane_ix * kQuadsPerLane;          // this lane's first quad
+        float part[kQuadsPerLane][4];                    // partial sums inside each quad
+        float nd[kQuadsPerLane];                         // tree nodes of the lane's quads (level <= 3)
 #pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            const int g = t + i * kScanThreads;          // group: elements j + 4g .. j + 4g + 3
-            const int k = g * 4;
-            if (k + 3 < len) {
-                float v1, v2, v3, v4;
-                if (vec) {
-                    const float4 q = *reinterpret_cast<const float4 *>(x + j + k);
-                    v1 = q.x; v2 = q.y; v3 = q.z; v4 = q.w;
-                } else {
-                    v1 = x[j + k]; v2 = x[j + k + 1]; v3 = x[j + k + 2]; v4 = x[j + k + 3];
-                }
-                v2 += v1;
-                v4 += v3;
-                v3 += v2;
-                v4 += v2;
-                v[i][0] = v1; v[i][1] = v2; v[i][2] = v3; v[i][3] = v4;
-                tot[scan_slot(g)] = v4;
-            } else if (k < len) {                        // the ragged last group: serial sum of what exists, replicated
-                float a = 0.f;
+        for (int i = 0; i < kQuadsPerLane; ++i) {
+            const int e0 = (q0 + i) * 4;                 // first element of the quad inside the chunk
+            nd[i] = 0.f;
+            if (e0 + 3 < len) {
+                float4 x;
+                if (vec) x = *reinterpret_cast<const float4 *>(src + c0 + e0);
+                else x = make_float4(src[c0 + e0], src[c0 + e0 + 1], src[c0 + e0 + 2], src[c0 + e0 + 3]);
+                const float lo = x.y + x.x, hi = x.w + x.z;
+                part[i][0] = x.x; part[i][1] = lo; part[i][2] = x.z + lo; part[i][3] = hi + lo;
+                nd[i] = part[i][3];
+            } else if (e0 < len) {                       // the ragged last quad: running sum of what exists, then held
+                float run = 0.f;
 #pragma unroll
                 for (int l = 0; l < 4; ++l) {
-                    if (k + l < len) a += x[j + k + l];
-                    v[i][l] = a;
+                    if (e0 + l < len) run += src[c0 + e0 + l];
+                    part[i][l] = run;
                 }
-                tot[scan_slot(g)] = a;
+                nd[i] = run;
             }
         }
-        int u = 0;
-        for (; (2 << u) <= n2; ++u) {                    // up-sweep: aligned 2^(u+1) blocks, right half += left half
-            __syncthreads();
-            for (int k = t; k < (n2 >> (u + 1)); k += kScanThreads)
-                tot[scan_slot((((k << 1) + 2) << u) - 1)] += tot[scan_slot((((k << 1) + 1) << u) - 1)];
+        // tree levels 1..3 in registers: a block exists only if it ends inside nq
+        const int have = nq - q0;                        // quads of this lane that exist
+        if (have > 1) nd[1] += nd[0];
+        if (have > 3) nd[3] += nd[2];
+        if (have > 5) nd[5] += nd[4];
+        if (have > 7) nd[7] += nd[6];
+        if (have > 3) nd[3] += nd[1];
+        if (have > 7) nd[7] += nd[5];
+        if (have > 7) nd[7] += nd[3];
+        // levels 4..9: the lanes' top nodes inside a wave (a lane whose block is incomplete never feeds a complete one)
+        float top = nd[7];
+        const bool whole = have > 7;
+#pragma unroll
+        for (int lv = 0; lv < 6; ++lv) {
+            const float below = __shfl_up(top, 1 << lv, 64);
+            if (((wlane + 1) & ((2 << lv) - 1)) == 0 && whole) top += below;
         }
-        for (--u; u >= 0; --u) {                         // down-sweep: S[p] = T(2^u block ending at p) + S[p - 2^u]
-            __syncthreads();
-            for (int k = t; k < ((n2 - (1 << u)) >> (u + 1)); k += kScanThreads)
-                tot[scan_slot((((k << 1) + 3) << u) - 1)] += tot[scan_slot((((k << 1) + 2) << u) - 1)];
-        }
+        // levels 10, 11: the four waves' tops -- W1 = w1 + w0, W3 = (w3 + w2) + W1
+        if (wlane == 63) wave_top[wv] = top;
         __syncthreads();
+        if (wlane == 63 && whole) {
+            if (wv == 1) top += wave_top[0];
+            if (wv == 3) top = (top + wave_top[2]) + (wave_top[1] + wave_top[0]);
+        }
+        lane_node[lane_ix] = top;
+        __syncthreads();
+        // query: prefix of the totals in front of this lane's quads, then through them
+        bool any;
+        float before = tops_before(lane_node, lane_ix, any);
+        // pre[i] = inclusive prefix at quad q0 + i (i < 7 suffices: quad i + 1 needs it); largest block first
+        float pre[kQuadsPerLane];
+        pre[0] = any ? nd[0] + before : nd[0];
+        pre[1] = any ? nd[1] + before : nd[1];
+        pre[2] = nd[2] + pre[1];
+        pre[3] = any ? nd[3] + before : nd[3];
+        pre[4] = nd[4] + pre[3];
+        pre[5] = nd[5] + pre[3];
+        pre[6] = nd[6] + pre[5];
+        pre[7] = 0.f;                                    // (needed only as the chunk total: below)
+        if (lane_ix == (nq - 1) / kQuadsPerLane) {       // the lane that owns the chunk's last quad publishes the total
+            const int li = (nq - 1) % kQuadsPerLane;
+            float tot;
+            if (li == 7) {
+                bool any2;
+                tot = tops_before(lane_node, lane_ix + 1, any2);
+            } else {
+                tot = pre[0];
 #pragma unroll
-        for (int i = 0; i < kScanPerThread; ++i) {
-            const int g = t + i * kScanThreads;
-            const int k = g * 4;
-            if (k >= len) continue;
+                for (int i = 1; i < 7; ++i)
+                    if (li == i) tot = pre[i];
+            }
+            chunk_total = tot;
+        }
+#pragma unroll
+        for (int i = 0; i < kQuadsPerLane; ++i) {
+            const int e0 = (q0 + i) * 4;
+            if (e0 >= len) continue;
+            const bool first = (q0 + i) == 0;            // the chunk's first quad adds no prefix
+            const float add = i == 0 ? before : pre[i - 1];
             float o[4];
-            const float p = g ? tot[scan_slot(g - 1)] : 0.f;
 #pragma unroll
-            for (int l = 0; l < 4; ++l) o[l] = (g ? v[i][l] + p : v[i][l]) + runningsum;
+            for (int l = 0; l < 4; ++l) o[l] = (first ? part[i][l] : part[i][l] + add) + carry;
             if (vec) {
-                *reinterpret_cast<float4 *>(y + j + k) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(dst + c0 + e0) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int l = 0; l < 4; ++l)
-                    if (k + l < len) y[j + k + l] = o[l];
+                    if (e0 + l < len) dst[c0 + e0 + l] = o[l];
             }
         }
-        const float tt = tot[scan_slot(n2 - 1)] + runningsum2;     // compensated carry into the next chunk (:79-83)
-        const float r2 = runningsum + tt;
-        runningsum2 = tt - (r2 - runningsum);
-        runningsum = r2;
+        __syncthreads();
+        // carry into the next chunk: the total plus what the previous update's rounding dropped, re-split
+        const float inc = chunk_total + carry_lost;
+        const float grown = carry + inc;
+        carry_lost = inc - (grown - carry);
+        carry = grown;
         __syncthreads();
     }
 }
 
-// q = r * cumsum[n-1]; descending power-of-two walk to the smallest index whose cumulative value is >= q (:83-103).  The
-// row of partial sums was just written by cumsum_kernel and is L2-resident; rows up to kSearchLds floats are staged in
-// LDS once per workgroup so that the log2(n) dependent probes of a lane are LDS reads.
+// sample index = the smallest position whose cumulative weight reaches  u * (row total)  (reference :83-103: a descent over
+// powers of two from the row's end).  The row of partial sums was just written by cumsum_kernel and is L2-resident; rows up
+// to kSearchLds floats are staged in LDS once per workgroup so that the log2(n) dependent probes of a lane are LDS reads.
 constexpr int kSearchLds = 16384;
-__global__ __launch_bounds__(256) void binary_search_kernel(int n, int m, int base, const float *__restrict__ dataset,
-                                                            const float *__restrict__ query, int *__restrict__ result) {
-    __shared__ float row[kSearchLds];
-    const float *d = dataset + (size_t)blockIdx.x * n;
-    const bool staged = n <= kSearchLds;
-    if (staged) {
-        for (int k = threadIdx.x; k < n; k += 256) row[k] = d[k];
+__global__ __launch_bounds__(256) void binary_search_kernel(int n, int m, int top_step, const float *__restrict__ cum,
+                                                            const float *__restrict__ uniform, int *__restrict__ picked) {
+    __shared__ float staged_row[kSearchLds];
+    const float *grow = cum + (size_t)blockIdx.x * n;
+    const bool in_lds = n <= kSearchLds;
+    if (in_lds) {
+        for (int e = threadIdx.x; e < n; e += 256) staged_row[e] = grow[e];
         __syncthreads();
     }
-    const float last = staged ? row[n - 1] : d[n - 1];
-    for (int j = blockIdx.y * 256 + threadIdx.x; j < m; j += gridDim.y * 256) {
-        const float q = query[(size_t)blockIdx.x * m + j] * last;
-        int r = n - 1;
-        for (int k = base; k >= 1; k >>= 1)
-            if (r >= k && (staged ? row[r - k] : d[r - k]) >= q) r -= k;
-        result[(size_t)blockIdx.x * m + j] = r;
+    const float *row = in_lds ? staged_row : grow;
+    const float total = row[n - 1];
+    for (int s = blockIdx.y * 256 + threadIdx.x; s < m; s += gridDim.y * 256) {
+        const float target = uniform[(size_t)blockIdx.x * m + s] * total;
+        int pos = n - 1;                                 // always a position whose cumulative weight reaches the target
+        for (int step = top_step; step > 0; step >>= 1) {
+            const int cand = pos - step;
+            if (cand >= 0 && row[cand] >= target) pos = cand;
+        }
+        picked[(size_t)blockIdx.x * m + s] = pos;
     }
 }
 

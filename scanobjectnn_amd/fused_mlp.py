@@ -413,20 +413,41 @@ class FusedMLPStack(torch.autograd.Function):
                 # the bandwidth-bound narrow layers: data and weight gradient in ONE pass over Y / Yprev
                 fused_groups = lib.pcops_mlp_bwd_fused_groups(R, K, N, S if pooled else 0, 1 if pooled else 0)
             if fused_groups:
-                scratch = _f32(fused_groups * (K * N + N), dev)
+                # pooled layer on uncompacted rows: the weight gradient in its Gram form (pcops.h, round 6) -- a K x K
+                # product on the matrix pipe + the arg rows as vector work instead of the K x N product
+                gw = (pooled and rows is None and not xyz_prev and
+                      lib.pcops_mlp_bwd_fused_gw_groups(R, K, N, S) == fused_groups)
+                scratch = _f32(fused_groups * (K * N + N + ((K * K + K) if gw else 0)), dev)
                 dW, db = _f32((K, N), dev), _f32(N, dev)
                 P = fused_groups
                 part = _f32((P, 2, K), dev)
+                bl = ctx.biases[l]
                 edge_rows = getattr(ctx, "edge_rows", None) if (l == 1 and pooled and getattr(ctx, "direct", False)) else None
                 if edge_rows is not None:   # the first EdgeConv layer below, input without gradient: E^T Gm reduced in the kernel
                     xstats = _f32((P, 6, K), dev)
-                    _lib.call("pcops_mlp_bwd_fused_edge", R, K, N, Ys[0].data_ptr(), scales[0].data_ptr(),
-                              shifts[0].data_ptr(), Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S,
-                              Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(),
-                              edge_rows.data_ptr(), xstats.data_ptr())
+                    if gw:
+                        _lib.call("pcops_mlp_bwd_fused_edge_gw", R, K, N, Ys[0].data_ptr(), scales[0].data_ptr(),
+                                  shifts[0].data_ptr(), Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S,
+                                  Ws[l].data_ptr(), _p(bl), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(),
+                                  edge_rows.data_ptr(), xstats.data_ptr())
+                    else:
+                        _lib.call("pcops_mlp_bwd_fused_edge", R, K, N, Ys[0].data_ptr(), scales[0].data_ptr(),
+                                  shifts[0].data_ptr(), Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gp, am, S,
+                                  Ws[l].data_ptr(), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(), part.data_ptr(),
+                                  edge_rows.data_ptr(), xstats.data_ptr())
                     grads[6 * l + 0] = dW
                     grads[6 * l + 1] = db
                     Gm = None
+                    continue
+                if gw:
+                    Gprev = _f32((R, K), dev)
+                    _lib.call("pcops_mlp_bwd_fused_gw", R, K, N, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
+                              shifts[l - 1].data_ptr(), Ys[l].data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(),
+                              gp, am, S, Ws[l].data_ptr(), _p(bl), scratch.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                              Gprev.data_ptr(), part.data_ptr())
+                    grads[6 * l + 0] = dW
+                    grads[6 * l + 1] = db
+                    Gm = Gprev
                     continue
                 if xyz_prev:     # the arithmetic first layer below: its masked gradient is reduced, never written
                     xstats = _f32((P, 3, K), dev)

@@ -260,8 +260,11 @@ def test_bga_logits_and_mask_at_bench_size_eval():
 # the batch, so the float64 truth cannot be chunked by cloud; it does not have to be -- the float64 autograd graph of the
 # whole (256, 2048) batch is ~100 GB and the MI355X has 288.  The fused path's loss, its decisions (read back as in
 # test_models_parity_gpu.py) and the gradient of EVERY variable are compared with float64 autograd of the restatement on
-# those decisions (masked gradient error <= 1e-4, every variable's own gradient <= 5e-3 of its norm), at the size bench.py times.
-@pytest.mark.parametrize("name,batch", [("ssg", 256), ("bga", 128)])
+# those decisions (masked gradient error <= 1e-4, every variable's own gradient <= 2e-3 of its norm), at the size bench.py times.
+# Round 6 (VERDICT r5 missing #3): configs 3's two models too -- DGCNN at 256 clouds (its float64 graph is the largest of the
+# five: ~200 GB of the chip's 288) and DGCNN-BGA at 128 -- and the per-variable bar at 2e-3 (it was 5e-3; one variable of the
+# five models sits above 1e-3: SA3's top-layer beta at 1.3e-3, 1 024 sums of 256 pooled rows each).
+@pytest.mark.parametrize("name,batch", [("ssg", 256), ("bga", 128), ("dgcnn", 256), ("dgcnn_bga", 128)])
 def test_train_step_at_bench_batch(name, batch, monkeypatch):
     import json
     import test_models_parity_gpu as T
@@ -283,7 +286,7 @@ def test_train_step_at_bench_batch(name, batch, monkeypatch):
     for k, v in c["per_variable_fused"].items():
         if k.endswith("biases") and (k[:-len("biases")] + "bn/gamma") in c["per_variable_fused"]:
             continue
-        assert v <= 5e-3, (k, v)          # (the small vectors -- a top layer's beta: 1024 sums of a few pooled rows -- sit at 1e-3)
+        assert v <= 2e-3, (k, v)          # (the small vectors -- a top layer's beta: 1024 sums of a few pooled rows -- sit at 1e-3)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(path, exist_ok=True)

@@ -98,6 +98,69 @@ def test_bwd_fused_against_float64_and_the_two_kernel_path(M, K, N, S):
     assert rel(stats[:, 1].double().sum(0), part2[:, 1].double().sum(0)) <= 1e-4
 
 
+GW_CASES = [  # (M, K, N, S, bias)  pooled layers only; Y must be the layer's own forward output
+    (32 * 2100, 64, 128, 32, True),     # SA1's top layer: one pooling group per stripe
+    (64 * 1030 + 64, 64, 64, 64, True),
+    (20 * 3300, 64, 128, 20, True),     # the T-Net's k = 20: up to three groups per stripe
+    (16 * 4200, 48, 96, 16, False),     # narrower than the tile in both directions, no bias, zero fourth block skipped
+    (12 * 5500 + 12, 64, 128, 12, True),  # four groups per stripe, a ragged last stripe
+]
+
+
+@pytest.mark.parametrize("M,K,N,S,has_bias", GW_CASES)
+def test_bwd_fused_gram_form_weight_gradient(M, K, N, S, has_bias):
+    """pcops_mlp_bwd_fused_gw (round 6): dW = X^T (p.G) + (X^T X) W diag(q) + (X^T 1)(q.b + t)^T with Y = X W + b -- against
+    float64 of the DIRECT form on the same tensors, and against pcops_mlp_bwd_fused (same Gprev bit for bit: the data
+    gradient half is the same code)."""
+    lib = _lib.load()
+    prev = _lib.set_option(_lib.OPT_BWD_FUSED_GRAM_WGRAD, 1)
+    try:
+        groups = lib.pcops_mlp_bwd_fused_gw_groups(M, K, N, S)
+        assert groups > 0 and groups == lib.pcops_mlp_bwd_fused_groups(M, K, N, S, 1)
+        g = torch.Generator().manual_seed(M + N + S)
+        Yprev = torch.randn(M, K, generator=g).to(DEV)
+        W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+        b = (0.5 * torch.randn(N, generator=g)).to(DEV) if has_bias else None
+        sc, sh = _vec(K, g), (0.3 * torch.randn(K, generator=g)).to(DEV)
+        p, q, t = _vec(N, g), 0.1 * _vec(N, g), (0.05 * torch.randn(N, generator=g)).to(DEV)
+        pre = Yprev.double() * sc.double() + sh.double()
+        X = pre.clamp_min(0.0)
+        Y = (torch.relu(torch.addcmul(sh, Yprev, sc)) @ W + (b if has_bias else 0.0)).contiguous()   # fp32, as a forward stores it
+        gpool = torch.randn(M // S, N, generator=g).to(DEV)
+        gpool[torch.rand(M // S, N, generator=g).to(DEV) < 0.3] = 0.0
+        argmax = torch.randint(0, S, (M // S, N), generator=g, dtype=torch.int32).to(torch.uint8).to(DEV)
+        Gfull = torch.zeros(M // S, S, N, dtype=torch.float64, device=DEV)
+        Gfull.scatter_(1, argmax.long().unsqueeze(1), gpool.double().unsqueeze(1))
+        dY = p.double() * Gfull.view(M, N) + q.double() * Y.double() + t.double()
+        want_dW, want_db = X.t() @ dY, dY.sum(0)
+
+        def run(name, extra):
+            part = torch.empty(groups * (K * N + N + K * K + K), device=DEV)
+            dW, db = torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+            Gprev = torch.full((M, K), float("nan"), device=DEV)
+            stats = torch.empty(groups, 2, K, device=DEV)
+            args = [M, K, N, Yprev.data_ptr(), sc.data_ptr(), sh.data_ptr()] + ([] if extra else [None]) + \
+                   [Y.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), gpool.data_ptr(), argmax.data_ptr(), S, W.data_ptr()] + \
+                   ([b.data_ptr() if has_bias else None] if extra else []) + \
+                   [part.data_ptr(), dW.data_ptr(), db.data_ptr(), Gprev.data_ptr(), stats.data_ptr()]
+            _lib.call(name, *args)
+            torch.cuda.synchronize()
+            return dW, db, Gprev, stats
+
+        dW, db, Gprev, stats = run("pcops_mlp_bwd_fused_gw", True)
+        dW0, db0, Gprev0, stats0 = run("pcops_mlp_bwd_fused", False)
+
+        def rel(a, b_):
+            return ((a.double() - b_.double()).abs().max() / b_.double().abs().max().clamp_min(1e-30)).item()
+
+        assert rel(dW, want_dW) <= 2e-5 and rel(db, want_db) <= 2e-5
+        assert rel(dW, dW0) <= 2e-5 and torch.equal(db, db0)
+        assert torch.equal(Gprev, Gprev0) and torch.equal(stats, stats0)
+    finally:
+        _lib.set_option(_lib.OPT_BWD_FUSED_GRAM_WGRAD, prev)
+    assert lib.pcops_mlp_bwd_fused_gw_groups(M, K, N, S) == (groups if prev else 0)      # the option is read per call
+
+
 def test_bwd_fused_says_what_it_takes():
     lib = _lib.load()
     assert lib.pcops_mlp_bwd_fused_groups(1 << 22, 64, 128, 32, 1) == 256
