@@ -512,8 +512,11 @@ int pcops_sa_scatter_bwd(int b, int n, int m, int s, int c, const float *G, cons
  *             dCtr[g] = q (SQ + k Ctr) + k t + a[g],  a = p gpool [relu(bn(ysel)) > 0],
  *             dQ[i] = cnt_i (q Q[i] + t) + q sum_{(g,s)->i} Ctr[g] + sum_{g: arg row -> i} a[g]   (inverse index of idx)
  * workspace: pcops_sa_scatter_workspace_bytes(b,n,m,s) bytes.  s <= 256. */
-int pcops_edge_pool_stats_rows(long long groups);
-/* rows of stats_partial THIS call shape writes (<= pcops_edge_pool_stats_rows(b*m)): the 64-channel-slice kernels of
+int pcops_edge_pool_stats_rows(long long groups);     /* ABI >= 4: an UPPER BOUND (buffer size) only, see below */
+/* ABI version 4 (round 6, was an unversioned change of round 5): pcops_edge_pool_fwd and pcops_sa_gather_fwd write the number
+ * of rows THESE per-shape queries return -- rows beyond stay untouched -- so pcops_mlp_bn_finalize must be given that count,
+ * not the shape-less one; a caller built against the round-4 header must be rebuilt (pcops_abi_version() tells).
+ * rows of stats_partial THIS call shape writes (<= pcops_edge_pool_stats_rows(b*m)): the 64-channel-slice kernels of
  * csrc/edgeconv.hip write one row per 64 groups, or one per cloud when the cloud's slice is LDS-resident */
 int pcops_edge_pool_fwd_stats_rows(int b, int n, int m, int s, int c);
 int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const float *Ctr, const int *idx,
@@ -745,6 +748,13 @@ int pcops_fc_bn_fwd(int R, int C, const float *x, const float *gamma, const floa
 int pcops_fc_bn_bwd(int R, int C, const float *dy, const float *x, const float *y, const float *gamma,
                     const float *save_mean, const float *save_rstd, int training, int relu, float *dx,
                     float *dgamma, float *dbeta, pcops_stream_t stream);
+
+/* the learned 3 x 3 input transform applied to a cloud (tf.matmul(point_cloud, transform): dgcnn/models/dgcnn.py:37,
+ * pointnet/models/pointnet_cls.py:27): out (b, n, 3) = x (b, n, 3) T (b, 3, 3); backward dT (b, 3, 3) = x^T grad_out per cloud in a
+ * fixed order, dx = grad_out T^T (dx may be NULL: the input cloud needs no gradient). */
+int pcops_transform3_fwd(int b, int n, const float *x, const float *T, float *out, pcops_stream_t stream);
+int pcops_transform3_bwd(int b, int n, const float *x, const float *T, const float *grad_out, float *dT, float *dx,
+                         pcops_stream_t stream);
 
 #ifdef __cplusplus
 }

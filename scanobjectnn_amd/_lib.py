@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCOPS_LIB") or os.path.join(_HERE, "libpcops.so")      # PCOPS_LIB: A/B runs of two builds
 
 _I, _F, _P, _U64, _LL = C.c_int, C.c_float, C.c_void_p, C.c_ulonglong, C.c_longlong
-ABI_VERSION = 3      # pcops_abi_version() of the library this binding matches (include/pcops.h), checked in load()
+ABI_VERSION = 4      # pcops_abi_version() of the library this binding matches (include/pcops.h), checked in load()
 
 # name -> (argtypes without the trailing stream, has_stream)
 SIGNATURES = {
@@ -102,6 +102,8 @@ SIGNATURES = {
     "pcops_sa_scatter_bwd_ld": ([_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P], True),
     "pcops_edge_weights_fwd": ([_I, _I, _I, _P, _P, _P, _P], True),
     "pcops_edge_weights_bwd": ([_I, _I, _P, _P, _P, _P], True),
+    "pcops_transform3_fwd": ([_I, _I, _P, _P, _P], True),
+    "pcops_transform3_bwd": ([_I, _I, _P, _P, _P, _P, _P], True),
     "pcops_fc_bn_fwd": ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P], True),
     "pcops_fc_bn_bwd": ([_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P], True),
 }

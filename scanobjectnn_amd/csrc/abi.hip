@@ -17,8 +17,10 @@ extern "C" const char *pcops_strerror(int status) {
     }
 }
 
-extern "C" int pcops_abi_version(void) { return 3; }   // 2: stat_pivot (shifted BN moments) on the forward-statistics producers
+extern "C" int pcops_abi_version(void) { return 4; }   // 2: stat_pivot (shifted BN moments) on the forward-statistics producers
                                                         // 3: one-pass backward (pcops_mlp_bwd_fused*), pcops_adam_step
+                                                        // 4: pcops_edge_pool_fwd / pcops_sa_gather_fwd write pcops_*_fwd_stats_rows(shape)
+                                                        //    rows of partial statistics; the shape-less queries are upper bounds only
 
 // bit-reproducible backward passes (reference hazard tf_grouping_g.cu:61-78, tf_sampling_g.cu:183-192:
 // float atomics).  Off: scatter-adds may use atomics / unordered lists.  On: every sum is taken by one owner in

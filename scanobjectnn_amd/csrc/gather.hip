@@ -1680,12 +1680,8 @@ int pcops_sa_gather_fwd_rows(int b, int n, int m, int s, int c, const float *Q, 
     if (Wxyz) { PCOPS_REQUIRE_PTR(xyz); PCOPS_REQUIRE_PTR(new_xyz); }
     if (gather_fwd_is_ec(b, n, m, s, c, Q != nullptr, Ctr != nullptr, Wxyz != nullptr || bias != nullptr || off4 != nullptr ||
                          moments != nullptr, rows != nullptr) && Y != nullptr) {
-        // the edgeconv.hip kernel writes ec_stats_rows(G) rows of partial statistics; a caller that sized and finalises the
-        // buffer with the shape-less query of round 4 (pcops_sa_gather_stats_rows) must not meet uninitialised rows
-        const int wr = ec_stats_rows(G), old = pcops_sa_gather_stats_rows(G);
-        if (stats_partial && wr < old &&
-            hipMemsetAsync(stats_partial + (long long)wr * 2 * c, 0, (size_t)(old - wr) * 2 * c * sizeof(float), as_stream(stream)) != hipSuccess)
-            return PCOPS_ERR_LAUNCH;
+        // (writes pcops_sa_gather_fwd_stats_rows(...) rows of partial statistics -- fewer than the shape-less upper bound
+        // pcops_sa_gather_stats_rows(G): ABI version 4, pcops.h)
         return ec_gather_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, Y, stats_partial, stat_pivot, as_stream(stream));
     }
     const int rl = 256 / (c / 4);
@@ -1934,12 +1930,7 @@ int pcops_edge_pool_fwd(int b, int n, int m, int s, int c, const float *Q, const
     // round 5: 64-channel slices, offsets staged in LDS, XCD-contiguous clouds (edgeconv.hip); same outputs, and
     // b m / 64 = pcops_edge_pool_stats_rows(G) rows of partial statistics
     if (ec_fwd_supported(b, n, m, s, c) && s <= 256) {
-        // (rows beyond what this shape's kernel writes are zeroed: the shape-less query pcops_edge_pool_stats_rows is still
-        // a valid size for the buffer and a valid row count for pcops_mlp_bn_finalize)
-        const int wr = ec_edge_pool_stats_rows(b, n, m), old = pcops_edge_pool_stats_rows(G);
-        if (stats_partial && wr < old &&
-            hipMemsetAsync(stats_partial + (long long)wr * 2 * c, 0, (size_t)(old - wr) * 2 * c * sizeof(float), as_stream(stream)) != hipSuccess)
-            return PCOPS_ERR_LAUNCH;
+        // (writes pcops_edge_pool_fwd_stats_rows(...) rows, not the shape-less upper bound: ABI version 4, pcops.h)
         return ec_edge_pool_fwd(b, n, m, s, c, Q, c, Ctr, c, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot, as_stream(stream));
     }
     const int gl = 256 / (c / 4);

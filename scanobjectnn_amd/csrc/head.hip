@@ -96,6 +96,55 @@ __global__ __launch_bounds__(256) void fc_bn_bwd_kernel(int R, int C, const floa
     }
 }
 
+// ---- the learned 3 x 3 input transform applied to a cloud: out[b][n][:] = x[b][n][:] T[b]  (dgcnn/models/dgcnn.py:37,
+// pointnet/models/pointnet_cls.py:27: tf.matmul(point_cloud, transform)).  Rounds 1-5 left it to a library GEMM -- two Tensile
+// kernels of 30-40 us per step for 9 multiply-adds per point.
+__global__ __launch_bounds__(256) void transform3_fwd_kernel(long long total, int n, const float *__restrict__ x,
+                                                             const float *__restrict__ T, float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const float *t = T + (i / n) * 9;
+        const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+        out[3 * i] = fmaf(c, t[6], fmaf(b, t[3], a * t[0]));
+        out[3 * i + 1] = fmaf(c, t[7], fmaf(b, t[4], a * t[1]));
+        out[3 * i + 2] = fmaf(c, t[8], fmaf(b, t[5], a * t[2]));
+    }
+}
+
+// dT[b][i][j] = sum_n x[b][n][i] g[b][n][j] (one workgroup per cloud, fixed summation order);  dx = g T^T when asked for
+__global__ __launch_bounds__(256) void transform3_bwd_kernel(int n, const float *__restrict__ x, const float *__restrict__ T,
+                                                             const float *__restrict__ g, float *__restrict__ dT,
+                                                             float *__restrict__ dx) {
+    __shared__ float sm[4][9];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *xb = x + (long long)b * n * 3, *gb = g + (long long)b * n * 3;
+    float t[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) t[e] = T[b * 9 + e];
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = tid; p < n; p += 256) {
+        const float xv[3] = {xb[3 * p], xb[3 * p + 1], xb[3 * p + 2]};
+        const float gv[3] = {gb[3 * p], gb[3 * p + 1], gb[3 * p + 2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[3 * i + j] = fmaf(xv[i], gv[j], acc[3 * i + j]);
+        if (dx) {
+            float *d = dx + ((long long)b * n + p) * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) d[i] = fmaf(gv[2], t[3 * i + 2], fmaf(gv[1], t[3 * i + 1], gv[0] * t[3 * i]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        float v = acc[e];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) sm[wave][e] = v;
+    }
+    __syncthreads();
+    if (tid < 9) dT[b * 9 + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+}
+
 }  // namespace
 
 extern "C" int pcops_fc_bn_fwd(int R, int C, const float *x, const float *gamma, const float *beta, float *moving_mean,
@@ -118,5 +167,24 @@ extern "C" int pcops_fc_bn_bwd(int R, int C, const float *dy, const float *x, co
     if (relu) PCOPS_REQUIRE_PTR(y);
     hipLaunchKernelGGL(fc_bn_bwd_kernel, dim3((C + kHeadCh - 1) / kHeadCh), dim3(256), 0, as_stream(stream), R, C, dy, x, y,
                        gamma, save_mean, save_rstd, training, relu, dx, dgamma, dbeta);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_transform3_fwd(int b, int n, const float *x, const float *T, float *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0);
+    const long long total = (long long)b * n;
+    if (total == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(x); PCOPS_REQUIRE_PTR(T); PCOPS_REQUIRE_PTR(out);
+    const unsigned grid = cdiv(total, 256) < 4096u ? cdiv(total, 256) : 4096u;
+    hipLaunchKernelGGL(transform3_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total, n, x, T, out);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_transform3_bwd(int b, int n, const float *x, const float *T, const float *grad_out, float *dT, float *dx,
+                                    pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 1);
+    if (b == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(x); PCOPS_REQUIRE_PTR(T); PCOPS_REQUIRE_PTR(grad_out); PCOPS_REQUIRE_PTR(dT);
+    hipLaunchKernelGGL(transform3_bwd_kernel, dim3(b), dim3(256), 0, as_stream(stream), n, x, T, grad_out, dT, dx);
     return pcops_launch_status();
 }

@@ -1127,6 +1127,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         for (int nt = 0; nt < NT; ++nt) sm[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nt], sm[nt], 0, 0, 0);
                     }
                 }
+                // (the steps of a chunk as ONE basic block -- no wave-uniform branch per step, so that a step's LDS reads may move
+                // under the previous step's matrix instructions -- measured in round 6: the 128-column forward kernels then
+                // spill (fwd_pool 64 -> 128: 683 -> 2 250 us), the 64-column data gradients do not move (1 127 -> 1 148 us))
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             } else {
             const float *arow = &Aw[(lane & 31) * LDW + 4 * (lane >> 5)];
@@ -1221,7 +1224,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             }
             if (EM == E_MASK || EM == E_MASKA) {
                 // the mask tensor is requested HERE (not a tile ahead): it would cost NST more live float4 across the
-                // whole MFMA phase, and with two waves per SIMD the partner wave covers this latency
+                // whole MFMA phase, and with two waves per SIMD the partner wave covers this latency.  (Round 6 measured the
+                // request a phase ahead on the split-operand data gradients, which have the registers: 1 127 -> 1 148 us and
+                // 587 -> 579 us -- nothing.)
 #pragma unroll
                 for (int j = 0; j < NST; ++j) py[j] = buf_load4(rprev, yvoff, (unsigned)j * yrowstep);
             }

@@ -46,7 +46,7 @@ def backbone(point_cloud, is_training, bn_decay, k=20):
         else:
             edge_feature = tf_util.get_edge_feature(point_cloud, nn_idx=nn_idx, k=k)
             transform = input_transform_net(edge_feature, is_training, bn_decay, K=3)
-    point_cloud_transformed = torch.matmul(point_cloud, transform)
+    point_cloud_transformed = tf_util.apply_transform(point_cloud, transform)
     cat = None
     if point_cloud.is_cuda and tf_util.fused_ok(point_cloud_transformed, [64]):
         # the four EdgeConv layers store their outputs straight into their column blocks of the (B, N, 1, 320) tensor the

@@ -221,6 +221,37 @@ def get_edge_feature(point_cloud, nn_idx, k=20):
 
 
 # ---------------------------------------------------------------------------- fused EdgeConv / conv stacks
+class _Transform3(torch.autograd.Function):
+    """point_cloud (B, N, 3) x transform (B, 3, 3) -- tf.matmul(point_cloud, transform) of dgcnn.py:37 -- on
+    pcops_transform3_fwd / _bwd (one launch per direction; a library GEMM ran two Tensile kernels of 30-40 us for it)"""
+
+    @staticmethod
+    def forward(ctx, pc, T):
+        pc, T = pc.contiguous(), T.contiguous()
+        out = torch.empty_like(pc)
+        _lib.call("pcops_transform3_fwd", pc.shape[0], pc.shape[1], pc.data_ptr(), T.data_ptr(), out.data_ptr())
+        ctx.save_for_backward(pc, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pc, T = ctx.saved_tensors
+        g = g.contiguous()
+        dT = torch.empty_like(T)
+        dx = torch.empty_like(pc) if ctx.needs_input_grad[0] else None
+        _lib.call("pcops_transform3_bwd", pc.shape[0], pc.shape[1], pc.data_ptr(), T.data_ptr(), g.data_ptr(), dT.data_ptr(),
+                  None if dx is None else dx.data_ptr())
+        return dx, dT
+
+
+def apply_transform(point_cloud, transform):
+    """tf.matmul(point_cloud, transform) for a (B, N, 3) cloud and a (B, 3, 3) transform"""
+    if (point_cloud.is_cuda and point_cloud.dtype == torch.float32 and point_cloud.dim() == 3 and point_cloud.shape[-1] == 3
+            and tuple(transform.shape) == (point_cloud.shape[0], 3, 3)):
+        return _Transform3.apply(point_cloud, transform)
+    return torch.matmul(point_cloud, transform)
+
+
 def fused_ok(x, widths):
     return (_pn2.FUSED_MLP and x.is_cuda and x.dtype == torch.float32 and all(w % 32 == 0 for w in widths)
             and 256 % (widths[0] // 4) == 0 and (widths[0] >= 256 or 256 % widths[0] == 0) and widths[0] <= 1024)
@@ -322,6 +353,23 @@ def conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist=False, p
                              unbiased_moving_var=False, mov_names=names)
 
 
+class _FirstMax(torch.autograd.Function):
+    """amax over one dimension whose gradient goes to the FIRST maximal member (the contract of every pooling
+    kernel here; torch's own amax backward splits the gradient evenly over exact fp32 ties)"""
+
+    @staticmethod
+    def forward(ctx, x, dim):
+        out = x.amax(dim=dim, keepdim=True)
+        ctx.save_for_backward(x.argmax(dim=dim, keepdim=True))
+        ctx.dim, ctx.shape = dim, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).scatter_(ctx.dim, arg, g), None
+
+
 def conv2d_stack_global_max(inputs, widths, scopes, is_training, bn_decay, is_dist=False):
     """conv stack on (B,N,1,C) followed by the max over ALL points (the reference's `agg` conv + max_pool2d over
     [num_point,1], dgcnn.py:79-84): the max is associative, so it is taken inside the fused stack over chunks of 256
@@ -333,4 +381,4 @@ def conv2d_stack_global_max(inputs, widths, scopes, is_training, bn_decay, is_di
         return conv2d_stack(inputs, widths, scopes, is_training, bn_decay, is_dist).amax(dim=1, keepdim=True)
     part = conv2d_stack(inputs.reshape(b, n // chunk, chunk, c), widths, scopes, is_training, bn_decay, is_dist,
                         pool_max=True)                               # (B, N/chunk, 1, C')
-    return part.amax(dim=1, keepdim=True)
+    return _FirstMax.apply(part, 1)

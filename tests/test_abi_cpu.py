@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 35
     for s in syms:
         assert hasattr(lib, s), "libpcops.so does not export %s (declared in include/pcops.h)" % s
-    assert lib.pcops_abi_version() >= 3
+    assert lib.pcops_abi_version() >= 4
     assert _lib.strerror(0) == "ok" and "null" in _lib.strerror(-1)
 
 

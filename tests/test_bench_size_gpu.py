@@ -260,10 +260,10 @@ def test_bga_logits_and_mask_at_bench_size_eval():
 # the batch, so the float64 truth cannot be chunked by cloud; it does not have to be -- the float64 autograd graph of the
 # whole (256, 2048) batch is ~100 GB and the MI355X has 288.  The fused path's loss, its decisions (read back as in
 # test_models_parity_gpu.py) and the gradient of EVERY variable are compared with float64 autograd of the restatement on
-# those decisions (masked gradient error <= 1e-4, every variable's own gradient <= 2e-3 of its norm), at the size bench.py times.
+# those decisions (masked gradient error <= 1e-4, every variable's own gradient <= 1e-3 of its norm), at the size bench.py times.
 # Round 6 (VERDICT r5 missing #3): configs 3's two models too -- DGCNN at 256 clouds (its float64 graph is the largest of the
-# five: ~200 GB of the chip's 288) and DGCNN-BGA at 128 -- and the per-variable bar at 2e-3 (it was 5e-3; one variable of the
-# five models sits above 1e-3: SA3's top-layer beta at 1.3e-3, 1 024 sums of 256 pooled rows each).
+# five: ~200 GB of the chip's 288) and DGCNN-BGA at 128 -- and the per-variable bar at 1e-3 (it was 5e-3), for every variable whose gradient is at least 1e-4 of the whole (the
+# variables below have the exact gradient 0: their fp32 value is rounding residue).  The DGCNN-BGA case found a product bug: torch's amax over the chunk maxima of a whole-cloud pool split the gradient over exact ties (dgcnn/tf_util._FirstMax).
 @pytest.mark.parametrize("name,batch", [("ssg", 256), ("bga", 128), ("dgcnn", 256), ("dgcnn_bga", 128)])
 def test_train_step_at_bench_batch(name, batch, monkeypatch):
     import json
@@ -278,15 +278,20 @@ def test_train_step_at_bench_batch(name, batch, monkeypatch):
     # 16x the rows of the 16-cloud tests behind every weight-gradient sum: fp32 accumulation noise grows with them (measured
     # 4.3e-5 on ssg against 6e-6 at 16 clouds); the bar here is the contract's 1e-4, the 16-cloud tests keep 3e-5
     assert c["em_fused"] <= 1e-4, c["em_fused"]
-    judged = {k: v for k, v in c["per_variable_fused"].items()
-              if not (k.endswith("biases") and (k[:-len("biases")] + "bn/gamma") in c["per_variable_fused"])}
-    worst = max(judged.items(), key=lambda kv: kv[1])
-    # per variable: relative error of its gradient on the path's own decisions (biases in front of a batch norm have the exact
-    # gradient 0 -- pure rounding residue on both sides -- and are judged by the whole-gradient figure above only)
-    for k, v in c["per_variable_fused"].items():
-        if k.endswith("biases") and (k[:-len("biases")] + "bn/gamma") in c["per_variable_fused"]:
-            continue
-        assert v <= 2e-3, (k, v)          # (the small vectors -- a top layer's beta: 1024 sums of a few pooled rows -- sit at 1e-3)
+    # per variable: relative error of its gradient on the path's own decisions.  A relative error needs a gradient to be
+    # relative to: biases in front of a batch norm have the EXACT gradient 0 (pure rounding residue on both sides), and so has
+    # the beta of a pooled top layer in front of a batch-normalised FC layer -- variables whose gradient is below 1e-4 of the
+    # whole are judged by the whole-gradient figure above only
+    def exempt(k):
+        return k.endswith("biases") and ((k[:-len("biases")] + "bn/gamma") in c["per_variable_fused"] or
+                                         (k[:-len("biases")] + "bn/beta") in c["per_variable_fused"])
+    judged = {k: v for k, v in c["per_variable_fused"].items() if not exempt(k)}
+    nrm = c["grad_norm_fused"]
+    total = sum(v * v for v in nrm.values()) ** 0.5
+    worst = max(((k, v) for k, v in judged.items() if nrm[k] >= 1e-4 * total), key=lambda kv: kv[1])
+    for k, v in judged.items():
+        if nrm[k] >= 1e-4 * total:
+            assert v <= 1e-3, (k, v)          # (measured worst over the four models: 2.3e-4, a T-Net weight)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(path, exist_ok=True)

@@ -81,3 +81,26 @@ def test_fc_layers_use_the_head_kernel():
         assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-5
         for k in outs[0][1]:
             assert torch.allclose(outs[0][1][k], outs[1][1][k], atol=1e-5, rtol=1e-5), k
+
+
+@pytest.mark.parametrize("B,N,need_dx", [(5, 257, True), (256, 2048, False)])
+def test_input_transform_applied_by_the_head_kernel(B, N, need_dx):
+    """pcops_transform3_fwd / _bwd = tf.matmul(point_cloud, transform) (dgcnn/models/dgcnn.py:37) and its gradients, against
+    float64; dgcnn/tf_util.apply_transform routes (B, N, 3) x (B, 3, 3) through it."""
+    from scanobjectnn_amd.dgcnn import tf_util as td
+    g = torch.Generator().manual_seed(B + N)
+    pc = torch.randn(B, N, 3, generator=g).to(DEV).requires_grad_(need_dx)
+    T = (torch.eye(3) + 0.3 * torch.randn(B, 3, 3, generator=g)).to(DEV).requires_grad_(True)
+    w = torch.randn(B, N, 3, generator=g).to(DEV)
+    out = td.apply_transform(pc, T)
+    (out * w).sum().backward()
+    pc64 = pc.detach().double().requires_grad_(need_dx)
+    T64 = T.detach().double().requires_grad_(True)
+    want = torch.matmul(pc64, T64)
+    (want * w.double()).sum().backward()
+    assert (out.double() - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+    assert (T.grad.double() - T64.grad).abs().max().item() <= 1e-5 * T64.grad.abs().max().item()
+    if need_dx:
+        assert (pc.grad.double() - pc64.grad).abs().max().item() <= 1e-6 * pc64.grad.abs().max().item()
+    else:
+        assert pc.grad is None

@@ -44,8 +44,14 @@ for name, x in cases.items():
     ok = np.array_equal(nn[pick].cpu().numpy(), O.knn_graph(x[pick].numpy(), 20))
     c = x.shape[2]
     flops = 2.0 * B * N * N * c
-    line = "%-14s c=%-3d %8.1f us  %6.1f TF/s  (%.3f of the 157.3 TF/s fp32 MFMA peak)  bit-exact vs oracle: %s" % (
-        name, c, us, flops / us / 1e6, flops / us / 1e6 / 157.3, ok)
+    # priced against the pipe the distances run on: the 64-channel graphs' filter is fp16 MFMA
+    # (2 500 TF/s dense), the coordinate graphs' distances fp32 MFMA (157.3 TF/s) -- and the kernel is bound by neither: the
+    # selection is vector-instruction issue, so the pair rate against 9 lane-operations per pair test is printed too
+    path = int(lib.pcops_knn_graph_path(B, N, c, 20, xd.data_ptr()))          # bits 0-3: 3 = fp16 pre-filter kernel
+    peak, pipe = (2500.0, "fp16 MFMA") if (path & 15) == 3 else (157.3, "fp32 MFMA")
+    pairs = float(B) * N * N
+    line = "%-14s c=%-3d %8.1f us  %6.1f TF/s = %.4f of the %s peak (%.0f TF/s); %.2f T pair tests/s = %.3f of the fp32 VALU rate at 9 lane-ops per pair;  bit-exact vs oracle: %s" % (
+        name, c, us, flops / us / 1e6, flops / us / 1e6 / peak, pipe, peak, pairs / us / 1e6, pairs * 9 / (us * 1e-6) / 78.6e12, ok)
     if has_stats and out[0]:
         line += "   pairs %d  survivors/query %.1f  accepted/query %.1f  rounds/wave %.1f" % (
             out[0], out[1] / (B * N), out[2] / (B * N), out[3] / (B * N / 32.0))

@@ -23,6 +23,9 @@ OUT = os.path.join(ROOT, "gpurun_out")
 # gemm_ws_kernel<NT, AM, EM, KC, WAVES, EH, VAR>, wgrad_pc_kernel<TK, TN, AMODE, DMODE>
 KEYS = [
     # round 2: SA2 runs on compacted rows (bench.py tags those shapes 'compacted'; the grid is the launch's upper bound)
+    # round 6: the data gradients of SA2 on split operands, 64-column passes (PCOPS_DGRAD_BF3=0 keeps the fp32 names below)
+    ("gemm_ws_kernel<2, 6, 1, 32, 8, 2, 4>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
+    ("gemm_ws_kernel<2, 2, 1, 32, 8, 2, 4>", None, "pcops_mlp_gemm_dgrad(2097152, 128, 128, 'compacted')"),
     ("gemm_ws_kernel<4, 6, 1, 64, 8, 2, 2>", None, "pcops_mlp_gemm_dgrad(2097152, 256, 128, 'compacted')"),
     # round 4: SA2's two weight gradients run as ONE template instantiation of the split-operand kernel with equal grid
     # sizes (128 x 1 x 2 and 256 x 1 x 1 workgroups): the counters cannot tell them apart, the entry is their average
@@ -124,7 +127,7 @@ def main():
     for (name, grid), f in sorted(fetch.items(), key=lambda kv: -kv[1]):
         w = write.get((name, grid), 0.0)
         total = int((2.0 * f + w) * 1024)
-        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").split("(")[0].replace("void ", "")
         detail["%s|grid=%d" % (short, grid)] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "fetch_correction": 2.0,
                                                 "bytes_per_launch": total, "launches": nf[(name, grid)]}
         for frag, g, key in KEYS:

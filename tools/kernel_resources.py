@@ -29,7 +29,7 @@ def main():
                            capture_output=True, text=True).stdout.splitlines()
     print("%-6s %-6s %-6s %-8s %-5s %-7s %s" % ("VGPR", "AGPR", "SGPR", "scratch", "occ", "vspill", "kernel"))
     for r, n in zip(rows, names):
-        n = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        n = n.replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").split("(")[0].replace("void ", "")
         if flt and flt not in n:
             continue
         print("%-6s %-6s %-6s %-8s %-5s %-7s %s" % (r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"),

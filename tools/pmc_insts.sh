@@ -11,7 +11,7 @@ import collections, csv, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_insts/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").split("(")[0].replace("void ", ""), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
 for (k, g), c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}

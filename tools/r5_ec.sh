@@ -12,7 +12,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/kt/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], int(r.get("Grid_Size") or 0))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").replace("void ", "").split("(")[0][:60], int(r.get("Grid_Size") or 0))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(sys.argv[1] + "/kernels.txt", "w") as o:
     for (n, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         o.write("%-62s grid %9d n=%3d avg %9.1f us\n" % (n, g, len(v), sum(v) / len(v) / 1e3))
@@ -27,7 +27,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(sys.argv[1] + "/pmc_%s/**/*counter_collection.csv" % c, recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
-                tab[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], int(r["Grid_Size"]))][c].append(float(r["Counter_Value"]))
+                tab[(r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").replace("void ", "").split("(")[0][:60], int(r["Grid_Size"]))][c].append(float(r["Counter_Value"]))
 with open(sys.argv[1] + "/traffic.txt", "w") as o:
     for k, v in sorted(tab.items(), key=lambda kv: -sum(kv[1].get("FETCH_SIZE", [0]))):
         f = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [0])))

@@ -14,7 +14,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40], int(r["Grid_Size"]))
+        k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pcops_mlp::", "").replace("void ", "").split("(")[0][:40], int(r["Grid_Size"]))
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[1] + "/counters.txt", "w") as o:
     for k, c in sorted(agg.items(), key=lambda kv: -sum(kv[1].get("GRBM_GUI_ACTIVE", [0]))):

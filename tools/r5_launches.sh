@@ -30,7 +30,7 @@ with open(O + "/summary.txt", "w") as o:
         sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6))
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:70]:
         o.write("%7.1f calls/step %9.1f us/step  avg %8.1f us  %s\n" % (int(r["Calls"]) / steps, float(r["TotalDurationNs"]) / steps / 1e3,
-                                                                 float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "")[:110]))
+                                                                 float(r["AverageNs"]) / 1e3, r["Name"].replace("(anonymous namespace)::", "").replace("pcops_mlp::", "")[:110]))
 PY
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 rm -rf $O/kt
