@@ -1462,6 +1462,11 @@ static bool ws_stream256_enabled() {
     return on;
 }
 
+static bool ws_mask_bn64_enabled() {
+    static const bool on = [] { const char *e = getenv("PCOPS_WS_MASK_BN64"); return !(e && e[0] == '0'); }();   // kernel A/B only
+    return on;
+}
+
 static bool ws_n96_enabled() {
     static const bool on = [] {
         const char *e = getenv("PCOPS_WS_N96");
@@ -1539,6 +1544,15 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, int kind = 0) {
             pl->bf3 = true; pl->kc = 32; pl->bn = bn3; pl->eh = bn3 / 32; pl->wst = false;
             pl->lds = ws_lds_bytes_bf3(a.K, bn3, 8, false, nc);
         }
+    }
+    // masked data gradients that stay on the fp32 pipe (K > 256, the algebraic top-layer forms): their 128-column variants
+    // SPILL -- hipcc reports 148 .. 388 bytes of scratch per lane (36 .. 96 registers) for gemm_ws_kernel<4, *, E_MASK*, 64, ..>,
+    // which is what round 5's "1.46 x counted traffic" of SA2's 256 -> 128 data gradient was (scratch stores and reloads are
+    // global memory: profiles/r06_pmc_dgrad_f32.txt) -- the 64-column variants (195 .. 240 registers) do not
+    if (kind >= 2 && !pl->bf3 && pl->bn == 128 && ws_mask_bn64_enabled()) {
+        pl->bn = 64; pl->eh = 1;
+        pl->lds = pl->wst ? ws_lds_bytes_streamed((a.K + 63) / 64 * 64, pl->kc, 64, pl->waves, 1, ws_ncoef(am))
+                          : ws_lds_bytes((a.K + 63) / 64 * 64, pl->kc, 64, pl->waves, 1);
     }
     if (pl->lds > 160 * 1024) return false;
     pl->ncb = (a.N + pl->bn - 1) / pl->bn;
@@ -1693,7 +1707,7 @@ static bool ws_enabled() {
 template <int AM, int EM>
 static int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : 0))) {
+    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : (is_mask(EM) ? 3 : 0)))) {
         int rc;
         if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
         else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
@@ -4488,7 +4502,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
 template <int AM, int EM>
 static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : 0)))) return PCOPS_ERR_UNSUPPORTED;
+    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : (is_mask(EM) ? 3 : 0))))) return PCOPS_ERR_UNSUPPORTED;
     int rc;
     if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
     else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);

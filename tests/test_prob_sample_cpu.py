@@ -105,3 +105,103 @@ def test_prob_sample_exact_boundaries():
     out, temp = O.prob_sample(p, r, return_temp=True)
     np.testing.assert_array_equal(temp, [[1, 2, 4, 8, 8, 8, 16]])
     np.testing.assert_array_equal(out, [[0, 0, 1, 2, 2, 3, 6, 6]])
+
+
+# ---- round 6: the kernel's own organisation of the same tree (csrc/sampling.hip cumsum_kernel), restated in numpy float32:
+# a lane owns eight consecutive quads (three tree levels in its registers), the lanes' top nodes climb six levels by wave
+# shuffles and two over the four waves' tops, and a quad's prefix is the Fenwick query from the LARGEST block down.
+def cumsum_lane_layout(x):
+    x = np.asarray(x, F)
+    n = len(x)
+    out = np.zeros(n, F)
+    carry, lost = F(0), F(0)
+    for c0 in range(0, n, 8192):
+        c = x[c0:c0 + 8192]
+        ln = len(c)
+        nq = (ln + 3) // 4
+        part = np.zeros((256, 8, 4), F)
+        nd = np.zeros((256, 8), F)
+        for lane in range(256):
+            for i in range(8):
+                e0 = (lane * 8 + i) * 4
+                if e0 + 3 < ln:
+                    a, b, cc, d = c[e0:e0 + 4]
+                    lo, hi = F(b + a), F(d + cc)
+                    part[lane, i] = (a, lo, F(cc + lo), F(hi + lo))
+                    nd[lane, i] = part[lane, i, 3]
+                elif e0 < ln:
+                    run = F(0)
+                    for l in range(4):
+                        if e0 + l < ln:
+                            run = F(run + c[e0 + l])
+                        part[lane, i, l] = run
+                    nd[lane, i] = run
+        have = nq - 8 * np.arange(256)
+        for a_, b_, need in ((1, 0, 1), (3, 2, 3), (5, 4, 5), (7, 6, 7), (3, 1, 3), (7, 5, 7), (7, 3, 7)):
+            m = have > need
+            nd[m, a_] = (nd[m, a_] + nd[m, b_]).astype(F)
+        top = nd[:, 7].copy()
+        whole = have > 7
+        for lv in range(6):                                   # inside a wave of 64 lanes
+            below = np.empty_like(top)
+            for lane in range(256):
+                src = lane - (1 << lv)
+                below[lane] = top[src] if (lane % 64) >= (1 << lv) else top[lane]
+            m = (((np.arange(256) % 64) + 1) & ((2 << lv) - 1)) == 0
+            m &= whole
+            top[m] = (top[m] + below[m]).astype(F)
+        w = [top[63], top[127], top[191], top[255]]
+        if whole[127]:
+            top[127] = F(w[1] + w[0])
+        if whole[255]:
+            top[255] = F(F(w[3] + w[2]) + F(w[1] + w[0]))
+
+        def tops_before(lane_ix):
+            acc, any_ = F(0), False
+            for bit in range(8, -1, -1):
+                if (lane_ix >> bit) & 1:
+                    at = (lane_ix & ~((1 << bit) - 1)) - 1
+                    acc = F(top[at] + acc) if any_ else top[at]
+                    any_ = True
+            return acc, any_
+        total = None
+        for lane in range(256):
+            if lane * 8 >= nq:
+                break
+            before, any_ = tops_before(lane)
+            pre = np.zeros(8, F)
+            pre[0] = F(nd[lane, 0] + before) if any_ else nd[lane, 0]
+            pre[1] = F(nd[lane, 1] + before) if any_ else nd[lane, 1]
+            pre[2] = F(nd[lane, 2] + pre[1])
+            pre[3] = F(nd[lane, 3] + before) if any_ else nd[lane, 3]
+            pre[4] = F(nd[lane, 4] + pre[3])
+            pre[5] = F(nd[lane, 5] + pre[3])
+            pre[6] = F(nd[lane, 6] + pre[5])
+            if lane == (nq - 1) // 8:
+                li = (nq - 1) % 8
+                total = tops_before(lane + 1)[0] if li == 7 else pre[li]
+            for i in range(8):
+                q = lane * 8 + i
+                e0 = q * 4
+                if e0 >= ln:
+                    continue
+                add = before if i == 0 else pre[i - 1]
+                for l in range(4):
+                    if e0 + l < ln:
+                        v = part[lane, i, l] if q == 0 else F(part[lane, i, l] + add)
+                        out[c0 + e0 + l] = F(v + carry)
+        inc = F(total + lost)
+        grown = F(carry + inc)
+        lost = F(inc - F(grown - carry))
+        carry = grown
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 31, 32, 33, 36, 255, 1000, 2047, 2048, 4100, 8191, 8192, 8193, 8200, 16384 + 29, 20000])
+def test_cumsum_kernel_layout_has_the_contract_association(n):
+    rng = np.random.default_rng(1000 + n)
+    x = rng.random((2, n)).astype(F)
+    x[1] *= rng.integers(0, 2, n).astype(F)
+    want = O.cumsum(x)
+    for i in range(2):
+        np.testing.assert_array_equal(cumsum_lane_layout(x[i]), want[i])

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scanobjectnn_amd import _lib
 lib = _lib.load()
+_lib.set_option(_lib.OPT_BWD_FUSED_GRAM_WGRAD, 1)     # (opt-in: DESIGN.md section 4.16)
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 

@@ -21,4 +21,11 @@ grep -v amdgpu.ids $R/knn_bench.txt > ${P}_knn_bench.txt
 [ -f $R/launches_pointnet2_cls_ssg.txt ] && cp $R/launches_pointnet2_cls_ssg.txt ${P}_ssg_launches.txt
 python tools/traffic_table.py ${P}_pmc_traffic_detail_dgcnn.json dgcnn > ${P}_pmc_traffic_dgcnn.json
 python tools/traffic_table.py ${P}_pmc_traffic_detail_msg.json msg > ${P}_pmc_traffic_msg.json
+if [ -f $R/pmc_traffic_detail_pointnet2_cls_bga.json ]; then
+  cp $R/pmc_traffic_detail_pointnet2_cls_bga.json ${P}_pmc_traffic_detail_bga.json
+  python tools/traffic_table.py ${P}_pmc_traffic_detail_bga.json bga > ${P}_pmc_traffic_bga.json
+fi
+[ -f $R/pmc_dgrad_bf3.txt ] && cp $R/pmc_dgrad_bf3.txt ${P}_pmc_dgrad_bf3.txt
+[ -f $R/pmc_dgrad_f32.txt ] && cp $R/pmc_dgrad_f32.txt ${P}_pmc_dgrad_f32.txt
+[ -f $R/bwd_fused_gw_micro.txt ] && grep -v amdgpu.ids $R/bwd_fused_gw_micro.txt > ${P}_bwd_fused_gw_micro.txt
 ls -la profiles | grep "r${N}_" | wc -l

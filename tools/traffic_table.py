@@ -51,7 +51,9 @@ def dgcnn_rows():
 def msg_rows():
     M1, M2 = 256 * 512 * 128, 256 * 128 * 128          # padded rows of the two widest scales (compaction leaves fewer)
     return [
-        ("gemm_ws_kernel<3, 6, 1, 64, 8, 3, 0>", None, "SA1 scale 2 data gradient 128 -> 96 (<= 16.8 M rows, compacted)", F * M1 * (128 + 96 + 96)),
+        ("gemm_ws_kernel<3, 6, 1, 32, 8, 3, 4>", None, "SA1 scale 2 data gradient 128 -> 96, split operands, three column blocks (round 6; <= 16.8 M rows, compacted)", F * M1 * (128 + 96 + 96)),
+        ("gemm_ws_kernel<3, 6, 1, 64, 8, 3, 0>", None, "SA1 scale 2 data gradient 128 -> 96 on the fp32 pipe (rounds 4-5)", F * M1 * (128 + 96 + 96)),
+        ("gemm_ws_kernel<2, 6, 1, 32, 8, 2, 4>", None, "SA2 data gradients 256 -> 128, split operands, 64-column passes (round 6; several scales share the instantiation)", None),
         ("bwd_fused_kernel<2, 7", None, "SA1 scale 2 one-pass backward 64 -> 96 (arithmetic first layer: offsets, G and Y in)", F * M1 * (96 + 96 + 4)),
         ("wgrad_bf3_kernel<1, 6>", None, "weight gradients of the 128-wide layers (several shapes share the instantiation)", None),
         ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 5>", 262144, "forward products with the pooled epilogue (several shapes)", None),
@@ -60,9 +62,26 @@ def msg_rows():
     ]
 
 
+def bga_rows():
+    """cfg4 (pointnet2_cls_bga at its per-GPU batch of 128 clouds): the feature-propagation kernels (VERDICT r5 missing #4)
+    and the largest MLP launches"""
+    Bb = 128
+    R1 = Bb * 512 * 64                 # SA1 rows before compaction (nsample 64)
+    return [
+        ("scatter_rows_sorted_kernel", None, "three_interpolate gradient (ordered owner walk): averaged over the three FP levels", None),
+        ("three_nn_kernel", None, "three_nn: unknown + known clouds in, 3 distances + 3 indices out (largest level n 2048, m 512)", Bb * (12 * 2048 + 12 * 512 + 24 * 2048)),
+        ("three_interpolate_kernel", None, "three_interpolate (largest level: C 128, n 2048, m 512)", Bb * (4 * 512 * 128 + 24 * 2048 + 4 * 2048 * 128)),
+        ("bwd_fused_kernel<2, 6", None, "SA1 one-pass backward 64 -> 128 on compacted rows (<= 4.19 M): Yprev, Y in; Gprev out", F * R1 * (64 + 128 + 64)),
+        ("bwd_fused_kernel<1, 7", None, "SA1 one-pass backward 64 -> 64 above the arithmetic first layer (compacted)", F * R1 * (64 + 64 + 4)),
+        ("gemm_ws_kernel<2, 6, 1, 32, 8, 2, 4>", None, "SA2 data gradient 256 -> 128, split operands, 64-column passes (<= 1.05 M rows)", F * Bb * 128 * 64 * (256 + 128 + 128)),
+        ("gemm_ws_kernel<4, 1, 0, 32, 8, 4, 5>", None, "forward products with the pooled epilogue (several shapes share the instantiation)", None),
+        ("sa_scatter_csr_kernel<32", None, "SA2 scatter (gather form), 128 wide", 2 * F * Bb * 128 * 64 * 128),
+    ]
+
+
 def main():
     detail = json.load(open(sys.argv[1]))
-    rows = dgcnn_rows() if sys.argv[2] == "dgcnn" else msg_rows()
+    rows = dgcnn_rows() if sys.argv[2] == "dgcnn" else (bga_rows() if sys.argv[2] == "bga" else msg_rows())
     out = []
     for frag, grid, what, alg in rows:
         for k, v in detail.items():
