@@ -16,6 +16,7 @@ def vec(n):
 
 
 def timeit(fn):
+    global reps
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -48,5 +49,16 @@ for (M, K, N, S) in [(4194304, 64, 128, 32), (10485760, 64, 128, 20)]:
     print("M=%d S=%d: max |dW_gw - dW| / max|dW| = %.3e" % (M, S, float((d1 - d0).abs().max() / d0.abs().max())))
     for rnd in range(3):
         print("   plain %8.1f us   gram form %8.1f us" % (timeit(f0), timeit(f1)), flush=True)
+    # sustained (0.5 s each) with the shader clock and socket power the chip holds meanwhile (bench.py's hwmon poller)
+    import bench
+    keep = reps
+    for label, fn in (("plain", f0), ("gram form", f1), ("plain", f0), ("gram form", f1)):
+        reps = max(30, int(0.5e6 / max(timeit(fn), 1.0)))
+        with bench.ClockPoller() as poller:
+            us = timeit(fn)
+        c = poller.summary() or {}
+        print("   sustained %-9s %8.1f us   sclk %6.0f MHz   %6.0f W   (%d launches)" % (
+            label, us, c.get("sclk_mhz", float("nan")), c.get("power_w", float("nan")), reps), flush=True)
+    reps = keep
     del Yp, Y, Gprev
     torch.cuda.empty_cache()
