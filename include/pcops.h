@@ -58,7 +58,8 @@ int pcops_abi_version(void);
  *   PCOPS_OPT_GEMM_SPLIT_BF16          0 fp32 MFMA, 1 (default) split operands on the bf16 matrix pipe, 2 split only where
  *                                      the weight pieces stay LDS-resident       (pcops_mlp_gemm_fwd* and the dX products)
  *   PCOPS_OPT_WGRAD_SPLIT_BF16         0 / 1 (default): pcops_mlp_wgrad* of layers wider than 64 on both sides
- *   PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16  0 / 1 (default): the dX half of pcops_mlp_bwd_fused*
+ *   PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16  0 fp32 MFMA, 1: the dX half of pcops_mlp_bwd_fused* on the bf16 pipe, 2 (default): the dW
+ *                                      half too where that is faster (layers of 65..128 columns whose input rows are read)
  *   PCOPS_OPT_KNN_F16_PREFILTER        0 / 1 (default): pcops_knn_graph* at c == 64, k <= 20, n >= 256 (seeded or not)
  *   PCOPS_OPT_DGRAD_SPLIT_BF16         0 fp32 MFMA, 1 (default): pcops_mlp_gemm_dgrad* with 128..256 dY columns on the bf16 pipe in
  *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit
@@ -360,7 +361,8 @@ int pcops_mlp_transpose(int K, int N, const float *W, float *Wt, pcops_stream_t 
  * data gradient dX = dY W^T is evaluated on the bf16 matrix pipe with split operands (three bf16 pieces per fp32 value,
  * six exact partial products, the large ones accumulated apart from the small ones): fp32 in, fp32 out, no less accurate
  * than the fp32 chain, not bit-identical to it (environment PCOPS_BWD_FUSED_DX3=0 selects the fp32 pipe); the weight
- * gradient half runs on the fp32 pipe. */
+ * gradient half runs on the fp32 pipe -- round 6: on the bf16 pipe as well, from transposed pieces the staging waves split
+ * (option value 2, the default), for 65..128 output columns over rows that are read (not the xyz form). */
 int pcops_mlp_bwd_fused_groups(long long M, int K, int N, int S, int pooled);
 int pcops_mlp_bwd_fused(long long M, int K, int N, const float *Yprev, const float *a_scale, const float *a_shift,
                         const float *G, const float *Y, const float *p, const float *q, const float *t,

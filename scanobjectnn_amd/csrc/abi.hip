@@ -49,7 +49,7 @@ void options_init() {
     if (!g_options_init.load(std::memory_order_relaxed)) {
         g_options[PCOPS_OPT_GEMM_SPLIT_BF16].store(env_int("PCOPS_GEMM_BF3", 1));
         g_options[PCOPS_OPT_WGRAD_SPLIT_BF16].store(env_int("PCOPS_WGRAD_BF3", 1) != 0);
-        g_options[PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16].store(env_int("PCOPS_BWD_FUSED_DX3", 1) != 0);
+        g_options[PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16].store(env_int("PCOPS_BWD_FUSED_DX3", 2));
         g_options[PCOPS_OPT_KNN_F16_PREFILTER].store(env_int("PCOPS_KNN_F16", 1) != 0);
         g_options[PCOPS_OPT_DGRAD_SPLIT_BF16].store(env_int("PCOPS_DGRAD_BF3", 1));
         g_options[PCOPS_OPT_BWD_FUSED_GRAM_WGRAD].store(env_int("PCOPS_BWD_FUSED_GW", 0) != 0);
@@ -67,7 +67,8 @@ extern "C" int pcops_get_option(int option) {
 
 extern "C" int pcops_set_option(int option, int value) {
     if (option <= 0 || option >= PCOPS_OPT_COUNT || value < 0) return PCOPS_ERR_BAD_ARGUMENT;
-    if ((option == PCOPS_OPT_GEMM_SPLIT_BF16 || option == PCOPS_OPT_DGRAD_SPLIT_BF16) ? value > 2 : value > 1)
+    if ((option == PCOPS_OPT_GEMM_SPLIT_BF16 || option == PCOPS_OPT_DGRAD_SPLIT_BF16 ||
+         option == PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) ? value > 2 : value > 1)
         return PCOPS_ERR_BAD_ARGUMENT;
     options_init();
     return g_options[option].exchange(value);
@@ -75,7 +76,7 @@ extern "C" int pcops_set_option(int option, int value) {
 extern "C" int pcops_get_deterministic(void) { return g_deterministic.load(); }
 
 // diagnostics (bench.py): which matrix pipe the LAST matrix-product launch of the calling thread took -- 0 the fp32 pipe
-// (or no product), 1 the bf16 pipe with split operands, 2 half and half (one-pass backward: dW fp32, dX split).  The
+// (or no product), 1 the bf16 pipe with split operands, 2 half and half (one-pass backward: dW fp32, dX split; 1 where dW is split too).  The
 // launchers note it where they decide, so a roofline label is the library's own decision, not a mirror of its rules.
 static thread_local int t_last_pipe = 0;
 void pcops_note_pipe(int pipe) { t_last_pipe = pipe; }

@@ -3116,17 +3116,28 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
 // p g X[arg row][slice] -- NB / 4 fused multiply-adds per group and lane.  The K x N product with W diag(q) happens once,
 // on the summed partials (bwd_fused_gw_finish_kernel).  Kernel time is issue time on this chip (matrix and vector
 // instructions of the two waves of a SIMD add up), so half the dW matrix cycles is ~16 % of the pass.
-template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false, bool SIDE = false, bool GW = false>
+// DW3 (round 6): the dW half on the bf16 matrix pipe with split operands as well.  dW = X^T dY reduces over ROWS, so the producers
+// hand X and dY over a second time, TRANSPOSED and pre-split (T[piece][column slot][row], wgrad_bf3_kernel's layout: a lane owns
+// two / four CONSECUTIVE rows of a column quad and stores each column's rows as one 4- / 8-byte word per piece); a consumer
+// fragment is one ds_read_b128 per piece, 24 v_mfma_f32_32x32x16_bf16 per stripe and wave (768 cycles) where 32
+// v_mfma_f32_32x32x2_f32 (2 048) ran, h.h products in the block's accumulator, the five small ones in a second set.  X leaves the
+// fp32 stripe (only dW read it): [raw | dY | pad] + the pieces = 144 KB; the W staging area lies under the second piece buffer.
+template <int TN, int DMODE, bool XYZ, bool NSK = false, bool DX3 = false, bool SIDE = false, bool GW = false, bool DW3 = false>
 __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     static_assert(!GW || (is_pool(DMODE) && DMODE != A_DYPOOLB && !XYZ), "Gram form: pooled, uncompacted rows");
+    static_assert(!DW3 || (DX3 && !GW), "split-operand dW: with the split-operand dX half, not with the Gram form");
     // XYZ: the layer below is the arithmetic first layer (A_XYZ above): its raw rows are rebuilt from 16 bytes of offsets,
     // its masked gradient is never written -- only the sums its own gradients are linear in leave (gstats, xstats)
     constexpr int KB = 64, NB = 64 * TN, RS = 32;
     static_assert(!(XYZ && SIDE), "one reduced first layer below");
     constexpr int NX = XYZ ? 3 : (SIDE ? 6 : 0);              // per-row inputs the masked gradient is reduced against
-    constexpr int LD = 2 * KB + NB + (SIDE ? 12 : 4);         // X | raw | dY | pad (row stride = 4 banks mod 32; SIDE: 12 mod 32)
+    // fp32 stripe row:  X | raw | dY | pad  (row stride = 4 banks mod 32; SIDE: 12 mod 32);  DW3: raw | dY | pad
+    constexpr int OXC = 0, ORC = DW3 ? 0 : KB, ODC = DW3 ? KB : 2 * KB, OPC = ODC + NB;
+    constexpr int LD = OPC + (SIDE ? 12 : 4);
     constexpr int A4 = KB / 4, D4 = NB / 4;
     constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;
+    constexpr int RSP = 40, SLOTS = KB + NB;                  // DW3: bf16 per slot (32 rows + 8: 80-byte slots), slots per piece
+    constexpr int TBUF = 3 * SLOTS * RSP;                     // bf16 per piece buffer
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3143,8 +3154,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     constexpr int CA = XYZ ? 6 : 2;
     float *coefA = lds;                        // [CA][KB]  scale, shift of the layer below | xyz form: w0 w1 w2 b
     float *coefD = coefA + CA * KB;            // [3][NB]  p, q, t
-    float *wq = coefD + 3 * NB;                // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
-    float *buf = wq + NB * KB;                 // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][5][KB]
+    // DW3: [2][RS][LD] stripes, then the piece buffers T[2][3][SLOTS][RSP]; the W staging area lies under T[1] (dead once the
+    // consumers hold their slices in registers, and T[1] is first written after the barrier that follows)
+    float *buf = DW3 ? coefD + 3 * NB : coefD + 3 * NB + NB * KB;   // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][5][KB]
+    __bf16 *Tp = reinterpret_cast<__bf16 *>(buf + 2 * RS * LD);
+    float *wq = DW3 ? reinterpret_cast<float *>(Tp + TBUF) : coefD + 3 * NB;     // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
 
     for (int e = tid; e < KB; e += 512) {
         coefA[e] = e < K ? a.asc[e] : 0.f;
@@ -3198,6 +3212,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         constexpr int NBLK = RS / kBlk;                        // blocks per stripe
         constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
         static_assert(QD <= kBlk && kBlk % QD == 0, "block of row pt / D4 + j QD is (j QD) / 16");
+        static_assert(!DW3 || (kBlk % ND == 0), "DW3: a lane's consecutive rows lie inside one 16-row block");
+        const int dhb = DW3 ? (ND * (pt / D4)) / kBlk : 0;     // DW3: the block of this lane's rows (0 / 1)
         struct Regs {
             float4 px[NA], pg[ND], py[ND];
             float4 pe;                                         // SIDE: one float4 of the stripe's 32 x 8 side rows (lanes 0..63)
@@ -3211,10 +3227,14 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
 #endif
         constexpr int NSET = PCOPS_BF_NSET;                   // stripes in flight per producer wave (register sets)
         Regs rs0, rs1, rs2, rs3;                               // (named objects: an array of sets went to scratch)
-        const unsigned xvoff = ain ? (unsigned)((pt / A4) * a.ldx + acq) * 4u : kOOB;
-        const unsigned dvoff = din ? (unsigned)((pt / D4) * a.ldy + dcq) * 4u : kOOB;
-        const unsigned xstep = (unsigned)(256 / A4) * (unsigned)a.ldx * 4u;
-        const unsigned dstep = (unsigned)(256 / D4) * (unsigned)a.ldy * 4u;
+        // rows of a lane: pt / A4 + j (256 / A4) (strided) -- DW3: NA (ND) CONSECUTIVE rows NA (pt / A4) + j, so that a column's
+        // rows leave as one word per piece
+        constexpr int XR0 = DW3 ? NA : 1, XRS = DW3 ? 1 : 256 / A4;       // row of (lane, j) = XR0 (pt / A4) + XRS j
+        constexpr int DR0 = DW3 ? ND : 1, DRS = DW3 ? 1 : 256 / D4;
+        const unsigned xvoff = ain ? (unsigned)(XR0 * (pt / A4) * a.ldx + acq) * 4u : kOOB;
+        const unsigned dvoff = din ? (unsigned)(DR0 * (pt / D4) * a.ldy + dcq) * 4u : kOOB;
+        const unsigned xstep = (unsigned)XRS * (unsigned)a.ldx * 4u;
+        const unsigned dstep = (unsigned)DRS * (unsigned)a.ldy * 4u;
         const long long glast = is_pool(DMODE) ? (M - 1) / a.S : 0;
         const int dcl = din ? dcq : 0;
         constexpr bool U_ = DMODE == A_DYPOOLU;                // one pooling group per stripe
@@ -3238,7 +3258,22 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             if (dbg & 16) return;
             const int left = Mi - irow;
             const unsigned rows_here = (unsigned)(left < RS ? left : RS);
-            if (compact) {
+            if (compact && DW3) {
+                // a lane's rows lie in ONE block of the stripe: both block records are wave-uniform (scalar) loads, the
+                // lane keeps its own block's
+                static_assert(NBLK == 2, "two 16-row blocks per stripe");
+                int b0 = irow / kBlk, b1 = b0 + 1;
+                b0 = b0 < nblk ? b0 : nblk - 1;
+                b1 = b1 < nblk ? b1 : nblk - 1;
+                const RowBlock r0 = a.blocks[b0], r1 = a.blocks[b1];
+                rg_.bw[0] = dhb ? r1.w : r0.w;
+                if (B_) {
+                    const long long gsel = dhb ? r1.g : r0.g;
+                    rg_.bs0[0] = dhb ? r1.s0 : r0.s0;
+                    rg_.pg[0] = *reinterpret_cast<const float4 *>(a.gpool + gsel * N + dcl);
+                    rg_.pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gsel * N + dcl);
+                }
+            } else if (compact) {
 #pragma unroll
                 for (int h = 0; h < NBLK; ++h) {
                     int bi = irow / kBlk + h;
@@ -3258,7 +3293,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             if (XYZ) {     // 16 bytes per ROW, broadcast over the A4 lanes of a row
 #pragma unroll
                 for (int j = 0; j < NA; ++j)
-                    rg_.px[j] = buf_load4(rx, (unsigned)(pt / A4) * 16u, (unsigned)j * (256 / A4) * 16u);
+                    rg_.px[j] = buf_load4(rx, (unsigned)(XR0 * (pt / A4)) * 16u, (unsigned)j * XRS * 16u);
             } else {
 #pragma unroll
                 for (int j = 0; j < NA; ++j) rg_.px[j] = buf_load4(rx, xvoff, (unsigned)j * xstep);
@@ -3285,7 +3320,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     } else {
                         long long gi;
                         unsigned sdummy;
-                        pr.split(pt / D4 + j * (256 / D4), glast, gi, sdummy);
+                        pr.split(DR0 * (pt / D4) + j * DRS, glast, gi, sdummy);
                         rg_.pg[j] = *reinterpret_cast<const float4 *>(a.gpool + gi * N + dcl);
                         rg_.pm[j] = *reinterpret_cast<const unsigned *>(a.argmax + gi * N + dcl);
                     }
@@ -3303,22 +3338,55 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         // last; the other variant carries the range selects (a sixth of the producers' instructions, which compete with
         // the consumer wave of the same SIMD for issue slots)
         int srow = grp * RS, sg0 = srow / Sg, ss0 = srow % Sg;  // the stripe stage() is at (same running form)
-        auto stage_ = [&](float *dst, const Regs &rg_, auto full_) {
+        // DW3: RW consecutive rows x four columns of one operand -> three pieces, one (2 RW)-byte store per column and piece;
+        // column c of an operand of width 4 Q lives in slot  Q (c % 4) + c / 4  (a wave's stores then fall on distinct banks)
+        auto put_rows = [&](const auto &v, __bf16 *tb, int slot0, int Q, int cq, int r0) {
+            constexpr int RW = (int)(sizeof(v) / sizeof(float4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 *dstp = tb + (slot0 + Q * e + cq) * RSP + r0;
+                __bf16 h[RW], m[RW], l[RW];
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const float x = e == 0 ? v[i].x : (e == 1 ? v[i].y : (e == 2 ? v[i].z : v[i].w));
+                    const __bf16 hh = (__bf16)x;
+                    const float r1 = x - (float)hh;
+                    const __bf16 mm = (__bf16)r1;
+                    h[i] = hh; m[i] = mm; l[i] = (__bf16)(r1 - (float)mm);
+                }
+                if constexpr (RW == 4) {
+                    typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                    bf16x4_ hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]}, lv = {l[0], l[1], l[2], l[3]};
+                    *reinterpret_cast<bf16x4_ *>(dstp) = hv;
+                    *reinterpret_cast<bf16x4_ *>(dstp + SLOTS * RSP) = mv;
+                    *reinterpret_cast<bf16x4_ *>(dstp + 2 * SLOTS * RSP) = lv;
+                } else {
+                    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+                    static_assert(RW == 2, "two or four consecutive rows per lane");
+                    bf16x2_ hv = {h[0], h[1]}, mv = {m[0], m[1]}, lv = {l[0], l[1]};
+                    *reinterpret_cast<bf16x2_ *>(dstp) = hv;
+                    *reinterpret_cast<bf16x2_ *>(dstp + SLOTS * RSP) = mv;
+                    *reinterpret_cast<bf16x2_ *>(dstp + 2 * SLOTS * RSP) = lv;
+                }
+            }
+        };
+        auto stage_ = [&](float *dst, __bf16 *tdst, const Regs &rg_, auto full_) {
             constexpr bool FULL = decltype(full_)::value;
             if (dbg & 8) return;
             const int row0 = srow;
             const PoolRows prs((long long)sg0, ss0, Sg);
-            if (SIDE && pt < 64) *reinterpret_cast<float4 *>(&dst[(pt >> 1) * LD + 2 * KB + NB + 4 * (pt & 1)]) = rg_.pe;
+            if (SIDE && pt < 64) *reinterpret_cast<float4 *>(&dst[(pt >> 1) * LD + OPC + 4 * (pt & 1)]) = rg_.pe;
+            float4 xt[DW3 ? NA : 1];                           // DW3: the lane's X rows, for the transposed pieces
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
-                const int r = pt / A4 + j * (256 / A4);
+                const int r = XR0 * (pt / A4) + j * XRS;
                 float4 y = rg_.px[j], x;
                 if (XYZ) {
                     float4 o = y;
                     if (!FULL && !(row0 + r < M)) o = make_float4(0.f, 0.f, 0.f, 0.f);
                     y = make_float4(xyz_y(o, xw0.x, xw1.x, xw2.x, xb.x), xyz_y(o, xw0.y, xw1.y, xw2.y, xb.y),
                                     xyz_y(o, xw0.z, xw1.z, xw2.z, xb.z), xyz_y(o, xw0.w, xw1.w, xw2.w, xb.w));
-                    if (acq == 0) *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + NB]) = o;   // the row's offsets, beside dY
+                    if (acq == 0) *reinterpret_cast<float4 *>(&dst[r * LD + OPC]) = o;   // the row's offsets, beside dY
                 }
                 if (!FULL && !(ain && row0 + r < M)) y = make_float4(0.f, 0.f, 0.f, 0.f);
                 x.x = fmaxf(fmaf(y.x, casc.x, cash.x), 0.f);
@@ -3327,14 +3395,18 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 x.w = fmaxf(fmaf(y.w, casc.w, cash.w), 0.f);
                 if (!FULL && !(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (GW) { xs[0] += x.x; xs[1] += x.y; xs[2] += x.z; xs[3] += x.w; }
-                *reinterpret_cast<float4 *>(&dst[r * LD + acq]) = x;
-                *reinterpret_cast<float4 *>(&dst[r * LD + KB + acq]) = y;
+                if (DW3) xt[DW3 ? j : 0] = x;
+                else *reinterpret_cast<float4 *>(&dst[r * LD + OXC + acq]) = x;
+                *reinterpret_cast<float4 *>(&dst[r * LD + ORC + acq]) = y;
             }
+            if constexpr (DW3) put_rows(xt, tdst, 0, KB / 4, pt % A4, NA * (pt / A4));
+            float4 dt[DW3 ? ND : 1];
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
-                const int r = pt / D4 + j * (256 / D4);
+                const int r = DR0 * (pt / D4) + j * DRS;
                 const float4 y = rg_.py[j];
-                const int hb = (j * QD) / kBlk;                // block of this row inside the stripe (compile time)
+                const int hb = DW3 ? 0 : (j * QD) / kBlk;      // block of this row inside the stripe (compile time; DW3: the lane's
+                                                               // own block was selected at issue time and sits in entry 0)
                 float4 g = rg_.pg[U_ ? 0 : (B_ ? hb : j)];
                 if (is_pool(DMODE)) {
                     long long gdummy;
@@ -3350,7 +3422,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     g.w = ((am >> 24) == s) ? g.w : 0.f;
                 }
                 float4 d;
-                if (compact && (j * QD) % kBlk == 0) {
+                if (compact && (DW3 ? j == 0 : (j * QD) % kBlk == 0)) {
                     // a row that opens a block (r % 16 == 0) stands for w rows: dY = p.G + w (q.Y + t)
                     const float w = (r & (kBlk - 1)) == 0 ? rg_.bw[compact ? hb : 0] : 1.f;
                     d.x = fmaf(cp.x, g.x, w * fmaf(cq.x, y.x, ct.x));
@@ -3365,12 +3437,14 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 }
                 if (!FULL && !(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
                 dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
-                *reinterpret_cast<float4 *>(&dst[r * LD + 2 * KB + dcq]) = d;
+                *reinterpret_cast<float4 *>(&dst[r * LD + ODC + dcq]) = d;
+                if (DW3) dt[DW3 ? j : 0] = d;
             }
+            if constexpr (DW3) put_rows(dt, tdst, KB, NB / 4, pt % D4, ND * (pt / D4));
         };
-        auto stage = [&](float *dst, const Regs &rg_) {
-            if (srow + RS <= Mi && K == KB && N == NB) stage_(dst, rg_, std::true_type{});
-            else stage_(dst, rg_, std::false_type{});
+        auto stage = [&](float *dst, __bf16 *tdst, const Regs &rg_) {
+            if (srow + RS <= Mi && K == KB && N == NB) stage_(dst, tdst, rg_, std::true_type{});
+            else stage_(dst, tdst, rg_, std::false_type{});
             srow += rstep;
             if (DMODE == A_DYPOOL) {
                 sg0 += dq; ss0 += dr;
@@ -3383,7 +3457,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         if (NSET > 2 && cnt > 2) issue(rs2);
         if (NSET > 3 && cnt > 3) issue(rs3);
         if (cnt > 0) {
-            stage(buf, rs0);
+            stage(buf, Tp, rs0);
             if (cnt > NSET) issue(rs0);
         }
         __syncthreads();                                       // stripe 0 is in buf[0]
@@ -3394,7 +3468,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             if (j < cnt) {
                 // (a set is named by a wave-uniform index: one copy of the code per set, so that the sets stay in registers)
                 auto body = [&](Regs &rg_) {
-                    stage(buf + (j & 1) * RS * LD, rg_);
+                    stage(buf + (j & 1) * RS * LD, Tp + (j & 1) * TBUF, rg_);
                     if (j + NSET < cnt) issue(rg_);
                 };
                 if (si == 0) body(rs0);
@@ -3421,11 +3495,16 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const int rh = wave >> 1, cbp = wave & 1;              // dX blocks: rows 16 rh .., columns 32 cbp + {0, 16} ..
         const int c16 = lane & 15, g4 = lane >> 4;
         f32x16 accw[GW ? 1 : TN];                              // GW: the wave's 32 x 32 block (ck, cn) of X^T X
+        f32x16 smw[DW3 ? TN : 1];                              // DW3: the five small partial products of each block
         f32x4 accd[2];
 #pragma unroll
         for (int j = 0; j < (GW ? 1 : TN); ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) accw[j][v] = 0.f;
+#pragma unroll
+        for (int j = 0; j < (DW3 ? TN : 1); ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) smw[j][v] = 0.f;
         // GW: the arg-row term X^T (p.G): lane (channel sc, k slice skq) of the 256 consumer lanes holds KPL sums
         constexpr int KPL = NB / 4;
         const int sc = tid & (NB - 1), skq = tid / NB;
@@ -3442,9 +3521,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v) accd[b][v] = 0.f;
-        const int aoff = half * LD + ck * 32 + li;
-        const int doff = GW ? half * LD + cn * 32 + li : half * LD + 2 * KB + cn * TN * 32 + li;   // GW: the X column block cn
-        const int daoff = (16 * rh + c16) * LD + 2 * KB + (DX3 ? 8 : 4) * g4;   // + 16 J (split operands: + 32 J, and + 4)
+        const int aoff = half * LD + OXC + ck * 32 + li;
+        const int doff = GW ? half * LD + cn * 32 + li : half * LD + ODC + cn * TN * 32 + li;   // GW: the X column block cn
+        const int daoff = (16 * rh + c16) * LD + ODC + (DX3 ? 8 : 4) * g4;   // + 16 J (split operands: + 32 J, and + 4)
+        // DW3: fragments of the transposed pieces: A = slots 32 ck + li, B = slots KB + 32 (cn TN + y) + li; rows 16 s + 8 half ..
+        const int taoff = (32 * ck + li) * RSP + 8 * half, tdoff = (KB + 32 * cn * TN + li) * RSP + 8 * half;
         const int nyw = NSK ? (N - cn * TN * 32 + 31) / 32 : TN;            // dW blocks of this wave with real columns
         const int jreal = NSK ? (DX3 ? (N + 31) / 32 : (N + 15) / 16) : (DX3 ? NB / 32 : NB / 16);   // steps with real columns
         const int wboff = (g4 * KB + 32 * cbp + c16) * 4;                   // + 16 b * 4, + J * 4 KB * 4
@@ -3501,9 +3582,9 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             const float *sb = buf + (i & 1) * RS * LD;
             const long long row0 = (grp + i * ngrp) * RS;
             constexpr int TW = GW ? 1 : TN;                    // B blocks of the weight-gradient product per wave
-            float av_n = sb[aoff], dv_n[TW];
+            float av_n = DW3 ? 0.f : sb[aoff], dv_n[TW];
 #pragma unroll
-            for (int y = 0; y < TW; ++y) dv_n[y] = sb[doff + 32 * y];
+            for (int y = 0; y < TW; ++y) dv_n[y] = DW3 ? 0.f : sb[doff + 32 * y];
             // GW: this stripe's groups' (masked pooled gradient, arg row) of the lane's channel, requested here and used
             // behind the matrix loop
             float sgv[GW ? NGS : 1];
@@ -3524,6 +3605,69 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             float4 da_n = *reinterpret_cast<const float4 *>(&sb[daoff]);
             float4 da2_n = DX3 ? *reinterpret_cast<const float4 *>(&sb[daoff + 4]) : da_n;     // split operands: columns + 4 .. + 7
             float yr[2][4];                                    // the raw Yprev under this wave's Gprev elements
+            if constexpr (DW3) {
+                // JN data-gradient steps (12 x 16 cycles each), the two 16-row steps of the weight gradient (6 TN x 32 cycles)
+                // behind steps 0 and JN / 2; a step's fragments are requested in front of the data-gradient MFMAs before it
+                const __bf16 *tb = Tp + (i & 1) * TBUF;
+                constexpr int SJ = JN / 2;
+#pragma unroll
+                for (int J = 0; J < JN; ++J) {
+                    const bool wstep = J % SJ == 0;
+                    const int s_ = J / SJ;
+                    bf16x8 fa[3], fb[TN][3];
+                    if (wstep) {
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            fa[pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + taoff + 16 * s_);
+#pragma unroll
+                            for (int y = 0; y < TN; ++y)
+                                fb[y][pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + tdoff + 32 * y * RSP + 16 * s_);
+                        }
+                    }
+                    const float4 da = da_n, da2 = da2_n;
+                    if (J + 1 < JN) {
+                        da_n = *reinterpret_cast<const float4 *>(&sb[daoff + 32 * (J + 1)]);
+                        da2_n = *reinterpret_cast<const float4 *>(&sb[daoff + 32 * (J + 1) + 4]);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                yr[b][v] = sb[(16 * rh + 4 * g4 + v) * LD + ORC + 32 * cbp + 16 * b + c16];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((!NSK || J < jreal) && !(dbg & 1)) {
+                        bf16x8 eh, em, el;
+                        split3(da, da2, eh, em, el);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, wph[J][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wpl[J][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, wpm[J][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(em, wph[J][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wpm[J][b], smd[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) accd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eh, wph[J][b], accd[b], 0, 0, 0);
+                    }
+                    if (wstep && !(dbg & 4)) {
+                        // one product at a time over the blocks: consecutive matrix instructions do not share an accumulator
+#define PCOPS_MMW(A_, B_, C_)                                                                              \
+    _Pragma("unroll") for (int y = 0; y < TN; ++y)                                                         \
+        C_[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[A_], fb[y][B_], C_[y], 0, 0, 0)
+                        PCOPS_MMW(2, 0, smw);
+                        PCOPS_MMW(0, 2, smw);
+                        PCOPS_MMW(1, 1, smw);
+                        PCOPS_MMW(1, 0, smw);
+                        PCOPS_MMW(0, 1, smw);
+                        PCOPS_MMW(0, 0, accw);
+#undef PCOPS_MMW
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < RS / 2; ++it) {
                 const float av = av_n;
@@ -3547,7 +3691,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     for (int b = 0; b < 2; ++b)
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
-                            yr[b][v] = sb[(16 * rh + 4 * g4 + v) * LD + KB + 32 * cbp + 16 * b + c16];
+                            yr[b][v] = sb[(16 * rh + 4 * g4 + v) * LD + ORC + 32 * cbp + 16 * b + c16];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(dbg & 4)) {
@@ -3586,6 +3730,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             if constexpr (GW) {
                 // ---- the arg rows of this stripe's groups: row (gi S - cs0 + arg) of the stripe, if it lies inside
                 const int rows_here = (int)(M - row0 < RS ? M - row0 : RS);
@@ -3616,8 +3761,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 if (NX) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        ofs[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + 2 * KB + NB]);
-                        if (SIDE) of2[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + 2 * KB + NB + 4]);
+                        ofs[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + OPC]);
+                        if (SIDE) of2[v] = *reinterpret_cast<const float4 *>(&sb[(16 * rh + 4 * g4 + v) * LD + OPC + 4]);
                     }
                 }
 #pragma unroll
@@ -3661,6 +3806,17 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             for (int v = 0; v < 16; ++v) {
                 const int kk = ck * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
                 if (kk < K && jj < K) gout[(long long)kk * K + jj] = accw[0][v];
+            }
+        } else if constexpr (DW3) {
+            // slots back to channels: X slot 16 e + m -> channel 4 m + e; dY slot (NB / 4) e + m -> column 4 m + e
+#pragma unroll
+            for (int y = 0; y < TN; ++y) {
+                const int sn = (cn * TN + y) * 32 + li, nn = 4 * (sn % D4) + sn / D4;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int sk = ck * 32 + (v & 3) + 8 * (v >> 2) + 4 * half, kk = 4 * (sk % A4) + sk / A4;
+                    if (kk < K && nn < N) out[(long long)kk * N + nn] = accw[y][v] + smw[y][v];
+                }
             }
         } else {
 #pragma unroll
@@ -4659,6 +4815,24 @@ int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t s
 #endif
 
 #if PCOPS_PART(5)
+static bool nsk_on() {
+    static const bool on = [] {
+        const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+// (the split-operand dW variant exists for the 128-column tile over read rows only -- see bwd_fused_launch)
+template <int TN, int DM, bool X>
+static auto bwd_fused_dw3_kernel() -> void (*)(WgradArgs) {
+    if constexpr (TN == 2 && !X) return bwd_fused_kernel<TN, DM, X, false, true, false, false, true>;
+    else return nullptr;
+}
+template <int TN>
+static auto bwd_fused_dw3_side_kernel() -> void (*)(WgradArgs) {
+    if constexpr (TN == 2) return bwd_fused_kernel<TN, A_DYPOOL, false, false, true, true, false, true>;
+    else return nullptr;
+}
 int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
                      bool side, const float *gw_bias) {
     const int K = a.K, N = a.N;
@@ -4667,15 +4841,19 @@ int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *
                                                 // holds [groups][K][K] + [groups][K] behind the dW / db partials
     const int tn = N <= 64 ? 1 : 2;
     const int NB = 64 * tn;
-    const size_t lds = (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
+    const int optv = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16);
+    const bool dx3 = optv != 0;
+    // split-operand dW half (bwd_fused_kernel<.., DW3>; option value 2, the default): on the 128-column tile of layers whose
+    // input is READ.  Measured where it is not built (round 6, profiles/r06_bwd_fused_dw3.txt): the 64-column tile (+7 %: two
+    // waves' worth of matrix work saved, the producers' piece splitting added) and the xyz forms (+9 %: their producers
+    // already rebuild the first layer per row) are slower with it; nor with the Gram form or the column skip (N <= 96).
+    const bool dw3 = optv >= 2 && tn == 2 && !xyz && !a.gram_part && !(nsk_on() && N <= 96);
+    const size_t lds = dw3 ? (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + 2 * 32 * (64 + NB + (side ? 12 : 4))) * sizeof(float) +
+                                 (size_t)2 * 3 * (64 + NB) * 40 * 2
+                           : (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
     const bool pooled = a.gpool != nullptr;
-    static const bool nsk_on = [] {
-        const char *e = getenv("PCOPS_BWD_FUSED_NSKIP");
-        return !(e && e[0] == '0');
-    }();
-    const bool nsk = nsk_on && tn == 2 && N <= 96;
-    const bool dx3 = pcops_get_option(PCOPS_OPT_BWD_FUSED_DX_SPLIT_BF16) != 0;
-    pcops_note_pipe(dx3 ? 2 : 0);
+    const bool nsk = nsk_on() && tn == 2 && N <= 96;
+    pcops_note_pipe(dw3 ? 1 : (dx3 ? 2 : 0));
     if (gw) {
         if (!dx3 || xyz || a.blocks || !a.gpool) return PCOPS_ERR_UNSUPPORTED;
 #define PCOPS_BFG_LAUNCH(TN_, DM_, NSK_, SIDE_)                                                            \
@@ -4709,7 +4887,8 @@ int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *
     }
 #define PCOPS_BF_LAUNCH(TN_, DM_, X_)                                                                      \
     do {                                                                                                   \
-        auto kern = dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
+        auto kern = dw3 ? bwd_fused_dw3_kernel<TN_, DM_, X_>()                                               \
+                  : dx3 ? ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2, true>                  \
                                               : bwd_fused_kernel<TN_, DM_, X_, false, true>)                    \
                         : ((TN_ == 2 && nsk) ? bwd_fused_kernel<TN_, DM_, X_, TN_ == 2> : bwd_fused_kernel<TN_, DM_, X_>);                                                      \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
@@ -4729,7 +4908,8 @@ int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *
         // (the first EdgeConv layer below: pooled groups of k neighbours, plain rows -- pcops_mlp_bwd_fused_edge checks)
 #define PCOPS_BF_SIDE(TN_)                                                                                 \
     do {                                                                                                   \
-        auto kern = dx3 ? bwd_fused_kernel<TN_, A_DYPOOL, false, false, true, true>                        \
+        auto kern = dw3 ? bwd_fused_dw3_side_kernel<TN_>()                                                 \
+                  : dx3 ? bwd_fused_kernel<TN_, A_DYPOOL, false, false, true, true>                        \
                         : bwd_fused_kernel<TN_, A_DYPOOL, false, false, false, true>;                      \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
