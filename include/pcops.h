@@ -64,7 +64,8 @@ int pcops_abi_version(void);
  *   PCOPS_OPT_DGRAD_SPLIT_BF16         0 fp32 MFMA, 1 (default): pcops_mlp_gemm_dgrad* with 128..256 dY columns on the bf16 pipe in
  *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit
  *   PCOPS_OPT_BWD_FUSED_GRAM_WGRAD     0 (default) / 1: pcops_mlp_bwd_fused_gw* take shapes (pcops_mlp_bwd_fused_gw_groups > 0);
- *                                      measured 15 % fewer shader cycles and -4 % .. +1 % time: the step runs at its power cap
+ *                                      measured -4 % .. +1 % time against the direct form (its vector arg-row term costs what
+ *                                      the halved matrix work saves); superseded by value 2 of the option above
  * pcops_set_option returns the PREVIOUS value (>= 0) or PCOPS_ERR_BAD_ARGUMENT.  The environment variables of rounds 3-4
  * (PCOPS_GEMM_BF3, PCOPS_WGRAD_BF3, PCOPS_BWD_FUSED_DX3, PCOPS_KNN_F16; round 6: PCOPS_DGRAD_BF3, PCOPS_BWD_FUSED_GW) only seed the initial values (test overrides). */
 typedef enum pcops_option {
