@@ -571,19 +571,29 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         const int f = tid + NTHR * j;
         wsgf[j] = colsign(n0 + 32 * ((f >> 6) % NT) + (f & 31));
     }
+    // (split operands: eight single words per fragment, rows k .. k + 7 of one column.  Through a descriptor over the K N words
+    // of W -- a row beyond K answers 0 by the bounds check, a column beyond N or a fragment beyond the chunk gets an offset no
+    // tensor reaches -- these are eight loads and nothing else; as predicated pointer loads hipcc made each its own exec-masked
+    // branch with 64-bit address arithmetic and waited for every second one: four exposed L2 round trips per chunk, with all
+    // eight waves of the workgroup in step)
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc_u32(a.W, (WST && BF3) ? (unsigned)K * (unsigned)N * 4u : 0u);
+    unsigned wfoff[(WST && BF3) ? FPB : 1];
+#pragma unroll
+    for (int j = 0; j < ((WST && BF3) ? FPB : 1); ++j) {
+        const int f = tid + NTHR * j;
+        const int ln = f & 63, nt = (f >> 6) % NT, ksl = f / (64 * NT);
+        const int n = n0 + 32 * nt + (ln & 31);
+        wfoff[j] = (f < FR && n < N) ? (unsigned)((16 * ksl + 8 * (ln >> 5)) * N + n) * 4u : kOOB;
+    }
     auto wload = [&](int kc) {
         if constexpr (BF3) {
+            const unsigned cbase = (unsigned)(kc * KC) * (unsigned)N * 4u;      // wave-uniform: the chunk's first row
 #pragma unroll
-            for (int j = 0; j < FPB; ++j) {
-                const int f = tid + NTHR * j;
-                const int ln = f & 63, nt = (f >> 6) % NT, ksl = f / (64 * NT);
-                const int n = n0 + 32 * nt + (ln & 31);
+            for (int j = 0; j < FPB; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int k = kc * KC + 16 * ksl + 8 * (ln >> 5) + e;
-                    wfr[8 * j + e] = (f < FR && k < K && n < N) ? a.W[(long long)k * N + n] : 0.f;
-                }
-            }
+                for (int e = 0; e < 8; ++e)
+                    wfr[8 * j + e] = __uint_as_float(
+                        __builtin_amdgcn_raw_buffer_load_b32(rw, wfoff[j], cbase + (unsigned)e * (unsigned)N * 4u, 0));
             return;
         }
 #pragma unroll
@@ -1070,7 +1080,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             for (int v = 0; v < 16; ++v) sm[i][v] = 0.f;
 
         for (int kc = 0; kc < nchunk; ++kc) {
-            if (WST && !(round + 1 == nrounds && kc + 1 == nchunk)) wload(kc + 1 < nchunk ? kc + 1 : 0);
+            // streamed weights: the next chunk's words are requested BEHIND this chunk's stage() and the next stripe's request, so
+            // that the stage's wait for its stripe (in-order counter) does not also wait for them; wstore() at the bottom, a whole
+            // matrix phase later, takes both
+            // (split-operand kernels only: the fp32 ones, whose float4 weight loads the stage does not meet, measured 7 % slower so)
+            const bool wl = WST && !(round + 1 == nrounds && kc + 1 == nchunk);
+            if (wl && !(BF3 && active)) wload(kc + 1 < nchunk ? kc + 1 : 0);
             if (active) {
 #ifdef PCOPS_PHASE_PROF
             pf_t = PROF_T();
@@ -1086,6 +1101,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             // next stripe: the next K chunk of this tile, or chunk 0 of this wave's next tile
             if (kc + 1 < nchunk) issue(tile, kc + 1);
             else if (more) issue(next_tile, 0);
+            if (BF3 && wl) wload(kc + 1 < nchunk ? kc + 1 : 0);
 
 #ifdef PCOPS_PHASE_PROF
             { const unsigned long long n_ = PROF_T(); pf_stage += n_ - pf_t; pf_t = n_; }
@@ -1094,8 +1110,14 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 // split operands: a step is 16 k -- the lane's eight stripe values of its row (two ds_read_b128) split into
                 // three bf16 pieces, the weight pieces as 16-byte fragments, six matrix instructions per column block.  The
                 // fragments of one weight piece are requested while the products of the previous one issue.
-                const float *arow = &Aw[(lane & 31) * LDW + 8 * (lane >> 5)];
-                const bf16x8 *wf = Wf + ((WST ? (wt & 1) : kc) * (KC / 16)) * NT * 64 + lane;
+                // (the fragment addresses are rebuilt from an opaque copy of the lane number per chunk: hoisted out of the tile loop
+                // they were the registers that went to scratch in the 128-column pooled forward kernel -- and a scratch RELOAD is a
+                // vector-memory load, so the first read of the reloaded address, right behind issue(), carried s_waitcnt vmcnt(0):
+                // every chunk waited for the stripe it had just requested)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const float *arow = &Aw[(ln & 31) * LDW + 8 * (ln >> 5)];
+                const bf16x8 *wf = Wf + ((WST ? (wt & 1) : kc) * (KC / 16)) * NT * 64 + ln;
                 const int pst = KSW * NT * 64;                       // piece stride (fragments)
                 const int kleft = K - kc * KC;
                 const int nstep = kleft >= KC ? KC / 16 : (kleft + 15) / 16;
