@@ -79,6 +79,18 @@ constexpr int A_DYW = 7;
 constexpr bool is_pool(int am) { return am == A_DYPOOL || am == A_DYPOOLU || am == A_DYPOOLB; }
 constexpr int kBlk = 16;        // rows per block of a compacted row set
 struct RowBlock { int g, s0; float w; int pad; };   // group, row-in-group of the block's first row, weight of that row
+// A block record read at a WAVE-UNIFORM index, through the constant address space: one s_load_dwordx4 on the scalar unit.  As
+// a plain global read hipcc issues a vector load (the table may alias the kernel's stores for all it knows), and the
+// (pooled gradient, arg-max) row reads that depend on it then sit behind an s_waitcnt vmcnt: two exposed L2 round trips in
+// every chunk's issue(), in front of the stripe prefetch.  The table is written by an earlier kernel (rows_plan_fill_kernel).
+__device__ __forceinline__ RowBlock uniform_block(const RowBlock *table, long long i) {
+    typedef int i32x4_ __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) i32x4_ *kptr;
+    const i32x4_ v = *(kptr)(table + i);
+    RowBlock r;
+    r.g = v.x; r.s0 = v.y; r.w = __int_as_float(v.z); r.pad = v.w;
+    return r;
+}
 // A_XYZ: the operand is the BN+ReLU of a first layer that is ARITHMETIC in three per-row offsets,
 //   y[row][k] = fma(dz, w2[k], fma(dy, w1[k], fma(dx, w0[k], b[k])))      (csrc/gather.hip first_layer_quad order)
 // rebuilt from off4[row] = (dx, dy, dz, 0) instead of being read: 16 bytes per row instead of 4 K (wave-stream only)
@@ -761,7 +773,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             for (int h = 0; h < 2; ++h) {
                 long long bi = tile * 2 + h;
                 bi = bi < nblk ? bi : nblk - 1;
-                const RowBlock rb = a.blocks[bi];            // wave-uniform
+                const RowBlock rb = uniform_block(a.blocks, bi);
                 bw[h] = rb.w;
                 bs0[h] = rb.s0;
                 if (B_) {
@@ -934,7 +946,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             for (int b = 0; b < 2; ++b) {
                 const long long blk = tile * 2 + b;
                 if (blk >= nblk) continue;                                   // wave-uniform
-                const int s0 = a.blocks[blk].s0;                             // row-in-group of the block's first row
+                const int s0 = uniform_block(a.blocks, blk).s0;              // row-in-group of the block's first row
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     float m = acc[nt][8 * b];
@@ -1275,7 +1287,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                 for (int hb = 0; hb < 2; ++hb) {
                     long long bi = tile * 2 + hb;
                     bi = bi < nblk ? bi : nblk - 1;
-                    const RowBlock rb = a.blocks[bi];
+                    const RowBlock rb = uniform_block(a.blocks, bi);
                     ew[hb] = rb.w;
                 }
             }
@@ -2554,7 +2566,7 @@ __global__ __launch_bounds__(512, (TK * TN == 1) ? 2 : 1) void wgrad_pc_kernel(W
                 for (int h = 0; h < NBLK; ++h) {
                     long long bi = stripe * NBLK + h;
                     bi = bi < nblk ? bi : nblk - 1;
-                    const RowBlock rb = a.blocks[bi];          // wave-uniform
+                    const RowBlock rb = uniform_block(a.blocks, bi);
                     bw[h] = rb.w;
                     if (B_) {
                         bs0[h] = rb.s0;
@@ -2876,14 +2888,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
             const long long row0 = stripe * RS;
             if (compact) {
                 const long long nblk = (M + kBlk - 1) / kBlk;
-                long long bi = stripe * (RS / kBlk) + hb;
-                bi = bi < nblk ? bi : nblk - 1;
-                const RowBlock rb = a.blocks[bi];
-                bw = rb.w;
+                // (the lane's block: both records of the stripe are scalar loads, the lane keeps its own)
+                static_assert(RS / kBlk == 2, "two 16-row blocks per stripe");
+                long long b0 = stripe * (RS / kBlk), b1 = b0 + 1;
+                b0 = b0 < nblk ? b0 : nblk - 1;
+                b1 = b1 < nblk ? b1 : nblk - 1;
+                const RowBlock r0 = uniform_block(a.blocks, b0), r1 = uniform_block(a.blocks, b1);
+                bw = hb ? r1.w : r0.w;
                 if (B_) {
-                    bs0 = rb.s0;
-                    pg[0] = *reinterpret_cast<const float4 *>(a.gpool + (long long)rb.g * N + dcl);
-                    pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + (long long)rb.g * N + dcl);
+                    const long long gsel = hb ? r1.g : r0.g;
+                    bs0 = hb ? r1.s0 : r0.s0;
+                    pg[0] = *reinterpret_cast<const float4 *>(a.gpool + gsel * N + dcl);
+                    pm[0] = *reinterpret_cast<const unsigned *>(a.argmax + gsel * N + dcl);
                 }
             }
             const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.X + row0 * a.ldx, (M - row0) * a.ldx * 4);
@@ -3287,7 +3303,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 int b0 = irow / kBlk, b1 = b0 + 1;
                 b0 = b0 < nblk ? b0 : nblk - 1;
                 b1 = b1 < nblk ? b1 : nblk - 1;
-                const RowBlock r0 = a.blocks[b0], r1 = a.blocks[b1];
+                const RowBlock r0 = uniform_block(a.blocks, b0), r1 = uniform_block(a.blocks, b1);
                 rg_.bw[0] = dhb ? r1.w : r0.w;
                 if (B_) {
                     const long long gsel = dhb ? r1.g : r0.g;
@@ -3300,7 +3316,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 for (int h = 0; h < NBLK; ++h) {
                     int bi = irow / kBlk + h;
                     bi = bi < nblk ? bi : nblk - 1;
-                    const RowBlock rb = a.blocks[bi];          // wave-uniform
+                    const RowBlock rb = uniform_block(a.blocks, bi);
                     rg_.bw[h] = rb.w;
                     if (B_) {
                         rg_.bs0[h] = rb.s0;
