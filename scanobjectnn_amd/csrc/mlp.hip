@@ -4874,6 +4874,9 @@ static auto bwd_fused_dw3_side_kernel() -> void (*)(WgradArgs) {
 int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *dW, float *db, hipStream_t st,
                      bool side, const float *gw_bias) {
     const int K = a.K, N = a.N;
+#ifdef PCOPS_BF_DEBUG
+    { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }      // tools/ablate_bwd_fused.py
+#endif
     a.part = partial; a.dbpart = db ? partial + (long long)groups * K * N : nullptr;
     const bool gw = a.gram_part != nullptr;     // Gram form of the weight gradient (pcops_mlp_bwd_fused_gw*): partial also
                                                 // holds [groups][K][K] + [groups][K] behind the dW / db partials
@@ -5546,9 +5549,6 @@ int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, cons
     a.W = W; a.Gprev = Gprev; a.gstats = stats_partial;
     a.nt_out = nt_for_bytes((long long)M * K * 4);
     PCOPS_ROWS(a, rows);
-#ifdef PCOPS_BF_DEBUG
-    { const char *e = getenv("PCOPS_BF_DEBUG"); a.rows_per_block = e ? atoi(e) : 0; }
-#endif
     return bwd_fused_launch(a, false, groups, partial, dW, db, as_stream(stream));
 }
 
