@@ -1111,6 +1111,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // next stripe: the next K chunk of this tile, or chunk 0 of this wave's next tile
+            // (two call sites on purpose.  As ONE -- issue(same ? tile : next_tile, same ? kc + 1 : 0) -- the pooled data gradients
+            // lose the register copies that meet the two inlined bodies behind their loads, but the 128-column forward kernel
+            // gets its scratch reload back: dgrad 256 -> 128 946 -> 974 us, fwd 128 -> 256 673 -> 705 us, round 6)
             if (kc + 1 < nchunk) issue(tile, kc + 1);
             else if (more) issue(next_tile, 0);
             if (BF3 && wl) wload(kc + 1 < nchunk ? kc + 1 : 0);
