@@ -33,7 +33,7 @@ for path in sys.argv[1:]:
                 last_load = i
             if "v_mfma" in l and last_load is not None:
                 w = [x.strip() for x in ls[last_load:i] if "s_waitcnt" in x and "vmcnt(0)" in x]
-                if w:
+                if w and i - last_load < 150:      # (further away it is a later phase's own wait, e.g. the streamed weights' store)
                     waits.append(i - last_load)
                 last_load = None
         if sc_all or waits:
