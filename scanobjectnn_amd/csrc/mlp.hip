@@ -1518,6 +1518,17 @@ static bool ws_n96_enabled() {
 // gradients of the layers that are matrix-pipe bound (K >= 128 dY columns) take the split form in 64-column passes --
 // 32 + 32 accumulator registers, and the weight pieces of 64 columns stay RESIDENT up to K = 256 (96 KB): no streaming, no
 // workgroup barrier; the two column blocks of a row group run on one XCD, so the second reader of a dY stripe hits its L2
+static int dgrad_top_bf3_cols() {
+    static const int v = [] {
+        const char *e = getenv("PCOPS_DGRAD_TOP_BF3");
+        return e ? atoi(e) : 128;
+    }();
+    return v;
+}
+// what ws_plan is asked for: 1 forward, 2 masked data gradient, 3 its xyz form, 4 / 5 the algebraic top-layer forms (masked / plain)
+constexpr int ws_kind(int em) {
+    return em == E_FWD ? 1 : (em == E_MASK ? 2 : (em == E_MASKA ? 4 : (em == E_PLAINA ? 5 : (is_mask(em) ? 3 : 0))));
+}
 static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, int kind = 0) {
     const bool fwd = kind == 1;
     if (a.M < 8 * 1024) return false;                        // small problems: the tiled kernel is fine
@@ -1582,11 +1593,26 @@ static bool ws_plan(const GemmArgs &a, int am, WsPlan *pl, int kind = 0) {
             pl->lds = ws_lds_bytes_bf3(a.K, bn3, 8, false, nc);
         }
     }
+    // kinds 4, 5: the algebraic top-layer data gradients (E_MASKA / E_PLAINA: acc + addend[rowmap[row]] + vconst).  Their product
+    // relu(bn(Yprev)) . (W diag(q) W^T) is K x K with K = 128 .. 1024: split operands, weights resident where 64 columns of all
+    // K rows fit and streamed (from L2, one workgroup barrier per 32-row chunk) beyond that.  PCOPS_DGRAD_TOP_BF3 = 0 / 64 / 128
+    // (columns per pass; default 128)
+    if ((kind == 4 || kind == 5) && dgrad_bf3_mode() && dgrad_top_bf3_cols() && !(reinterpret_cast<uintptr_t>(a.W) & 15) && a.K >= 128 &&
+        a.K % 32 == 0) {
+        const int nc = ws_ncoef(am);
+        // (the masked form's 128-column variant spills: 184 .. 228 bytes of scratch; the plain form's does not)
+        const int bn3 = (a.N > 64 && dgrad_top_bf3_cols() == 128 && kind == 5) ? 128 : 64;
+        const bool wst3 = ws_lds_bytes_bf3(a.K, bn3, 8, false, nc) > 160 * 1024;
+        if (ws_lds_bytes_bf3(a.K, bn3, 8, wst3, nc) <= 160 * 1024) {
+            pl->bf3 = true; pl->kc = 32; pl->bn = bn3; pl->eh = bn3 / 32; pl->wst = wst3;
+            pl->lds = ws_lds_bytes_bf3(a.K, bn3, 8, wst3, nc);
+        }
+    }
     // masked data gradients that stay on the fp32 pipe (K > 256, the algebraic top-layer forms): their 128-column variants
     // SPILL -- hipcc reports 148 .. 388 bytes of scratch per lane (36 .. 96 registers) for gemm_ws_kernel<4, *, E_MASK*, 64, ..>,
     // which is what round 5's "1.46 x counted traffic" of SA2's 256 -> 128 data gradient was (scratch stores and reloads are
     // global memory: profiles/r06_pmc_dgrad_f32.txt) -- the 64-column variants (195 .. 240 registers) do not
-    if (kind >= 2 && !pl->bf3 && pl->bn == 128 && ws_mask_bn64_enabled()) {
+    if (kind >= 2 && kind != 5 && !pl->bf3 && pl->bn == 128 && ws_mask_bn64_enabled()) {
         pl->bn = 64; pl->eh = 1;
         pl->lds = pl->wst ? ws_lds_bytes_streamed((a.K + 63) / 64 * 64, pl->kc, 64, pl->waves, 1, ws_ncoef(am))
                           : ws_lds_bytes((a.K + 63) / 64 * 64, pl->kc, 64, pl->waves, 1);
@@ -1627,7 +1653,7 @@ PCOPS_HIDDEN int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
     pcops_note_pipe(pl.bf3 ? 1 : 0);
-    if constexpr (EM == E_FWD || (EM == E_MASK && is_dy(AM))) {
+    if constexpr (EM == E_FWD || (EM == E_MASK && is_dy(AM)) || has_add(EM)) {
     if (pl.bf3) {
 #define PCOPS_WS3_LAUNCH(NT_, EH_)                                                                    \
     do {                                                                                              \
@@ -1643,7 +1669,7 @@ PCOPS_HIDDEN int launch_gemm_ws(GemmArgs &a, const WsPlan &pl, hipStream_t st) {
         const int P_ = (a.stats && EM != E_PLAIN && EM != E_PLAINA) ? pcops_mlp_stats_rows(a.M) : 0;  \
         hipLaunchKernelGGL(kern, dim3(pl.gy > P_ ? pl.gy : P_, pl.ncb), dim3(512), pl.lds, st, a);    \
     } while (0)
-        if constexpr (AM == A_BNRELU || AM == A_PLAIN) {
+        if constexpr ((AM == A_BNRELU || AM == A_PLAIN) && EM == E_FWD) {
             if (a.pool_s4 > 0) {     // groups that are not whole tiles: their own instantiations (VAR | 8), split operands only
 #define PCOPS_WS3S4_LAUNCH(NT_, EH_)                                                                  \
     do {                                                                                              \
@@ -1744,7 +1770,7 @@ static bool ws_enabled() {
 template <int AM, int EM>
 static int launch_gemm(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : (is_mask(EM) ? 3 : 0)))) {
+    if (ws_enabled() && ws_plan(a, AM, &pl, ws_kind(EM))) {
         int rc;
         if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
         else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
@@ -4699,7 +4725,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
 template <int AM, int EM>
 static int launch_gemm_ws_only(GemmArgs &a, hipStream_t st) {
     WsPlan pl;
-    if (!(ws_enabled() && ws_plan(a, AM, &pl, EM == E_FWD ? 1 : (EM == E_MASK ? 2 : (is_mask(EM) ? 3 : 0))))) return PCOPS_ERR_UNSUPPORTED;
+    if (!(ws_enabled() && ws_plan(a, AM, &pl, ws_kind(EM)))) return PCOPS_ERR_UNSUPPORTED;
     int rc;
     if (AM == A_DYPOOL && a.blocks) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLB : AM), EM>(a, pl, st);
     else if (AM == A_DYPOOL && a.S % 32 == 0) rc = launch_gemm_ws<(AM == A_DYPOOL ? A_DYPOOLU : AM), EM>(a, pl, st);
