@@ -936,6 +936,19 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
         m = take ? om : m;
         r = take ? orow : r;
     };
+    // the pooled pair of group g, column block nt.  The column part of the address is rebuilt from an opaque copy of the lane
+    // number at every store: hoisted, hipcc kept the two per-lane 64-bit column addresses alive across the kernel -- in scratch in the
+    // S4 kernels, reloaded behind s_waitcnt vmcnt(0) in front of every store, which also waited for the next tile's stripe request.
+    // (Descriptor stores were tried first: their eight scalar registers push the 128-column kernels into scratch elsewhere.)
+    auto pool_store = [&](long long g, int nt, float yv, int r) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int n = n0 + 32 * nt + (ln & 31);
+        if (ln < 32 && n < N) {
+            a.ysel[g * N + n] = yv;
+            a.psel[g * N + n] = (unsigned char)r;
+        }
+    };
     auto pool_acc = [&](const f32x16 (&acc)[NT], long long tile, int sub, long long st) {
         const int hrow = 4 * (lane >> 5);
         const bool low = lane < 32;
@@ -960,11 +973,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     }
                     r += hrow;
                     meet(m, r);
-                    const int n = n0 + 32 * nt + (lane & 31);
-                    if (low && n < N) {
+                    {
                         const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
-                        a.ysel[blk * N + n] = fmaf(m, sg, pv);               // the raw y at that row, as it is stored
-                        a.psel[blk * N + n] = (unsigned char)(s0 + r);
+                        pool_store(blk, nt, fmaf(m, sg, pv), s0 + r);        // the raw y at that row, as it is stored
                     }
                 }
             }
@@ -1012,11 +1023,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                         float m = gmx[nt];
                         int r = (int)((prw >> (8 * nt)) & 0xffu);
                         meet(m, r);
-                        const int n = n0 + 32 * nt + (lane & 31);
-                        if (low && n < N) {
+                        {
                             const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
-                            a.ysel[gg * N + n] = fmaf(m, sg, pv);
-                            a.psel[gg * N + n] = (unsigned char)r;
+                            pool_store(gg, nt, fmaf(m, sg, pv), r);
                         }
                         gmx[nt] = gmy[nt];
                         gmy[nt] = -INFINITY;
@@ -1047,11 +1056,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
                     float m = gmx[nt];
                     int r = grw[nt];
                     meet(m, r);
-                    const int n = n0 + 32 * nt + (lane & 31);
-                    if (low && n < N) {
+                    {
                         const float sg = ecoef[BN + 32 * nt + (lane & 31)], pv = ecoef[2 * BN + 32 * nt + (lane & 31)];
-                        a.ysel[st * N + n] = fmaf(m, sg, pv);
-                        a.psel[st * N + n] = (unsigned char)r;
+                        pool_store(st, nt, fmaf(m, sg, pv), r);
                     }
                     gmx[nt] = -INFINITY;
                     grw[nt] = 0;
