@@ -951,7 +951,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void gemm_ws_kernel(GemmArgs
     };
     auto pool_acc = [&](const f32x16 (&acc)[NT], long long tile, int sub, long long st) {
         const int hrow = 4 * (lane >> 5);
-        const bool low = lane < 32;
         if (compact) {
             // 16-row blocks: block b = accumulator registers 8 b .. 8 b + 7; one partial (value, row-in-group) per block
             const int nblk = (M + kBlk - 1) / kBlk;
@@ -4670,7 +4669,9 @@ __global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int 
 
 // C [M][N] = A [M][K] B [K][N] for the SMALL products around the big kernels (weights x weights: K x K Gram algebra,
 // matrix-vector rows).  One 32 x 32 tile per workgroup so that even a 512 x 512 result fills the chip; the 4 waves split
-// K and add their accumulators through LDS in a fixed order.
+// K and add their accumulators through LDS in a fixed order.  (Eight waves over K for the long reductions -- the partial tiles
+// meeting in the staging area -- were measured in round 6: the SSG and DGCNN steps within noise, 24.55 / 24.46 / 24.63 against
+// 24.47 / 24.44 / 25.03 k clouds/s; not kept.)
 __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
                                                          int ldc, int transA, int transB, const float *__restrict__ bias) {
