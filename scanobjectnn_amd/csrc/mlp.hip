@@ -3280,7 +3280,8 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         // NSET register sets: the loads of stripes i + 2 .. i + NSET are in flight while stripe i + 1 is staged (29 KB per CU
         // and set).  Round 3 measured two sets within noise of one; round 6 measured three and four (-DPCOPS_BF_NSET=3 / 4,
         // no spills at three): SA1's layer 1 430 -> 1 515 -> 1 605 us -- more requests in flight make the pass SLOWER, so it
-        // is not bound by latency x bytes in flight either (profiles/r06_bwd_fused_gw.txt)
+        // is not bound by latency x bytes in flight either (profiles/r06_bwd_fused_gw.txt).  Again with the dW half on split operands
+        // (lighter consumers): three sets 1 320 -> 1 408-1 426 us, SSG 24.35 -> 23.89 k clouds/s over three alternations.
         constexpr bool B_ = DMODE == A_DYPOOLB;                // compacted rows: one pooling group per 16-row block
         constexpr int NBLK = RS / kBlk;                        // blocks per stripe
         constexpr int QD = 256 / D4;                           // rows between a lane's consecutive D rows (divides 16)
