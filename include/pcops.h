@@ -62,7 +62,8 @@ int pcops_abi_version(void);
  *                                      half too where that is faster (layers of 65..128 columns whose input rows are read)
  *   PCOPS_OPT_KNN_F16_PREFILTER        0 / 1 (default): pcops_knn_graph* at c == 64, k <= 20, n >= 256 (seeded or not)
  *   PCOPS_OPT_DGRAD_SPLIT_BF16         0 fp32 MFMA, 1 (default): pcops_mlp_gemm_dgrad* with 128..256 dY columns on the bf16 pipe in
- *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit
+ *                                      64-column passes (weight pieces LDS-resident), 2: 128-column passes where they fit.  The same option
+ *                                      carries pcops_mlp_gemm_dgrad_top (Kp = 128 .. 1024, Kp % 32 == 0; weights resident or streamed)
  *   PCOPS_OPT_BWD_FUSED_GRAM_WGRAD     0 (default) / 1: pcops_mlp_bwd_fused_gw* take shapes (pcops_mlp_bwd_fused_gw_groups > 0);
  *                                      measured -4 % .. +1 % time against the direct form (its vector arg-row term costs what
  *                                      the halved matrix work saves); superseded by value 2 of the option above

@@ -57,3 +57,54 @@ def test_split_operand_data_gradient(M, K, Nout):
     for which in (0, 1):
         a, b = s1[:, which].double().sum(0), s0[:, which].double().sum(0)
         assert ((a - b).abs().max() / b.abs().max()).item() <= 1e-5
+
+
+TOP_CASES = [  # (M, Kp, masked)   the algebraic top-layer data gradient: Gprev = mask . (X Mq + addend[rowmap] + vconst)
+    (40000 + 17, 320, False),     # DGCNN's aggregation layer: the stack's raw input, weights streamed (Kp > 256)
+    (33000, 128, False),          # resident weight pieces, one 128-column pass
+    (36000 + 5, 512, True),       # SA3's form: masked by the layer below, 64-column passes, streamed
+    (34000, 128, True),
+]
+
+
+@pytest.mark.parametrize("M,Kp,masked", TOP_CASES)
+def test_dgrad_top_on_split_operands(M, Kp, masked):
+    """pcops_mlp_gemm_dgrad_top on the bf16 pipe with split operands (round 6; ws_plan kinds 4 / 5): against float64 on the same
+    tensors, the library's own word on the pipe, and -- masked form -- the same mask as float64 away from the fma's rounding edge."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + Kp)
+    Yprev = torch.randn(M, Kp, generator=g).to(DEV)
+    Mq = (torch.randn(Kp, Kp, generator=g) / Kp ** 0.5).to(DEV)
+    vconst = (0.1 * torch.randn(Kp, generator=g)).to(DEV)
+    nadd = 777
+    addend = torch.randn(nadd, Kp, generator=g).to(DEV)
+    rowmap = torch.full((M,), -1, dtype=torch.int32)
+    picks = torch.randperm(M, generator=g)[:nadd]
+    rowmap[picks] = torch.arange(nadd, dtype=torch.int32)
+    rowmap = rowmap.to(DEV)
+    sc = ((0.5 + torch.rand(Kp, generator=g)) * (1.0 - 2.0 * (torch.arange(Kp) % 3 == 1))).to(DEV) if masked else None
+    sh = (0.3 * torch.randn(Kp, generator=g)).to(DEV) if masked else None
+    Gprev = torch.full((M, Kp), float("nan"), device=DEV)
+    P = lib.pcops_mlp_stats_rows(M)
+    stats = torch.zeros(P, 2, Kp, device=DEV)
+    _lib.call("pcops_mlp_gemm_dgrad_top", M, Kp, Yprev.data_ptr(), None if sc is None else sc.data_ptr(),
+              None if sh is None else sh.data_ptr(), Mq.data_ptr(), vconst.data_ptr(), addend.data_ptr(), nadd,
+              rowmap.data_ptr(), Gprev.data_ptr(), stats.data_ptr() if masked else None)
+    assert lib.pcops_last_launch_pipe() == 1
+    torch.cuda.synchronize()
+    assert not torch.isnan(Gprev).any()
+    if masked:
+        pre = Yprev.double() * sc.double() + sh.double()
+        X = pre.clamp_min(0.0)
+    else:
+        X = Yprev.double()
+    want = X @ Mq.double() + vconst.double()
+    want[picks.to(DEV)] += addend.double()
+    if masked:
+        safe = pre.abs() > 1e-5
+        want = want * (pre > 0)
+        got = torch.where(safe, Gprev.double(), want)
+    else:
+        got = Gprev.double()
+    err = ((got - want).abs().max() / want.abs().max()).item()
+    assert err <= 1e-5, err
