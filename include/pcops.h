@@ -702,7 +702,9 @@ int pcops_sa_scatter_bwd_rows(int b, int n, int m, int s, int c, const float *G,
  * instead of twice (and autograd has nothing to add up).  ldq / ldc / lddq / lddc: row strides in floats (multiples of 4,
  * >= c) of Q / Ctr / dQ / dCtr; everything else as in the dense entry points; n == m.  Only shapes
  * pcops_edge_ld_supported() accepts have kernels (64-channel slices, whole 64-group chunks, LDS-resident clouds);
- * PCOPS_ERR_UNSUPPORTED otherwise, and in deterministic mode.  The sa_* pair is the Q + Ctr form of
+ * PCOPS_ERR_UNSUPPORTED otherwise.  In deterministic mode the QUERY answers 0 (the backward's arg-row sums are LDS float
+ * atomics; keep the dense entry points and their ordered kernels); the entry points themselves check the shape only, so a
+ * backward whose forward chose this family still runs when the switch is thrown in between.  The sa_* pair is the Q + Ctr form of
  * pcops_sa_gather_fwd / pcops_sa_scatter_bwd (no coordinate term, G materialised, dQ and dCtr both produced). */
 int pcops_edge_ld_supported(int b, int n, int m, int s, int c);
 int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,

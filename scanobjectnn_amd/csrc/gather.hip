@@ -2051,9 +2051,14 @@ int pcops_edge_pool_bwd(int b, int n, int m, int s, int c, const float *Q, const
 // with the concatenated weight [W_b | W_a - W_b] (dgcnn/tf_util.edge_conv_stack), so the two per-point GEMMs, their two
 // weight gradients and the sum of their two data gradients become one of each.  Only the csrc/edgeconv.hip kernels take
 // row strides: pcops_edge_ld_supported says whether a shape has them (the caller otherwise keeps two dense tensors).
+// The QUERY also answers no in deterministic mode (the backward's arg-row sums are LDS float atomics: the caller then keeps the
+// dense tensors and their ordered kernels); the ENTRY POINTS check the shape only, so that a step whose forward chose this family
+// still has its backward when the switch is thrown in between (that one step is then correct but not bit-reproducible).
+static bool edge_ld_shape_ok(int b, int n, int m, int s, int c) {
+    return n == m && s <= 256 && ec_fwd_supported(b, n, m, s, c) && ec_bwd_supported(b, n, m, s, c) && ec_sparse_ok(n);
+}
 int pcops_edge_ld_supported(int b, int n, int m, int s, int c) {
-    return (n == m && s <= 256 && ec_fwd_supported(b, n, m, s, c) && ec_bwd_supported(b, n, m, s, c) && ec_sparse_ok(n) &&
-            !pcops_get_deterministic()) ? 1 : 0;
+    return (edge_ld_shape_ok(b, n, m, s, c) && !pcops_get_deterministic()) ? 1 : 0;
 }
 
 int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, int ldq, const float *Ctr, int ldc,
@@ -2062,7 +2067,7 @@ int pcops_edge_pool_fwd_ld(int b, int n, int m, int s, int c, const float *Q, in
     PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && ldq % 4 == 0 && ldc % 4 == 0);
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gamma);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(qsel); PCOPS_REQUIRE_PTR(arg);
-    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    if (!edge_ld_shape_ok(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
     return ec_edge_pool_fwd(b, n, m, s, c, Q, ldq, Ctr, ldc, idx, gamma, SQ, qsel, arg, stats_partial, stat_pivot,
                             as_stream(stream));
 }
@@ -2116,7 +2121,7 @@ int pcops_edge_pool_bwd_ld(int b, int n, int m, int s, int c, const float *Q, in
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(gpool); PCOPS_REQUIRE_PTR(ysel);
     PCOPS_REQUIRE_PTR(SQ); PCOPS_REQUIRE_PTR(arg); PCOPS_REQUIRE_PTR(scale); PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(p);
     PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(dQ); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
-    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    if (!edge_ld_shape_ok(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     if (ec_bwd_fused_ok(n, m, s, c)) {
         int rc0 = ec_csr_build(b, n, m, s, idx, workspace, st);
@@ -2135,7 +2140,7 @@ int pcops_sa_gather_fwd_ld(int b, int n, int m, int s, int c, const float *Q, in
                            const int *idx, float *Y, float *stats_partial, const float *stat_pivot, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(b >= 1 && n >= 1 && m >= 1 && s >= 1 && c >= 4 && ldq >= c && ldc >= c && ldq % 4 == 0 && ldc % 4 == 0);
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(idx); PCOPS_REQUIRE_PTR(Y);
-    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    if (!edge_ld_shape_ok(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
     return ec_gather_fwd(b, n, m, s, c, Q, ldq, Ctr, ldc, idx, Y, stats_partial, stat_pivot, as_stream(stream));
 }
 
@@ -2146,7 +2151,7 @@ int pcops_sa_scatter_bwd_ld(int b, int n, int m, int s, int c, const float *G, c
     PCOPS_REQUIRE_SHAPE(ldq % 4 == 0 && ldc % 4 == 0 && lddq % 4 == 0 && lddc % 4 == 0);
     PCOPS_REQUIRE_PTR(G); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(idx);
     PCOPS_REQUIRE_PTR(Q); PCOPS_REQUIRE_PTR(Ctr); PCOPS_REQUIRE_PTR(dQ); PCOPS_REQUIRE_PTR(dCtr); PCOPS_REQUIRE_PTR(workspace);
-    if (!pcops_edge_ld_supported(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
+    if (!edge_ld_shape_ok(b, n, m, s, c) || (long long)b * n * ldq * 4 >= (1ll << 32)) return PCOPS_ERR_UNSUPPORTED;
     hipStream_t st = as_stream(stream);
     int rc = ec_csr_build(b, n, m, s, idx, workspace, st);
     if (rc) return rc;

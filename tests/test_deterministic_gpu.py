@@ -195,3 +195,37 @@ def test_large_destination_sets_fall_back_to_atomics_or_say_why():
             tf_interpolate.three_interpolate(pts, idx, w).backward(up)
     finally:
         _lib.set_deterministic(False)
+
+
+def test_edge_family_backward_survives_the_switch_between_forward_and_backward():
+    """fused_mlp picks the [Q | Ctr] EdgeConv family at forward time; its backward entry points used to re-check
+    the process-wide deterministic switch and return UNSUPPORTED if it had been thrown in between.  They check the shape only
+    now: the step completes (correct, not bit-reproducible), and its gradients agree with an undisturbed step to rounding."""
+    from scanobjectnn_amd.dgcnn import dgcnn
+    _lib.set_deterministic(False)
+    B, n_pts = 8, 2048                     # (the LDS-resident [Q | Ctr] family: whole 64-group chunks)
+    x = torch.from_numpy(synth_clouds(B, n_pts, seed=4)).to(DEV)
+    y = torch.from_numpy(synth_labels(B, seed=4)).to(DEV)
+    assert _lib.load().pcops_edge_ld_supported(B, n_pts, n_pts, 20, 64) == 1
+    net = Model(dgcnn.get_model, device=DEV, seed=2).build(x)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def step(flip):
+        net.load_state_dict(sd)
+        net.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        out = net(x, is_training=True, bn_decay=0.9)
+        loss = dgcnn.get_loss(out[0], y)
+        try:
+            if flip:
+                _lib.set_deterministic(True)
+                assert _lib.load().pcops_edge_ld_supported(B, n_pts, n_pts, 20, 64) == 0      # the QUERY says no now
+            loss.backward()
+        finally:
+            _lib.set_deterministic(False)
+        return {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    g0, g1 = step(False), step(True)
+    num = sum(float(((g1[k] - g0[k]).double() ** 2).sum()) for k in g0)
+    den = sum(float((g0[k].double() ** 2).sum()) for k in g0)
+    assert (num / den) ** 0.5 <= 1e-3
