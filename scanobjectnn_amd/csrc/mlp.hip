@@ -2845,7 +2845,11 @@ __device__ __forceinline__ void split3x4(float v0, float v1, float v2, float v3,
     }
 }
 
-template <int AMODE, int DMODE>
+// K96 (round 6; 65 .. 96 input channels, MSG's 96 -> 128): the X columns take slots 24 e + cq = 0 .. 95 (the eight lanes per row without
+// columns put nothing), and the four consumer waves split the OUTPUT as 96 x 32 each -- three A blocks against ONE dY block, 18
+// matrix instructions per 16-row step instead of 24 (a quarter of the 128-slot layout's products were against 32 empty channels,
+// which its slot order 32 e + cq spread over all four blocks).
+template <int AMODE, int DMODE, bool K96 = false>
 __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
     constexpr int KB = 128, NB = 128, RS = 32;
     constexpr int RSP = 40;                    // bf16 per slot: 32 rows + 8 (80 bytes: 16-byte aligned, 5 x 16 -> b128 reads of
@@ -2976,7 +2980,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
             }
         };
         // four rows x four columns of one operand -> three pieces, one 8-byte store per column and piece
-        auto put = [&](const float4 (&v)[4], __bf16 *tbuf, int slot0) {
+        auto put = [&](const float4 (&v)[4], __bf16 *tbuf, int slot0, int q = 32) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 bf16x4 h, m, l;
@@ -2984,7 +2988,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
                          e == 0 ? v[1].x : (e == 1 ? v[1].y : (e == 2 ? v[1].z : v[1].w)),
                          e == 0 ? v[2].x : (e == 1 ? v[2].y : (e == 2 ? v[2].z : v[2].w)),
                          e == 0 ? v[3].x : (e == 1 ? v[3].y : (e == 2 ? v[3].z : v[3].w)), h, m, l);
-                __bf16 *dst = tbuf + (slot0 + 32 * e + cq) * RSP + 4 * rg;
+                __bf16 *dst = tbuf + (slot0 + q * e + cq) * RSP + 4 * rg;
                 *reinterpret_cast<bf16x4 *>(dst) = h;
                 *reinterpret_cast<bf16x4 *>(dst + SLOTS * RSP) = m;
                 *reinterpret_cast<bf16x4 *>(dst + 2 * SLOTS * RSP) = l;
@@ -3013,7 +3017,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
                 if (!FULL && !(ain && row0 + r < M)) x = make_float4(0.f, 0.f, 0.f, 0.f);
                 ax[j] = x;
             }
-            put(ax, tbuf, 0);
+            if (!K96) put(ax, tbuf, 0);
+            else if (cq < 24) put(ax, tbuf, 0, 24);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 4 * rg + j;
@@ -3085,30 +3090,32 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
         // ------------------------------------------------------------------ consumers
         const int ck = wave >> 1, cn = wave & 1;
         const int half = lane >> 5, li = lane & 31;
-        f32x16 acc[2][2], sm[2][2];
+        constexpr int NXB = K96 ? 3 : 2, NYB = K96 ? 1 : 2;    // A blocks x dY blocks of a consumer wave
+        f32x16 acc[NXB][NYB], sm[NXB][NYB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NXB; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NYB; ++j)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][j][v] = sm[i][j][v] = 0.f;
-        const int aslot = (2 * ck) * 32 + li, dslot = KB + (2 * cn) * 32 + li;      // + 32 x / + 32 y
+        const int aslot = K96 ? li : (2 * ck) * 32 + li;                            // + 32 x
+        const int dslot = K96 ? KB + wave * 32 + li : KB + (2 * cn) * 32 + li;      // + 32 y
         __syncthreads();
         for (long long i = 0; i < cnt; ++i) {
             const __bf16 *tb = T + (i & 1) * 3 * SLOTS * RSP;
 #pragma unroll
             for (int s = 0; s < RS / 16; ++s) {
                 const int ro = 16 * s + 8 * half;
-                bf16x8 ah[2], am[2], al[2], dh[2], dm[2], dl[2];
+                bf16x8 ah[NXB], am[NXB], al[NXB], dh[NYB], dm[NYB], dl[NYB];
 #pragma unroll
-                for (int x = 0; x < 2; ++x) {
+                for (int x = 0; x < NXB; ++x) {
                     const __bf16 *p0 = tb + (aslot + 32 * x) * RSP + ro;
                     ah[x] = *reinterpret_cast<const bf16x8 *>(p0);
                     am[x] = *reinterpret_cast<const bf16x8 *>(p0 + SLOTS * RSP);
                     al[x] = *reinterpret_cast<const bf16x8 *>(p0 + 2 * SLOTS * RSP);
                 }
 #pragma unroll
-                for (int y = 0; y < 2; ++y) {
+                for (int y = 0; y < NYB; ++y) {
                     const __bf16 *p0 = tb + (dslot + 32 * y) * RSP + ro;
                     dh[y] = *reinterpret_cast<const bf16x8 *>(p0);
                     dm[y] = *reinterpret_cast<const bf16x8 *>(p0 + SLOTS * RSP);
@@ -3116,7 +3123,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
                 }
                 // one product at a time over the four blocks: consecutive matrix instructions never share an accumulator
 #define PCOPS_MMX(A_, D_, C_)                                                                              \
-    _Pragma("unroll") for (int x = 0; x < 2; ++x) _Pragma("unroll") for (int y = 0; y < 2; ++y)            \
+    _Pragma("unroll") for (int x = 0; x < NXB; ++x) _Pragma("unroll") for (int y = 0; y < NYB; ++y)        \
         C_[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[x], D_[y], C_[x][y], 0, 0, 0)
                 PCOPS_MMX(al, dh, sm);
                 PCOPS_MMX(ah, dl, sm);
@@ -3131,6 +3138,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
         // acc[x][y][v]: A slot 32 (2 ck + x) + m with m = (v&3) + 8 (v>>2) + 4 half  ->  channel 4 m + (2 ck + x);
         //               dY slot 32 (2 cn + y) + li                                     ->  column  4 li + (2 cn + y)
         float *out = a.part + (long long)grp * K * N;
+        if constexpr (K96) {
+            // A slot 32 x + m = 24 e + cq  ->  channel 4 cq + e;  dY slot 32 wave + li  ->  column 4 li + wave
+            const int nn = n0 + 4 * li + wave;
+#pragma unroll
+            for (int x = 0; x < NXB; ++x)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int sl = 32 * x + (v & 3) + 8 * (v >> 2) + 4 * half;
+                    const int kk = 4 * (sl % 24) + sl / 24;                   // (k0 = 0: one block of input channels)
+                    if (kk < K && nn < N) out[(long long)kk * N + nn] = acc[x][0][v] + sm[x][0][v];
+                }
+        } else {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -3142,6 +3161,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_bf3_kernel(WgradArgs a) {
                     if (kk < K && nn < N) out[(long long)kk * N + nn] = acc[x][y][v] + sm[x][y][v];
                 }
             }
+        }
         __syncthreads();                                       // matches the producers' db hand-over
         if (blockIdx.y == 0 && a.dbpart) {
             const float *sdb = reinterpret_cast<const float *>(T);
@@ -4785,9 +4805,12 @@ int wgrad_impl(WgradArgs &a, float *partial, float *dW, float *db, hipStream_t s
         splits = b3.groups;
         a.part = partial; a.dbpart = partial + (long long)splits * K * N;
         const dim3 grid(b3.groups, b3.kblocks, b3.nblocks);
+        // 65 .. 96 input channels behind a BN + ReLU (MSG's 96 -> 128): the 96 x 32 consumer layout (PCOPS_WGRAD_BF3_K96=0: off)
+        static const bool k96_on = [] { const char *e = getenv("PCOPS_WGRAD_BF3_K96"); return !(e && e[0] == '0'); }();
+        const bool k96 = k96_on && K <= 96 && K % 4 == 0;
 #define PCOPS_B3_LAUNCH(AM_, DM_)                                                                          \
     do {                                                                                                   \
-        auto kern = wgrad_bf3_kernel<AM_, DM_>;                                                            \
+        auto kern = (k96 && AM_ == A_BNRELU) ? wgrad_bf3_kernel<AM_, DM_, AM_ == A_BNRELU> : wgrad_bf3_kernel<AM_, DM_>;   \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                      \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
             return PCOPS_ERR_LAUNCH;                                                                       \

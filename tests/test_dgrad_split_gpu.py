@@ -108,3 +108,51 @@ def test_dgrad_top_on_split_operands(M, Kp, masked):
         got = Gprev.double()
     err = ((got - want).abs().max() / want.abs().max()).item()
     assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("M,K,N,S", [(65536 + 77, 96, 128, 0), (64 * 1100, 96, 128, 64), (20 * 3500 + 20, 80, 128, 20),
+                                     (70000, 96, 256, 0), (32 * 2100, 72, 96, 32)])
+def test_wgrad_with_65_to_96_input_channels(M, K, N, S):
+    """pcops_mlp_wgrad with 65 .. 96 input channels (MSG's 96 -> 128): the 96 x 32 consumer layout of wgrad_bf3_kernel (round 6)
+    against float64 -- dense and pooled upstream gradients, a ragged tail, fewer than 96 channels, two column blocks."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=g).to(DEV)
+    Y = torch.randn(M, N, generator=g).to(DEV)
+    sc = ((0.5 + torch.rand(K, generator=g)) * (1.0 - 2.0 * (torch.arange(K) % 3 == 1))).to(DEV)
+    sh = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    p = (0.5 + torch.rand(N, generator=g)).to(DEV)
+    q = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    t = (0.05 * torch.randn(N, generator=g)).to(DEV)
+    if S:
+        G = None
+        gpool = torch.randn(M // S, N, generator=g).to(DEV)
+        argmax = torch.randint(0, S, (M // S, N), generator=g, dtype=torch.int32).to(torch.uint8).to(DEV)
+        Gfull = torch.zeros(M // S, S, N, dtype=torch.float64, device=DEV)
+        Gfull.scatter_(1, argmax.long().unsqueeze(1), gpool.double().unsqueeze(1))
+        Gfull = Gfull.view(M, N)
+    else:
+        G = torch.randn(M, N, generator=g).to(DEV)
+        gpool = argmax = None
+        Gfull = G.double()
+    dY = p.double() * Gfull + q.double() * Y.double() + t.double()
+    Xa = (X.double() * sc.double() + sh.double()).clamp_min(0.0)
+    want_dW, want_db = Xa.t() @ dY, dY.sum(0)
+
+    def ptr(x):
+        return None if x is None else x.data_ptr()
+
+    splits = lib.pcops_mlp_wgrad_splits(M, K, N)
+    scratch = torch.empty(splits * (K * N + N), device=DEV)
+    dW, db = torch.full((K, N), float("nan"), device=DEV), torch.empty(N, device=DEV)
+    dummy = p.data_ptr() if S else None
+    _lib.call("pcops_mlp_wgrad", M, K, N, X.data_ptr(), K, sc.data_ptr(), sh.data_ptr(), ptr(G), Y.data_ptr(),
+              p.data_ptr(), q.data_ptr(), t.data_ptr(), ptr(gpool), ptr(argmax), S if S else 1, dummy, dummy,
+              scratch.data_ptr(), dW.data_ptr(), db.data_ptr())
+    assert lib.pcops_last_launch_pipe() == 1
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    assert rel(dW, want_dW) <= 2e-5 and rel(db, want_db) <= 2e-5
