@@ -50,15 +50,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // fp32 -> three bf16 pieces, x = h + m + l up to 2^-25 |x| (each residual is exact in fp32; round-to-nearest pieces carry
 // their own signs, so 3 x 8 significant bits cover the 24 of the operand; below 2^-100 the residuals turn denormal and the
 // identity holds to an absolute 2^-133 instead).  Products of two pieces are exact in fp32.  (tests/test_split_operands_cpu.py)
+// Written on PAIRS of values (round 6): one v_cvt_pk_bf16_f32 per pair and piece, the widening as shift / mask of the packed word,
+// the residuals as v_pk_add_f32 -- 36 instructions for eight values.  As a loop over single values hipcc paired what it could and
+// left 46 (17 conversions, ten of the sixteen subtractions unpacked); same arithmetic, bit for bit.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float a, float b, bf16x2 &h, bf16x2 &m, bf16x2 &l) {
+    const f32x2 v = {a, b};
+    h = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    l = __builtin_convertvector(r2, bf16x2);
+}
 __device__ __forceinline__ void split3(const float4 &x0, const float4 &x1, bf16x8 &h, bf16x8 &m, bf16x8 &l) {
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 hh = (__bf16)x[e];
-        const float r1 = x[e] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;
-        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    for (int p = 0; p < 4; ++p) {
+        bf16x2 hh, mm, ll;
+        split3_pair(x[2 * p], x[2 * p + 1], hh, mm, ll);
+        h[2 * p] = hh.x; h[2 * p + 1] = hh.y;
+        m[2 * p] = mm.x; m[2 * p + 1] = mm.y;
+        l[2 * p] = ll.x; l[2 * p + 1] = ll.y;
     }
 }
 
@@ -2836,12 +2849,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3x4(float v0, float v1, float v2, float v3, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
     const float x[4] = {v0, v1, v2, v3};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = (__bf16)x[e];
-        const float r1 = x[e] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;
-        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    for (int p = 0; p < 2; ++p) {
+        bf16x2 hh, mm, ll;
+        split3_pair(x[2 * p], x[2 * p + 1], hh, mm, ll);
+        h[2 * p] = hh.x; h[2 * p + 1] = hh.y;
+        m[2 * p] = mm.x; m[2 * p + 1] = mm.y;
+        l[2 * p] = ll.x; l[2 * p + 1] = ll.y;
     }
 }
 
@@ -3441,12 +3454,12 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 __bf16 *dstp = tb + (slot0 + Q * e + cq) * RSP + r0;
                 __bf16 h[RW], m[RW], l[RW];
 #pragma unroll
-                for (int i = 0; i < RW; ++i) {
-                    const float x = e == 0 ? v[i].x : (e == 1 ? v[i].y : (e == 2 ? v[i].z : v[i].w));
-                    const __bf16 hh = (__bf16)x;
-                    const float r1 = x - (float)hh;
-                    const __bf16 mm = (__bf16)r1;
-                    h[i] = hh; m[i] = mm; l[i] = (__bf16)(r1 - (float)mm);
+                for (int i = 0; i < RW; i += 2) {
+                    const float xa = e == 0 ? v[i].x : (e == 1 ? v[i].y : (e == 2 ? v[i].z : v[i].w));
+                    const float xb = e == 0 ? v[i + 1].x : (e == 1 ? v[i + 1].y : (e == 2 ? v[i + 1].z : v[i + 1].w));
+                    bf16x2 hh, mm, ll;
+                    split3_pair(xa, xb, hh, mm, ll);
+                    h[i] = hh.x; h[i + 1] = hh.y; m[i] = mm.x; m[i + 1] = mm.y; l[i] = ll.x; l[i + 1] = ll.y;
                 }
                 if constexpr (RW == 4) {
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
