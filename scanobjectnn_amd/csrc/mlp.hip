@@ -41,6 +41,10 @@
 #define PCOPS_PART(p_) (PCOPS_MLP_PART < 0 || PCOPS_MLP_PART == (p_))
 #define PCOPS_HIDDEN __attribute__((visibility("hidden")))
 
+#ifndef PCOPS_BF_RM
+#define PCOPS_BF_RM 1      // one-pass backward with the split-operand dW half, EdgeConv (SIDE) form: dY's pieces row-major as well (bwd_fused_kernel, RM)
+#endif
+
 namespace pcops_mlp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -3238,11 +3242,22 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     static_assert(!(XYZ && SIDE), "one reduced first layer below");
     constexpr int NX = XYZ ? 3 : (SIDE ? 6 : 0);              // per-row inputs the masked gradient is reduced against
     // fp32 stripe row:  X | raw | dY | pad  (row stride = 4 banks mod 32; SIDE: 12 mod 32);  DW3: raw | dY | pad
-    constexpr int OXC = 0, ORC = DW3 ? 0 : KB, ODC = DW3 ? KB : 2 * KB, OPC = ODC + NB;
+    // RM (DW3 of the EdgeConv form, -DPCOPS_BF_RM=0 for the layout before it): dY ALSO leaves the fp32 stripe -- the producers hand its three pieces over a
+    // second time ROW-major, R[piece][row][column], and a consumer's dX operand is three 16-byte reads instead of two fp32 reads and a
+    // split3 (36 vector instructions per step and wave that four waves repeated on values the producers had split already).  The LDS
+    // for it comes out of the transposed pieces' padding: 32 rows per slot instead of 40, with the 16-byte unit of a slot XOR-ed with
+    // (slot / 4) % 4 so that the 16 lanes of a read phase still meet 16 different bank groups.
+    // Measured same-box (profiles/r06_bwd_fused_rm_ab.txt): the EdgeConv form 3 843 -> 3 790 us (DGCNN +0.3 .. 0.9 % over three
+    // alternations); the plain forms 1 373 -> 1 411 us (SA1) and 3 750 -> 3 862 us (T-Net) -- their producers spill ten registers
+    // with the second hand-over where the EdgeConv producers (which hold less per row) do not pay for it -- so they keep the fp32 dY.
+    constexpr bool RM = DW3 && SIDE && (PCOPS_BF_RM != 0);
+    constexpr int OXC = 0, ORC = DW3 ? 0 : KB, ODC = DW3 ? KB : 2 * KB, OPC = RM ? KB : ODC + NB;
     constexpr int LD = OPC + (SIDE ? 12 : 4);
+    constexpr int RLD = NB + 8;                               // RM: bf16 per row of the row-major pieces (272 bytes: a row shifts one bank group)
+    constexpr int RBUF = 3 * RS * RLD;                        // RM: bf16 per buffer
     constexpr int A4 = KB / 4, D4 = NB / 4;
     constexpr int NA = RS * A4 / 256, ND = RS * D4 / 256;
-    constexpr int RSP = 40, SLOTS = KB + NB;                  // DW3: bf16 per slot (32 rows + 8: 80-byte slots), slots per piece
+    constexpr int RSP = RM ? 32 : 40, SLOTS = KB + NB;        // DW3: bf16 per slot (32 rows + 8: 80-byte slots; RM: 32, swizzled), slots per piece
     constexpr int TBUF = 3 * SLOTS * RSP;                     // bf16 per piece buffer
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3264,6 +3279,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
     // consumers hold their slices in registers, and T[1] is first written after the barrier that follows)
     float *buf = DW3 ? coefD + 3 * NB : coefD + 3 * NB + NB * KB;   // [2][RS][LD]   | afterwards: db scratch [256][4], statistics [2][5][KB]
     __bf16 *Tp = reinterpret_cast<__bf16 *>(buf + 2 * RS * LD);
+    __bf16 *Rp = Tp + 2 * TBUF;                               // RM: [2][3][RS][RLD]
     float *wq = DW3 ? reinterpret_cast<float *>(Tp + TBUF) : coefD + 3 * NB;     // [NB / 4][KB][4]   W[k][4 nq .. 4 nq + 3]
 
     for (int e = tid; e < KB; e += 512) {
@@ -3447,11 +3463,14 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         int srow = grp * RS, sg0 = srow / Sg, ss0 = srow % Sg;  // the stripe stage() is at (same running form)
         // DW3: RW consecutive rows x four columns of one operand -> three pieces, one (2 RW)-byte store per column and piece;
         // column c of an operand of width 4 Q lives in slot  Q (c % 4) + c / 4  (a wave's stores then fall on distinct banks)
-        auto put_rows = [&](const auto &v, __bf16 *tb, int slot0, int Q, int cq, int r0) {
+        auto put_rows = [&](const auto &v, __bf16 *tb, int slot0, int Q, int cq, int r0, __bf16 *rb = nullptr) {
             constexpr int RW = (int)(sizeof(v) / sizeof(float4));
+            __bf16 rh[RM ? RW : 1][4], rm[RM ? RW : 1][4], rl[RM ? RW : 1][4];      // RM: the pieces again, row by row
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                __bf16 *dstp = tb + (slot0 + Q * e + cq) * RSP + r0;
+                const int slot = slot0 + Q * e + cq;
+                // RM: unit (8 rows = 16 bytes) u of slot s sits at unit u ^ ((s / 4) % 4)
+                __bf16 *dstp = RM ? tb + slot * RSP + ((((r0 >> 3) ^ (slot >> 2)) & 3) << 3) + (r0 & 7) : tb + slot * RSP + r0;
                 __bf16 h[RW], m[RW], l[RW];
 #pragma unroll
                 for (int i = 0; i < RW; i += 2) {
@@ -3460,6 +3479,10 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     bf16x2 hh, mm, ll;
                     split3_pair(xa, xb, hh, mm, ll);
                     h[i] = hh.x; h[i + 1] = hh.y; m[i] = mm.x; m[i + 1] = mm.y; l[i] = ll.x; l[i + 1] = ll.y;
+                }
+                if constexpr (RM) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) { rh[i][e] = h[i]; rm[i][e] = m[i]; rl[i][e] = l[i]; }
                 }
                 if constexpr (RW == 4) {
                     typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
@@ -3476,8 +3499,22 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     *reinterpret_cast<bf16x2_ *>(dstp + 2 * SLOTS * RSP) = lv;
                 }
             }
+            if constexpr (RM) {
+                if (rb) {                                      // (the dY operand only)
+                    typedef __bf16 bf16x4r __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        __bf16 *dr = rb + (r0 + i) * RLD + 4 * cq;
+                        const bf16x4r hv = {rh[i][0], rh[i][1], rh[i][2], rh[i][3]}, mv = {rm[i][0], rm[i][1], rm[i][2], rm[i][3]},
+                                      lv = {rl[i][0], rl[i][1], rl[i][2], rl[i][3]};
+                        *reinterpret_cast<bf16x4r *>(dr) = hv;
+                        *reinterpret_cast<bf16x4r *>(dr + RS * RLD) = mv;
+                        *reinterpret_cast<bf16x4r *>(dr + 2 * RS * RLD) = lv;
+                    }
+                }
+            }
         };
-        auto stage_ = [&](float *dst, __bf16 *tdst, const Regs &rg_, auto full_) {
+        auto stage_ = [&](float *dst, __bf16 *tdst, __bf16 *rdst, const Regs &rg_, auto full_) {
             constexpr bool FULL = decltype(full_)::value;
             if (dbg & 8) return;
             const int row0 = srow;
@@ -3544,14 +3581,14 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                 }
                 if (!FULL && !(din && row0 + r < M)) d = make_float4(0.f, 0.f, 0.f, 0.f);
                 dbs[0] += d.x; dbs[1] += d.y; dbs[2] += d.z; dbs[3] += d.w;
-                *reinterpret_cast<float4 *>(&dst[r * LD + ODC + dcq]) = d;
+                if (!RM) *reinterpret_cast<float4 *>(&dst[r * LD + ODC + dcq]) = d;
                 if (DW3) dt[DW3 ? j : 0] = d;
             }
-            if constexpr (DW3) put_rows(dt, tdst, KB, NB / 4, pt % D4, ND * (pt / D4));
+            if constexpr (DW3) put_rows(dt, tdst, KB, NB / 4, pt % D4, ND * (pt / D4), rdst);
         };
-        auto stage = [&](float *dst, __bf16 *tdst, const Regs &rg_) {
-            if (srow + RS <= Mi && K == KB && N == NB) stage_(dst, tdst, rg_, std::true_type{});
-            else stage_(dst, tdst, rg_, std::false_type{});
+        auto stage = [&](float *dst, __bf16 *tdst, __bf16 *rdst, const Regs &rg_) {
+            if (srow + RS <= Mi && K == KB && N == NB) stage_(dst, tdst, rdst, rg_, std::true_type{});
+            else stage_(dst, tdst, rdst, rg_, std::false_type{});
             srow += rstep;
             if (DMODE == A_DYPOOL) {
                 sg0 += dq; ss0 += dr;
@@ -3564,7 +3601,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         if (NSET > 2 && cnt > 2) issue(rs2);
         if (NSET > 3 && cnt > 3) issue(rs3);
         if (cnt > 0) {
-            stage(buf, Tp, rs0);
+            stage(buf, Tp, Rp, rs0);
             if (cnt > NSET) issue(rs0);
         }
         __syncthreads();                                       // stripe 0 is in buf[0]
@@ -3575,7 +3612,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             if (j < cnt) {
                 // (a set is named by a wave-uniform index: one copy of the code per set, so that the sets stay in registers)
                 auto body = [&](Regs &rg_) {
-                    stage(buf + (j & 1) * RS * LD, Tp + (j & 1) * TBUF, rg_);
+                    stage(buf + (j & 1) * RS * LD, Tp + (j & 1) * TBUF, Rp + (j & 1) * RBUF, rg_);
                     if (j + NSET < cnt) issue(rg_);
                 };
                 if (si == 0) body(rs0);
@@ -3632,7 +3669,11 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
         const int doff = GW ? half * LD + cn * 32 + li : half * LD + ODC + cn * TN * 32 + li;   // GW: the X column block cn
         const int daoff = (16 * rh + c16) * LD + ODC + (DX3 ? 8 : 4) * g4;   // + 16 J (split operands: + 32 J, and + 4)
         // DW3: fragments of the transposed pieces: A = slots 32 ck + li, B = slots KB + 32 (cn TN + y) + li; rows 16 s + 8 half ..
-        const int taoff = (32 * ck + li) * RSP + 8 * half, tdoff = (KB + 32 * cn * TN + li) * RSP + 8 * half;
+        const int taoff = (32 * ck + li) * RSP + (RM ? 0 : 8 * half), tdoff = (KB + 32 * cn * TN + li) * RSP + (RM ? 0 : 8 * half);
+        // RM: rows 16 s + 8 half .. = unit 2 s + half of a slot, stored at unit ^ ((slot / 4) % 4) = unit ^ ((li / 4) % 4) (the blocks
+        // start at multiples of 32 slots)
+        const int tsw0 = (((0 + half) ^ (li >> 2)) & 3) << 3, tsw1 = (((2 + half) ^ (li >> 2)) & 3) << 3;
+        const int reoff = (16 * rh + c16) * RLD + 8 * g4;      // RM: the lane's dX operand fragment in a row-major piece: + 32 J
         const int nyw = NSK ? (N - cn * TN * 32 + 31) / 32 : TN;            // dW blocks of this wave with real columns
         const int jreal = NSK ? (DX3 ? (N + 31) / 32 : (N + 15) / 16) : (DX3 ? NB / 32 : NB / 16);   // steps with real columns
         const int wboff = (g4 * KB + 32 * cbp + c16) * 4;                   // + 16 b * 4, + J * 4 KB * 4
@@ -3709,13 +3750,20 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
             constexpr int JP = (RS / 2) / JN;                  // data-gradient steps spread over the RS / 2 row pairs
             // every LDS fragment is requested one use AHEAD (the scheduler would otherwise sink the reads to just in
             // front of their first use and expose the LDS latency)
-            float4 da_n = *reinterpret_cast<const float4 *>(&sb[daoff]);
-            float4 da2_n = DX3 ? *reinterpret_cast<const float4 *>(&sb[daoff + 4]) : da_n;     // split operands: columns + 4 .. + 7
+            float4 da_n = RM ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(&sb[daoff]);
+            float4 da2_n = RM ? da_n : (DX3 ? *reinterpret_cast<const float4 *>(&sb[daoff + 4]) : da_n);     // split operands: columns + 4 .. + 7
             float yr[2][4];                                    // the raw Yprev under this wave's Gprev elements
             if constexpr (DW3) {
                 // JN data-gradient steps (12 x 16 cycles each), the two 16-row steps of the weight gradient (6 TN x 32 cycles)
                 // behind steps 0 and JN / 2; a step's fragments are requested in front of the data-gradient MFMAs before it
                 const __bf16 *tb = Tp + (i & 1) * TBUF;
+                const __bf16 *rbp = Rp + (i & 1) * RBUF;
+                bf16x8 eh_n, em_n, el_n;
+                if constexpr (RM) {
+                    eh_n = *reinterpret_cast<const bf16x8 *>(rbp + reoff);
+                    em_n = *reinterpret_cast<const bf16x8 *>(rbp + RS * RLD + reoff);
+                    el_n = *reinterpret_cast<const bf16x8 *>(rbp + 2 * RS * RLD + reoff);
+                }
                 constexpr int SJ = JN / 2;
 #pragma unroll
                 for (int J = 0; J < JN; ++J) {
@@ -3725,16 +3773,25 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     if (wstep) {
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc) {
-                            fa[pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + taoff + 16 * s_);
+                            const int so = RM ? (s_ ? tsw1 : tsw0) : 16 * s_;
+                            fa[pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + taoff + so);
 #pragma unroll
                             for (int y = 0; y < TN; ++y)
-                                fb[y][pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + tdoff + 32 * y * RSP + 16 * s_);
+                                fb[y][pc] = *reinterpret_cast<const bf16x8 *>(tb + pc * SLOTS * RSP + tdoff + 32 * y * RSP + so);
                         }
                     }
                     const float4 da = da_n, da2 = da2_n;
+                    bf16x8 eh, em, el;
+                    if constexpr (RM) { eh = eh_n; em = em_n; el = el_n; }
                     if (J + 1 < JN) {
+                        if constexpr (RM) {
+                            eh_n = *reinterpret_cast<const bf16x8 *>(rbp + reoff + 32 * (J + 1));
+                            em_n = *reinterpret_cast<const bf16x8 *>(rbp + RS * RLD + reoff + 32 * (J + 1));
+                            el_n = *reinterpret_cast<const bf16x8 *>(rbp + 2 * RS * RLD + reoff + 32 * (J + 1));
+                        } else {
                         da_n = *reinterpret_cast<const float4 *>(&sb[daoff + 32 * (J + 1)]);
                         da2_n = *reinterpret_cast<const float4 *>(&sb[daoff + 32 * (J + 1) + 4]);
+                        }
                     } else {
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
@@ -3744,8 +3801,7 @@ __global__ __launch_bounds__(512, 1) void bwd_fused_kernel(WgradArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if ((!NSK || J < jreal) && !(dbg & 1)) {
-                        bf16x8 eh, em, el;
-                        split3(da, da2, eh, em, el);
+                        if constexpr (!RM) split3(da, da2, eh, em, el);
 #pragma unroll
                         for (int b = 0; b < 2; ++b) smd[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(el, wph[J][b], smd[b], 0, 0, 0);
 #pragma unroll
@@ -4963,7 +5019,9 @@ int bwd_fused_launch(WgradArgs &a, bool xyz, int groups, float *partial, float *
     // waves' worth of matrix work saved, the producers' piece splitting added) and the xyz forms (+9 %: their producers
     // already rebuild the first layer per row) are slower with it; nor with the Gram form or the column skip (N <= 96).
     const bool dw3 = optv >= 2 && tn == 2 && !xyz && !a.gram_part && !(nsk_on() && N <= 96);
-    const size_t lds = dw3 ? (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + 2 * 32 * (64 + NB + (side ? 12 : 4))) * sizeof(float) +
+    const size_t lds = (dw3 && side && PCOPS_BF_RM) ? (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + 2 * 32 * (64 + (side ? 12 : 4))) * sizeof(float) +
+                                 (size_t)2 * 3 * (64 + NB) * 32 * 2 + (size_t)2 * 3 * 32 * (NB + 8) * 2
+                     : dw3 ? (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + 2 * 32 * (64 + NB + (side ? 12 : 4))) * sizeof(float) +
                                  (size_t)2 * 3 * (64 + NB) * 40 * 2
                            : (size_t)((xyz ? 6 : 2) * 64 + 3 * NB + NB * 64 + 2 * 32 * (2 * 64 + NB + (side ? 12 : 4))) * sizeof(float);
     const bool pooled = a.gpool != nullptr;
