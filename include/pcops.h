@@ -385,6 +385,11 @@ int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *
  * dX = dY W^T, dW = X^T dY) without a transposed copy of anything. */
 int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
                         const float *bias, float *C, int ldc, pcops_stream_t stream);
+/* ... and colsum [N] (may be NULL) = the column sums of op(B) over its K rows out of the same launch: the bias gradient
+ * db = 1^T dY of fully_connected next to dW = X^T dY (tf_util.py:187-213; round 6 -- it was a separate reduction launch
+ * of 12 us per layer).  Fixed summation order. */
+int pcops_small_gemm_colsum(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                            const float *bias, float *C, int ldc, float *colsum, pcops_stream_t stream);
 
 /* ---- algebraic backward of a POOLED top layer (the last conv of a set-abstraction stack / of a stack pooled over a
  * whole cloud: pointnet_util.py:139-147, dgcnn.py "agg", transform_nets.py "tconv3").
@@ -405,9 +410,18 @@ int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA
  *   pcops_mlp_gram                gram [Kp][Kp] = X^T X, xsum [Kp] = X^T 1; partial: pcops_mlp_wgrad_splits(M,Kp,Kp)
  *                                 copies of (Kp Kp + Kp) floats
  *   pcops_mlp_pool_top_wsparse    Ssp [Kp][N] = X^T (p.G), cfsum [N] = 1^T (p.G)
+ *   pcops_mlp_pool_top_prep       the small operands in one launch: Wt [N][Kp] = W^T, Wq [Kp][N] = W diag(q),
+ *                                 u [N] = q.b + t  (round 6: they were a transpose and two elementwise launches)
+ *   pcops_mlp_pool_top_finish     closes the sums in place: dW [Kp][N] = (dW + Ssp) + xsum u^T with dW = gram Wq on
+ *                                 entry, db [N] = (cfsum + q.(xw + M b)) + M t with xw = xsum^T W  (round 6: ten launches)
  * prev_scale == prev_shift == NULL: X is the stack's raw input (a one-layer stack) -- no mask, no statistics.
  * All sums in a fixed order (deterministic). */
 int pcops_mlp_pool_top_supported(int M, int Kp, int N, int S);
+int pcops_mlp_pool_top_prep(int Kp, int N, const float *W, const float *b, const float *q, const float *t, float *Wt,
+                            float *Wq, float *u, pcops_stream_t stream);
+int pcops_mlp_pool_top_finish(int Kp, int N, long long M, float *dW, const float *Ssp, const float *xsum, const float *u,
+                              const float *cfsum, const float *q, const float *xw, const float *b, const float *t,
+                              float *db, pcops_stream_t stream);
 int pcops_mlp_pool_top_addend(int M, int Kp, int N, int S, const float *gout, const float *ysel,
                             const unsigned char *argmax, const float *pool_scale, const float *pool_shift,
                             const float *p, const float *Wt, float *addend, int *rowmap, pcops_stream_t stream);
@@ -754,6 +768,14 @@ int pcops_fc_bn_fwd(int R, int C, const float *x, const float *gamma, const floa
 int pcops_fc_bn_bwd(int R, int C, const float *dy, const float *x, const float *y, const float *gamma,
                     const float *save_mean, const float *save_rstd, int training, int relu, float *dx,
                     float *dgamma, float *dbeta, pcops_stream_t stream);
+
+/* The classification loss of a batch (a few hundred rows) and its gradient in one launch: mean softmax cross entropy against
+ * q = s / C + (1 - s) onehot(labels) -- tf.losses.softmax_cross_entropy(..., label_smoothing = s) of dgcnn/models/dgcnn.py:99-105;
+ * s = 0 is the sparse softmax cross entropy + reduce_mean of pointnet2/models/pointnet2_cls_ssg.py:47-53.  loss [1],
+ * dlogits [R][C] = (softmax - q) / R (the gradient for an upstream factor of 1; the caller scales).  One workgroup: meant for
+ * R up to a few thousand rows.  Fixed summation order. */
+int pcops_softmax_ce(int R, int C, const float *logits, const int *labels, float label_smoothing, float *loss,
+                     float *dlogits, pcops_stream_t stream);
 
 /* the learned 3 x 3 input transform applied to a cloud (tf.matmul(point_cloud, transform): dgcnn/models/dgcnn.py:37,
  * pointnet/models/pointnet_cls.py:27): out (b, n, 3) = x (b, n, 3) T (b, 3, 3); backward dT (b, 3, 3) = x^T grad_out per cloud in a

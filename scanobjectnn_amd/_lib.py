@@ -51,6 +51,9 @@ SIGNATURES = {
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
     "pcops_small_gemm": ([_I, _I, _I, _P, _I, _P, _I, _P, _I], True),
     "pcops_small_gemm_ex": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I], True),
+    "pcops_small_gemm_colsum": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P], True),
+    "pcops_mlp_pool_top_prep": ([_I, _I] + [_P] * 7, True),
+    "pcops_mlp_pool_top_finish": ([_I, _I, _LL] + [_P] * 10, True),
     "pcops_mlp_pool_top_addend": ([_I, _I, _I, _I] + [_P] * 9, True),
     "pcops_mlp_gemm_dgrad_top": ([_I, _I] + [_P] * 6 + [_LL] + [_P] * 3, True),
     "pcops_mlp_gram": ([_LL, _I, _P, _I, _P, _P, _P, _P, _P], True),
@@ -106,6 +109,7 @@ SIGNATURES = {
     "pcops_transform3_bwd": ([_I, _I, _P, _P, _P, _P, _P], True),
     "pcops_fc_bn_fwd": ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P], True),
     "pcops_fc_bn_bwd": ([_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P], True),
+    "pcops_softmax_ce": ([_I, _I, _P, _P, _F, _P, _P], True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),

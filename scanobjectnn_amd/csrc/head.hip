@@ -145,6 +145,45 @@ __global__ __launch_bounds__(256) void transform3_bwd_kernel(int n, const float 
     if (tid < 9) dT[b * 9 + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
 }
 
+// Mean softmax cross entropy of a few hundred rows with label smoothing, and its gradient, in ONE launch
+// (tf.losses.softmax_cross_entropy(onehot, logits, label_smoothing = s): dgcnn/models/dgcnn.py:99-105; s = 0 is
+// tf.nn.sparse_softmax_cross_entropy_with_logits + reduce_mean: pointnet2/models/pointnet2_cls_ssg.py:47-53).  torch's
+// F.cross_entropy is 6 launches without and 26 with smoothing.  Target q = s / C + (1 - s) [c == y];
+//   loss_r = -sum_c q_c (x_c - lse_r),   dx[r][c] = (exp(x_c - lse_r) - q_c) / R,   loss = sum_r loss_r / R
+// One workgroup, a thread per row (strided), row losses added in a fixed order.  A label outside [0, C) contributes the
+// smoothing term only (no class row to pick) -- the callers hand over validated labels.
+__global__ __launch_bounds__(256) void softmax_ce_kernel(int R, int C, const float *__restrict__ x, const int *__restrict__ y,
+                                                         float smooth, float *__restrict__ loss, float *__restrict__ dx) {
+    __shared__ float sm[256];
+    const int t = threadIdx.x;
+    const float invR = 1.f / (float)R, qs = smooth / (float)C;
+    float acc = 0.f;
+    for (int r = t; r < R; r += 256) {
+        const float *xr = x + (long long)r * C;
+        float m = xr[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xr[c]);
+        float se = 0.f, sx = 0.f;
+        for (int c = 0; c < C; ++c) { se += expf(xr[c] - m); sx += xr[c]; }
+        const float lse = m + logf(se);
+        const int yr = y[r];
+        const bool ok = yr >= 0 && yr < C;
+        const float pick = ok ? xr[yr] - lse : 0.f;
+        acc += -((1.f - smooth) * pick + qs * (sx - (float)C * lse));
+        float *dr = dx + (long long)r * C;
+        for (int c = 0; c < C; ++c) {
+            const float q = qs + ((ok && c == yr) ? 1.f - smooth : 0.f);
+            dr[c] = (expf(xr[c] - lse) - q) * invR;
+        }
+    }
+    sm[t] = acc;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (t < w) sm[t] += sm[t + w];
+        __syncthreads();
+    }
+    if (t == 0) loss[0] = sm[0] * invR;
+}
+
 }  // namespace
 
 extern "C" int pcops_fc_bn_fwd(int R, int C, const float *x, const float *gamma, const float *beta, float *moving_mean,
@@ -186,5 +225,15 @@ extern "C" int pcops_transform3_bwd(int b, int n, const float *x, const float *T
     if (b == 0) return PCOPS_OK;
     PCOPS_REQUIRE_PTR(x); PCOPS_REQUIRE_PTR(T); PCOPS_REQUIRE_PTR(grad_out); PCOPS_REQUIRE_PTR(dT);
     hipLaunchKernelGGL(transform3_bwd_kernel, dim3(b), dim3(256), 0, as_stream(stream), n, x, T, grad_out, dT, dx);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_softmax_ce(int R, int C, const float *logits, const int *labels, float label_smoothing, float *loss,
+                                float *dlogits, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(R >= 1 && C >= 1);
+    PCOPS_REQUIRE_ARG(label_smoothing >= 0.f && label_smoothing <= 1.f);
+    PCOPS_REQUIRE_PTR(logits); PCOPS_REQUIRE_PTR(labels); PCOPS_REQUIRE_PTR(loss); PCOPS_REQUIRE_PTR(dlogits);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, as_stream(stream), R, C, logits, labels, label_smoothing, loss,
+                       dlogits);
     return pcops_launch_status();
 }

@@ -4403,6 +4403,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
         if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
 }
 
+// The algebraic top layer's small operands in ONE launch (they were a transpose, an elementwise product and an addcmul):
+//   Wt[n][k] = W[k][n],  Wq[k][n] = W[k][n] q[n],  u[n] = fma(q[n], b[n], t[n])  (tile row 0 writes u)
+__global__ __launch_bounds__(256) void pool_top_prep_kernel(int K, int N, const float *__restrict__ W,
+                                                            const float *__restrict__ b, const float *__restrict__ q,
+                                                            const float *__restrict__ tt, float *__restrict__ Wt,
+                                                            float *__restrict__ Wq, float *__restrict__ u) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float qn = n0 + tx < N ? q[n0 + tx] : 0.f;
+    for (int i = ty; i < 32; i += 8)
+        if (k0 + i < K && n0 + tx < N) {
+            const float w = W[(long long)(k0 + i) * N + n0 + tx];
+            t[i][tx] = w;
+            Wq[(long long)(k0 + i) * N + n0 + tx] = w * qn;
+        }
+    if (blockIdx.y == 0 && ty == 0 && n0 + tx < N) u[n0 + tx] = qn * b[n0 + tx] + tt[n0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
+}
+
+// ... and the sums that close its weight and bias gradient (an in-place add, an outer product and six vector launches):
+//   dW[k][n] = (dW[k][n] + Ssp[k][n]) + xsum[k] u[n],   db[n] = (cfsum[n] + q[n] (xw[n] + R b[n])) + R t[n]
+__global__ __launch_bounds__(256) void pool_top_finish_kernel(int K, int N, float R, float *__restrict__ dW,
+                                                              const float *__restrict__ Ssp, const float *__restrict__ xsum,
+                                                              const float *__restrict__ u, const float *__restrict__ cfsum,
+                                                              const float *__restrict__ q, const float *__restrict__ xw,
+                                                              const float *__restrict__ b, const float *__restrict__ tt,
+                                                              float *__restrict__ db) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float un = u[n];
+    for (int k = blockIdx.y * 8; k < min(K, blockIdx.y * 8 + 8); ++k) {
+        const long long e = (long long)k * N + n;
+        dW[e] = (dW[e] + Ssp[e]) + xsum[k] * un;
+    }
+    if (blockIdx.y == 0) db[n] = (cfsum[n] + q[n] * (xw[n] + R * b[n])) + R * tt[n];
+}
+
 // few partial rows (P <= kFusedRows): column reduction and the per-channel finalisation in ONE launch.
 // block = 32 columns x 32 row lanes; the row-lane totals meet in LDS in a fixed order (deterministic)
 [[maybe_unused]] constexpr int kFusedRows = 1024;
@@ -4764,8 +4804,11 @@ __global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int 
 // 24.47 / 24.44 / 25.03 k clouds/s; not kept.)
 __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
-                                                         int ldc, int transA, int transB, const float *__restrict__ bias) {
-    __shared__ float As[4][32][17], Bs[4][16][33], red[4][32][33];
+                                                         int ldc, int transA, int transB, const float *__restrict__ bias,
+                                                         float *__restrict__ colsum) {
+    // colsum (optional): column sums of B over its K rows next to the product -- the bias gradient of a fully connected layer
+    // out of its weight-gradient launch (dW = X^T dY, db = 1^T dY); the tile row blockIdx.y == 0 adds up what it stages anyway
+    __shared__ float As[4][32][17], Bs[4][16][33], red[4][32][33], cs[4][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int kchunks = (K + 15) / 16;
@@ -4788,6 +4831,8 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
         }
     };
     fetch(wave);
+    const bool sums = colsum != nullptr && blockIdx.y == 0;
+    float bsum = 0.f;                                // column lane & 31 over the rows (lane >> 5) + 2 i of this wave's chunks
     for (int ch = wave; ch < kchunks; ch += 4) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -4795,6 +4840,10 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
             const int e = lane + 64 * i;
             As[wave][e >> 4][e & 15] = ra[i];
             Bs[wave][e >> 5][e & 31] = rb[i];
+        }
+        if (sums) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum += rb[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -4807,7 +4856,11 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) red[wave][(v & 3) + 8 * (v >> 2) + 4 * (lane >> 5)][lane & 31] = acc[v];
+    cs[wave][lane >> 5][lane & 31] = bsum;
     __syncthreads();
+    if (sums && tid < 32 && n0 + tid < N)            // fixed order: the run-to-run bits do not depend on the schedule
+        colsum[n0 + tid] = ((cs[0][0][tid] + cs[0][1][tid]) + (cs[1][0][tid] + cs[1][1][tid])) +
+                           ((cs[2][0][tid] + cs[2][1][tid]) + (cs[3][0][tid] + cs[3][1][tid]));
     for (int e = tid; e < 32 * 32; e += 256) {
         const int r = e >> 5, c = e & 31;
         if (m0 + r < M && n0 + c < N)
@@ -5135,9 +5188,6 @@ int gram_full_launch(GramArgs &g, int nbk, bool bnrelu, int gg, size_t lds, hipS
 
 #if PCOPS_PART(0)
 extern "C" {
-
-int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
-                        const float *bias, float *C, int ldc, pcops_stream_t stream);
 
 int pcops_mlp_stats_rows(int M) {
     // upper bound of the partial-statistics rows any gemm kernel emits for M rows (buffers are sized with
@@ -5970,6 +6020,27 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
     return pcops_launch_status();
 }
 
+int pcops_mlp_pool_top_prep(int Kp, int N, const float *W, const float *b, const float *q, const float *t, float *Wt,
+                            float *Wq, float *u, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(Kp >= 1 && N >= 1);
+    PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(b); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
+    PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(Wq); PCOPS_REQUIRE_PTR(u);
+    hipLaunchKernelGGL(pool_top_prep_kernel, dim3((N + 31) / 32, (Kp + 31) / 32), dim3(256), 0, as_stream(stream), Kp, N, W,
+                       b, q, t, Wt, Wq, u);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_pool_top_finish(int Kp, int N, long long M, float *dW, const float *Ssp, const float *xsum, const float *u,
+                              const float *cfsum, const float *q, const float *xw, const float *b, const float *t,
+                              float *db, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(Kp >= 1 && N >= 1 && M >= 1);
+    PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(Ssp); PCOPS_REQUIRE_PTR(xsum); PCOPS_REQUIRE_PTR(u); PCOPS_REQUIRE_PTR(cfsum);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(xw); PCOPS_REQUIRE_PTR(b); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(db);
+    hipLaunchKernelGGL(pool_top_finish_kernel, dim3((N + 255) / 256, (Kp + 7) / 8), dim3(256), 0, as_stream(stream), Kp, N,
+                       (float)M, dW, Ssp, xsum, u, cfsum, q, xw, b, t, db);
+    return pcops_launch_status();
+}
+
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                      pcops_stream_t stream) {
     return pcops_small_gemm_ex(M, K, N, A, lda, 0, B, ldb, 0, nullptr, C, ldc, stream);
@@ -5977,11 +6048,16 @@ int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *
 
 int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
                         const float *bias, float *C, int ldc, pcops_stream_t stream) {
+    return pcops_small_gemm_colsum(M, K, N, A, lda, transA, B, ldb, transB, bias, C, ldc, nullptr, stream);
+}
+
+int pcops_small_gemm_colsum(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
+                            const float *bias, float *C, int ldc, float *colsum, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(M >= 1 && K >= 1 && N >= 1 && lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N);
     PCOPS_REQUIRE_PTR(A); PCOPS_REQUIRE_PTR(B); PCOPS_REQUIRE_PTR(C);
     pcops_note_pipe(0);                                     // fp32 MFMA (bench labels read pcops_last_launch_pipe per launch)
     hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), M, K, N, A,
-                       lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias);
+                       lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias, colsum);
     return pcops_launch_status();
 }
 

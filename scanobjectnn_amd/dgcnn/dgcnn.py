@@ -2,8 +2,8 @@
 get_model :24-102, get_loss :105-111).  BASELINE config 3.  The five graph rebuilds use the fused
 `knn_graph` (same indices as pairwise_distance+knn, no (B,N,N) tensor)."""
 import torch
-import torch.nn.functional as F
 
+from .. import fused_mlp
 from . import tf_util
 from ..graph import variable_scope
 from .transform_nets import input_transform_net
@@ -92,4 +92,4 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 
 def get_loss(pred, label, end_points=None, num_class=NUM_CLASSES):
     """softmax CE with label_smoothing 0.2 (tf.losses.softmax_cross_entropy: onehot*(1-s) + s/C)"""
-    return F.cross_entropy(pred, label.long(), label_smoothing=0.2)
+    return fused_mlp.softmax_cross_entropy(pred, label, label_smoothing=0.2)

@@ -532,9 +532,14 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
     products of pcops.h's algebraic form.  Returns (Gprev, stats_partial)."""
     lib = _lib.load()
     Wt = _f32((N, K), dev)
-    _lib.call("pcops_mlp_transpose", K, N, W.data_ptr(), Wt.data_ptr())
-    Wq = W * q[:N]                                  # W diag(q)
-    u = torch.addcmul(t[:N], q[:N], b)              # q.b + t
+    if TAIL_FOLD:       # W^T, W diag(q) and q.b + t out of one launch
+        Wq, u = _f32((K, N), dev), _f32(N, dev)
+        _lib.call("pcops_mlp_pool_top_prep", K, N, W.data_ptr(), b.data_ptr(), q.data_ptr(), t.data_ptr(), Wt.data_ptr(),
+                  Wq.data_ptr(), u.data_ptr())
+    else:
+        _lib.call("pcops_mlp_transpose", K, N, W.data_ptr(), Wt.data_ptr())
+        Wq = W * q[:N]                                  # W diag(q)
+        u = torch.addcmul(t[:N], q[:N], b)              # q.b + t
     Gprev = part = None
     if need_dx:
         Mq, v = _f32((K, K), dev), _f32(K, dev)
@@ -562,8 +567,15 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
     dW, xw = _f32((K, N), dev), _f32(N, dev)
     _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW.data_ptr(), N)
     _lib.call("pcops_small_gemm", 1, K, N, xsum.data_ptr(), K, W.data_ptr(), N, xw.data_ptr(), N)
-    grads[6 * l + 0] = torch.addr(dW.add_(Ssp), xsum, u)
-    grads[6 * l + 1] = cfsum + q[:N] * (xw + float(R) * b) + float(R) * t[:N]
+    if TAIL_FOLD:       # (dW + Ssp) + xsum u^T in place, db = (cfsum + q.(xw + R b)) + R t: one launch for ten
+        db = _f32(N, dev)
+        _lib.call("pcops_mlp_pool_top_finish", K, N, R, dW.data_ptr(), Ssp.data_ptr(), xsum.data_ptr(), u.data_ptr(),
+                  cfsum.data_ptr(), q.data_ptr(), xw.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
+        grads[6 * l + 0] = dW
+        grads[6 * l + 1] = db
+    else:
+        grads[6 * l + 0] = torch.addr(dW.add_(Ssp), xsum, u)
+        grads[6 * l + 1] = cfsum + q[:N] * (xw + float(R) * b) + float(R) * t[:N]
     return Gprev, part
 
 
@@ -593,12 +605,77 @@ class _SmallLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, K), dtype=torch.float32, device=x.device)
             _lib.call("pcops_small_gemm_ex", R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx.data_ptr(), K)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty((K, N), dtype=torch.float32, device=x.device)
-            _lib.call("pcops_small_gemm_ex", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db and TAIL_FOLD:     # db = 1^T dY out of the dW = X^T dY launch
+                db = torch.empty(N, dtype=torch.float32, device=x.device)
+            _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N,
+                      _p(db))
+        if want_db and db is None:
             db = gy.sum(dim=0)
         return dx, dw, db
+
+
+class _SplitRows(torch.autograd.Function):
+    """(w[:k], w[k:]) of a 2-D weight whose gradient comes back as ONE concatenation -- autograd's own slices answer with a
+    zero-filled full-size tensor per half plus their sum (five launches where this is one)."""
+
+    @staticmethod
+    def forward(ctx, w, k):
+        ctx.k, ctx.rows = int(k), w.shape[0]
+        return w[:k], w[k:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        k, n = ctx.k, ctx.rows
+        if ga is None and gb is None:
+            return None, None
+        like = ga if ga is not None else gb
+        if ga is None:
+            ga = like.new_zeros((k,) + tuple(like.shape[1:]))
+        if gb is None:
+            gb = like.new_zeros((n - k,) + tuple(like.shape[1:]))
+        return torch.cat([ga, gb], dim=0), None
+
+
+def split_rows(w, k):
+    """the first k rows of w and the rest (views), differentiable"""
+    if not TAIL_FOLD or not w.requires_grad:
+        return w[:k], w[k:]
+    return _SplitRows.apply(w, int(k))
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """mean softmax cross entropy (+ label smoothing) of a batch of logits: loss and gradient out of one launch
+    (csrc/head.hip, pcops_softmax_ce); backward scales the saved gradient by the upstream factor."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, smoothing):
+        R, C = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        _lib.call("pcops_softmax_ce", R, C, logits.data_ptr(), labels.data_ptr(), float(smoothing), loss.data_ptr(),
+                  dl.data_ptr())
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def softmax_cross_entropy(logits, labels, label_smoothing=0.0):
+    """F.cross_entropy(logits, labels.long(), label_smoothing=...) with mean reduction; on the device and for a batch of up
+    to a few thousand rows one launch per direction (torch: 6 launches, 26 with smoothing)"""
+    R, C = logits.shape
+    if (TAIL_FOLD and logits.is_cuda and logits.dtype == torch.float32 and 1 <= R <= 4096 and 1 <= C <= 4096):
+        lab = labels if labels.dtype == torch.int32 else labels.to(torch.int32)
+        return _SoftmaxCE.apply(logits.contiguous(), lab.contiguous(), float(label_smoothing))
+    import torch.nn.functional as F
+    return F.cross_entropy(logits, labels.long(), label_smoothing=float(label_smoothing))
 
 
 def small_linear(x, w, b):
@@ -949,6 +1026,10 @@ CLOUD_POINT = os.environ.get("PCOPS_CLOUD_POINT", "1") != "0"   # dgcnn_bga's he
 EDGE_DIRECT = os.environ.get("PCOPS_EDGE_DIRECT", "1") != "0"   # first EdgeConv layer of a stack on an input without gradient
 EDGE_DIRECT_FUSED = os.environ.get("PCOPS_EDGE_DIRECT_FUSED", "1") != "0"   # ... its E^T Gm inside the one-pass backward above
 POOL_TOP = os.environ.get("PCOPS_POOL_TOP", "1") != "0"     # algebraic backward of pooled top layers (fused_mlp._pool_top_backward)
+# the step's short generic launches folded into their neighbours (round 6): db out of the FC head's dW launch, the algebraic top
+# layer's operand / closing sums as one launch each, one concatenation for the gradient of a split weight (split_rows), the
+# whole-cloud group's index built once, the smoothed cross entropy as one launch per direction; "0": the torch forms (A/B, tests)
+TAIL_FOLD = os.environ.get("PCOPS_TAIL_FOLD", "1") != "0"
 COMPACT_MIN_S = int(os.environ.get("PCOPS_COMPACT_MIN_S", "48"))   # group sizes from which padding is compacted; 0: never
 EDGE_QC = os.environ.get("PCOPS_EDGE_QC", "1") != "0"        # EdgeConv's two per-point GEMMs as one [Q | Ctr] product
 

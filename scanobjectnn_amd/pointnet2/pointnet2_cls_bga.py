@@ -4,6 +4,7 @@ get_loss :78-93).  BASELINE config 4."""
 import torch
 import torch.nn.functional as F
 
+from .. import fused_mlp
 from . import tf_util
 from .pointnet_util import pointnet_fp_module, pointnet_sa_module
 
@@ -60,7 +61,7 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 
 def get_loss(class_pred, seg_pred, gt_label, gt_mask, seg_weight=0.5):
     """total = (1-w)*CE_cls + w*mean_b(mean_n CE_seg); returns (total, classify, seg)"""
-    classify_loss = F.cross_entropy(class_pred, gt_label.long())
+    classify_loss = fused_mlp.softmax_cross_entropy(class_pred, gt_label)
     b, n, c = seg_pred.shape
     per_point = F.cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n).long(),
                                 reduction='none').view(b, n)

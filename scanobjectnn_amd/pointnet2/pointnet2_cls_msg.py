@@ -4,8 +4,7 @@ The reference ships the layer (`pointnet_sa_module_msg`, utils/pointnet_util.py:
 model file for it.  The hyper-parameters below are upstream PointNet++
 `pointnet2_cls_msg` values -- external knowledge, not from the reference -- with the reference's
 15-class head."""
-import torch.nn.functional as F
-
+from .. import fused_mlp
 from . import tf_util
 from .pointnet_util import pointnet_sa_module, pointnet_sa_module_msg
 from .pointnet2_cls_ssg import placeholder_inputs  # noqa: F401  (same inputs)
@@ -36,4 +35,4 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 
 
 def get_loss(pred, label, end_points=None):
-    return F.cross_entropy(pred, label.long())
+    return fused_mlp.softmax_cross_entropy(pred, label)

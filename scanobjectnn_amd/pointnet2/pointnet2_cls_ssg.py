@@ -1,8 +1,8 @@
 """PointNet++ SSG classifier -- mirror of `pointnet2/models/pointnet2_cls_ssg.py`
 (placeholder_inputs :18-21, get_model :23-47, get_loss :50-57).  BASELINE config 2."""
 import torch
-import torch.nn.functional as F
 
+from .. import fused_mlp
 from . import tf_util
 from .pointnet_util import pointnet_sa_module
 
@@ -44,4 +44,4 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 
 def get_loss(pred, label, end_points=None):
     """mean sparse softmax cross-entropy; pred (B,C), label (B,)"""
-    return F.cross_entropy(pred, label.long())
+    return fused_mlp.softmax_cross_entropy(pred, label)

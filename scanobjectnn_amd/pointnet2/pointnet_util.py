@@ -87,7 +87,10 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
         pts2d = points.reshape(b * n, cf)
         lin = fused_mlp.rows_linear if cf % 4 == 0 else (lambda x, w, bias: torch.addmm(bias, x, w))
         if use_xyz:
-            w_xyz, w_f = (w1[:3], w1[3:]) if xyz_first else (w1[cf:], w1[:cf])
+            if xyz_first:
+                w_xyz, w_f = fused_mlp.split_rows(w1, 3)
+            else:
+                w_f, w_xyz = fused_mlp.split_rows(w1, cf)
             kw = dict(Q=lin(pts2d, w_f, b1).view(b, n, c1), xyz=xyz, new_xyz=new_xyz, wxyz=w_xyz)
         else:
             kw = dict(Q=lin(pts2d, w1, b1).view(b, n, c1))
@@ -97,6 +100,24 @@ def _grouped_mlp_fused(xyz, points, new_xyz, idx, widths, scope_fmt, is_training
     out = fused_mlp.gather_mlp_stack(idx, pool_max, is_training, decay, tf_util.BN_EPS, True, layers,
                                      identity_idx=identity_idx, pts_cnt=pts_cnt, **kw)
     return out.view(b, m, 1 if pool_max else s, widths[-1])
+
+
+_WHOLE_CLOUD = {}
+
+
+def _whole_cloud_group(b, n, device):
+    """(origin (b, 1, 3), idx (b, 1, n) = 0 .. n-1) of sample_and_group_all (:59-84) -- constants of the shape: built once per
+    (b, n, device) instead of three launches per step (nothing downstream writes into them)"""
+    key = (int(b), int(n), str(device))
+    if not fused_mlp.TAIL_FOLD or key not in _WHOLE_CLOUD:
+        new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=device)
+        idx = torch.arange(n, dtype=torch.int32, device=device).view(1, 1, n).expand(b, 1, n).contiguous()
+        if not fused_mlp.TAIL_FOLD:
+            return new_xyz, idx
+        if len(_WHOLE_CLOUD) > 8:
+            _WHOLE_CLOUD.clear()
+        _WHOLE_CLOUD[key] = (new_xyz, idx)
+    return _WHOLE_CLOUD[key]
 
 
 def _gather_fusable(points, widths, bn, nsample, pool_max, xyz=None):
@@ -128,8 +149,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
                 # one group holding the whole cloud around the origin (:59-84): idx = 0..n-1, so the "gather" is
                 # the identity and the K = 3 + C first layer becomes an aligned K = C contraction + 3 inline terms
                 b, n, _ = xyz.shape
-                new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
-                idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).expand(b, 1, n).contiguous()
+                new_xyz, idx = _whole_cloud_group(b, n, xyz.device)
             else:
                 new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
                 _pts_cnt = None

@@ -1,0 +1,163 @@
+"""The step's short generic launches folded into their neighbours (fused_mlp.TAIL_FOLD, round 6), each against float64 of the
+formula it replaces and the whole step against the unfolded torch forms:
+  * pcops_small_gemm_colsum     db = 1^T dY out of the dW = X^T dY launch of fully_connected (pointnet2/utils/tf_util.py:327-363)
+  * pcops_mlp_pool_top_prep / _finish   the algebraic top layer's operands and closing sums (include/pcops.h)
+  * pcops_softmax_ce            the classification losses (pointnet2_cls_ssg.py:47-53; dgcnn.py:99-105 with label smoothing 0.2)
+  * fused_mlp.split_rows        one concatenation as the gradient of a split first-layer weight (pointnet_util.py:50 concat order)"""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from scanobjectnn_amd import _lib, fused_mlp
+from scanobjectnn_amd.graph import Model
+from scanobjectnn_amd.synth import synth_clouds, synth_labels, synth_masks
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("R,K,N", [(256, 1024, 512), (256, 512, 256), (256, 256, 15), (200, 70, 9), (1, 5, 3), (1000, 33, 130)])
+def test_small_gemm_colsum(R, K, N):
+    g = torch.Generator().manual_seed(R + K + N)
+    x = torch.randn(R, K, generator=g).to(DEV)
+    gy = (torch.randn(R, N, generator=g) + 0.3).to(DEV)
+    dw, db = torch.empty(K, N, device=DEV), torch.full((N,), float("nan"), device=DEV)
+    _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N, db.data_ptr())
+    want_w = x.double().t() @ gy.double()
+    want_b = gy.double().sum(0)
+    assert (dw.double() - want_w).abs().max().item() <= 1e-5 * max(1.0, want_w.abs().max().item())
+    assert (db.double() - want_b).abs().max().item() <= 2e-6 * max(1.0, gy.abs().sum(0).max().item())
+    # the same launch without the sums, and the transposed-B form (B stored [N][K]) with them
+    dw2 = torch.empty(K, N, device=DEV)
+    _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw2.data_ptr(), N, None)
+    assert torch.equal(dw, dw2)
+    gyt = gy.t().contiguous()
+    dw3, db3 = torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gyt.data_ptr(), R, 1, None, dw3.data_ptr(), N, db3.data_ptr())
+    assert torch.equal(dw3, dw) and torch.equal(db3, db)
+    # run to run the same bits
+    db4 = torch.empty(N, device=DEV)
+    _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw2.data_ptr(), N, db4.data_ptr())
+    assert torch.equal(db4, db)
+
+
+def test_small_linear_bias_gradient():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(256, 512, generator=g).to(DEV)
+    w = (torch.randn(512, 40, generator=g) * 0.05).to(DEV)
+    b = torch.randn(40, generator=g).to(DEV)
+    go = torch.randn(256, 40, generator=g).to(DEV)
+    xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+    fused_mlp.small_linear(xs, ws, bs).backward(go)
+    xd, wd, bd = (t.double().clone().requires_grad_(True) for t in (x, w, b))
+    (xd @ wd + bd).backward(go.double())
+    for got, want in ((xs.grad, xd.grad), (ws.grad, wd.grad), (bs.grad, bd.grad)):
+        assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("K,N,R", [(512, 1024, 32768), (320, 1024, 524288), (128, 1024, 524288), (33, 70, 1000)])
+def test_pool_top_prep_and_finish(K, N, R):
+    g = torch.Generator().manual_seed(K + N)
+    W = torch.randn(K, N, generator=g).to(DEV)
+    b, q, t = (torch.randn(N, generator=g).to(DEV) for _ in range(3))
+    Wt, Wq, u = torch.empty(N, K, device=DEV), torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    _lib.call("pcops_mlp_pool_top_prep", K, N, W.data_ptr(), b.data_ptr(), q.data_ptr(), t.data_ptr(), Wt.data_ptr(),
+              Wq.data_ptr(), u.data_ptr())
+    assert torch.equal(Wt, W.t().contiguous())
+    assert torch.equal(Wq, W * q)
+    assert (u.double() - (q.double() * b.double() + t.double())).abs().max().item() <= 1e-6 * 10
+
+    dW0 = torch.randn(K, N, generator=g).to(DEV) * 50
+    Ssp = torch.randn(K, N, generator=g).to(DEV)
+    xsum = torch.randn(K, generator=g).to(DEV) * 30
+    cfsum, xw = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV) * 100
+    dW, db = dW0.clone(), torch.empty(N, device=DEV)
+    _lib.call("pcops_mlp_pool_top_finish", K, N, R, dW.data_ptr(), Ssp.data_ptr(), xsum.data_ptr(), u.data_ptr(),
+              cfsum.data_ptr(), q.data_ptr(), xw.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
+    want_w = dW0.double() + Ssp.double() + torch.outer(xsum.double(), u.double())
+    want_b = cfsum.double() + q.double() * (xw.double() + R * b.double()) + R * t.double()
+    assert (dW.double() - want_w).abs().max().item() <= 1e-6 * want_w.abs().max().item()
+    assert (db.double() - want_b).abs().max().item() <= 1e-6 * want_b.abs().max().item()
+    # the torch form it replaces, to rounding
+    old_w = torch.addr(dW0.clone().add_(Ssp), xsum, u)
+    old_b = cfsum + q * (xw + float(R) * b) + float(R) * t
+    assert (dW - old_w).abs().max().item() <= 2e-6 * old_w.abs().max().item()
+    assert (db - old_b).abs().max().item() <= 2e-6 * old_b.abs().max().item()
+
+
+@pytest.mark.parametrize("R,C", [(256, 15), (128, 15), (300, 40), (1, 2), (4096, 7)])
+@pytest.mark.parametrize("smoothing", [0.0, 0.2])
+def test_softmax_cross_entropy(R, C, smoothing):
+    g = torch.Generator().manual_seed(R * 31 + C)
+    x = (torch.randn(R, C, generator=g) * 4).to(DEV)
+    x[0, 0] = 60.0                                           # a saturated row
+    y = torch.randint(0, C, (R,), generator=g, dtype=torch.int32).to(DEV)
+    xs = x.clone().requires_grad_(True)
+    loss = fused_mlp.softmax_cross_entropy(xs, y, label_smoothing=smoothing)
+    (loss * 1.7).backward()
+    xd = x.double().clone().requires_grad_(True)
+    want = F.cross_entropy(xd, y.long(), label_smoothing=smoothing)
+    (want * 1.7).backward()
+    assert loss.shape == () and abs(loss.item() - want.item()) <= 2e-6 * max(1.0, abs(want.item()))
+    assert (xs.grad.double() - xd.grad).abs().max().item() <= 1e-6 * max(1.0 / R, xd.grad.abs().max().item())
+    # int64 labels, and the unfolded switch, give the same number
+    l2 = fused_mlp.softmax_cross_entropy(x, y.long(), label_smoothing=smoothing)
+    assert torch.equal(l2, loss.detach())
+
+
+def test_softmax_cross_entropy_leaves_large_batches_to_torch():
+    x = torch.randn(8192, 2, device=DEV, requires_grad=True)
+    y = torch.randint(0, 2, (8192,), device=DEV, dtype=torch.int32)
+    loss = fused_mlp.softmax_cross_entropy(x, y)
+    assert abs(loss.item() - F.cross_entropy(x.detach().double(), y.long()).item()) <= 1e-5
+    loss.backward()
+    assert torch.isfinite(x.grad).all()
+
+
+def test_split_rows_gradient_is_one_concatenation():
+    w = torch.randn(259, 256, device=DEV, requires_grad=True)
+    a, b = fused_mlp.split_rows(w, 3)
+    assert a.data_ptr() == w.data_ptr() and b.data_ptr() == w.data_ptr() + 3 * 256 * 4 and b.is_contiguous()
+    ga, gb = torch.randn(3, 256, device=DEV), torch.randn(256, 256, device=DEV)
+    (a * ga).sum().backward(retain_graph=True)
+    assert torch.equal(w.grad[:3], ga) and not w.grad[3:].any()        # one half without gradient: zeros for it
+    w.grad = None
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    assert torch.equal(w.grad, torch.cat([ga, gb]))
+
+
+def _step_grads(modpath, has_mask, B, N, fold, monkeypatch):
+    monkeypatch.setattr(fused_mlp, "TAIL_FOLD", fold)
+    mod = importlib.import_module(modpath)
+    x = torch.from_numpy(synth_clouds(B, N, seed=5)).to(DEV)
+    y = torch.from_numpy(synth_labels(B, seed=5)).to(DEV)
+    mask = torch.from_numpy(synth_masks(B, N, seed=5)).to(DEV) if has_mask else None
+    net = Model(mod.get_model, device=DEV, seed=0).build(x[:2].contiguous())
+    torch.manual_seed(11)                                    # the dropout masks
+    out = net(x, is_training=True, bn_decay=0.5)
+    loss = mod.get_loss(out[0], out[1], y, mask)[0] if has_mask else mod.get_loss(out[0], y, out[1])
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()] if hasattr(net, "named_parameters") else None
+    return loss.detach(), [p.grad.clone() for p in net.parameters()], names
+
+
+@pytest.mark.parametrize("modpath,has_mask,B,N", [
+    ("scanobjectnn_amd.pointnet2.pointnet2_cls_ssg", False, 16, 1024),
+    ("scanobjectnn_amd.pointnet2.pointnet2_cls_msg", False, 8, 1024),
+    ("scanobjectnn_amd.pointnet2.pointnet2_cls_bga", True, 8, 1024),
+    ("scanobjectnn_amd.dgcnn.dgcnn", False, 8, 1024),
+    ("scanobjectnn_amd.dgcnn.dgcnn_bga", True, 8, 1024),
+])
+def test_folded_step_equals_the_torch_forms(modpath, has_mask, B, N, monkeypatch):
+    """same decisions (the forward is untouched up to the loss), so every gradient agrees to summation order"""
+    l1, g1, _ = _step_grads(modpath, has_mask, B, N, True, monkeypatch)
+    l0, g0, _ = _step_grads(modpath, has_mask, B, N, False, monkeypatch)
+    assert abs(l1.item() - l0.item()) <= 2e-6 * max(1.0, abs(l0.item()))
+    whole = max(float(g.abs().max()) for g in g0)
+    for a, b in zip(g1, g0):
+        assert a.shape == b.shape
+        # (the biases in front of a BatchNorm have a zero gradient: both runs hold rounding noise of the whole gradient's scale there)
+        tol = 2e-4 * float(b.abs().max()) + 1e-5 * whole
+        assert float((a - b).abs().max()) <= tol, (a.shape, float((a - b).abs().max()), tol)
