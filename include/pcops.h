@@ -411,16 +411,17 @@ int pcops_small_gemm_colsum(int M, int K, int N, const float *A, int lda, int tr
  *                                 copies of (Kp Kp + Kp) floats
  *   pcops_mlp_pool_top_wsparse    Ssp [Kp][N] = X^T (p.G), cfsum [N] = 1^T (p.G)
  *   pcops_mlp_pool_top_prep       the small operands in one launch: Wt [N][Kp] = W^T, Wq [Kp][N] = W diag(q),
- *                                 u [N] = q.b + t  (round 6: they were a transpose and two elementwise launches)
+ *                                 u [N] = q.b + t, v [Kp] = W u (= vconst; v may be NULL)  (round 6: they were a transpose,
+ *                                 two elementwise launches and a matrix-vector launch)
  *   pcops_mlp_pool_top_finish     closes the sums in place: dW [Kp][N] = (dW + Ssp) + xsum u^T with dW = gram Wq on
- *                                 entry, db [N] = (cfsum + q.(xw + M b)) + M t with xw = xsum^T W  (round 6: ten launches)
+ *                                 entry, db [N] = (cfsum + q.(xsum^T W + M b)) + M t  (round 6: eleven launches)
  * prev_scale == prev_shift == NULL: X is the stack's raw input (a one-layer stack) -- no mask, no statistics.
  * All sums in a fixed order (deterministic). */
 int pcops_mlp_pool_top_supported(int M, int Kp, int N, int S);
 int pcops_mlp_pool_top_prep(int Kp, int N, const float *W, const float *b, const float *q, const float *t, float *Wt,
-                            float *Wq, float *u, pcops_stream_t stream);
+                            float *Wq, float *u, float *v, pcops_stream_t stream);
 int pcops_mlp_pool_top_finish(int Kp, int N, long long M, float *dW, const float *Ssp, const float *xsum, const float *u,
-                              const float *cfsum, const float *q, const float *xw, const float *b, const float *t,
+                              const float *cfsum, const float *q, const float *W, const float *b, const float *t,
                               float *db, pcops_stream_t stream);
 int pcops_mlp_pool_top_addend(int M, int Kp, int N, int S, const float *gout, const float *ysel,
                             const unsigned char *argmax, const float *pool_scale, const float *pool_shift,

@@ -52,7 +52,7 @@ SIGNATURES = {
     "pcops_small_gemm": ([_I, _I, _I, _P, _I, _P, _I, _P, _I], True),
     "pcops_small_gemm_ex": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I], True),
     "pcops_small_gemm_colsum": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P], True),
-    "pcops_mlp_pool_top_prep": ([_I, _I] + [_P] * 7, True),
+    "pcops_mlp_pool_top_prep": ([_I, _I] + [_P] * 8, True),
     "pcops_mlp_pool_top_finish": ([_I, _I, _LL] + [_P] * 10, True),
     "pcops_mlp_pool_top_addend": ([_I, _I, _I, _I] + [_P] * 9, True),
     "pcops_mlp_gemm_dgrad_top": ([_I, _I] + [_P] * 6 + [_LL] + [_P] * 3, True),

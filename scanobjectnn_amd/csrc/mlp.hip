@@ -4403,13 +4403,32 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
         if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
 }
 
-// The algebraic top layer's small operands in ONE launch (they were a transpose, an elementwise product and an addcmul):
-//   Wt[n][k] = W[k][n],  Wq[k][n] = W[k][n] q[n],  u[n] = fma(q[n], b[n], t[n])  (tile row 0 writes u)
+// The algebraic top layer's small operands in ONE launch (they were a transpose, an elementwise product, an addcmul and a
+// matrix-vector launch of the small-GEMM kernel):
+//   Wt[n][k] = W[k][n],  Wq[k][n] = W[k][n] q[n],  u[n] = q[n] b[n] + t[n]  (tile row 0 writes u),
+//   v[k] = sum_n W[k][n] u[n]  (the workgroups behind the tiles: eight rows each, a row per half-wave pair, lanes over n)
 __global__ __launch_bounds__(256) void pool_top_prep_kernel(int K, int N, const float *__restrict__ W,
                                                             const float *__restrict__ b, const float *__restrict__ q,
                                                             const float *__restrict__ tt, float *__restrict__ Wt,
-                                                            float *__restrict__ Wq, float *__restrict__ u) {
+                                                            float *__restrict__ Wq, float *__restrict__ u,
+                                                            float *__restrict__ v) {
     __shared__ float t[32][33];
+    const int tiles_y = (K + 31) / 32;
+    if ((int)blockIdx.y >= tiles_y) {                    // v: eight rows per workgroup, numbered along x then y
+        if (v == nullptr) return;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int vb = ((int)blockIdx.y - tiles_y) * (int)gridDim.x + (int)blockIdx.x;
+        for (int rr = 0; rr < 2; ++rr) {
+            const int k = vb * 8 + wave * 2 + rr;
+            if (k >= K) continue;                        // (wave-uniform)
+            float acc = 0.f;
+            for (int n = lane; n < N; n += 64) acc = fmaf(W[(long long)k * N + n], q[n] * b[n] + tt[n], acc);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) v[k] = acc;
+        }
+        return;
+    }
     const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float qn = n0 + tx < N ? q[n0 + tx] : 0.f;
@@ -4425,22 +4444,48 @@ __global__ __launch_bounds__(256) void pool_top_prep_kernel(int K, int N, const 
         if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
 }
 
-// ... and the sums that close its weight and bias gradient (an in-place add, an outer product and six vector launches):
+// ... and the sums that close its weight and bias gradient (an in-place add, an outer product, six vector launches and the
+// matrix-vector launch for xw = xsum^T W, which the first row of workgroups now adds up per column, k ascending):
 //   dW[k][n] = (dW[k][n] + Ssp[k][n]) + xsum[k] u[n],   db[n] = (cfsum[n] + q[n] (xw[n] + R b[n])) + R t[n]
 __global__ __launch_bounds__(256) void pool_top_finish_kernel(int K, int N, float R, float *__restrict__ dW,
                                                               const float *__restrict__ Ssp, const float *__restrict__ xsum,
                                                               const float *__restrict__ u, const float *__restrict__ cfsum,
-                                                              const float *__restrict__ q, const float *__restrict__ xw,
+                                                              const float *__restrict__ q, const float *__restrict__ W,
                                                               const float *__restrict__ b, const float *__restrict__ tt,
                                                               float *__restrict__ db) {
+    if (blockIdx.y < 8) {
+        // db: 32 columns per workgroup (block 8 x + y of the 256-column strip x), eight lanes of k per column, four chains each
+        // (a column's K loads would otherwise wait on one another: 61 us for K = 512 with one thread per column)
+        __shared__ float red[8][32];
+        const int c = threadIdx.x & 31, kl = threadIdx.x >> 5;
+        const int n = (blockIdx.x * 8 + blockIdx.y) * 32 + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (n < N) {
+            int k = kl;
+            for (; k + 24 < K; k += 32) {
+                a0 = fmaf(xsum[k], W[(long long)k * N + n], a0);
+                a1 = fmaf(xsum[k + 8], W[(long long)(k + 8) * N + n], a1);
+                a2 = fmaf(xsum[k + 16], W[(long long)(k + 16) * N + n], a2);
+                a3 = fmaf(xsum[k + 24], W[(long long)(k + 24) * N + n], a3);
+            }
+            for (; k < K; k += 8) a0 = fmaf(xsum[k], W[(long long)k * N + n], a0);
+        }
+        red[kl][c] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (kl == 0 && n < N) {
+            const float xw = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+            db[n] = (cfsum[n] + q[n] * (xw + R * b[n])) + R * tt[n];
+        }
+        return;
+    }
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float un = u[n];
-    for (int k = blockIdx.y * 8; k < min(K, blockIdx.y * 8 + 8); ++k) {
+    const int kb = ((int)blockIdx.y - 8) * 8;
+    for (int k = kb; k < min(K, kb + 8); ++k) {
         const long long e = (long long)k * N + n;
         dW[e] = (dW[e] + Ssp[e]) + xsum[k] * un;
     }
-    if (blockIdx.y == 0) db[n] = (cfsum[n] + q[n] * (xw[n] + R * b[n])) + R * tt[n];
 }
 
 // few partial rows (P <= kFusedRows): column reduction and the per-channel finalisation in ONE launch.
@@ -6021,23 +6066,24 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
 }
 
 int pcops_mlp_pool_top_prep(int Kp, int N, const float *W, const float *b, const float *q, const float *t, float *Wt,
-                            float *Wq, float *u, pcops_stream_t stream) {
+                            float *Wq, float *u, float *v, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(Kp >= 1 && N >= 1);
     PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(b); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t);
     PCOPS_REQUIRE_PTR(Wt); PCOPS_REQUIRE_PTR(Wq); PCOPS_REQUIRE_PTR(u);
-    hipLaunchKernelGGL(pool_top_prep_kernel, dim3((N + 31) / 32, (Kp + 31) / 32), dim3(256), 0, as_stream(stream), Kp, N, W,
-                       b, q, t, Wt, Wq, u);
+    const int gx = (N + 31) / 32;
+    hipLaunchKernelGGL(pool_top_prep_kernel, dim3(gx, (Kp + 31) / 32 + (v ? ((Kp + 7) / 8 + gx - 1) / gx : 0)), dim3(256), 0,
+                       as_stream(stream), Kp, N, W, b, q, t, Wt, Wq, u, v);
     return pcops_launch_status();
 }
 
 int pcops_mlp_pool_top_finish(int Kp, int N, long long M, float *dW, const float *Ssp, const float *xsum, const float *u,
-                              const float *cfsum, const float *q, const float *xw, const float *b, const float *t,
+                              const float *cfsum, const float *q, const float *W, const float *b, const float *t,
                               float *db, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(Kp >= 1 && N >= 1 && M >= 1);
     PCOPS_REQUIRE_PTR(dW); PCOPS_REQUIRE_PTR(Ssp); PCOPS_REQUIRE_PTR(xsum); PCOPS_REQUIRE_PTR(u); PCOPS_REQUIRE_PTR(cfsum);
-    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(xw); PCOPS_REQUIRE_PTR(b); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(db);
-    hipLaunchKernelGGL(pool_top_finish_kernel, dim3((N + 255) / 256, (Kp + 7) / 8), dim3(256), 0, as_stream(stream), Kp, N,
-                       (float)M, dW, Ssp, xsum, u, cfsum, q, xw, b, t, db);
+    PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(W); PCOPS_REQUIRE_PTR(b); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(db);
+    hipLaunchKernelGGL(pool_top_finish_kernel, dim3((N + 255) / 256, 8 + (Kp + 7) / 8), dim3(256), 0, as_stream(stream), Kp, N,
+                       (float)M, dW, Ssp, xsum, u, cfsum, q, W, b, t, db);
     return pcops_launch_status();
 }
 

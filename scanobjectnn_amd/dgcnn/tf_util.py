@@ -359,8 +359,8 @@ class _FirstMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dim):
-        out = x.amax(dim=dim, keepdim=True)
-        ctx.save_for_backward(x.argmax(dim=dim, keepdim=True))
+        out, arg = x.max(dim=dim, keepdim=True)          # one launch; of equal maxima torch.max reports the first, like argmax
+        ctx.save_for_backward(arg)
         ctx.dim, ctx.shape = dim, x.shape
         return out
 

@@ -534,17 +534,20 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
     Wt = _f32((N, K), dev)
     if TAIL_FOLD:       # W^T, W diag(q) and q.b + t out of one launch
         Wq, u = _f32((K, N), dev), _f32(N, dev)
+        v = _f32(K, dev) if need_dx else None           # ... and v = W u
         _lib.call("pcops_mlp_pool_top_prep", K, N, W.data_ptr(), b.data_ptr(), q.data_ptr(), t.data_ptr(), Wt.data_ptr(),
-                  Wq.data_ptr(), u.data_ptr())
+                  Wq.data_ptr(), u.data_ptr(), _p(v))
     else:
         _lib.call("pcops_mlp_transpose", K, N, W.data_ptr(), Wt.data_ptr())
         Wq = W * q[:N]                                  # W diag(q)
         u = torch.addcmul(t[:N], q[:N], b)              # q.b + t
     Gprev = part = None
     if need_dx:
-        Mq, v = _f32((K, K), dev), _f32(K, dev)
+        Mq = _f32((K, K), dev)
         _lib.call("pcops_small_gemm", K, N, K, Wq.data_ptr(), N, Wt.data_ptr(), K, Mq.data_ptr(), K)
-        _lib.call("pcops_small_gemm", 1, N, K, u.data_ptr(), N, Wt.data_ptr(), K, v.data_ptr(), K)
+        if not TAIL_FOLD:
+            v = _f32(K, dev)
+            _lib.call("pcops_small_gemm", 1, N, K, u.data_ptr(), N, Wt.data_ptr(), K, v.data_ptr(), K)
         G = R // S
         addend = _f32((G * min(S, N), K), dev)
         rowmap = torch.empty(R, dtype=torch.int32, device=dev)
@@ -564,16 +567,17 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
     _lib.call("pcops_mlp_pool_top_wsparse", R, K, N, S, grad_out.data_ptr(), ysel.data_ptr(), argmax.data_ptr(),
               sc.data_ptr(), sh.data_ptr(), p.data_ptr(), Yprev.data_ptr(), _p(psc), _p(psh),
               Ssp.data_ptr(), cfsum.data_ptr())
-    dW, xw = _f32((K, N), dev), _f32(N, dev)
+    dW = _f32((K, N), dev)
     _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW.data_ptr(), N)
-    _lib.call("pcops_small_gemm", 1, K, N, xsum.data_ptr(), K, W.data_ptr(), N, xw.data_ptr(), N)
-    if TAIL_FOLD:       # (dW + Ssp) + xsum u^T in place, db = (cfsum + q.(xw + R b)) + R t: one launch for ten
+    if TAIL_FOLD:       # (dW + Ssp) + xsum u^T in place, db = (cfsum + q.(xsum^T W + R b)) + R t: one launch for eleven
         db = _f32(N, dev)
         _lib.call("pcops_mlp_pool_top_finish", K, N, R, dW.data_ptr(), Ssp.data_ptr(), xsum.data_ptr(), u.data_ptr(),
-                  cfsum.data_ptr(), q.data_ptr(), xw.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
+                  cfsum.data_ptr(), q.data_ptr(), W.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
         grads[6 * l + 0] = dW
         grads[6 * l + 1] = db
     else:
+        xw = _f32(N, dev)
+        _lib.call("pcops_small_gemm", 1, K, N, xsum.data_ptr(), K, W.data_ptr(), N, xw.data_ptr(), N)
         grads[6 * l + 0] = torch.addr(dW.add_(Ssp), xsum, u)
         grads[6 * l + 1] = cfsum + q[:N] * (xw + float(R) * b) + float(R) * t[:N]
     return Gprev, part

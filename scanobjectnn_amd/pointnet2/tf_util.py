@@ -254,6 +254,8 @@ def max_pool2d(inputs, kernel_size, scope, stride=[2, 2], padding='VALID'):
     kh, kw = kernel_size
     b, h, w, c = inputs.shape
     if kh == h and kw == w:
+        if h == 1 and w == 1:           # a window of one element (the T-Net behind a stack that already pooled): the input itself
+            return inputs
         return inputs.amax(dim=(1, 2), keepdim=True)
     x = F.max_pool2d(inputs.permute(0, 3, 1, 2), (kh, kw), stride=tuple(stride))
     return x.permute(0, 2, 3, 1)

@@ -63,21 +63,30 @@ def test_pool_top_prep_and_finish(K, N, R):
     W = torch.randn(K, N, generator=g).to(DEV)
     b, q, t = (torch.randn(N, generator=g).to(DEV) for _ in range(3))
     Wt, Wq, u = torch.empty(N, K, device=DEV), torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+    v = torch.full((K,), float("nan"), device=DEV)
     _lib.call("pcops_mlp_pool_top_prep", K, N, W.data_ptr(), b.data_ptr(), q.data_ptr(), t.data_ptr(), Wt.data_ptr(),
-              Wq.data_ptr(), u.data_ptr())
+              Wq.data_ptr(), u.data_ptr(), v.data_ptr())
     assert torch.equal(Wt, W.t().contiguous())
     assert torch.equal(Wq, W * q)
-    assert (u.double() - (q.double() * b.double() + t.double())).abs().max().item() <= 1e-6 * 10
+    ud = q.double() * b.double() + t.double()
+    assert (u.double() - ud).abs().max().item() <= 1e-6 * 10
+    want_v = W.double() @ ud
+    assert (v.double() - want_v).abs().max().item() <= 1e-5 * (W.double().abs() @ ud.abs()).max().item()
+    Wt2, Wq2, u2 = torch.empty_like(Wt), torch.empty_like(Wq), torch.empty_like(u)      # v is optional
+    _lib.call("pcops_mlp_pool_top_prep", K, N, W.data_ptr(), b.data_ptr(), q.data_ptr(), t.data_ptr(), Wt2.data_ptr(),
+              Wq2.data_ptr(), u2.data_ptr(), None)
+    assert torch.equal(Wt2, Wt) and torch.equal(Wq2, Wq) and torch.equal(u2, u)
 
     dW0 = torch.randn(K, N, generator=g).to(DEV) * 50
     Ssp = torch.randn(K, N, generator=g).to(DEV)
     xsum = torch.randn(K, generator=g).to(DEV) * 30
-    cfsum, xw = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV) * 100
+    cfsum = torch.randn(N, generator=g).to(DEV)
     dW, db = dW0.clone(), torch.empty(N, device=DEV)
     _lib.call("pcops_mlp_pool_top_finish", K, N, R, dW.data_ptr(), Ssp.data_ptr(), xsum.data_ptr(), u.data_ptr(),
-              cfsum.data_ptr(), q.data_ptr(), xw.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
+              cfsum.data_ptr(), q.data_ptr(), W.data_ptr(), b.data_ptr(), t.data_ptr(), db.data_ptr())
     want_w = dW0.double() + Ssp.double() + torch.outer(xsum.double(), u.double())
-    want_b = cfsum.double() + q.double() * (xw.double() + R * b.double()) + R * t.double()
+    want_b = cfsum.double() + q.double() * (xsum.double() @ W.double() + R * b.double()) + R * t.double()
+    xw = xsum @ W
     assert (dW.double() - want_w).abs().max().item() <= 1e-6 * want_w.abs().max().item()
     assert (db.double() - want_b).abs().max().item() <= 1e-6 * want_b.abs().max().item()
     # the torch form it replaces, to rounding
@@ -161,3 +170,29 @@ def test_folded_step_equals_the_torch_forms(modpath, has_mask, B, N, monkeypatch
         # (the biases in front of a BatchNorm have a zero gradient: both runs hold rounding noise of the whole gradient's scale there)
         tol = 2e-4 * float(b.abs().max()) + 1e-5 * whole
         assert float((a - b).abs().max()) <= tol, (a.shape, float((a - b).abs().max()), tol)
+
+
+def test_first_max_on_the_device_gives_ties_to_the_first_member():
+    """dgcnn/tf_util._FirstMax takes value and position from one torch.max launch: of equal maxima the first one is reported"""
+    from scanobjectnn_amd.dgcnn.tf_util import _FirstMax
+    x = torch.zeros(64, 8, 1, 1024, device=DEV)
+    x[:, 2] = 1.0
+    x[:, 5] = 1.0                                            # exact ties in every (cloud, channel)
+    x[:, 7, :, ::2] = 1.0
+    x.requires_grad_(True)
+    out = _FirstMax.apply(x, 1)
+    assert out.shape == (64, 1, 1, 1024) and bool((out == 1.0).all())
+    g = torch.randn(64, 1, 1, 1024, device=DEV)
+    out.backward(g)
+    assert torch.equal(x.grad[:, 2:3], g) and not x.grad[:, 5].any() and not x.grad[:, 7].any()
+
+
+def test_max_pool_over_a_window_of_one_is_the_input():
+    from scanobjectnn_amd.pointnet2 import tf_util
+    x = torch.randn(4, 1, 1, 64, device=DEV, requires_grad=True)
+    y = tf_util.max_pool2d(x, [1, 1], "p")
+    assert y.shape == x.shape and torch.equal(y, x)
+    y.sum().backward()
+    assert bool((x.grad == 1).all())
+    z = torch.randn(4, 7, 1, 64, device=DEV)
+    assert torch.equal(tf_util.max_pool2d(z, [7, 1], "p"), z.amax(dim=(1, 2), keepdim=True))
