@@ -4846,7 +4846,8 @@ __global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int 
 // matrix-vector rows).  One 32 x 32 tile per workgroup so that even a 512 x 512 result fills the chip; the 4 waves split
 // K and add their accumulators through LDS in a fixed order.  (Eight waves over K for the long reductions -- the partial tiles
 // meeting in the staging area -- were measured in round 6: the SSG and DGCNN steps within noise, 24.55 / 24.46 / 24.63 against
-// 24.47 / 24.44 / 25.03 k clouds/s; not kept.)
+// 24.47 / 24.44 / 25.03 k clouds/s; not kept.  Three chunks per wave in flight instead of one, 48 more registers: 19.4 against
+// 15.5 us per launch in the SSG step, profiles/r06_tail_fold_ab.txt; not kept either.)
 __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
                                                          int ldc, int transA, int transB, const float *__restrict__ bias,
