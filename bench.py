@@ -262,9 +262,21 @@ def _algo(name, a):
     if name == "pcops_mlp_pool_top_wsparse":  # per (group, channel) 9 bytes in + a Kp-wide activation row
         M, Kp, N, S = a[:4]
         return (M // S) * N * (9 + 4 * Kp), 2 * (M // S) * N * Kp, "flop(VALU)"
-    if name == "pcops_small_gemm":
+    if name in ("pcops_small_gemm", "pcops_small_gemm_ex", "pcops_small_gemm_colsum"):
         M, K, N = a[:3]
         return 4 * (M * K + K * N + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_mlp_pool_top_prep":     # W read once; W^T and W diag(q) written (the row products re-read W through L2)
+        Kp, N = a[:2]
+        return 4 * 3 * Kp * N, 0, ""
+    if name == "pcops_mlp_pool_top_finish":   # dW read and written, Ssp read, W read for the column sums
+        Kp, N = a[:2]
+        return 4 * 4 * Kp * N, 0, ""
+    if name == "pcops_softmax_ce":            # logits in, gradient out
+        R, C = a[:2]
+        return 4 * 2 * R * C + 4 * R, 0, ""
+    if name == "pcops_mlp_dy_apply":          # G and Y read, dY written
+        M, N = a[:2]
+        return 4 * 3 * M * N, 0, ""
     if name == "pcops_mlp_bn_relu_maxpool":
         G, S, C = a[:3]
         return 4 * G * S * C + 5 * G * C, 0, ""
@@ -328,7 +340,9 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_mlp_gemm_dgrad_top": 2, "pcops_mlp_gram": 2, "pcops_mlp_pool_top_addend": 4,
            "pcops_mlp_pool_top_wsparse": 4, "pcops_scatter_rows_sorted": 5, "pcops_edge_feature_grad_central": 4,
            "pcops_edge_pool_fwd_ld": 5, "pcops_edge_pool_bwd_ld": 5, "pcops_edge_pool_out_ld": 2, "pcops_edge_pool_out_ld2": 2,
-           "pcops_sa_gather_fwd_ld": 5, "pcops_sa_scatter_bwd_ld": 5, "pcops_fc_bn_fwd": 2, "pcops_fc_bn_bwd": 2}
+           "pcops_sa_gather_fwd_ld": 5, "pcops_sa_scatter_bwd_ld": 5, "pcops_fc_bn_fwd": 2, "pcops_fc_bn_bwd": 2,
+           "pcops_small_gemm": 3, "pcops_small_gemm_ex": 3, "pcops_small_gemm_colsum": 3, "pcops_mlp_pool_top_prep": 2,
+           "pcops_mlp_pool_top_finish": 3, "pcops_softmax_ce": 2, "pcops_mlp_dy_apply": 2}
 
 
 class KernelTimer:

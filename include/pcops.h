@@ -376,6 +376,11 @@ int pcops_mlp_bwd_fused_rows(long long M, int K, int N, const float *Yprev, cons
                              const float *gpool, const unsigned char *argmax, int S, const float *W, float *partial,
                              float *dW, float *db, float *Gprev, float *stats_partial, const pcops_rows_t *rows,
                              pcops_stream_t stream);
+/* out [M][N] = (t + p.G) + q.Y row by row (N % 4 == 0, 16-byte aligned pointers; p / q / t [N]): the BatchNorm-backward
+ * combination dY = p.G + q.Y + t as a tensor -- the data gradient of a first layer whose gather is the identity (the
+ * whole-cloud group of sample_and_group_all, pointnet_util.py:59-84), where no scatter kernel is needed to form it. */
+int pcops_mlp_dy_apply(long long M, int N, const float *G, const float *Y, const float *p, const float *q, const float *t,
+                       float *out, pcops_stream_t stream);
 /* C [M][N] = A [M][K] B [K][N], row-major with leading dimensions: the small weight x weight products and row vectors
  * around the big kernels (32 x 32 output tile per workgroup, fp32 MFMA, fixed summation order) */
 int pcops_small_gemm(int M, int K, int N, const float *A, int lda, const float *B, int ldb, float *C, int ldc,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pcops_mlp_transpose": ([_I, _I, _P, _P], True),
     "pcops_small_gemm": ([_I, _I, _I, _P, _I, _P, _I, _P, _I], True),
     "pcops_small_gemm_ex": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I], True),
+    "pcops_mlp_dy_apply": ([_LL, _I] + [_P] * 6, True),
     "pcops_small_gemm_colsum": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P], True),
     "pcops_mlp_pool_top_prep": ([_I, _I] + [_P] * 8, True),
     "pcops_mlp_pool_top_finish": ([_I, _I, _LL] + [_P] * 10, True),

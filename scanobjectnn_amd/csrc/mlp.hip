@@ -4403,6 +4403,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(int K, int N, const floa
         if (n0 + i < N && k0 + tx < K) Wt[(long long)(n0 + i) * K + k0 + tx] = t[tx][i];
 }
 
+// dY = (t + p.G) + q.Y over whole rows (the data gradient of a first layer whose "gather" is the identity: the whole-cloud
+// group of sample_and_group_all, pointnet_util.py:59-84) -- it was an addcmul and an in-place addcmul over the tensor
+__global__ __launch_bounds__(256) void dy_apply_kernel(long long total4, int N4, const float4 *__restrict__ G,
+                                                       const float4 *__restrict__ Y, const float4 *__restrict__ p,
+                                                       const float4 *__restrict__ q, const float4 *__restrict__ t,
+                                                       float4 *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % N4);
+        const float4 g = G[e], y = Y[e], pp = p[c], qq = q[c], tt = t[c];
+        out[e] = make_float4((tt.x + g.x * pp.x) + y.x * qq.x, (tt.y + g.y * pp.y) + y.y * qq.y,
+                             (tt.z + g.z * pp.z) + y.z * qq.z, (tt.w + g.w * pp.w) + y.w * qq.w);
+    }
+}
+
 // The algebraic top layer's small operands in ONE launch (they were a transpose, an elementwise product, an addcmul and a
 // matrix-vector launch of the small-GEMM kernel):
 //   Wt[n][k] = W[k][n],  Wq[k][n] = W[k][n] q[n],  u[n] = q[n] b[n] + t[n]  (tile row 0 writes u),
@@ -6063,6 +6077,21 @@ int pcops_mlp_pool_top_wsparse(int M, int Kp, int N, int S, const float *gout, c
     PCOPS_REQUIRE_PTR(Ssp); PCOPS_REQUIRE_PTR(cfsum);
     hipLaunchKernelGGL(pool_top_wsparse_kernel, dim3(N), dim3(256), 0, as_stream(stream), (long long)(M / S), S, N,
                        Kp, gout, ysel, argmax, pool_scale, pool_shift, p, Yprev, prev_scale, prev_shift, Ssp, cfsum);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_dy_apply(long long M, int N, const float *G, const float *Y, const float *p, const float *q, const float *t,
+                       float *out, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(M >= 0 && N >= 4 && N % 4 == 0);
+    if (M == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(G); PCOPS_REQUIRE_PTR(Y); PCOPS_REQUIRE_PTR(p); PCOPS_REQUIRE_PTR(q); PCOPS_REQUIRE_PTR(t); PCOPS_REQUIRE_PTR(out);
+    PCOPS_REQUIRE_ARG(((uintptr_t)G | (uintptr_t)Y | (uintptr_t)p | (uintptr_t)q | (uintptr_t)t | (uintptr_t)out) % 16 == 0);
+    const long long total4 = M * (N / 4);
+    const unsigned grid = (unsigned)(cdiv(total4, 256) < 8192 ? cdiv(total4, 256) : 8192);
+    hipLaunchKernelGGL(dy_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), total4, N / 4,
+                       reinterpret_cast<const float4 *>(G), reinterpret_cast<const float4 *>(Y),
+                       reinterpret_cast<const float4 *>(p), reinterpret_cast<const float4 *>(q),
+                       reinterpret_cast<const float4 *>(t), reinterpret_cast<float4 *>(out));
     return pcops_launch_status();
 }
 

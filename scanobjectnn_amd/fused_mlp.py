@@ -383,7 +383,12 @@ class FusedMLPStack(torch.autograd.Function):
                 d0_out = d0
                 if d0 is not None and identity and not pooled:
                     # idx = 0..n-1: the scatter-add is the identity map, dQ = dY row for row
-                    d0_out = torch.addcmul(t[:N], Gm, p[:N]).addcmul_(Ys[0], q[:N]).view(B, Nsrc, N)
+                    if TAIL_FOLD and N % 4 == 0:
+                        d0_out = _f32((B, Nsrc, N), dev)
+                        _lib.call("pcops_mlp_dy_apply", B * Nsrc, N, Gm.data_ptr(), Ys[0].data_ptr(), p.data_ptr(),
+                                  q.data_ptr(), t.data_ptr(), d0_out.data_ptr())
+                    else:
+                        d0_out = torch.addcmul(t[:N], Gm, p[:N]).addcmul_(Ys[0], q[:N]).view(B, Nsrc, N)
                     d0 = None                # the kernel below then only reduces dWxyz / dbias / dCtr
                 if d0 is not None:   # gather formulation over an inverse index
                     wsp = torch.empty(int(lib.pcops_sa_scatter_workspace_bytes(B, Nsrc, M, S)) // 4,

@@ -196,3 +196,18 @@ def test_max_pool_over_a_window_of_one_is_the_input():
     assert bool((x.grad == 1).all())
     z = torch.randn(4, 7, 1, 64, device=DEV)
     assert torch.equal(tf_util.max_pool2d(z, [7, 1], "p"), z.amax(dim=(1, 2), keepdim=True))
+
+
+@pytest.mark.parametrize("M,N", [(32768, 256), (1000, 64), (1, 4), (70001, 12)])
+def test_dy_apply(M, N):
+    g = torch.Generator().manual_seed(M + N)
+    G, Y = torch.randn(M, N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    p, q, t = (torch.randn(N, generator=g).to(DEV) for _ in range(3))
+    out = torch.empty(M, N, device=DEV)
+    _lib.call("pcops_mlp_dy_apply", M, N, G.data_ptr(), Y.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), out.data_ptr())
+    want = t.double() + G.double() * p.double() + Y.double() * q.double()
+    assert (out.double() - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    old = torch.addcmul(t, G, p).addcmul_(Y, q)             # the torch form it replaces: the same association
+    assert (out - old).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    with pytest.raises(_lib.PcopsError):                    # N % 4 != 0 is refused
+        _lib.call("pcops_mlp_dy_apply", M, 6, G.data_ptr(), Y.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), out.data_ptr())
