@@ -775,13 +775,19 @@ int pcops_fc_bn_bwd(int R, int C, const float *dy, const float *x, const float *
                     const float *save_mean, const float *save_rstd, int training, int relu, float *dx,
                     float *dgamma, float *dbeta, pcops_stream_t stream);
 
-/* The classification loss of a batch (a few hundred rows) and its gradient in one launch: mean softmax cross entropy against
+/* The classification loss of a batch and its gradient in one launch: mean softmax cross entropy against
  * q = s / C + (1 - s) onehot(labels) -- tf.losses.softmax_cross_entropy(..., label_smoothing = s) of dgcnn/models/dgcnn.py:99-105;
- * s = 0 is the sparse softmax cross entropy + reduce_mean of pointnet2/models/pointnet2_cls_ssg.py:47-53.  loss [1],
- * dlogits [R][C] = (softmax - q) / R (the gradient for an upstream factor of 1; the caller scales).  One workgroup: meant for
- * R up to a few thousand rows.  Fixed summation order. */
+ * s = 0 is the sparse softmax cross entropy + reduce_mean of pointnet2/models/pointnet2_cls_ssg.py:47-53 and, over b n rows of
+ * two classes, the per-point mask loss of pointnet2_cls_bga.py:94-98 (equal point counts: the mean of the clouds' means is the
+ * mean of all rows).  dlogits [R][C] = (softmax - q) / R (the gradient for an upstream factor of 1; the caller scales).
+ * loss [pcops_softmax_ce_blocks(R)]: one workgroup up to 4096 rows -- loss[0] is the loss --, several beyond, each leaving
+ * its rows' share of the mean (the caller adds them up).  Fixed summation order. */
+int pcops_softmax_ce_blocks(int R);
 int pcops_softmax_ce(int R, int C, const float *logits, const int *labels, float label_smoothing, float *loss,
                      float *dlogits, pcops_stream_t stream);
+/* The interpolation weights of pointnet_fp_module (pointnet_util.py:212-215) from three_nn's squared distances:
+ * weight (b, n, 3) = inv / sum(inv), inv = 1 / max(dist, 1e-10); dist = +inf (fewer than three known points) -> 0. */
+int pcops_three_nn_weights(int b, int n, const float *dist, float *weight, pcops_stream_t stream);
 
 /* the learned 3 x 3 input transform applied to a cloud (tf.matmul(point_cloud, transform): dgcnn/models/dgcnn.py:37,
  * pointnet/models/pointnet_cls.py:27): out (b, n, 3) = x (b, n, 3) T (b, 3, 3); backward dT (b, 3, 3) = x^T grad_out per cloud in a

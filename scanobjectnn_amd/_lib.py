@@ -111,10 +111,12 @@ SIGNATURES = {
     "pcops_fc_bn_fwd": ([_I, _I, _P, _P, _P, _P, _P, _I, _F, _F, _I, _I, _P, _P, _P], True),
     "pcops_fc_bn_bwd": ([_I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P], True),
     "pcops_softmax_ce": ([_I, _I, _P, _P, _F, _P, _P], True),
+    "pcops_three_nn_weights": ([_I, _I, _P, _P], True),
 }
 PLAIN = {
     "pcops_strerror": ([_I], C.c_char_p),
     "pcops_abi_version": ([], _I),
+    "pcops_softmax_ce_blocks": ([_I], _I),
     "pcops_farthest_point_sample_workspace_bytes": ([_I, _I], _U64),
     "pcops_mlp_stats_rows": ([_I], _I),
     "pcops_mlp_reduce_workspace_bytes": ([_I], _U64),

@@ -150,16 +150,18 @@ __global__ __launch_bounds__(256) void transform3_bwd_kernel(int n, const float 
 // tf.nn.sparse_softmax_cross_entropy_with_logits + reduce_mean: pointnet2/models/pointnet2_cls_ssg.py:47-53).  torch's
 // F.cross_entropy is 6 launches without and 26 with smoothing.  Target q = s / C + (1 - s) [c == y];
 //   loss_r = -sum_c q_c (x_c - lse_r),   dx[r][c] = (exp(x_c - lse_r) - q_c) / R,   loss = sum_r loss_r / R
-// One workgroup, a thread per row (strided), row losses added in a fixed order.  A label outside [0, C) contributes the
-// smoothing term only (no class row to pick) -- the callers hand over validated labels.
+// A thread per row (strided over the grid), row losses added in a fixed order; workgroup g leaves loss[g] = its rows' share of
+// the mean (one workgroup: the loss itself; several -- the per-point mask loss of the BGA models, b n rows of two classes,
+// pointnet2_cls_bga.py:94-98 -- the caller adds the few shares up).  A label outside [0, C) contributes the smoothing term
+// only (no class row to pick) -- the callers hand over validated labels.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(int R, int C, const float *__restrict__ x, const int *__restrict__ y,
                                                          float smooth, float *__restrict__ loss, float *__restrict__ dx) {
     __shared__ float sm[256];
     const int t = threadIdx.x;
     const float invR = 1.f / (float)R, qs = smooth / (float)C;
     float acc = 0.f;
-    for (int r = t; r < R; r += 256) {
-        const float *xr = x + (long long)r * C;
+    for (long long r = (long long)blockIdx.x * 256 + t; r < R; r += (long long)gridDim.x * 256) {
+        const float *xr = x + r * C;
         float m = xr[0];
         for (int c = 1; c < C; ++c) m = fmaxf(m, xr[c]);
         float se = 0.f, sx = 0.f;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int R, int C, const flo
         const bool ok = yr >= 0 && yr < C;
         const float pick = ok ? xr[yr] - lse : 0.f;
         acc += -((1.f - smooth) * pick + qs * (sx - (float)C * lse));
-        float *dr = dx + (long long)r * C;
+        float *dr = dx + r * C;
         for (int c = 0; c < C; ++c) {
             const float q = qs + ((ok && c == yr) ? 1.f - smooth : 0.f);
             dr[c] = (expf(xr[c] - lse) - q) * invR;
@@ -181,7 +183,20 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int R, int C, const flo
         if (t < w) sm[t] += sm[t + w];
         __syncthreads();
     }
-    if (t == 0) loss[0] = sm[0] * invR;
+    if (t == 0) loss[blockIdx.x] = sm[0] * invR;
+}
+
+// The three interpolation weights of a point from its squared 3-NN distances: w_i = (1 / max(d_i, 1e-10)) / sum_j (1 / max(d_j, 1e-10))
+// (pointnet_util.py:212-215 of pointnet_fp_module; five elementwise / reduce launches per level as tensor expressions).
+// d = +inf (fewer than three known points) gives the weight 0.
+__global__ __launch_bounds__(256) void three_nn_weights_kernel(long long rows, const float *__restrict__ dist,
+                                                               float *__restrict__ w) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float i0 = 1.f / fmaxf(dist[3 * r], 1e-10f), i1 = 1.f / fmaxf(dist[3 * r + 1], 1e-10f),
+                i2 = 1.f / fmaxf(dist[3 * r + 2], 1e-10f);
+    const float nrm = (i0 + i1) + i2;
+    w[3 * r] = i0 / nrm; w[3 * r + 1] = i1 / nrm; w[3 * r + 2] = i2 / nrm;
 }
 
 }  // namespace
@@ -228,12 +243,26 @@ extern "C" int pcops_transform3_bwd(int b, int n, const float *x, const float *T
     return pcops_launch_status();
 }
 
+extern "C" int pcops_softmax_ce_blocks(int R) {
+    // one workgroup up to 4096 rows (the class loss of a batch: a single fixed-order sum), 1024 rows per workgroup beyond (<= 256)
+    return R <= 4096 ? 1 : ((R + 1023) / 1024 < 256 ? (R + 1023) / 1024 : 256);
+}
+
 extern "C" int pcops_softmax_ce(int R, int C, const float *logits, const int *labels, float label_smoothing, float *loss,
                                 float *dlogits, pcops_stream_t stream) {
     PCOPS_REQUIRE_SHAPE(R >= 1 && C >= 1);
     PCOPS_REQUIRE_ARG(label_smoothing >= 0.f && label_smoothing <= 1.f);
     PCOPS_REQUIRE_PTR(logits); PCOPS_REQUIRE_PTR(labels); PCOPS_REQUIRE_PTR(loss); PCOPS_REQUIRE_PTR(dlogits);
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(256), 0, as_stream(stream), R, C, logits, labels, label_smoothing, loss,
-                       dlogits);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(pcops_softmax_ce_blocks(R)), dim3(256), 0, as_stream(stream), R, C, logits,
+                       labels, label_smoothing, loss, dlogits);
+    return pcops_launch_status();
+}
+
+extern "C" int pcops_three_nn_weights(int b, int n, const float *dist, float *weight, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(b >= 0 && n >= 0);
+    const long long rows = (long long)b * n;
+    if (rows == 0) return PCOPS_OK;
+    PCOPS_REQUIRE_PTR(dist); PCOPS_REQUIRE_PTR(weight);
+    hipLaunchKernelGGL(three_nn_weights_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, as_stream(stream), rows, dist, weight);
     return pcops_launch_status();
 }

@@ -61,7 +61,10 @@ def get_model(point_cloud, is_training, bn_decay=None, num_class=NUM_CLASSES):
 def get_loss(class_pred, seg_pred, gt_label, gt_mask, seg_weight=0.5):
     classify_loss = fused_mlp.softmax_cross_entropy(class_pred, gt_label)
     b, n, c = seg_pred.shape
-    per_point = F.cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n).long(),
-                                reduction='none').view(b, n)
-    seg_loss = per_point.mean(dim=1).mean()
+    if fused_mlp.TAIL_FOLD and seg_pred.is_cuda:        # every cloud has n points: the mean of the clouds' means = the mean of all rows
+        seg_loss = fused_mlp.softmax_cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n))
+    else:
+        per_point = F.cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n).long(),
+                                    reduction='none').view(b, n)
+        seg_loss = per_point.mean(dim=1).mean()
     return (1 - seg_weight) * classify_loss + seg_weight * seg_loss, classify_loss, seg_loss

@@ -662,12 +662,13 @@ class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, smoothing):
         R, C = logits.shape
-        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        blocks = int(_lib.load().pcops_softmax_ce_blocks(R))
+        loss = torch.empty(blocks, dtype=torch.float32, device=logits.device)
         dl = torch.empty_like(logits)
         _lib.call("pcops_softmax_ce", R, C, logits.data_ptr(), labels.data_ptr(), float(smoothing), loss.data_ptr(),
                   dl.data_ptr())
         ctx.save_for_backward(dl)
-        return loss
+        return loss.view(()) if blocks == 1 else loss.sum()
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -677,10 +678,10 @@ class _SoftmaxCE(torch.autograd.Function):
 
 
 def softmax_cross_entropy(logits, labels, label_smoothing=0.0):
-    """F.cross_entropy(logits, labels.long(), label_smoothing=...) with mean reduction; on the device and for a batch of up
-    to a few thousand rows one launch per direction (torch: 6 launches, 26 with smoothing)"""
+    """F.cross_entropy(logits, labels.long(), label_smoothing=...) with mean reduction; on the device one launch per direction
+    (+ one to add up the workgroups' shares beyond 4096 rows; torch: 6 launches, 26 with smoothing)"""
     R, C = logits.shape
-    if (TAIL_FOLD and logits.is_cuda and logits.dtype == torch.float32 and 1 <= R <= 4096 and 1 <= C <= 4096):
+    if TAIL_FOLD and logits.is_cuda and logits.dtype == torch.float32 and 1 <= R and R * C < 2 ** 31 and 1 <= C <= 4096:
         lab = labels if labels.dtype == torch.int32 else labels.to(torch.int32)
         return _SoftmaxCE.apply(logits.contiguous(), lab.contiguous(), float(label_smoothing))
     import torch.nn.functional as F

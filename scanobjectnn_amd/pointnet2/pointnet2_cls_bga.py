@@ -63,8 +63,11 @@ def get_loss(class_pred, seg_pred, gt_label, gt_mask, seg_weight=0.5):
     """total = (1-w)*CE_cls + w*mean_b(mean_n CE_seg); returns (total, classify, seg)"""
     classify_loss = fused_mlp.softmax_cross_entropy(class_pred, gt_label)
     b, n, c = seg_pred.shape
-    per_point = F.cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n).long(),
-                                reduction='none').view(b, n)
-    seg_loss = per_point.mean(dim=1).mean()
+    if fused_mlp.TAIL_FOLD and seg_pred.is_cuda:        # every cloud has n points: the mean of the clouds' means = the mean of all rows
+        seg_loss = fused_mlp.softmax_cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n))
+    else:
+        per_point = F.cross_entropy(seg_pred.reshape(b * n, c), gt_mask.reshape(b * n).long(),
+                                    reduction='none').view(b, n)
+        seg_loss = per_point.mean(dim=1).mean()
     total_loss = (1 - seg_weight) * classify_loss + seg_weight * seg_loss
     return total_loss, classify_loss, seg_loss

@@ -8,7 +8,7 @@ follows SURVEY.md Appendix A9.
 import torch
 
 from . import tf_util
-from .. import fused_mlp
+from .. import _lib, fused_mlp
 from ..graph import variable_scope
 from .tf_grouping import group_point, knn_point, query_ball_point, query_ball_point_multi
 from .tf_interpolate import three_interpolate, three_nn
@@ -221,8 +221,12 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     points2 (B,n2,C2) -> (B,n1,mlp[-1])."""
     with variable_scope(scope):
         dist, idx = three_nn(xyz1, xyz2)
-        inv = 1.0 / torch.clamp_min(dist, 1e-10)            # (:212-215), 1/inf = 0 for m<3
-        weight = inv / inv.sum(dim=2, keepdim=True)
+        if fused_mlp.TAIL_FOLD and dist.is_cuda:            # (:212-215) in one launch, 1/inf = 0 for m<3
+            weight = torch.empty_like(dist)
+            _lib.call("pcops_three_nn_weights", dist.shape[0], dist.shape[1], dist.data_ptr(), weight.data_ptr())
+        else:
+            inv = 1.0 / torch.clamp_min(dist, 1e-10)        # (:212-215), 1/inf = 0 for m<3
+            weight = inv / inv.sum(dim=2, keepdim=True)
         interpolated = three_interpolate(points2, idx, weight)
         new_points1 = interpolated if points1 is None else torch.cat([interpolated, points1], dim=2)
         new_points1 = _mlp_stack(new_points1.unsqueeze(2), mlp, 'conv_%d', bn, is_training, bn_decay,
