@@ -359,8 +359,8 @@ class _FirstMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dim):
-        out, arg = x.max(dim=dim, keepdim=True)          # one launch; of equal maxima torch.max reports the first, like argmax
-        ctx.save_for_backward(arg)
+        out = x.amax(dim=dim, keepdim=True)              # (amax: the decision reader of the parity tests hooks it, tests/decisions.py)
+        ctx.save_for_backward(x.argmax(dim=dim, keepdim=True))
         ctx.dim, ctx.shape = dim, x.shape
         return out
 

@@ -195,7 +195,7 @@ def test_folded_step_equals_the_torch_forms(modpath, has_mask, B, N, monkeypatch
 
 
 def test_first_max_on_the_device_gives_ties_to_the_first_member():
-    """dgcnn/tf_util._FirstMax takes value and position from one torch.max launch: of equal maxima the first one is reported"""
+    """dgcnn/tf_util._FirstMax on the device: of equal maxima the first one takes the gradient"""
     from scanobjectnn_amd.dgcnn.tf_util import _FirstMax
     x = torch.zeros(64, 8, 1, 1024, device=DEV)
     x[:, 2] = 1.0
