@@ -319,6 +319,13 @@ int pcops_mlp_relu_mask_stats(long long R, int C, const float *Gout, const float
                               const float *shift, float *Gm, float *stats_partial, pcops_stream_t stream);
 int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float *ysel, const float *scale,
                              const float *shift, float *stats_partial, float *gmasked, pcops_stream_t stream);
+/* ... of a pooled gradient that arrives as two pieces and / or with a row stride (an EdgeConv output that feeds the next layer AND a
+ * column block of the concatenation, dgcnn/models/dgcnn.py:39-81): the sums of (ga + gb) -- gb may be NULL -- with rows lda / ldb
+ * floats apart (multiples of 4, 16-byte aligned pointers), and gsum [G][C] = ga + gb, UNMASKED and contiguous, for the data-gradient
+ * kernel behind (pcops_edge_pool_bwd*); round 6: autograd's sum of the two was a launch over the tensor, a strided piece a copy. */
+int pcops_mlp_pool_bwd_stats_sum(long long G, int C, const float *ga, long long lda, const float *gb, long long ldb,
+                                 const float *ysel, const float *scale, const float *shift, float *stats_partial,
+                                 float *gsum, pcops_stream_t stream);
 int pcops_mlp_bn_bwd_coeffs(int P, int N, long long R, const float *stats_partial, void *workspace,
                             const float *gamma, const float *mean, const float *rstd, float *dgamma,
                             float *dbeta, float *p, float *q, float *t, pcops_stream_t stream);

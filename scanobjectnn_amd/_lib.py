@@ -45,6 +45,7 @@ SIGNATURES = {
     "pcops_mlp_bn_relu_apply": ([_LL, _I, _P, _P, _P, _P], True),
     "pcops_mlp_relu_mask_stats": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_pool_bwd_stats": ([_LL, _I, _P, _P, _P, _P, _P, _P], True),
+    "pcops_mlp_pool_bwd_stats_sum": ([_LL, _I, _P, _LL, _P, _LL, _P, _P, _P, _P, _P], True),
     "pcops_mlp_bn_bwd_coeffs": ([_I, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_gemm_dgrad": ([_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], True),
     "pcops_mlp_wgrad": ([_LL, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P], True),

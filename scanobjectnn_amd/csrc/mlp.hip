@@ -2084,6 +2084,61 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_sel_kernel(long long G, in
     }
 }
 
+// ... of a pooled gradient that arrives in TWO pieces and / or strided (an EdgeConv output that feeds the next layer and a column
+// block of the concatenation, dgcnn.py:39-81: autograd's sum was a 134 MB launch of its own, a strided piece a copy): the pieces
+// are added while the sums are taken and leave as ONE contiguous tensor gsum [G][C] for the data-gradient kernel behind
+__global__ __launch_bounds__(256) void pool_bwd_stats_sum_kernel(long long G, int C, const float *__restrict__ ga, long long lda,
+                                                                 const float *__restrict__ gb, long long ldb,
+                                                                 const float *__restrict__ ysel,
+                                                                 const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift,
+                                                                 float *__restrict__ stats, int groups_per_block,
+                                                                 float *__restrict__ gsum) {
+    extern __shared__ float sm[];                     // [RL][2][C]
+    const int c4n = C / 4;
+    const int RL = c4n >= 256 ? 1 : 256 / c4n;
+    const int rl = c4n >= 256 ? 0 : threadIdx.x / c4n;
+    const long long g0 = (long long)blockIdx.x * groups_per_block;
+    const long long g1 = min(G, g0 + groups_per_block);
+    for (int cq = threadIdx.x % (c4n >= 256 ? 256 : c4n); cq < c4n; cq += 256) {
+        const int c = cq * 4;
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl < RL)
+            for (long long g = g0 + rl; g < g1; g += RL) {
+                const float4 y = *reinterpret_cast<const float4 *>(ysel + g * C + c);
+                float4 gp = *reinterpret_cast<const float4 *>(ga + g * lda + c);
+                if (gb) {
+                    const float4 g2 = *reinterpret_cast<const float4 *>(gb + g * ldb + c);
+                    gp.x += g2.x; gp.y += g2.y; gp.z += g2.z; gp.w += g2.w;
+                }
+                *reinterpret_cast<float4 *>(gsum + g * C + c) = gp;
+                const float gm0 = fmaf(y.x, sc.x, sh.x) > 0.f ? gp.x : 0.f;
+                const float gm1 = fmaf(y.y, sc.y, sh.y) > 0.f ? gp.y : 0.f;
+                const float gm2 = fmaf(y.z, sc.z, sh.z) > 0.f ? gp.z : 0.f;
+                const float gm3 = fmaf(y.w, sc.w, sh.w) > 0.f ? gp.w : 0.f;
+                a1[0] += gm0; a1[1] += gm1; a1[2] += gm2; a1[3] += gm3;
+                a2[0] = fmaf(gm0, y.x, a2[0]); a2[1] = fmaf(gm1, y.y, a2[1]);
+                a2[2] = fmaf(gm2, y.z, a2[2]); a2[3] = fmaf(gm3, y.w, a2[3]);
+            }
+        if (rl < RL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sm[(rl * 2 + 0) * C + c + e] = a1[e];
+                sm[(rl * 2 + 1) * C + c + e] = a2[e];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        float t = 0.f;
+        for (int l = 0; l < RL; ++l) t += sm[(l * 2 + which) * C + c];
+        stats[((long long)blockIdx.x * 2 + which) * C + c] = t;
+    }
+}
+
 // A[r][c] = relu(scale[c]*Y[r][c] + shift[c])   (stack output without pooling)
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(long long total4, int C,
                                                             const float *__restrict__ Y,
@@ -5525,6 +5580,22 @@ int pcops_mlp_pool_bwd_stats(long long G, int C, const float *gpool, const float
     if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pool_bwd_stats_sel_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), lds,
                        as_stream(stream), G, C, gpool, ysel, scale, shift, stats_partial, 16, gmasked);
+    return pcops_launch_status();
+}
+
+int pcops_mlp_pool_bwd_stats_sum(long long G, int C, const float *ga, long long lda, const float *gb, long long ldb,
+                                 const float *ysel, const float *scale, const float *shift, float *stats_partial,
+                                 float *gsum, pcops_stream_t stream) {
+    PCOPS_REQUIRE_SHAPE(G >= 1 && C >= 4 && C % 4 == 0 && lda >= C && lda % 4 == 0 && (!gb || (ldb >= C && ldb % 4 == 0)));
+    PCOPS_REQUIRE_PTR(ga); PCOPS_REQUIRE_PTR(ysel); PCOPS_REQUIRE_PTR(scale);
+    PCOPS_REQUIRE_PTR(shift); PCOPS_REQUIRE_PTR(stats_partial); PCOPS_REQUIRE_PTR(gsum);
+    PCOPS_REQUIRE_ARG(((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)gsum) % 16 == 0);
+    const int c4n = C / 4;
+    const int rl = c4n >= 256 ? 1 : 256 / c4n;
+    const size_t lds = (size_t)rl * 2 * C * sizeof(float);
+    if (lds > 64 * 1024) return PCOPS_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pool_bwd_stats_sum_kernel, dim3(pcops_mlp_bwd_pool_stats_rows(G)), dim3(256), lds,
+                       as_stream(stream), G, C, ga, lda, gb, ldb, ysel, scale, shift, stats_partial, 16, gsum);
     return pcops_launch_status();
 }
 

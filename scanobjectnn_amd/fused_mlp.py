@@ -873,6 +873,25 @@ def cat_assemble(cat, slices):
     return _CatAssemble.apply(cat, *slices)
 
 
+def _row_stride(g):
+    """floats between consecutive rows of g viewed as (rows, C) when that view exists without a copy (unit stride along C, the
+    leading dimensions collapse to one uniform row stride, 16-byte alignment); None otherwise"""
+    if g.dtype != torch.float32 or g.dim() < 2 or g.stride(-1) != 1 or g.data_ptr() % 16:
+        return None
+    ld = span = None
+    for d in range(g.dim() - 2, -1, -1):
+        if g.shape[d] == 1:
+            continue                                        # (a dimension of one element has no say)
+        if ld is None:
+            ld, span = g.stride(d), g.stride(d) * g.shape[d]
+        elif g.stride(d) != span:
+            return None
+        else:
+            span *= g.shape[d]
+    ld = g.shape[-1] if ld is None else ld
+    return int(ld) if (ld >= g.shape[-1] and ld % 4 == 0) else None
+
+
 class EdgeConvPool(torch.autograd.Function):
     """apply(Q, Ctr, idx, gamma, beta, mm, mv, training, decay, eps, unbiased[, cat, col]) -> (B*M, C)
     [cat (a CatBuffer over (B, M, C_total)) and col: the output is ALSO stored as columns col..col+C of cat.buf, and a second
@@ -950,7 +969,10 @@ class EdgeConvPool(torch.autograd.Function):
         # the gradient of the dense output and (cat form) of the block stored into the concatenation
         given = [g for g in grads if g is not None]
         assert given, "EdgeConvPool.backward without any gradient"
-        grad_out = given[0] if len(given) == 1 else given[0] + given[1]
+        # two pieces, or one that is a column block of a wider tensor: added / gathered inside the statistics pass below
+        lds_ = [_row_stride(g) for g in given]
+        fold = TAIL_FOLD and all(l is not None for l in lds_) and (len(given) == 2 or lds_[0] != given[0].shape[-1])
+        grad_out = None if fold else (given[0] if len(given) == 1 else given[0] + given[1])
         Q, Ctr, idx, gamma, SQ, arg, ysel, mean, rstd, scale, shift = ctx.saved
         training, sync = ctx.flags
         B, M, S = idx.shape
@@ -958,11 +980,17 @@ class EdgeConvPool(torch.autograd.Function):
         Nsrc, C = Q.shape[1], (Q.shape[2] // 2 if qc else Q.shape[2])
         dev = Q.device
         G = B * M
-        grad_out = grad_out.contiguous()
         P = lib.pcops_mlp_bwd_pool_stats_rows(G)
         part = _f32((P, 2, C), dev)
-        _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(), scale.data_ptr(),
-                  shift.data_ptr(), part.data_ptr(), None)
+        if fold:
+            grad_out = _f32((G, C), dev)
+            gb = given[1] if len(given) == 2 else None
+            _lib.call("pcops_mlp_pool_bwd_stats_sum", G, C, given[0].data_ptr(), lds_[0], _p(gb), lds_[1] if gb is not None else 0,
+                      ysel.data_ptr(), scale.data_ptr(), shift.data_ptr(), part.data_ptr(), grad_out.data_ptr())
+        else:
+            grad_out = grad_out.contiguous()
+            _lib.call("pcops_mlp_pool_bwd_stats", G, C, grad_out.data_ptr(), ysel.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), part.data_ptr(), None)
         vecs = _VecArena([C], 3, dev)
         p, q, t = vecs.take(C), vecs.take(C), vecs.take(C)
         dgamma, dbeta = _f32(C, dev), _f32(C, dev)

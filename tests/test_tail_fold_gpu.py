@@ -233,3 +233,38 @@ def test_dy_apply(M, N):
     assert (out - old).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
     with pytest.raises(_lib.PcopsError):                    # N % 4 != 0 is refused
         _lib.call("pcops_mlp_dy_apply", M, 6, G.data_ptr(), Y.data_ptr(), p.data_ptr(), q.data_ptr(), t.data_ptr(), out.data_ptr())
+
+
+@pytest.mark.parametrize("G,C,two,ld", [(524288, 64, True, 320), (524288, 128, False, 320), (1000, 32, True, 32), (37, 256, False, 260)])
+def test_pool_bwd_stats_sum(G, C, two, ld):
+    """the pooled gradient of an EdgeConv layer arriving as two pieces and / or as a column block of the concatenation's gradient
+    (dgcnn.py:39-81): statistics and the contiguous sum out of one pass -- the same bits as autograd's sum + pcops_mlp_pool_bwd_stats"""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(G + C)
+    wide = torch.randn(G, ld, generator=g).to(DEV)
+    off = 0 if ld == C else 4 * ((ld - C) // 8)
+    gb = wide[:, off:off + C]                                # a strided column block
+    ga = torch.randn(G, C, generator=g).to(DEV) if two else None
+    ysel = torch.randn(G, C, generator=g).to(DEV)
+    scale, shift = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV)
+    P = lib.pcops_mlp_bwd_pool_stats_rows(G)
+    part, gsum = torch.empty(P, 2, C, device=DEV), torch.empty(G, C, device=DEV)
+    if two:
+        assert fused_mlp._row_stride(ga) == C and fused_mlp._row_stride(gb) == ld
+        _lib.call("pcops_mlp_pool_bwd_stats_sum", G, C, ga.data_ptr(), C, gb.data_ptr(), ld, ysel.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), part.data_ptr(), gsum.data_ptr())
+        want = ga + gb
+    else:
+        _lib.call("pcops_mlp_pool_bwd_stats_sum", G, C, gb.data_ptr(), ld, None, 0, ysel.data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), part.data_ptr(), gsum.data_ptr())
+        want = gb.contiguous()
+    assert torch.equal(gsum, want)
+    part0 = torch.empty(P, 2, C, device=DEV)
+    _lib.call("pcops_mlp_pool_bwd_stats", G, C, want.data_ptr(), ysel.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+              part0.data_ptr(), None)
+    assert torch.equal(part, part0)
+    mask = (ysel.double() * scale.double() + shift.double()) > 0
+    gm = want.double() * mask
+    tot = part.double().sum(0)
+    assert (tot[0] - gm.sum(0)).abs().max().item() <= 1e-5 * gm.abs().sum(0).max().item()
+    assert (tot[1] - (gm * ysel.double()).sum(0)).abs().max().item() <= 1e-5 * (gm * ysel.double()).abs().sum(0).max().item()
