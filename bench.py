@@ -274,6 +274,9 @@ def _algo(name, a):
     if name == "pcops_softmax_ce":            # logits in, gradient out
         R, C = a[:2]
         return 4 * 2 * R * C + 4 * R, 0, ""
+    if name == "pcops_mlp_pool_bwd_stats_sum":    # both pieces and ysel read, the contiguous sum written
+        G, C = a[:2]
+        return 4 * G * C * (3 + (1 if a[4] is not None else 0)), 0, ""
     if name == "pcops_mlp_dy_apply":          # G and Y read, dY written
         M, N = a[:2]
         return 4 * 3 * M * N, 0, ""
@@ -342,7 +345,8 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_edge_pool_fwd_ld": 5, "pcops_edge_pool_bwd_ld": 5, "pcops_edge_pool_out_ld": 2, "pcops_edge_pool_out_ld2": 2,
            "pcops_sa_gather_fwd_ld": 5, "pcops_sa_scatter_bwd_ld": 5, "pcops_fc_bn_fwd": 2, "pcops_fc_bn_bwd": 2,
            "pcops_small_gemm": 3, "pcops_small_gemm_ex": 3, "pcops_small_gemm_colsum": 3, "pcops_mlp_pool_top_prep": 2,
-           "pcops_mlp_pool_top_finish": 3, "pcops_softmax_ce": 2, "pcops_mlp_dy_apply": 2}
+           "pcops_mlp_pool_top_finish": 3, "pcops_softmax_ce": 2, "pcops_mlp_dy_apply": 2,
+           "pcops_mlp_pool_bwd_stats_sum": 2}
 
 
 class KernelTimer:
