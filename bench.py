@@ -265,6 +265,9 @@ def _algo(name, a):
     if name in ("pcops_small_gemm", "pcops_small_gemm_ex", "pcops_small_gemm_colsum"):
         M, K, N = a[:3]
         return 4 * (M * K + K * N + M * N), 2 * M * K * N, "flop"
+    if name == "pcops_small_gemm_pair":       # two products in one launch
+        M0, K0, N0, M1, K1, N1 = a[:6]
+        return 4 * (M0 * K0 + K0 * N0 + M0 * N0 + M1 * K1 + K1 * N1 + M1 * N1), 2 * (M0 * K0 * N0 + M1 * K1 * N1), "flop"
     if name == "pcops_mlp_pool_top_prep":     # W read once; W^T and W diag(q) written (the row products re-read W through L2)
         Kp, N = a[:2]
         return 4 * 3 * Kp * N, 0, ""
@@ -346,7 +349,7 @@ _NSHAPE = {"pcops_query_ball_point": 5, "pcops_query_ball_point_multi": 4, "pcop
            "pcops_sa_gather_fwd_ld": 5, "pcops_sa_scatter_bwd_ld": 5, "pcops_fc_bn_fwd": 2, "pcops_fc_bn_bwd": 2,
            "pcops_small_gemm": 3, "pcops_small_gemm_ex": 3, "pcops_small_gemm_colsum": 3, "pcops_mlp_pool_top_prep": 2,
            "pcops_mlp_pool_top_finish": 3, "pcops_softmax_ce": 2, "pcops_mlp_dy_apply": 2,
-           "pcops_mlp_pool_bwd_stats_sum": 2}
+           "pcops_mlp_pool_bwd_stats_sum": 2, "pcops_small_gemm_pair": 6}
 
 
 class KernelTimer:

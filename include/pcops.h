@@ -402,6 +402,18 @@ int pcops_small_gemm_ex(int M, int K, int N, const float *A, int lda, int transA
  * of 12 us per layer).  Fixed summation order. */
 int pcops_small_gemm_colsum(int M, int K, int N, const float *A, int lda, int transA, const float *B, int ldb, int transB,
                             const float *bias, float *C, int ldc, float *colsum, pcops_stream_t stream);
+/* TWO independent products of that form in ONE launch -- p[0] and p[1]: the data and the weight gradient of a fully connected
+ * layer (dX = dY W^T, dW = X^T dY with db as colsum), which share dY and each fill half the chip when launched alone; the
+ * two K x K / K x N products of the algebraic top layer.  Same results as two pcops_small_gemm_colsum calls, bit for bit. */
+typedef struct pcops_gemm_problem {
+    int M, K, N;
+    const float *A; int lda, transA;
+    const float *B; int ldb, transB;
+    const float *bias;              /* [N] or NULL */
+    float *C; int ldc;
+    float *colsum;                  /* [N] or NULL */
+} pcops_gemm_problem_t;
+int pcops_small_gemm_pair(const pcops_gemm_problem_t *p, pcops_stream_t stream);
 
 /* ---- algebraic backward of a POOLED top layer (the last conv of a set-abstraction stack / of a stack pooled over a
  * whole cloud: pointnet_util.py:139-147, dgcnn.py "agg", transform_nets.py "tconv3").

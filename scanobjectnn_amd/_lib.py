@@ -54,6 +54,7 @@ SIGNATURES = {
     "pcops_small_gemm_ex": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I], True),
     "pcops_mlp_dy_apply": ([_LL, _I] + [_P] * 6, True),
     "pcops_small_gemm_colsum": ([_I, _I, _I, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P], True),
+    "pcops_small_gemm_pair": ([_P], True),
     "pcops_mlp_pool_top_prep": ([_I, _I] + [_P] * 8, True),
     "pcops_mlp_pool_top_finish": ([_I, _I, _LL] + [_P] * 10, True),
     "pcops_mlp_pool_top_addend": ([_I, _I, _I, _I] + [_P] * 9, True),
@@ -155,6 +156,29 @@ PLAIN = {
     "pcops_set_deterministic": ([_I], None),
     "pcops_get_deterministic": ([], _I),
 }
+
+
+class GemmProblem(C.Structure):
+    """pcops_gemm_problem_t: one product C = op(A) op(B) + bias (+ column sums of op(B)) of pcops_small_gemm_pair"""
+    _fields_ = [("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("A", C.c_void_p), ("lda", C.c_int), ("transA", C.c_int),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("transB", C.c_int), ("bias", C.c_void_p), ("C", C.c_void_p),
+                ("ldc", C.c_int), ("colsum", C.c_void_p)]
+
+
+def small_gemm_pair(p0, p1):
+    """two independent small products in one launch; p = (M, K, N, A, lda, transA, B, ldb, transB, bias, C, ldc, colsum) with device
+    pointers as integers or None"""
+    arr = (GemmProblem * 2)(GemmProblem(*p0), GemmProblem(*p1))
+    lib = load()
+    stream = torch.cuda.current_stream().cuda_stream
+    shape = tuple(int(v) for v in p0[:3]) + tuple(int(v) for v in p1[:3])     # what a profiling hook sees of the launch
+    for h in _hooks:
+        h("pcops_small_gemm_pair", "pre", shape)
+    status = lib.pcops_small_gemm_pair(arr, stream)
+    for h in _hooks:
+        h("pcops_small_gemm_pair", "post", shape)
+    if status != 0:
+        raise PcopsError("pcops_small_gemm_pair failed: %s (status %d)" % (strerror(status), status))
 
 
 class RowsT(C.Structure):

@@ -4917,15 +4917,15 @@ __global__ __launch_bounds__(256) void pool_top_wsparse_kernel(long long G, int 
 // meeting in the staging area -- were measured in round 6: the SSG and DGCNN steps within noise, 24.55 / 24.46 / 24.63 against
 // 24.47 / 24.44 / 25.03 k clouds/s; not kept.  Three chunks per wave in flight instead of one, 48 more registers: 19.4 against
 // 15.5 us per launch in the SSG step, profiles/r06_tail_fold_ab.txt; not kept either.)
-__global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
+__device__ __forceinline__ void small_gemm_tile(int bx, int by, int M, int K, int N, const float *__restrict__ A, int lda,
                                                          const float *__restrict__ B, int ldb, float *__restrict__ C,
                                                          int ldc, int transA, int transB, const float *__restrict__ bias,
                                                          float *__restrict__ colsum) {
     // colsum (optional): column sums of B over its K rows next to the product -- the bias gradient of a fully connected layer
-    // out of its weight-gradient launch (dW = X^T dY, db = 1^T dY); the tile row blockIdx.y == 0 adds up what it stages anyway
+    // out of its weight-gradient launch (dW = X^T dY, db = 1^T dY); the tile row 0 adds up what it stages anyway
     __shared__ float As[4][32][17], Bs[4][16][33], red[4][32][33], cs[4][2][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int m0 = by * 32, n0 = bx * 32;
     const int kchunks = (K + 15) / 16;
     f32x16 acc;
 #pragma unroll
@@ -4946,7 +4946,7 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
         }
     };
     fetch(wave);
-    const bool sums = colsum != nullptr && blockIdx.y == 0;
+    const bool sums = colsum != nullptr && by == 0;
     float bsum = 0.f;                                // column lane & 31 over the rows (lane >> 5) + 2 i of this wave's chunks
     for (int ch = wave; ch < kchunks; ch += 4) {
         __builtin_amdgcn_wave_barrier();
@@ -4982,6 +4982,30 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, co
             C[(long long)(m0 + r) * ldc + n0 + c] =
                 ((red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c])) + (bias ? bias[n0 + c] : 0.f);
     }
+}
+
+__global__ __launch_bounds__(256) void small_gemm_kernel(int M, int K, int N, const float *__restrict__ A, int lda,
+                                                         const float *__restrict__ B, int ldb, float *__restrict__ C,
+                                                         int ldc, int transA, int transB, const float *__restrict__ bias,
+                                                         float *__restrict__ colsum) {
+    small_gemm_tile(blockIdx.x, blockIdx.y, M, K, N, A, lda, B, ldb, C, ldc, transA, transB, bias, colsum);
+}
+
+// TWO independent products in one launch (the data and the weight gradient of a fully connected layer, dX = dY W^T and
+// dW = X^T dY: each alone fills half the chip with 16 us of dependent chunks; the pooled top layer's W diag(q) W^T and gram W diag(q)):
+// workgroups [0, tiles0) take the first problem's tiles, the rest the second's -- one call site, the operands chosen by a uniform test
+struct SgProblem {
+    int M, K, N, lda, ldb, ldc, transA, transB;
+    const float *A, *B, *bias;
+    float *C, *colsum;
+};
+__global__ __launch_bounds__(256) void small_gemm_pair_kernel(SgProblem p0, SgProblem p1, int tiles0, int gx0, int gx1) {
+    const bool second = (int)blockIdx.x >= tiles0;
+    const int t = second ? (int)blockIdx.x - tiles0 : (int)blockIdx.x, gx = second ? gx1 : gx0;
+    small_gemm_tile(t % gx, t / gx, second ? p1.M : p0.M, second ? p1.K : p0.K, second ? p1.N : p0.N, second ? p1.A : p0.A,
+                    second ? p1.lda : p0.lda, second ? p1.B : p0.B, second ? p1.ldb : p0.ldb, second ? p1.C : p0.C,
+                    second ? p1.ldc : p0.ldc, second ? p1.transA : p0.transA, second ? p1.transB : p0.transB,
+                    second ? p1.bias : p0.bias, second ? p1.colsum : p0.colsum);
 }
 
 #endif  // PCOPS_PART(0)
@@ -6205,6 +6229,25 @@ int pcops_small_gemm_colsum(int M, int K, int N, const float *A, int lda, int tr
     pcops_note_pipe(0);                                     // fp32 MFMA (bench labels read pcops_last_launch_pipe per launch)
     hipLaunchKernelGGL(small_gemm_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, as_stream(stream), M, K, N, A,
                        lda, B, ldb, C, ldc, transA ? 1 : 0, transB ? 1 : 0, bias, colsum);
+    return pcops_launch_status();
+}
+
+int pcops_small_gemm_pair(const pcops_gemm_problem_t *p, pcops_stream_t stream) {
+    PCOPS_REQUIRE_PTR(p);
+    SgProblem q[2];
+    int tiles[2], gx[2];
+    for (int i = 0; i < 2; ++i) {
+        const pcops_gemm_problem_t &a = p[i];
+        PCOPS_REQUIRE_SHAPE(a.M >= 1 && a.K >= 1 && a.N >= 1 && a.lda >= (a.transA ? a.M : a.K) && a.ldb >= (a.transB ? a.K : a.N) &&
+                            a.ldc >= a.N);
+        PCOPS_REQUIRE_PTR(a.A); PCOPS_REQUIRE_PTR(a.B); PCOPS_REQUIRE_PTR(a.C);
+        q[i] = SgProblem{a.M, a.K, a.N, a.lda, a.ldb, a.ldc, a.transA ? 1 : 0, a.transB ? 1 : 0, a.A, a.B, a.bias, a.C, a.colsum};
+        gx[i] = (a.N + 31) / 32;
+        tiles[i] = gx[i] * ((a.M + 31) / 32);
+    }
+    pcops_note_pipe(0);
+    hipLaunchKernelGGL(small_gemm_pair_kernel, dim3(tiles[0] + tiles[1]), dim3(256), 0, as_stream(stream), q[0], q[1], tiles[0],
+                       gx[0], gx[1]);
     return pcops_launch_status();
 }
 

@@ -547,9 +547,23 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
         Wq = W * q[:N]                                  # W diag(q)
         u = torch.addcmul(t[:N], q[:N], b)              # q.b + t
     Gprev = part = None
-    if need_dx:
+    # the Gram matrix of the input first: with it the layer's two K-sized products (W diag(q) W^T for the data gradient, gram W diag(q)
+    # for the weight gradient) are independent of everything else and leave in ONE launch
+    splits = lib.pcops_mlp_wgrad_splits(R, K, K)
+    scratch = _f32(splits * (K * K + K), dev)
+    gram, xsum = _f32((K, K), dev), _f32(K, dev)
+    _lib.call("pcops_mlp_gram", R, K, Yprev.data_ptr(), K, _p(psc), _p(psh), scratch.data_ptr(),
+              gram.data_ptr(), xsum.data_ptr())
+    dW = _f32((K, N), dev)
+    paired = TAIL_FOLD and need_dx
+    if paired:
         Mq = _f32((K, K), dev)
-        _lib.call("pcops_small_gemm", K, N, K, Wq.data_ptr(), N, Wt.data_ptr(), K, Mq.data_ptr(), K)
+        _lib.small_gemm_pair((K, N, K, Wq.data_ptr(), N, 0, Wt.data_ptr(), K, 0, None, Mq.data_ptr(), K, None),
+                             (K, K, N, gram.data_ptr(), K, 0, Wq.data_ptr(), N, 0, None, dW.data_ptr(), N, None))
+    if need_dx:
+        if not paired:
+            Mq = _f32((K, K), dev)
+            _lib.call("pcops_small_gemm", K, N, K, Wq.data_ptr(), N, Wt.data_ptr(), K, Mq.data_ptr(), K)
         if not TAIL_FOLD:
             v = _f32(K, dev)
             _lib.call("pcops_small_gemm", 1, N, K, u.data_ptr(), N, Wt.data_ptr(), K, v.data_ptr(), K)
@@ -563,17 +577,12 @@ def _pool_top_backward(R, K, N, S, W, b, p, q, t, grad_out, ysel, argmax, sc, sh
         _lib.call("pcops_mlp_gemm_dgrad_top", R, K, Yprev.data_ptr(), _p(psc), _p(psh), Mq.data_ptr(),
                   v.data_ptr(), addend.data_ptr(), addend.shape[0], rowmap.data_ptr(), Gprev.data_ptr(), _p(part))
     # weight gradient
-    splits = lib.pcops_mlp_wgrad_splits(R, K, K)
-    scratch = _f32(splits * (K * K + K), dev)
-    gram, xsum = _f32((K, K), dev), _f32(K, dev)
-    _lib.call("pcops_mlp_gram", R, K, Yprev.data_ptr(), K, _p(psc), _p(psh), scratch.data_ptr(),
-              gram.data_ptr(), xsum.data_ptr())
     Ssp, cfsum = _f32((K, N), dev), _f32(N, dev)
     _lib.call("pcops_mlp_pool_top_wsparse", R, K, N, S, grad_out.data_ptr(), ysel.data_ptr(), argmax.data_ptr(),
               sc.data_ptr(), sh.data_ptr(), p.data_ptr(), Yprev.data_ptr(), _p(psc), _p(psh),
               Ssp.data_ptr(), cfsum.data_ptr())
-    dW = _f32((K, N), dev)
-    _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW.data_ptr(), N)
+    if not paired:
+        _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW.data_ptr(), N)
     if TAIL_FOLD:       # (dW + Ssp) + xsum u^T in place, db = (cfsum + q.(xsum^T W + R b)) + R t: one launch for eleven
         db = _f32(N, dev)
         _lib.call("pcops_mlp_pool_top_finish", K, N, R, dW.data_ptr(), Ssp.data_ptr(), xsum.data_ptr(), u.data_ptr(),
@@ -611,10 +620,18 @@ class _SmallLinear(torch.autograd.Function):
         N = w.shape[1]
         gy = gy.contiguous()
         dx = dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if TAIL_FOLD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            # dX = dY W^T and dW = X^T dY (+ db) share dY and nothing else: one launch, both halves of the chip busy
+            dx = torch.empty((R, K), dtype=torch.float32, device=x.device)
+            dw = torch.empty((K, N), dtype=torch.float32, device=x.device)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if want_db else None
+            _lib.small_gemm_pair((R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx.data_ptr(), K, None),
+                                 (K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N, _p(db)))
+            return dx, dw, db
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, K), dtype=torch.float32, device=x.device)
             _lib.call("pcops_small_gemm_ex", R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx.data_ptr(), K)
-        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty((K, N), dtype=torch.float32, device=x.device)
             if want_db and TAIL_FOLD:     # db = 1^T dY out of the dW = X^T dY launch

@@ -268,3 +268,33 @@ def test_pool_bwd_stats_sum(G, C, two, ld):
     tot = part.double().sum(0)
     assert (tot[0] - gm.sum(0)).abs().max().item() <= 1e-5 * gm.abs().sum(0).max().item()
     assert (tot[1] - (gm * ysel.double()).sum(0)).abs().max().item() <= 1e-5 * (gm * ysel.double()).abs().sum(0).max().item()
+
+
+def test_small_gemm_pair_equals_two_launches():
+    """pcops_small_gemm_pair: the two products of a fully connected layer's backward (dX = dY W^T, dW = X^T dY + db) and the
+    algebraic top layer's two K-sized products in ONE launch -- bit for bit what two launches give"""
+    g = torch.Generator().manual_seed(9)
+    for (R, K, N) in [(256, 1024, 512), (256, 256, 15), (200, 70, 9), (1, 33, 5)]:
+        x, w, gy = (torch.randn(R, K, generator=g).to(DEV), torch.randn(K, N, generator=g).to(DEV),
+                    torch.randn(R, N, generator=g).to(DEV))
+        dx0, dw0, db0 = torch.empty(R, K, device=DEV), torch.empty(K, N, device=DEV), torch.empty(N, device=DEV)
+        _lib.call("pcops_small_gemm_ex", R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx0.data_ptr(), K)
+        _lib.call("pcops_small_gemm_colsum", K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw0.data_ptr(), N, db0.data_ptr())
+        dx, dw, db = torch.empty_like(dx0), torch.empty_like(dw0), torch.empty_like(db0)
+        _lib.small_gemm_pair((R, N, K, gy.data_ptr(), N, 0, w.data_ptr(), N, 1, None, dx.data_ptr(), K, None),
+                             (K, R, N, x.data_ptr(), K, 1, gy.data_ptr(), N, 0, None, dw.data_ptr(), N, db.data_ptr()))
+        assert torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
+        assert (dx.double() - gy.double() @ w.double().t()).abs().max().item() <= 1e-5 * max(1.0, (gy.double() @ w.double().t()).abs().max().item())
+    K, N = 320, 1024
+    Wq, Wt, gram = (torch.randn(K, N, generator=g).to(DEV), torch.randn(N, K, generator=g).to(DEV), torch.randn(K, K, generator=g).to(DEV))
+    bias = torch.randn(K, generator=g).to(DEV)
+    Mq0, dW0 = torch.empty(K, K, device=DEV), torch.empty(K, N, device=DEV)
+    _lib.call("pcops_small_gemm_ex", K, N, K, Wq.data_ptr(), N, 0, Wt.data_ptr(), K, 0, bias.data_ptr(), Mq0.data_ptr(), K)
+    _lib.call("pcops_small_gemm", K, K, N, gram.data_ptr(), K, Wq.data_ptr(), N, dW0.data_ptr(), N)
+    Mq, dW = torch.empty_like(Mq0), torch.empty_like(dW0)
+    _lib.small_gemm_pair((K, N, K, Wq.data_ptr(), N, 0, Wt.data_ptr(), K, 0, bias.data_ptr(), Mq.data_ptr(), K, None),
+                         (K, K, N, gram.data_ptr(), K, 0, Wq.data_ptr(), N, 0, None, dW.data_ptr(), N, None))
+    assert torch.equal(Mq, Mq0) and torch.equal(dW, dW0)
+    with pytest.raises(_lib.PcopsError):
+        _lib.small_gemm_pair((0, N, K, Wq.data_ptr(), N, 0, Wt.data_ptr(), K, 0, None, Mq.data_ptr(), K, None),
+                             (K, K, N, gram.data_ptr(), K, 0, Wq.data_ptr(), N, 0, None, dW.data_ptr(), N, None))
