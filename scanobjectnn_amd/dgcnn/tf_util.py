@@ -337,9 +337,15 @@ def conv2d_stack_cloud_point(per_cloud, per_point, widths, scopes, is_training, 
     names = ('pop_mean', 'pop_var') if is_dist else ('moving_mean', 'moving_variance')
     layers = _pn2._stack_variables(cc + cx, widths, list(scopes), 1e-3, None, True, names)
     w1, b1 = layers[0][0], layers[0][1]
-    q = fused_mlp.rows_linear(per_point.reshape(b * n, cx), w1[cc:]).view(b, n, widths[0])
-    ctr = torch.addmm(b1, per_cloud.reshape(b, cc), w1[:cc]).view(b, 1, widths[0])
-    idx = torch.arange(n, dtype=torch.int32, device=q.device).view(1, 1, n).expand(b, 1, n).contiguous()
+    w_c, w_x = fused_mlp.split_rows(w1, cc)                  # (one concatenation as their gradient)
+    q = fused_mlp.rows_linear(per_point.reshape(b * n, cx), w_x).view(b, n, widths[0])
+    if fused_mlp.TAIL_FOLD and per_cloud.is_cuda:           # the per-cloud rows on the small-GEMM kernel, not a library GEMM
+        ctr = fused_mlp.small_linear(per_cloud.reshape(b, cc), w_c, b1).view(b, 1, widths[0])
+        from ..pointnet2.pointnet_util import _whole_cloud_group
+        _, idx = _whole_cloud_group(b, n, q.device)
+    else:
+        ctr = torch.addmm(b1, per_cloud.reshape(b, cc), w_c).view(b, 1, widths[0])
+        idx = torch.arange(n, dtype=torch.int32, device=q.device).view(1, 1, n).expand(b, 1, n).contiguous()
     decay = bn_decay if bn_decay is not None else 0.9
     out = fused_mlp.gather_mlp_stack(idx, False, is_training, decay, BN_EPS, False, layers, Q=q, Ctr=ctr, identity_idx=True)
     return out.view(b, n, 1, widths[-1])
